@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Golden-vector generator.  Runs ONLY in the build container (needs /root/reference).
+
+Imports the reference's own Python (``models/detector.py``, ``process_ocr_base.py``,
+``util_func.py``) from /root/reference -- with ``oracle/tv_efficientnet.py`` standing in for the
+absent torchvision wheel -- feeds it seeded inputs and deterministic weights
+(``findtextcenternet_amd.weights``) and writes small input/output fixtures next to this file.
+Nothing of the reference's source travels: fixtures are data only.
+
+    python tests/golden/gen_golden.py            # regenerates every fixture (~2 min on 8 cores)
+"""
+from __future__ import annotations
+
+import gzip
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, REF)
+
+from oracle.tv_efficientnet import install_as_torchvision  # noqa: E402
+
+install_as_torchvision()
+import models.detector as ref_detector  # noqa: E402  (reference code)
+import process_ocr_base as ref_ocr  # noqa: E402  (reference code)
+import util_func as ref_util  # noqa: E402  (reference code)
+
+from findtextcenternet_amd.weights import deterministic_state_dict  # noqa: E402
+import synth  # noqa: E402
+
+SEED_W = 0
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print("wrote", name, os.path.getsize(path) // 1024, "KiB")
+
+
+def gen_schema(model):
+    sd = model.state_dict()
+    rec = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]
+    with gzip.open(os.path.join(HERE, "state_dict_schema_xl.json.gz"), "wt") as f:
+        json.dump({"n_keys": len(rec), "backbone_params": sum(p.numel() for p in model.detector.backbone.parameters()),
+                   "detector_params": sum(p.numel() for p in model.detector.parameters()),
+                   "total_params": sum(p.numel() for p in model.parameters()), "keys": rec}, f)
+    print("wrote state_dict_schema_xl.json.gz", len(rec), "keys")
+
+
+def gen_forward(det):
+    # G1: 128x128, batch 2 (one noise image, one page-like image), full outputs
+    x = np.concatenate([synth.noise_images(1234, 1, 128, 128), synth.page_images(77, 1, 128, 128)])
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)        # NHWC memory, NCHW view: the callers' convention
+    with torch.no_grad():
+        hm, ft = det(xt)
+    save("g1_fwd128.npz", heatmap=hm.numpy(), features=ft.numpy(), seeds=np.array([1234, 77]))
+
+    # G2: 768x768, img/test1.png padded white exactly as test_image1_torch.py:303-311
+    from PIL import Image
+    im0 = np.asarray(Image.open(os.path.join(REF, "img", "test1.png")).convert("RGB"))
+    w = h = 768
+    stepx, stepy = w * 3 // 4, h * 3 // 4
+    padx = max(0, (w - im0.shape[1]) % stepx, w - im0.shape[1])
+    pady = max(0, (h - im0.shape[0]) % stepy, h - im0.shape[0])
+    im0 = np.pad(im0, [[0, pady], [0, padx], [0, 0]], "constant", constant_values=((255, 255), (255, 255), (255, 255)))
+    assert im0.shape == (768, 768, 3), im0.shape
+    Image.fromarray(im0).save(os.path.join(HERE, "test1_padded.png"), optimize=True)
+    inp = np.expand_dims(im0.astype(np.float32), 0)
+    xt = torch.from_numpy(inp / 255.).permute(0, 3, 1, 2)   # process_ocr_torch.py:44 (float64 there)
+    with torch.no_grad():
+        hm, ft = det(xt.float())
+    hm, ft = hm.numpy(), ft.numpy()
+    rng = np.random.Generator(np.random.PCG64(5))
+    pos = rng.choice(192 * 192, 1024, replace=False)
+    fstats = np.stack([ft[0].reshape(100, -1).min(1), ft[0].reshape(100, -1).max(1), ft[0].reshape(100, -1).mean(1),
+                       np.sqrt((ft[0].reshape(100, -1).astype(np.float64) ** 2).sum(1))])
+    save("g2_fwd768_test1.npz", heatmap=hm, feat_pos=pos, feat_at=ft[0].reshape(100, -1)[:, pos], feat_stats=fstats)
+
+    # second 768 image: seeded page-like synthetic (input regenerable from the seed)
+    x = synth.page_images(4242, 1, 768, 768)
+    with torch.no_grad():
+        hm, ft = det(torch.from_numpy(x).permute(0, 3, 1, 2))
+    hm, ft = hm.numpy(), ft.numpy()
+    save("g2_fwd768_page.npz", heatmap=hm, feat_pos=pos, feat_at=ft[0].reshape(100, -1)[:, pos], seed=np.array(4242))
+
+
+def gen_nms():
+    # G4: NMS on a hand-made map with ties, plateaus, -inf and borders, through the reference's
+    # CenterNetDetector.forward (models/detector.py:289-296) with a stub detector.
+    rng = np.random.Generator(np.random.PCG64(9))
+    maps = rng.standard_normal((2, 9, 16, 20)).astype(np.float32)
+    k = maps[:, 0]
+    k[0, 3, 3] = k[0, 3, 4] = 5.0            # horizontal tie
+    k[0, 8:10, 8:10] = 4.0                   # 2x2 plateau
+    k[0, 0, 0] = 9.0; k[0, 15, 19] = 9.0; k[0, 0, 19] = 8.5   # corners
+    k[0, 7, 0] = 7.0; k[0, 7, 1] = 7.0       # tie on the border
+    k[1, 5, 5] = -np.inf
+    k[1, 12, :] = 3.0                        # a whole row plateau
+    feat = rng.standard_normal((2, 100, 16, 20)).astype(np.float32)
+    det = ref_detector.CenterNetDetector(lambda x: (torch.from_numpy(maps), torch.from_numpy(feat)))
+    with torch.no_grad():
+        hm, ft = det(torch.zeros(2, 3, 64, 80))
+    save("g4_nms_ties.npz", maps=maps, heatmap=hm.numpy())
+
+
+class _Replay(ref_ocr.OCR_Processer):
+    """The reference's pipeline with a detector that replays prepared maps."""
+
+    def __init__(self, outs, **kw):
+        super().__init__(**kw)
+        self.outs = list(outs)
+        self.i = 0
+
+    def call_detector(self, image_input):
+        o = self.outs[self.i]
+        self.i += 1
+        return o
+
+    def call_transformer(self, encoder_input):
+        raise NotImplementedError
+
+
+def gen_decode():
+    # G3a: one tile, page == tile
+    img = synth.page_uint8(31, 768, 768).astype(np.float32)
+    hm, ft = synth.detector_maps(101)
+    ds = [{"input": img[None], "offsetx": 0, "offsety": 0}]
+    loc, gf, lines, seps = _Replay([(hm, ft)]).run_detector(ds, img)
+    save("g3_decode_single.npz", locations=loc, glyphfeatures=gf, lines=lines, seps=seps)
+
+    # G3b: 2x2 tiles at the production stride (step_ratio 0.6 -> 460 px, process_ocr_base.py:43-45)
+    step = int(768 * 0.6)
+    ph = pw = 768 + step
+    img = synth.page_uint8(32, ph, pw).astype(np.float32)
+    ds, outs = [], []
+    for n, (y, x) in enumerate([(0, 0), (0, step), (step, 0), (step, step)]):
+        ds.append({"input": img[None, y:y + 768, x:x + 768], "offsetx": x, "offsety": y})
+        outs.append(synth.detector_maps(200 + n))
+    loc, gf, lines, seps = _Replay(outs).run_detector(ds, img)
+    save("g3_decode_2x2.npz", locations=loc, glyphfeatures=gf, lines=lines, seps=seps)
+
+    # G3c: sparse, well separated peaks on a high-contrast page with low separator map: the
+    # page-level suppression removes nothing, so the output IS the per-tile decode (all rows).
+    rng = np.random.Generator(np.random.PCG64(303))
+    hm = np.full((1, 10, 192, 192), -20.0, np.float32)
+    feat = rng.standard_normal((1, 100, 192, 192)).astype(np.float32)
+    pts = [(y, x) for y in range(6, 186, 12) for x in range(6, 186, 12)]
+    for (y, x) in pts:
+        hm[0, 0, y, x] = rng.uniform(-0.3, 6.0)
+    hm[0, 0, 6, 6] = np.float32(np.log(0.4 / 0.6)) + np.float32(1e-3)     # just above the cut-off
+    hm[0, 0, 6, 18] = np.float32(np.log(0.4 / 0.6)) - np.float32(1e-3)    # just below
+    pad = np.pad(hm[0, 0], 1, constant_values=-np.inf)
+    win = np.stack([pad[dy:dy + 192, dx:dx + 192] for dy in range(3) for dx in range(3)]).max(0)
+    hm[0, 1] = np.where(hm[0, 0] < win, -np.inf, hm[0, 0])
+    hm[0, 2] = np.log(rng.uniform(10, 30, (192, 192)).astype(np.float32) / 1024) + 3
+    hm[0, 3] = np.log(rng.uniform(10, 30, (192, 192)).astype(np.float32) / 1024) + 3
+    hm[0, 2, 30, 30] = 10.0                  # w > page width -> skipped (process_ocr_base.py:527)
+    hm[0, 3, 42, 42] = -200.0                # h underflows to 0 -> skipped (:525)
+    hm[0, 6:10] = rng.standard_normal((4, 192, 192)).astype(np.float32)
+    img = (rng.integers(0, 2, (768, 768, 1)) * 255).astype(np.float32).repeat(3, axis=2)
+    ds = [{"input": img[None], "offsetx": 0, "offsety": 0}]
+    loc, gf, lines, seps = _Replay([(hm, feat)]).run_detector(ds, img)
+    save("g3_decode_sparse.npz", heatmap=hm, locations=loc, glyphfeatures=gf, image_seed=np.array(303))
+
+    # util_func.sigmoid known answers (float32 in, float32 out)
+    xs = np.concatenate([np.linspace(-30, 30, 241, dtype=np.float32),
+                         np.array([np.log(0.4 / 0.6), np.log(0.35 / 0.65), 0.0, -0.0, np.inf, -np.inf], np.float32)])
+    save("g3_sigmoid.npz", x=xs, y=ref_util.sigmoid(xs))
+
+
+def main():
+    torch.manual_seed(0)
+    model = ref_detector.TextDetectorModel(pre_weights=False)
+    gen_schema(model)
+    model.load_state_dict(deterministic_state_dict(SEED_W))
+    det = ref_detector.CenterNetDetector(model.detector)
+    det.eval()
+    gen_forward(det)
+    gen_nms()
+    gen_decode()
+
+
+if __name__ == "__main__":
+    main()

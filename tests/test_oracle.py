@@ -1,0 +1,131 @@
+"""CPU: the oracle against the golden vectors produced by the reference's own code
+(tests/golden/gen_golden.py).  Tolerances are stated per test."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from findtextcenternet_amd import schema
+from findtextcenternet_amd.weights import deterministic_state_dict
+from oracle import decode_oracle, detector_oracle
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return deterministic_state_dict(0, prefix_detector=False)
+
+
+def test_state_dict_schema_matches_reference():
+    with gzip.open(os.path.join(G, "state_dict_schema_xl.json.gz"), "rt") as f:
+        ref = json.load(f)
+    mine = schema.text_detector_schema("xl")
+    assert ref["n_keys"] == 2444 == len(mine)
+    assert [k for k, _, _ in ref["keys"]] == list(mine.keys())
+    for k, shape, _ in ref["keys"]:
+        assert tuple(shape) == tuple(mine[k][0]), k
+    # published EfficientNetV2-XL size minus the classifier
+    assert ref["backbone_params"] == 206_838_808
+    n = sum(int(np.prod(s)) for k, (s, kind) in mine.items() if kind not in ("bn_mean", "bn_var", "bn_count"))
+    assert n == ref["total_params"] == 262_350_422
+
+
+def test_forward_128_matches_reference(sd):
+    g = np.load(os.path.join(G, "g1_fwd128.npz"))
+    x = np.concatenate([synth.noise_images(1234, 1, 128, 128), synth.page_images(77, 1, 128, 128)])
+    hm, ft = detector_oracle.detector_forward(sd, torch.from_numpy(x).permute(0, 3, 1, 2))
+    hm, ft = hm.numpy(), ft.numpy()
+    fin = np.isfinite(g["heatmap"])
+    assert np.array_equal(np.isfinite(hm), fin)                 # -inf (suppressed) positions exact
+    assert np.abs(hm[fin] - g["heatmap"][fin]).max() < 2e-5     # fp32 summation-order noise only
+    assert np.abs(ft - g["features"]).max() < 5e-5
+    assert np.abs(g["heatmap"][fin]).max() > 3 and g["features"].std() > 1   # fixture is not degenerate
+
+
+@pytest.mark.parametrize("name", ["test1", "page"])
+def test_forward_768_matches_reference(sd, name):
+    g = np.load(os.path.join(G, f"g2_fwd768_{name}.npz"))
+    if name == "test1":
+        from PIL import Image
+        im = np.asarray(Image.open(os.path.join(G, "test1_padded.png")).convert("RGB")).astype(np.float32)
+        x = torch.from_numpy(im[None] / 255.).permute(0, 3, 1, 2).float()
+    else:
+        x = torch.from_numpy(synth.page_images(4242, 1, 768, 768)).permute(0, 3, 1, 2)
+    hm, ft = detector_oracle.detector_forward(sd, x)
+    hm, ft = hm.numpy(), ft.numpy()
+    fin = np.isfinite(g["heatmap"])
+    assert np.array_equal(np.isfinite(hm), fin)
+    assert np.abs(hm[fin] - g["heatmap"][fin]).max() < 1e-4
+    assert np.abs(ft[0].reshape(100, -1)[:, g["feat_pos"]] - g["feat_at"]).max() < 2e-4
+
+
+def test_nms_ties_match_reference():
+    g = np.load(os.path.join(G, "g4_nms_ties.npz"))
+    out = detector_oracle.nms_forward(torch.from_numpy(g["maps"])).numpy()
+    assert np.array_equal(out, g["heatmap"])                   # comparisons only: bit exact
+    k = g["heatmap"][0, 1]
+    assert k[3, 3] == 5.0 and k[3, 4] == 5.0                   # ties are BOTH kept (`<`, detector.py:295)
+    assert np.isfinite(k[8:10, 8:10]).all()
+
+
+def test_sigmoid_known_answers():
+    g = np.load(os.path.join(G, "g3_sigmoid.npz"))
+    y = decode_oracle.sigmoid(g["x"])
+    assert y.dtype == np.float32 and np.array_equal(y, g["y"])
+
+
+class _Replay:
+    def __init__(self, outs):
+        self.outs, self.i = list(outs), 0
+
+    def __call__(self, image_input):
+        o = self.outs[self.i]
+        self.i += 1
+        return o
+
+
+def test_decode_single_tile_matches_reference():
+    g = np.load(os.path.join(G, "g3_decode_single.npz"))
+    img = synth.page_uint8(31, 768, 768).astype(np.float32)
+    ds = [{"input": img[None], "offsetx": 0, "offsety": 0}]
+    loc, gf, lines, seps, raw = decode_oracle.run_detector(ds, img, _Replay([synth.detector_maps(101)]))
+    assert loc.shape == g["locations"].shape and loc.shape[0] > 50
+    assert np.array_equal(loc, g["locations"]) and np.array_equal(gf, g["glyphfeatures"])
+    assert np.array_equal(lines, g["lines"]) and np.array_equal(seps, g["seps"])
+
+
+def test_decode_2x2_tiles_matches_reference():
+    g = np.load(os.path.join(G, "g3_decode_2x2.npz"))
+    step = int(768 * 0.6)
+    img = synth.page_uint8(32, 768 + step, 768 + step).astype(np.float32)
+    ds, outs = [], []
+    for n, (y, x) in enumerate([(0, 0), (0, step), (step, 0), (step, step)]):
+        ds.append({"input": img[None, y:y + 768, x:x + 768], "offsetx": x, "offsety": y})
+        outs.append(synth.detector_maps(200 + n))
+    loc, gf, lines, seps, raw = decode_oracle.run_detector(ds, img, _Replay(outs))
+    assert np.array_equal(loc, g["locations"]) and np.array_equal(gf, g["glyphfeatures"])
+    assert np.array_equal(lines, g["lines"]) and np.array_equal(seps, g["seps"])
+
+
+def test_decode_sparse_equals_per_tile_decode():
+    """Fixture where the reference's page-level suppression removes nothing: its output is exactly
+    the per-tile decode, which pins decode_tile (incl. cut-off boundary and the w/h skips)."""
+    g = np.load(os.path.join(G, "g3_decode_sparse.npz"))
+    hm = g["heatmap"]
+    rng = np.random.Generator(np.random.PCG64(303))
+    feat = rng.standard_normal((1, 100, 192, 192)).astype(np.float32)
+    rect = decode_oracle.tile_keep_rect(0, 0, 768, 768, 0.6)
+    loc, gf, idx = decode_oracle.decode_tile(hm, feat, 0, 0, 768, 768, 0.4, rect)
+    ref = g["locations"]
+    assert loc.shape[0] == ref.shape[0] > 100
+    # page_merge only raises the code columns (3x3 max, process_ocr_base.py:628-648): compare p, ix, iy, w, h
+    assert np.array_equal(loc[:, :5].astype(np.float32), ref[:, :5])
+    assert np.array_equal(gf, g["glyphfeatures"])
+    ys, xs = idx // 192, idx % 192
+    assert (6, 6) in set(zip(ys.tolist(), xs.tolist())) and (6, 18) not in set(zip(ys.tolist(), xs.tolist()))
+    assert (30, 30) not in set(zip(ys.tolist(), xs.tolist())) and (42, 42) not in set(zip(ys.tolist(), xs.tolist()))

@@ -1,0 +1,84 @@
+"""ctypes binding of include/ftc.h.  The HIP library is REQUIRED: there is no CPU or eager-PyTorch
+fallback anywhere in the product path -- if ``libftc_hip.so`` is missing or fails to load, importing
+callers get a loud ``FtcLibraryError``."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libftc_hip.so")
+
+FTC_ABI_VERSION = 1
+F32, BF16 = 0, 1
+(BASE_NULL, BASE_WORKSPACE, BASE_WEIGHTS, BASE_INPUT, BASE_HEATMAP, BASE_FEATURES, NUM_BASES) = range(7)
+OP_STEM, OP_CONV, OP_DWCONV, OP_SE, OP_UPCAT, OP_NMS = 1, 2, 3, 4, 5, 6
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+FLAG_RESIDUAL, FLAG_SE_SCALE, FLAG_IN_NCHW = 1, 2, 4
+
+EXPORTS = ["ftc_abi_version", "ftc_last_error", "ftc_device_info", "ftc_plan_create", "ftc_plan_destroy",
+           "ftc_plan_num_ops", "ftc_plan_run", "ftc_plan_profile", "ftc_decode_scratch_bytes", "ftc_decode"]
+
+
+class FtcLibraryError(RuntimeError):
+    pass
+
+
+class FtcError(RuntimeError):
+    pass
+
+
+class Ref(C.Structure):
+    _fields_ = [("base", C.c_int32), ("reserved", C.c_int32), ("offset", C.c_int64)]
+
+
+class Op(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "kind", "flags", "act", "in_dtype", "out_dtype", "w_dtype", "B", "H", "W", "Ho", "Wo", "Cin", "Cin_total",
+        "cin_off", "Cout", "Cout_total", "cout_off", "ksize", "stride", "aux0", "aux1", "res_dtype")] + [
+        (n, Ref) for n in ("in_", "in2", "out", "w", "w2", "bias", "bias2", "scale", "shift", "aux")]
+
+
+class Tile(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("offset_x", "offset_y", "page_w", "page_h", "x_min", "x_max", "y_min", "y_max")]
+
+
+_lib = None
+
+
+def load():
+    """Loads (once) and returns the ctypes handle; raises FtcLibraryError if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FtcLibraryError(
+            f"{LIB_PATH} not found: build it with `python -m findtextcenternet_amd.build` "
+            "(hipcc, gfx950). There is no CPU fallback for the detector path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise FtcLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    lib.ftc_abi_version.restype = i32
+    lib.ftc_last_error.restype = C.c_char_p
+    lib.ftc_device_info.argtypes = [C.POINTER(i32), C.c_char_p, i32]
+    lib.ftc_plan_create.argtypes = [C.POINTER(Op), i32, i64, i64, C.POINTER(vp)]
+    lib.ftc_plan_destroy.argtypes = [vp]
+    lib.ftc_plan_destroy.restype = None
+    lib.ftc_plan_num_ops.argtypes = [vp]
+    lib.ftc_plan_run.argtypes = [vp, C.POINTER(vp), vp, i32, i32]
+    lib.ftc_plan_profile.argtypes = [vp, C.POINTER(vp), vp, C.POINTER(C.c_float)]
+    lib.ftc_decode_scratch_bytes.argtypes = [i32, i32, i32]
+    lib.ftc_decode_scratch_bytes.restype = i64
+    lib.ftc_decode.argtypes = [vp, vp, i32, i32, i32, i32, vp, C.c_float, i32, i32, vp, vp, vp, vp, vp, vp]
+    if lib.ftc_abi_version() != FTC_ABI_VERSION:
+        raise FtcLibraryError(f"ABI mismatch: library {lib.ftc_abi_version()} vs binding {FTC_ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().ftc_last_error().decode(errors="replace")
+        raise FtcError(f"{what} failed (status {rc}): {msg}")

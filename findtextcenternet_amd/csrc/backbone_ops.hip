@@ -1,0 +1,217 @@
+// HBM-bound backbone kernels: stem conv, LDS-tiled depthwise 3x3 (+SE partial sums) and the SE
+// excitation (wave-shuffle reductions).  NHWC throughout, 4 channels (16 B fp32 / 8 B bf16) per lane.
+//
+// Reference ops: torchvision Conv2dNormActivation / MBConv / SqueezeExcitation as instantiated by
+// /root/reference/models/detector.py:12-28 (structure restated in SURVEY.md Appendix D), and the
+// input scaling of CenterNetDetection.forward (/root/reference/models/detector.py:218).
+#include "ftc_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Stem: y = SiLU(conv3x3_s2(x*2-1, W') + b'), W'/b' = BN-folded.  Cin = 3, so K = 27: direct
+// convolution on the VALU; lanes = (pixel, channel quad) so a wave writes 1 KiB contiguous.
+// ------------------------------------------------------------------------------------------
+template <typename OutT>
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, OutT* __restrict__ out,
+                                                   int B, int H, int W, int Ho, int Wo, int C0, int nchw) {
+    extern __shared__ __attribute__((aligned(16))) float sw[];   // [27][C0]
+    for (int i = threadIdx.x; i < 27 * C0; i += blockDim.x) sw[i] = w[i];
+    __syncthreads();
+    const int CQ = C0 >> 2;
+    const long total = (long)B * Ho * Wo * CQ;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int cq = (int)(idx % CQ);
+        const long pix = idx / CQ;
+        const int ox = (int)(pix % Wo);
+        const int oy = (int)((pix / Wo) % Ho);
+        const int b = (int)(pix / ((long)Wo * Ho));
+        f32x4 acc = *reinterpret_cast<const f32x4*>(bias + cq * 4);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iy = oy * 2 - 1 + r;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int ix = ox * 2 - 1 + s;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float v = nchw ? in[(((long)b * 3 + c) * H + iy) * W + ix]
+                                             : in[(((long)b * H + iy) * W + ix) * 3 + c];
+                        const float xv = v * 2.0f - 1.0f;                       // detector.py:218
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(sw + ((r * 3 + s) * 3 + c) * C0 + cq * 4);
+                        acc += xv * wv;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = act_silu_precise(acc[e]);
+        store4<OutT>(out + pix * C0 + cq * 4, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Depthwise 3x3 (stride 1|2, pad 1) + folded BN + SiLU, and per-tile channel sums of the
+// OUTPUT for the SE squeeze (deterministic: one partial per (image, tile, channel), reduced in a
+// fixed order by se_kernel).
+// Workgroup = 64 channels x (TH x TW) output pixels; the input halo tile is staged once in LDS
+// (16 lanes x 16 B = one 256-B pixel row, coalesced), then every output reads its 9 taps from LDS.
+// ------------------------------------------------------------------------------------------
+template <typename T, int STRIDE>
+__global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, T* __restrict__ out,
+                                                     float* __restrict__ partial, int H, int W, int Ho, int Wo,
+                                                     int C, int tilesX, int P) {
+    constexpr int TH = STRIDE == 1 ? 8 : 4;
+    constexpr int TW = 8;
+    constexpr int IH = (TH - 1) * STRIDE + 3;
+    constexpr int IW = (TW - 1) * STRIDE + 3;
+    __shared__ __attribute__((aligned(16))) float tile[IH * IW * 64];
+    __shared__ __attribute__((aligned(16))) float red[16 * 64];
+
+    const int t = threadIdx.x;
+    const int cq = t & 15;          // channel quad inside the 64-channel slab
+    const int pt = t >> 4;          // pixel slot 0..15
+    const int c = blockIdx.x * 64 + cq * 4;
+    const int tileId = blockIdx.y;
+    const int ty = tileId / tilesX, tx = tileId - ty * tilesX;
+    const int b = blockIdx.z;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+    const bool cok = c < C;
+
+    for (int i = pt; i < IH * IW; i += 16) {
+        const int ry = i / IW, rx = i - ry * IW;
+        const int iy = iy0 + ry, ix = ix0 + rx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (cok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+            v = load4<T>(in + (((long)b * H + iy) * W + ix) * C + c);
+        *reinterpret_cast<f32x4*>(tile + i * 64 + cq * 4) = v;
+    }
+    f32x4 wv[9];
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (cok) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const f32x4*>(w + (long)k * C + c);
+        bv = *reinterpret_cast<const f32x4*>(bias + c);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wv[k] = bv;
+    }
+    __syncthreads();
+
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < TH * TW / 16; ++k) {
+        const int o = pt + 16 * k;
+        const int ly = o / TW, lx = o - ly * TW;
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        f32x4 acc = bv;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                acc += wv[r * 3 + s] * *reinterpret_cast<const f32x4*>(tile + ((ly * STRIDE + r) * IW + lx * STRIDE + s) * 64 + cq * 4);
+        if (cok && oy < Ho && ox < Wo) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = act_silu_precise(acc[e]);
+            store4<T>(out + (((long)b * Ho + oy) * Wo + ox) * C + c, acc);
+            sum += acc;
+        }
+    }
+    *reinterpret_cast<f32x4*>(red + pt * 64 + cq * 4) = sum;
+    __syncthreads();
+    if (t < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k * 64 + t];
+        const int cc = blockIdx.x * 64 + t;
+        if (cc < C) partial[((long)b * P + tileId) * C + cc] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// SE excitation: scale[b,c] = sigmoid(fc2(SiLU(fc1(mean_hw(x))))).  grid = (NSPLIT, B); every
+// workgroup of an image recomputes the tiny squeeze + fc1 (wave-per-hidden-unit dot products,
+// wave64 shuffle reductions) and then produces its slice of the C outputs.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void se_kernel(const float* __restrict__ partial, const float* __restrict__ w1,
+                                                 const float* __restrict__ b1, const float* __restrict__ w2t,
+                                                 const float* __restrict__ b2, float* __restrict__ scale,
+                                                 int C, int S, int P, float inv_hw) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // mean[C] | hidden[S]
+    float* mean = sm;
+    float* hidden = sm + C;
+    const int b = blockIdx.y;
+    const int t = threadIdx.x;
+    for (int c = t; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) s += partial[((long)b * P + p) * C + c];
+        mean[c] = s * inv_hw;
+    }
+    __syncthreads();
+    const int lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+    for (int s = wave; s < S; s += nw) {
+        const float* wr = w1 + (long)s * C;
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc += wr[c] * mean[c];
+        acc = wave_sum(acc);
+        if (lane == 0) hidden[s] = act_silu_precise(acc + b1[s]);
+    }
+    __syncthreads();
+    const int per = (C + gridDim.x - 1) / gridDim.x;
+    const int c0 = blockIdx.x * per;
+    const int c1 = min(C, c0 + per);
+    for (int c = c0 + t; c < c1; c += blockDim.x) {
+        float acc = b2[c];
+        for (int s = 0; s < S; ++s) acc += hidden[s] * w2t[(long)s * C + c];
+        scale[(long)b * C + c] = sigmoid_precise(acc);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_stem(const OpArgs& a, hipStream_t s) {
+    const ftc_op& o = *a.op;
+    const long total = (long)o.B * o.Ho * o.Wo * (o.Cout / 4);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    const size_t lds = (size_t)27 * o.Cout * sizeof(float);
+    const int nchw = (o.flags & FTC_FLAG_IN_NCHW) ? 1 : 0;
+    if (o.out_dtype == FTC_F32)
+        hipLaunchKernelGGL(stem_kernel<float>, dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
+                           a.bias, (float*)a.out, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw);
+    else
+        hipLaunchKernelGGL(stem_kernel<__bf16>, dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
+                           a.bias, (__bf16*)a.out, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw);
+    return hipGetLastError();
+}
+
+hipError_t launch_dwconv(const OpArgs& a, hipStream_t s) {
+    const ftc_op& o = *a.op;
+    const int TH = o.stride == 1 ? 8 : 4, TW = 8;
+    const int tilesX = (o.Wo + TW - 1) / TW, tilesY = (o.Ho + TH - 1) / TH;
+    const int P = tilesX * tilesY;
+    if (P != o.aux0) return hipErrorInvalidValue;
+    dim3 grid((o.Cin + 63) / 64, P, o.B);
+#define DW_LAUNCH(T, ST)                                                                                      \
+    hipLaunchKernelGGL((dwconv_kernel<T, ST>), grid, dim3(256), 0, s, (const T*)a.in, (const float*)a.w, a.bias, \
+                       (T*)a.out, a.aux, o.H, o.W, o.Ho, o.Wo, o.Cin, tilesX, P)
+    if (o.in_dtype == FTC_F32) { if (o.stride == 1) DW_LAUNCH(float, 1); else DW_LAUNCH(float, 2); }
+    else { if (o.stride == 1) DW_LAUNCH(__bf16, 1); else DW_LAUNCH(__bf16, 2); }
+#undef DW_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_se(const OpArgs& a, hipStream_t s) {
+    const ftc_op& o = *a.op;
+    const int C = o.Cin, S = o.aux0, P = o.aux1;
+    int nsplit = 64 / (o.B > 0 ? o.B : 1);
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > 16) nsplit = 16;
+    const size_t lds = (size_t)(C + S) * sizeof(float);
+    hipLaunchKernelGGL(se_kernel, dim3(nsplit, o.B), dim3(512), lds, s, (const float*)a.aux, (const float*)a.w, a.bias,
+                       (const float*)a.w2, a.bias2, (float*)a.out, C, S, P, 1.0f / (float)(o.H * o.W));
+    return hipGetLastError();
+}

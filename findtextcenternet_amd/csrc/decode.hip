@@ -1,0 +1,125 @@
+// GPU peak decode + 100-d feature gather: the replacement of the reference's per-tile host loop
+// (/root/reference/process_ocr_base.py:518-538 == /root/reference/test_image1_torch.py:123-143;
+// sigmoid = /root/reference/util_func.py:14-15).
+//
+// The reference copies the whole [10,h,w] + [100,h,w] maps to the host, argsorts 36 864 scores and
+// walks them in a Python loop.  Here only the kept peaks leave the GPU:
+//   1. select : every pixel of the trusted rectangle whose NMS'd key logit passes the cut-off and
+//               whose decoded box passes the reference's w/h checks gets a 64-bit sort key
+//               (orderable logit bits << 32 | ~pixel index)  -> per-image candidate list;
+//   2. rank   : rank[i] = #candidates with a larger key (keys staged through LDS in 256-wide
+//               chunks) -- a total order (score desc, pixel index asc), deterministic whatever
+//               order step 1's atomics produced;
+//   3. gather : the first max_boxes ranks write their 9-float box record and copy their
+//               contiguous NHWC feature row (100 floats = 25 lanes x 16 B).
+#include "ftc_common.h"
+
+namespace {
+
+__device__ __forceinline__ float ref_sigmoid(float x) { return (tanhf(x * 0.5f) + 1.0f) * 0.5f; }   // util_func.py:15
+
+__device__ __forceinline__ uint32_t orderable(float v) {
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void decode_select_kernel(const float* __restrict__ heat, const ftc_tile* __restrict__ tiles,
+                                                            int h, int w, float logit_cut, unsigned long long* __restrict__ cand,
+                                                            int32_t* __restrict__ counts) {
+    const int b = blockIdx.y;
+    const ftc_tile tl = tiles[b];
+    const int rw = tl.x_max - tl.x_min, rh = tl.y_max - tl.y_min;
+    const int n = rw * rh;
+    const float* hb = heat + (long)b * h * w * 10;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int y = tl.y_min + i / rw, x = tl.x_min + i % rw;
+        const int idx = y * w + x;
+        const float v = hb[(long)idx * 10 + 1];
+        if (!(v >= logit_cut)) continue;                          // -inf (suppressed) and NaN fail
+        const float bw = expf(hb[(long)idx * 10 + 2] - 3.0f) * 1024.0f;   // process_ocr_base.py:523-524
+        const float bh = expf(hb[(long)idx * 10 + 3] - 3.0f) * 1024.0f;
+        if (bw <= 0.f || bh <= 0.f) continue;                     // :525
+        if (bw > (float)tl.page_w || bh > (float)tl.page_h) continue;   // :527
+        const int slot = atomicAdd(&counts[b], 1);
+        cand[(long)b * h * w + slot] = ((unsigned long long)orderable(v) << 32) | (uint32_t)(~(uint32_t)idx);
+    }
+}
+
+__global__ __launch_bounds__(256) void decode_rank_gather_kernel(const float* __restrict__ heat, const float* __restrict__ feat,
+                                                                 const ftc_tile* __restrict__ tiles, int h, int w, int C, int scale,
+                                                                 const unsigned long long* __restrict__ cand,
+                                                                 const int32_t* __restrict__ counts, int max_boxes,
+                                                                 float* __restrict__ boxes, float* __restrict__ feats,
+                                                                 int32_t* __restrict__ index) {
+    __shared__ unsigned long long keys[256];
+    __shared__ int s_rank[256];
+    __shared__ int s_idx[256];
+    const int b = blockIdx.y;
+    const int n = counts[b];
+    const int base = blockIdx.x * 256;
+    if (base >= n) return;
+    const unsigned long long* cb = cand + (long)b * h * w;
+    const int t = threadIdx.x;
+    const int me = base + t;
+    const unsigned long long mykey = me < n ? cb[me] : 0ull;
+    int rank = 0;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        __syncthreads();
+        keys[t] = (c0 + t < n) ? cb[c0 + t] : 0ull;
+        __syncthreads();
+        const int lim = min(256, n - c0);
+        for (int j = 0; j < lim; ++j) rank += keys[j] > mykey ? 1 : 0;
+    }
+    const int idx = (int)(~(uint32_t)(mykey & 0xffffffffull));
+    s_rank[t] = (me < n && rank < max_boxes) ? rank : -1;
+    s_idx[t] = idx;
+    __syncthreads();
+
+    const ftc_tile tl = tiles[b];
+    const float* hb = heat + (long)b * h * w * 10;
+    if (s_rank[t] >= 0) {
+        const float* px = hb + (long)idx * 10;
+        const int y = idx / w, x = idx - y * w;
+        float* o = boxes + ((long)b * max_boxes + rank) * 9;
+        o[0] = ref_sigmoid(px[1]);
+        o[1] = (float)(x * scale + tl.offset_x);
+        o[2] = (float)(y * scale + tl.offset_y);
+        o[3] = expf(px[2] - 3.0f) * 1024.0f;
+        o[4] = expf(px[3] - 3.0f) * 1024.0f;
+        o[5] = ref_sigmoid(px[6]);
+        o[6] = ref_sigmoid(px[7]);
+        o[7] = ref_sigmoid(px[8]);
+        o[8] = ref_sigmoid(px[9]);
+        index[(long)b * max_boxes + rank] = idx;
+    }
+    // feature rows: one wave per candidate, 16 B per lane
+    const int lane = t & 63, wave = t >> 6;
+    const int CQ = C >> 2;
+    const float* fb = feat + (long)b * h * w * C;
+    for (int k = wave; k < 256; k += 4) {
+        const int r = s_rank[k];
+        if (r < 0) continue;
+        const float* src = fb + (long)s_idx[k] * C;
+        float* dst = feats + ((long)b * max_boxes + r) * C;
+        for (int q = lane; q < CQ; q += 64) reinterpret_cast<f32x4*>(dst)[q] = reinterpret_cast<const f32x4*>(src)[q];
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t ftc_decode_scratch_bytes(int B, int h, int w) { return (int64_t)B * h * w * 8; }
+
+hipError_t launch_decode(const float* heat, const float* feat, int B, int h, int w, int C, const ftc_tile* tiles,
+                         float logit_cut, int scale, int max_boxes, float* boxes, float* feats, int32_t* index,
+                         int32_t* counts, void* scratch, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * B, s);
+    if (e != hipSuccess) return e;
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(scratch);
+    const int nb = (h * w + 255) / 256;
+    hipLaunchKernelGGL(decode_select_kernel, dim3(nb < 36 ? nb : 36, B), dim3(256), 0, s, heat, tiles, h, w, logit_cut, cand, counts);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(decode_rank_gather_kernel, dim3(nb, B), dim3(256), 0, s, heat, feat, tiles, h, w, C, scale, cand, counts,
+                       max_boxes, boxes, feats, index);
+    return hipGetLastError();
+}

@@ -1,0 +1,108 @@
+// FPN-side bandwidth kernels: bilinear x2 upsample (align_corners=True) + concat + per-head input
+// BatchNorm, and the 3x3 max-pool NMS of the key heat-map.
+//
+// Reference: Leafmap.forward (/root/reference/models/detector.py:192-201; nn.UpsamplingBilinear2d
+// at :170/:177 == F.interpolate(mode='bilinear', align_corners=True)) and
+// CenterNetDetector.forward (/root/reference/models/detector.py:289-296).
+#include "ftc_common.h"
+
+namespace {
+
+// out[b,y,x, 0:Cy]      = bilinear_x2(prev[b,:,:,0:Cy])           (Cy = 0: absent)
+// out[b,y,x, Cy:Cy+Ct]  = tap[b,y,x,:] * scale + shift            (eval-mode BatchNorm2d)
+// One lane = one pixel x 4 channels; consecutive lanes walk the channel axis (coalesced).
+template <typename T, typename TapT>
+__global__ __launch_bounds__(256) void upcat_kernel(const T* __restrict__ prev, const TapT* __restrict__ tap,
+                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    T* __restrict__ out, int B, int Hi, int Wi, int Ho, int Wo,
+                                                    int Cy, int Ct, float ry, float rx) {
+    const int Ctot = Cy + Ct;
+    const int Q = Ctot >> 2;
+    const long total = (long)B * Ho * Wo * Q;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % Q);
+        const long pix = idx / Q;
+        const int c = q * 4;
+        f32x4 v;
+        if (c < Cy) {
+            const int x = (int)(pix % Wo);
+            const int y = (int)((pix / Wo) % Ho);
+            const int b = (int)(pix / ((long)Wo * Ho));
+            // ATen upsample_bilinear2d, align_corners=True: src = dst * (in-1)/(out-1)
+            const float sy = ry * (float)y, sx = rx * (float)x;
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+            const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+            const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+            const T* base = prev + (long)b * Hi * Wi * Cy + c;
+            const f32x4 v00 = load4<T>(base + ((long)y0 * Wi + x0) * Cy);
+            const f32x4 v01 = load4<T>(base + ((long)y0 * Wi + x1) * Cy);
+            const f32x4 v10 = load4<T>(base + ((long)y1 * Wi + x0) * Cy);
+            const f32x4 v11 = load4<T>(base + ((long)y1 * Wi + x1) * Cy);
+            v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        } else {
+            const int ct = c - Cy;
+            const f32x4 xv = load4<TapT>(tap + pix * Ct + ct);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + ct);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + ct);
+            v = xv * sc + sh;
+        }
+        store4<T>(out + pix * Ctot + c, v);
+    }
+}
+
+// heat[b,y,x,1] = heat[b,y,x,0] < max3x3(heat[..,0]) ? -inf : heat[b,y,x,0]   (pad = -inf)
+// 32x32 pixel tile per workgroup, 34x34 halo of channel 0 staged in LDS.
+__global__ __launch_bounds__(256) void nms_kernel(float* __restrict__ heat, int h, int w, int CH) {
+    __shared__ float tile[34][35];
+    const int b = blockIdx.z;
+    const int y0 = blockIdx.y * 32, x0 = blockIdx.x * 32;
+    float* hb = heat + (long)b * h * w * CH;
+    const float ninf = -__builtin_huge_valf();
+    for (int i = threadIdx.x; i < 34 * 34; i += 256) {
+        const int ry = i / 34, rx = i - ry * 34;
+        const int y = y0 + ry - 1, x = x0 + rx - 1;
+        tile[ry][rx] = ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) ? hb[((long)y * w + x) * CH] : ninf;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+        const int ly = i >> 5, lx = i & 31;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= h || x >= w) continue;
+        const float k = tile[ly + 1][lx + 1];
+        float m = ninf;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) m = fmaxf(m, tile[ly + dy][lx + dx]);
+        hb[((long)y * w + x) * CH + 1] = (k < m) ? ninf : k;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_upcat(const OpArgs& a, hipStream_t s) {
+    const ftc_op& o = *a.op;
+    const int Cy = o.aux0, Ct = o.aux1;
+    const long total = (long)o.B * o.Ho * o.Wo * ((Cy + Ct) / 4);
+    long nb = (total + 255) / 256;
+    if (nb > 16384) nb = 16384;
+    const float ry = o.Ho > 1 ? (float)(o.H - 1) / (float)(o.Ho - 1) : 0.f;
+    const float rx = o.Wo > 1 ? (float)(o.W - 1) / (float)(o.Wo - 1) : 0.f;
+#define UPCAT_LAUNCH(T, TT)                                                                                       \
+    hipLaunchKernelGGL((upcat_kernel<T, TT>), dim3((unsigned)nb), dim3(256), 0, s, (const T*)a.in, (const TT*)a.in2, \
+                       a.scale, a.shift, (T*)a.out, o.B, o.H, o.W, o.Ho, o.Wo, Cy, Ct, ry, rx)
+    // res_dtype = dtype of the backbone tap (the trunk stays fp32 in bf16 mode)
+    if (o.in_dtype == FTC_F32) UPCAT_LAUNCH(float, float);
+    else if (o.res_dtype == FTC_F32) UPCAT_LAUNCH(__bf16, float);
+    else UPCAT_LAUNCH(__bf16, __bf16);
+#undef UPCAT_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_nms(const OpArgs& a, hipStream_t s) {
+    const ftc_op& o = *a.op;
+    hipLaunchKernelGGL(nms_kernel, dim3((o.W + 31) / 32, (o.H + 31) / 32, o.B), dim3(256), 0, s, (float*)a.out, o.H, o.W,
+                       o.Cout_total);
+    return hipGetLastError();
+}

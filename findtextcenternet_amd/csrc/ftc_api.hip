@@ -1,0 +1,236 @@
+// C ABI (include/ftc.h): plan validation / execution and the decode entry point.
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ftc_common.h"
+
+hipError_t launch_decode(const float* heat, const float* feat, int B, int h, int w, int C, const ftc_tile* tiles,
+                         float logit_cut, int scale, int max_boxes, float* boxes, float* feats, int32_t* index,
+                         int32_t* counts, void* scratch, hipStream_t s);
+
+struct ftc_plan {
+    std::vector<ftc_op> ops;
+    int64_t workspace_bytes;
+    int64_t weights_bytes;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+int fail_hip(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return FTC_ERR_HIP;
+}
+
+bool ref_ok(const ftc_ref& r, const ftc_plan* pl, bool required, std::string* why) {
+    if (r.base == FTC_BASE_NULL) {
+        if (required) { *why = "missing required operand"; return false; }
+        return true;
+    }
+    if (r.base < 0 || r.base >= FTC_NUM_BASES) { *why = "bad base id"; return false; }
+    if (r.offset < 0 || (r.offset & 15)) { *why = "operand offset must be >= 0 and 16-byte aligned"; return false; }
+    if (r.base == FTC_BASE_WORKSPACE && r.offset >= pl->workspace_bytes) { *why = "workspace offset out of range"; return false; }
+    if (r.base == FTC_BASE_WEIGHTS && r.offset >= pl->weights_bytes) { *why = "weights offset out of range"; return false; }
+    return true;
+}
+
+const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
+    auto need = [&](const ftc_ref& r, bool req, const char* name) -> bool {
+        std::string w;
+        if (!ref_ok(r, pl, req, &w)) { *why = std::string(name) + ": " + w; return false; }
+        return true;
+    };
+    if (o.B <= 0 || o.H <= 0 || o.W <= 0) return "B/H/W must be positive";
+    switch (o.kind) {
+    case FTC_OP_STEM:
+        if (!need(o.in, true, "in") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.bias, true, "bias")) return why->c_str();
+        if (o.Cout % 4 || o.Cout > 256) return "stem: Cout must be a multiple of 4 (<= 256)";
+        if (o.Ho != (o.H - 1) / 2 + 1 || o.Wo != (o.W - 1) / 2 + 1) return "stem: Ho/Wo inconsistent";
+        return nullptr;
+    case FTC_OP_CONV: {
+        if (!need(o.in, true, "in") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.bias, true, "bias")) return why->c_str();
+        if (!need(o.in2, (o.flags & FTC_FLAG_RESIDUAL) != 0, "in2") || !need(o.scale, (o.flags & FTC_FLAG_SE_SCALE) != 0, "scale")) return why->c_str();
+        return conv_validate(o);
+    }
+    case FTC_OP_DWCONV:
+        if (!need(o.in, true, "in") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.bias, true, "bias") || !need(o.aux, true, "aux")) return why->c_str();
+        if (o.Cin % 4 || o.Cin != o.Cout) return "dwconv: C must be a multiple of 4 and Cin == Cout";
+        if (o.stride != 1 && o.stride != 2) return "dwconv: stride must be 1 or 2";
+        if (o.Ho != (o.H - 1) / o.stride + 1 || o.Wo != (o.W - 1) / o.stride + 1) return "dwconv: Ho/Wo inconsistent";
+        if (o.in_dtype != o.out_dtype) return "dwconv: in/out dtype must match";
+        return nullptr;
+    case FTC_OP_SE:
+        if (!need(o.aux, true, "aux") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.w2, true, "w2") ||
+            !need(o.bias, true, "bias") || !need(o.bias2, true, "bias2")) return why->c_str();
+        if (o.aux0 <= 0 || o.aux1 <= 0 || o.Cin <= 0) return "se: C, S, P must be positive";
+        if ((size_t)(o.Cin + o.aux0) * 4 > 60000) return "se: C + S too large for LDS";
+        return nullptr;
+    case FTC_OP_UPCAT:
+        if (!need(o.in, o.aux0 > 0, "in") || !need(o.in2, true, "in2") || !need(o.out, true, "out") || !need(o.scale, true, "scale") ||
+            !need(o.shift, true, "shift")) return why->c_str();
+        if (o.aux0 % 4 || o.aux1 % 4 || o.aux1 <= 0) return "upcat: channel counts must be multiples of 4";
+        if (o.in_dtype != o.out_dtype) return "upcat: in/out dtype must match";
+        return nullptr;
+    case FTC_OP_NMS:
+        if (!need(o.out, true, "out")) return why->c_str();
+        if (o.Cout_total < 2) return "nms: heat-map needs >= 2 channels";
+        return nullptr;
+    default:
+        return "unknown op kind";
+    }
+}
+
+inline void* resolve(const ftc_ref& r, void* const bases[FTC_NUM_BASES]) {
+    if (r.base == FTC_BASE_NULL) return nullptr;
+    return static_cast<char*>(bases[r.base]) + r.offset;
+}
+
+hipError_t run_one(const ftc_op& o, void* const bases[FTC_NUM_BASES], hipStream_t s) {
+    OpArgs a;
+    a.op = &o;
+    a.in = resolve(o.in, bases);
+    a.in2 = resolve(o.in2, bases);
+    a.out = resolve(o.out, bases);
+    a.w = resolve(o.w, bases);
+    a.w2 = resolve(o.w2, bases);
+    a.bias = static_cast<const float*>(resolve(o.bias, bases));
+    a.bias2 = static_cast<const float*>(resolve(o.bias2, bases));
+    a.scale = static_cast<const float*>(resolve(o.scale, bases));
+    a.shift = static_cast<const float*>(resolve(o.shift, bases));
+    a.aux = static_cast<float*>(resolve(o.aux, bases));
+    switch (o.kind) {
+    case FTC_OP_STEM: return launch_stem(a, s);
+    case FTC_OP_CONV: return launch_conv(a, s);
+    case FTC_OP_DWCONV: return launch_dwconv(a, s);
+    case FTC_OP_SE: return launch_se(a, s);
+    case FTC_OP_UPCAT: return launch_upcat(a, s);
+    case FTC_OP_NMS: return launch_nms(a, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+int check_bases(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], int first, int last) {
+    for (int i = first; i <= last; ++i) {
+        const ftc_op& o = plan->ops[i];
+        const ftc_ref* refs[] = {&o.in, &o.in2, &o.out, &o.w, &o.w2, &o.bias, &o.bias2, &o.scale, &o.shift, &o.aux};
+        for (const ftc_ref* r : refs)
+            if (r->base != FTC_BASE_NULL && bases[r->base] == nullptr)
+                return fail(FTC_ERR_INVALID, "ftc_plan_run: op " + std::to_string(i) + " needs base " + std::to_string(r->base) + " which is NULL");
+    }
+    return FTC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ftc_abi_version(void) { return FTC_ABI_VERSION; }
+
+const char* ftc_last_error(void) { return g_err.c_str(); }
+
+int ftc_device_info(int* n_cu, char* name, int name_len) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(FTC_ERR_NO_DEVICE, std::string("hipGetDevice: ") + hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return fail(FTC_ERR_NO_DEVICE, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (name && name_len > 0) { std::strncpy(name, prop.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(FTC_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    return FTC_OK;
+}
+
+int ftc_plan_create(const ftc_op* ops, int n_ops, int64_t workspace_bytes, int64_t weights_bytes, ftc_plan** out) {
+    if (!ops || n_ops <= 0 || !out) return fail(FTC_ERR_INVALID, "ftc_plan_create: null/empty arguments");
+    ftc_plan* pl = new (std::nothrow) ftc_plan();
+    if (!pl) return fail(FTC_ERR_NOMEM, "ftc_plan_create: out of host memory");
+    pl->workspace_bytes = workspace_bytes;
+    pl->weights_bytes = weights_bytes;
+    pl->ops.assign(ops, ops + n_ops);
+    for (int i = 0; i < n_ops; ++i) {
+        std::string why;
+        const char* bad = validate_op(pl->ops[i], pl, &why);
+        if (bad) {
+            std::string msg = "ftc_plan_create: op " + std::to_string(i) + " (kind " + std::to_string(pl->ops[i].kind) + "): " + bad;
+            delete pl;
+            return fail(FTC_ERR_INVALID, msg);
+        }
+    }
+    *out = pl;
+    return FTC_OK;
+}
+
+void ftc_plan_destroy(ftc_plan* plan) { delete plan; }
+
+int ftc_plan_num_ops(const ftc_plan* plan) { return plan ? (int)plan->ops.size() : 0; }
+
+int ftc_plan_run(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], void* stream, int first_op, int last_op) {
+    if (!plan || !bases) return fail(FTC_ERR_INVALID, "ftc_plan_run: null arguments");
+    const int n = (int)plan->ops.size();
+    if (last_op < 0 || last_op >= n) last_op = n - 1;
+    if (first_op < 0) first_op = 0;
+    if (first_op > last_op) return fail(FTC_ERR_INVALID, "ftc_plan_run: empty op range");
+    int rc = check_bases(plan, bases, first_op, last_op);
+    if (rc != FTC_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int i = first_op; i <= last_op; ++i) {
+        hipError_t e = run_one(plan->ops[i], bases, s);
+        if (e != hipSuccess) {
+            char buf[64];
+            std::snprintf(buf, sizeof buf, "ftc_plan_run: op %d (kind %d)", i, plan->ops[i].kind);
+            return fail_hip(e, buf);
+        }
+    }
+    return FTC_OK;
+}
+
+int ftc_plan_profile(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], void* stream, float* ms_out) {
+    if (!plan || !bases || !ms_out) return fail(FTC_ERR_INVALID, "ftc_plan_profile: null arguments");
+    const int n = (int)plan->ops.size();
+    int rc = check_bases(plan, bases, 0, n - 1);
+    if (rc != FTC_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev)
+        if (hipEventCreate(&e) != hipSuccess) return fail(FTC_ERR_HIP, "ftc_plan_profile: hipEventCreate failed");
+    (void)hipEventRecord(ev[0], s);
+    int ret = FTC_OK;
+    for (int i = 0; i < n; ++i) {
+        hipError_t e = run_one(plan->ops[i], bases, s);
+        if (e != hipSuccess) { ret = fail_hip(e, "ftc_plan_profile: launch"); break; }
+        (void)hipEventRecord(ev[i + 1], s);
+    }
+    hipError_t se = hipStreamSynchronize(s);
+    if (ret == FTC_OK && se != hipSuccess) ret = fail_hip(se, "ftc_plan_profile: sync");
+    if (ret == FTC_OK)
+        for (int i = 0; i < n; ++i) (void)hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return ret;
+}
+
+int ftc_decode(const float* heatmap, const float* features, int B, int h, int w, int C, const ftc_tile* tiles_dev,
+               float logit_cut, int scale, int max_boxes, float* boxes, float* feats, int32_t* index, int32_t* counts,
+               void* scratch_dev, void* stream) {
+    if (!heatmap || !features || !tiles_dev || !boxes || !feats || !index || !counts || !scratch_dev)
+        return fail(FTC_ERR_INVALID, "ftc_decode: null pointer argument");
+    if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || (C & 3) || max_boxes <= 0 || scale <= 0)
+        return fail(FTC_ERR_INVALID, "ftc_decode: bad sizes (C must be a multiple of 4)");
+    if ((long)h * w > 0x7fffffffL / 16) return fail(FTC_ERR_INVALID, "ftc_decode: map too large");
+    hipError_t e = launch_decode(heatmap, features, B, h, w, C, tiles_dev, logit_cut, scale, max_boxes, boxes, feats, index,
+                                 counts, scratch_dev, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "ftc_decode");
+    return FTC_OK;
+}
+
+}  // extern "C"

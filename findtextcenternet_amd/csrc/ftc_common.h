@@ -1,0 +1,86 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA, NHWC).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ftc.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// Resolved (absolute-pointer) form of an ftc_op, what the launchers consume.
+struct OpArgs {
+    const ftc_op* op;
+    const void* in;
+    const void* in2;
+    void* out;
+    const void* w;
+    const void* w2;
+    const float* bias;
+    const float* bias2;
+    const float* scale;
+    const float* shift;
+    float* aux;
+};
+
+__device__ __forceinline__ float bf16_to_f32(__bf16 v) { return (float)v; }
+__device__ __forceinline__ __bf16 f32_to_bf16(float v) { return (__bf16)v; }   // RNE (v_cvt_pk_bf16_f32)
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<__bf16>(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+// 4 consecutive elements <-> float4
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 load4<__bf16>(const __bf16* p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void store4<__bf16>(__bf16* p, f32x4 v) {
+    bf16x4 r = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = r;
+}
+
+// Activations.  SiLU = x*sigmoid(x); GELU = exact erf form (nn.GELU default, detector.py:169).
+__device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float act_silu_precise(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sigmoid_precise(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int ACT> __device__ __forceinline__ float apply_act(float x) {
+    if constexpr (ACT == FTC_ACT_SILU) return act_silu_precise(x);
+    else if constexpr (ACT == FTC_ACT_GELU) return act_gelu(x);
+    else return x;
+}
+__device__ __forceinline__ float apply_act_rt(float x, int act) {
+    if (act == FTC_ACT_SILU) return act_silu_precise(x);
+    if (act == FTC_ACT_GELU) return act_gelu(x);
+    return x;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Host-side launch entry points (one per .hip file); return hipError_t of the launch.
+hipError_t launch_stem(const OpArgs& a, hipStream_t s);
+hipError_t launch_conv(const OpArgs& a, hipStream_t s);
+hipError_t launch_dwconv(const OpArgs& a, hipStream_t s);
+hipError_t launch_se(const OpArgs& a, hipStream_t s);
+hipError_t launch_upcat(const OpArgs& a, hipStream_t s);
+hipError_t launch_nms(const OpArgs& a, hipStream_t s);
+const char* conv_validate(const ftc_op& op);   // NULL if supported, else reason

@@ -1,0 +1,374 @@
+"""Host-side construction of the HIP execution plan for the detector forward pass.
+
+Mirrors, as data, what the reference expresses as nn.Module composition:
+``CenterNetDetection.forward`` (``/root/reference/models/detector.py:217-230``) = stem + 100
+Fused-MBConv/MBConv blocks with taps (``BackboneModel.forward`` ``:139-146``) + nine ``Leafmap`` heads
+(``:192-201``), followed by the NMS of ``CenterNetDetector.forward`` (``:289-296``).
+
+Two steps:
+
+* ``pack_weights``  -- once per checkpoint: folds every eval-mode BatchNorm that directly follows a
+  convolution into that convolution (scale into the weights, shift into a bias; fp64 arithmetic),
+  re-lays weights out K-major ``[Cout][kh*kw][Cin]`` for the NHWC implicit GEMM, converts to the
+  MFMA compute type, and concatenates everything into one blob that is uploaded to HBM once.
+  The per-head input BatchNorm (``Leafmap.in_bn``) is NOT folded into the following zero-padded
+  3x3 conv (its shift would leak into the padding ring); it is applied by the UPCAT kernel.
+* ``build_plan``    -- once per input shape: the op list (``ftc_op`` records) with activation
+  buffers placed in one workspace arena by a liveness-based first-fit allocator.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .schema import (BACKBONE_BN_EPS, FPN_DIM, HEAD_BN_EPS, HEADS, LAST_CHANNEL, STAGES, TAP_DIMS, backbone_blocks,
+                     feature_dim)
+
+ALIGN = 256
+
+
+def _align(n: int, a: int = ALIGN) -> int:
+    return (n + a - 1) // a * a
+
+
+# ------------------------------------------------------------------------------------------------
+# weights
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class PackedWeights:
+    blob: np.ndarray                      # uint8
+    table: Dict[str, int]                 # name -> byte offset
+    mode: str                             # "fp32" | "bf16"
+    model_size: str
+
+    @property
+    def nbytes(self) -> int:
+        return int(self.blob.nbytes)
+
+
+class _Blob:
+    def __init__(self):
+        self.parts: List[Tuple[int, np.ndarray]] = []
+        self.table: Dict[str, int] = {}
+        self.size = 0
+
+    def add(self, name: str, arr: np.ndarray) -> None:
+        raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+        self.table[name] = self.size
+        self.parts.append((self.size, raw))
+        self.size = _align(self.size + raw.nbytes)
+
+    def finish(self) -> np.ndarray:
+        out = np.zeros(self.size, np.uint8)
+        for off, raw in self.parts:
+            out[off:off + raw.nbytes] = raw
+        return out
+
+
+def _to_compute(a: np.ndarray, mode: str) -> np.ndarray:
+    if mode == "fp32":
+        return a.astype(np.float32)
+    t = torch.from_numpy(a.astype(np.float32)).to(torch.bfloat16)      # round-to-nearest-even
+    return t.view(torch.int16).numpy()
+
+
+def _fold(sd, conv_key: str, bn_prefix: str, eps: float):
+    """conv weight [O,I,kh,kw] and eval BN -> (W*s [O,I,kh,kw] f64, b f64)."""
+    w = sd[conv_key].detach().cpu().double().numpy()
+    g = sd[bn_prefix + ".weight"].detach().cpu().double().numpy()
+    b = sd[bn_prefix + ".bias"].detach().cpu().double().numpy()
+    m = sd[bn_prefix + ".running_mean"].detach().cpu().double().numpy()
+    v = sd[bn_prefix + ".running_var"].detach().cpu().double().numpy()
+    s = g / np.sqrt(v + eps)
+    return w * s[:, None, None, None], b - m * s
+
+
+def _kmajor(w: np.ndarray) -> np.ndarray:
+    """[O,I,kh,kw] -> [O, kh*kw, I]."""
+    o, i, kh, kw = w.shape
+    return np.ascontiguousarray(w.transpose(0, 2, 3, 1)).reshape(o, kh * kw, i)
+
+
+def pack_weights(sd: Dict[str, torch.Tensor], mode: str = "fp32", model_size: str = "xl") -> PackedWeights:
+    """sd: ``CenterNetDetection`` state_dict (keys without the ``detector.`` prefix)."""
+    assert mode in ("fp32", "bf16")
+    if any(k.startswith("detector.") for k in sd):
+        sd = {k[len("detector."):]: v for k, v in sd.items() if k.startswith("detector.")}
+    bl = _Blob()
+
+    def conv_bn(name: str, conv_key: str, bn_prefix: str, eps: float):
+        w, b = _fold(sd, conv_key, bn_prefix, eps)
+        bl.add(name + ".w", _to_compute(_kmajor(w), mode))
+        bl.add(name + ".b", b.astype(np.float32))
+
+    # stem: [C0,3,3,3] -> [(r*3+s)*3+c][C0] fp32 (VALU kernel, always fp32)
+    w, b = _fold(sd, "backbone.features.0.0.weight", "backbone.features.0.1", BACKBONE_BN_EPS)
+    bl.add("stem.w", np.ascontiguousarray(w.transpose(2, 3, 1, 0)).reshape(27, -1).astype(np.float32))
+    bl.add("stem.b", b.astype(np.float32))
+    for stage in backbone_blocks(model_size):
+        for blk in stage:
+            p = blk.prefix + ".block"
+            if blk.kind == "fused":
+                conv_bn(p + ".0", p + ".0.0.weight", p + ".0.1", BACKBONE_BN_EPS)
+                if blk.exp != blk.cin:
+                    conv_bn(p + ".1", p + ".1.0.weight", p + ".1.1", BACKBONE_BN_EPS)
+            else:
+                conv_bn(p + ".0", p + ".0.0.weight", p + ".0.1", BACKBONE_BN_EPS)
+                w, b = _fold(sd, p + ".1.0.weight", p + ".1.1", BACKBONE_BN_EPS)          # [C,1,3,3]
+                bl.add(p + ".1.w", np.ascontiguousarray(w.reshape(w.shape[0], 9).T).astype(np.float32))   # [9][C]
+                bl.add(p + ".1.b", b.astype(np.float32))
+                w1 = sd[p + ".2.fc1.weight"].detach().cpu().float().numpy()
+                w2 = sd[p + ".2.fc2.weight"].detach().cpu().float().numpy()
+                bl.add(p + ".2.w1", w1.reshape(w1.shape[0], w1.shape[1]))                 # [S][C]
+                bl.add(p + ".2.b1", sd[p + ".2.fc1.bias"].detach().cpu().float().numpy())
+                bl.add(p + ".2.w2t", np.ascontiguousarray(w2.reshape(w2.shape[0], w2.shape[1]).T))   # [S][C]
+                bl.add(p + ".2.b2", sd[p + ".2.fc2.bias"].detach().cpu().float().numpy())
+                conv_bn(p + ".3", p + ".3.0.weight", p + ".3.1", BACKBONE_BN_EPS)
+    nfeat = len(STAGES[model_size]) + 1
+    hp = f"backbone.features.{nfeat}"
+    conv_bn(hp, hp + ".0.weight", hp + ".1", BACKBONE_BN_EPS)
+    ntap = len(TAP_DIMS[model_size])
+    for name, out_dim, _ in HEADS:
+        for i in range(ntap):
+            q = f"{name}.in_bn.{i}"
+            g = sd[q + ".weight"].detach().cpu().double().numpy()
+            s = g / np.sqrt(sd[q + ".running_var"].detach().cpu().double().numpy() + HEAD_BN_EPS)
+            t = sd[q + ".bias"].detach().cpu().double().numpy() - sd[q + ".running_mean"].detach().cpu().double().numpy() * s
+            bl.add(q + ".scale", s.astype(np.float32))
+            bl.add(q + ".shift", t.astype(np.float32))
+        for i in range(ntap):
+            q = f"{name}.upsamplers.{i}"
+            conv_bn(q, q + ".0.weight", q + ".1", HEAD_BN_EPS)
+        w = sd[f"{name}.top_conv.0.weight"].detach().cpu().double().numpy()
+        bl.add(f"{name}.top_conv.w", _to_compute(_kmajor(w), mode))
+        bl.add(f"{name}.top_conv.b", sd[f"{name}.top_conv.0.bias"].detach().cpu().float().numpy())
+    return PackedWeights(bl.finish(), bl.table, mode, model_size)
+
+
+# ------------------------------------------------------------------------------------------------
+# plan
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class OpMeta:
+    name: str
+    kind: str
+    flops: float = 0.0          # 2*MACs of the convolution (bias/activation excluded)
+    bytes: float = 0.0          # algorithmic bytes: inputs + outputs + weights, each once
+
+
+@dataclass
+class Plan:
+    ops: "C.Array"
+    meta: List[OpMeta]
+    workspace_bytes: int
+    B: int
+    H: int
+    W: int
+    h: int
+    w: int
+    mode: str
+    handle: Optional[int] = None
+    peak_live_bytes: int = 0
+    total_buffer_bytes: int = 0
+
+
+@dataclass
+class _Buf:
+    nbytes: int
+    first: int = 10 ** 9
+    last: int = -1
+    offset: int = -1
+
+
+class _Builder:
+    def __init__(self, pw: PackedWeights, B: int, H: int, W: int, nchw: bool):
+        self.pw, self.B, self.H, self.W, self.nchw = pw, B, H, W, nchw
+        self.mode = pw.mode
+        self.act = L.F32 if self.mode == "fp32" else L.BF16       # expanded / FPN activations
+        self.trunk = L.F32                                         # residual trunk + taps stay fp32
+        self.cdt = L.F32 if self.mode == "fp32" else L.BF16       # MFMA compute type
+        self.ops: List[dict] = []
+        self.meta: List[OpMeta] = []
+        self.bufs: List[_Buf] = []
+
+    @staticmethod
+    def esize(dt: int) -> int:
+        return 4 if dt == L.F32 else 2
+
+    def buf(self, nelem: int, dt: int) -> int:
+        self.bufs.append(_Buf(_align(nelem * self.esize(dt))))
+        return len(self.bufs) - 1
+
+    def wref(self, name: str):
+        return ("w", self.pw.table[name])
+
+    def emit(self, meta: OpMeta, **f) -> None:
+        idx = len(self.ops)
+        for k in ("in_", "in2", "out", "aux", "scale"):
+            r = f.get(k)
+            if isinstance(r, tuple) and r[0] == "buf":
+                b = self.bufs[r[1]]
+                b.first, b.last = min(b.first, idx), max(b.last, idx)
+        self.ops.append(f)
+        self.meta.append(meta)
+
+    # --- op helpers ---------------------------------------------------------------------------
+    def conv(self, name, x, xdt, H, W, cin, cin_total, cin_off, wname, cout, k, stride, act, out, odt, cout_total=None,
+             cout_off=0, residual=None, res_dt=0, se=None):
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        flags = (L.FLAG_RESIDUAL if residual is not None else 0) | (L.FLAG_SE_SCALE if se is not None else 0)
+        macs = self.B * Ho * Wo * cout * cin * k * k
+        byt = self.B * H * W * cin * self.esize(xdt) + self.B * Ho * Wo * cout * self.esize(odt) + cout * cin * k * k * self.esize(self.cdt)
+        if residual is not None:
+            byt += self.B * Ho * Wo * cout * self.esize(res_dt)
+        self.emit(OpMeta(name, f"conv{k}x{k}", 2.0 * macs, byt), kind=L.OP_CONV, flags=flags, act=act, in_dtype=xdt,
+                  out_dtype=odt, w_dtype=self.cdt, B=self.B, H=H, W=W, Ho=Ho, Wo=Wo, Cin=cin, Cin_total=cin_total,
+                  cin_off=cin_off, Cout=cout, Cout_total=cout_total or cout, cout_off=cout_off, ksize=k, stride=stride,
+                  res_dtype=res_dt, in_=x, in2=residual, out=out, w=self.wref(wname + ".w"), bias=self.wref(wname + ".b"),
+                  scale=se)
+        return Ho, Wo
+
+    def build(self) -> Plan:
+        B, H, W = self.B, self.H, self.W
+        ms = self.pw.model_size
+        stages = backbone_blocks(ms)
+        c0 = STAGES[ms][0][4]
+        T, A = self.trunk, self.act
+        # stem
+        h, w = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        x = ("buf", self.buf(B * h * w * c0, T))
+        self.emit(OpMeta("backbone.features.0", "stem", 2.0 * B * h * w * c0 * 27, B * H * W * 3 * 4 + B * h * w * c0 * self.esize(T)),
+                  kind=L.OP_STEM, flags=L.FLAG_IN_NCHW if self.nchw else 0, act=L.ACT_SILU, in_dtype=L.F32, out_dtype=T,
+                  B=B, H=H, W=W, Ho=h, Wo=w, Cin=3, Cout=c0, ksize=3, stride=2, in_=("input", 0), out=x,
+                  w=self.wref("stem.w"), bias=self.wref("stem.b"))
+        taps = []
+        for si, stage in enumerate(stages):
+            for blk in stage:
+                p = blk.prefix + ".block"
+                ho, wo = (h - 1) // blk.stride + 1, (w - 1) // blk.stride + 1
+                res = x if blk.residual else None
+                if blk.kind == "fused" and blk.exp == blk.cin:
+                    y = ("buf", self.buf(B * ho * wo * blk.cout, T))
+                    self.conv(p + ".0", x, T, h, w, blk.cin, blk.cin, 0, p + ".0", blk.cout, 3, blk.stride, L.ACT_SILU, y, T,
+                              residual=res, res_dt=T)
+                elif blk.kind == "fused":
+                    e = ("buf", self.buf(B * ho * wo * blk.exp, A))
+                    self.conv(p + ".0", x, T, h, w, blk.cin, blk.cin, 0, p + ".0", blk.exp, 3, blk.stride, L.ACT_SILU, e, A)
+                    y = ("buf", self.buf(B * ho * wo * blk.cout, T))
+                    self.conv(p + ".1", e, A, ho, wo, blk.exp, blk.exp, 0, p + ".1", blk.cout, 1, 1, L.ACT_NONE, y, T,
+                              residual=res, res_dt=T)
+                else:
+                    e = ("buf", self.buf(B * h * w * blk.exp, A))
+                    self.conv(p + ".0", x, T, h, w, blk.cin, blk.cin, 0, p + ".0", blk.exp, 1, 1, L.ACT_SILU, e, A)
+                    th = 8 if blk.stride == 1 else 4
+                    P = ((ho + th - 1) // th) * ((wo + 7) // 8)
+                    d = ("buf", self.buf(B * ho * wo * blk.exp, A))
+                    part = ("buf", self.buf(B * P * blk.exp, L.F32))
+                    self.emit(OpMeta(p + ".1", "dwconv3x3", 2.0 * B * ho * wo * blk.exp * 9,
+                                     B * (h * w + ho * wo) * blk.exp * self.esize(A) + blk.exp * 40),
+                              kind=L.OP_DWCONV, act=L.ACT_SILU, in_dtype=A, out_dtype=A, B=B, H=h, W=w, Ho=ho, Wo=wo,
+                              Cin=blk.exp, Cout=blk.exp, ksize=3, stride=blk.stride, aux0=P, in_=e, out=d,
+                              w=self.wref(p + ".1.w"), bias=self.wref(p + ".1.b"), aux=part)
+                    sc = ("buf", self.buf(B * blk.exp, L.F32))
+                    self.emit(OpMeta(p + ".2", "se", 4.0 * B * blk.exp * blk.squeeze, 8.0 * blk.exp * blk.squeeze + B * P * blk.exp * 4),
+                              kind=L.OP_SE, B=B, H=ho, W=wo, Cin=blk.exp, Cout=blk.exp, aux0=blk.squeeze, aux1=P, aux=part,
+                              out=sc, w=self.wref(p + ".2.w1"), w2=self.wref(p + ".2.w2t"), bias=self.wref(p + ".2.b1"),
+                              bias2=self.wref(p + ".2.b2"))
+                    y = ("buf", self.buf(B * ho * wo * blk.cout, T))
+                    self.conv(p + ".3", d, A, ho, wo, blk.exp, blk.exp, 0, p + ".3", blk.cout, 1, 1, L.ACT_NONE, y, T,
+                              residual=res, res_dt=T, se=sc)
+                x, h, w = y, ho, wo
+            if (si + 1) in (2, 3, 5):
+                taps.append((x, stage[-1].cout, h, w, T))
+        nfeat = len(stages) + 1
+        hp = f"backbone.features.{nfeat}"
+        x4 = ("buf", self.buf(B * h * w * LAST_CHANNEL, A))
+        self.conv(hp, x, T, h, w, stages[-1][-1].cout, stages[-1][-1].cout, 0, hp, LAST_CHANNEL, 1, 1, L.ACT_SILU, x4, A)
+        taps.append((x4, LAST_CHANNEL, h, w, A))
+        mh, mw = taps[0][2], taps[0][3]
+        # heads
+        ntap = len(taps)
+        for name, out_dim, ch0 in HEADS:
+            y, yh, yw = None, 0, 0
+            for i in range(ntap):
+                tbuf, tc, th_, tw_, tdt = taps[ntap - 1 - i]
+                cy = FPN_DIM if y is not None else 0
+                cat = ("buf", self.buf(B * th_ * tw_ * (cy + tc), A))
+                q = f"{name}.in_bn.{ntap - 1 - i}"
+                self.emit(OpMeta(f"{name}.cat{i}", "upcat", 0.0,
+                                 B * th_ * tw_ * ((cy + tc) * self.esize(A) + tc * self.esize(tdt)) + B * yh * yw * cy * self.esize(A)),
+                          kind=L.OP_UPCAT, in_dtype=A, out_dtype=A, res_dtype=tdt, B=B, H=yh if y is not None else th_,
+                          W=yw if y is not None else tw_, Ho=th_, Wo=tw_, Cin=cy + tc, Cout=cy + tc, aux0=cy, aux1=tc,
+                          in_=y, in2=tbuf, out=cat, scale=self.wref(q + ".scale"), shift=self.wref(q + ".shift"))
+                y = ("buf", self.buf(B * th_ * tw_ * FPN_DIM, A))
+                self.conv(f"{name}.upsamplers.{i}", cat, A, th_, tw_, cy + tc, cy + tc, 0, f"{name}.upsamplers.{i}", FPN_DIM, 3, 1,
+                          L.ACT_GELU, y, A)
+                yh, yw = th_, tw_
+            if ch0 >= 0:       # map heads write straight into their channel slice; channel 1 is the NMS slot
+                off = 0 if ch0 == 0 else ch0 + 1
+                self.conv(f"{name}.top_conv", y, A, yh, yw, FPN_DIM, FPN_DIM, 0, f"{name}.top_conv", out_dim, 3, 1, L.ACT_NONE,
+                          ("heatmap", 0), L.F32, cout_total=10, cout_off=off)
+            else:
+                self.conv(f"{name}.top_conv", y, A, yh, yw, FPN_DIM, FPN_DIM, 0, f"{name}.top_conv", out_dim, 3, 1, L.ACT_NONE,
+                          ("features", 0), L.F32, cout_total=feature_dim, cout_off=0)
+        self.emit(OpMeta("nms", "nms", 0.0, B * mh * mw * 8.0), kind=L.OP_NMS, B=B, H=mh, W=mw, Ho=mh, Wo=mw, Cout_total=10,
+                  out=("heatmap", 0))
+        return self.finish(mh, mw)
+
+    # --- arena allocation + ctypes ---------------------------------------------------------------
+    def finish(self, mh: int, mw: int) -> Plan:
+        order = sorted(range(len(self.bufs)), key=lambda i: self.bufs[i].first)
+        live: List[Tuple[int, int, int]] = []        # (offset, end, last_use)
+        top = peak = 0
+        for bi in order:
+            b = self.bufs[bi]
+            if b.last < 0:
+                raise RuntimeError("buffer never used")
+            live = [iv for iv in live if iv[2] >= b.first]
+            live.sort()
+            off = 0
+            for (o, e, _) in live:
+                if off + b.nbytes <= o:
+                    break
+                off = max(off, e)
+            b.offset = off
+            live.append((off, off + b.nbytes, b.last))
+            top = max(top, off + b.nbytes)
+            peak = max(peak, sum(e - o for o, e, _ in live))
+        ws = _align(top)
+        arr = (L.Op * len(self.ops))()
+        base_of = {"buf": L.BASE_WORKSPACE, "w": L.BASE_WEIGHTS, "input": L.BASE_INPUT, "heatmap": L.BASE_HEATMAP,
+                   "features": L.BASE_FEATURES}
+        for i, f in enumerate(self.ops):
+            o = arr[i]
+            for k, v in f.items():
+                if k in ("in_", "in2", "out", "w", "w2", "bias", "bias2", "scale", "shift", "aux"):
+                    if v is None:
+                        continue
+                    r = getattr(o, k)
+                    r.base = base_of[v[0]]
+                    r.offset = self.bufs[v[1]].offset if v[0] == "buf" else v[1]
+                else:
+                    setattr(o, k, int(v))
+        return Plan(arr, self.meta, ws, self.B, self.H, self.W, mh, mw, self.mode, None, peak,
+                    sum(b.nbytes for b in self.bufs))
+
+
+def build_plan(pw: PackedWeights, B: int, H: int, W: int, nchw_input: bool = False) -> Plan:
+    if H % 32 or W % 32:
+        raise ValueError("H and W must be multiples of 32 (the reference always uses 768)")
+    return _Builder(pw, B, H, W, nchw_input).build()
+
+
+def create_handle(plan: Plan, weights_bytes: int) -> int:
+    """ftc_plan_create (host-only: validates shapes/offsets, copies the op list)."""
+    lib = L.load()
+    h = C.c_void_p()
+    L.check(lib.ftc_plan_create(plan.ops, len(plan.ops), plan.workspace_bytes, weights_bytes, C.byref(h)), "ftc_plan_create")
+    plan.handle = h.value
+    return plan.handle

@@ -1,0 +1,182 @@
+/*
+ * ftc.h -- C ABI of the MI355X (gfx950) detector hot path of findtextCenterNet.
+ *
+ * The reference has NO foreign-function interface for this path: its detector is a Python
+ * nn.Module (`CenterNetDetector`, /root/reference/models/detector.py:283-296) called through the
+ * plug-in point `OCR_Processer.call_detector` (/root/reference/process_ocr_base.py:49-51, torch
+ * implementation /root/reference/process_ocr_torch.py:43-49), and its peak decode is inline host
+ * NumPy (/root/reference/process_ocr_base.py:496-538).  This header is therefore the boundary a
+ * maintainer would bind from that Python (ctypes stub in INTEGRATION.md): plain pointers, sizes
+ * and a hipStream_t -- no torch types.
+ *
+ * Conventions
+ *   - every entry point returns 0 on success or a negative ftc_status; nothing throws across the
+ *     ABI; ftc_last_error() gives a thread-local message for the last failure;
+ *   - all device buffers are owned by the caller (PyTorch allocates them); the library allocates
+ *     no device memory and never synchronises -- work is enqueued on the stream passed in;
+ *   - a plan is immutable after ftc_plan_create, so one plan may be run from several host
+ *     threads as long as each uses its own workspace and stream;
+ *   - activations are NHWC; `heatmap` is [B,h,w,10] fp32 and `features` [B,h,w,100] fp32 in
+ *     memory (the Python side returns them as NCHW *views*, which is what PyTorch itself
+ *     produces for the channels_last-strided input the reference's callers pass,
+ *     process_ocr_torch.py:44).
+ */
+#ifndef FTC_H_
+#define FTC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FTC_ABI_VERSION 1
+
+typedef enum ftc_status {
+    FTC_OK = 0,
+    FTC_ERR_INVALID = -1,      /* bad argument / unsupported shape */
+    FTC_ERR_HIP = -2,          /* a HIP runtime call or launch failed */
+    FTC_ERR_NO_DEVICE = -3,    /* no gfx950 device visible */
+    FTC_ERR_NOMEM = -4
+} ftc_status;
+
+typedef enum ftc_dtype { FTC_F32 = 0, FTC_BF16 = 1 } ftc_dtype;
+
+/* Address bases an op operand can be relative to; resolved at ftc_plan_run time. */
+typedef enum ftc_base {
+    FTC_BASE_NULL = 0,
+    FTC_BASE_WORKSPACE = 1,    /* activation arena (caller-allocated, ftc_plan workspace bytes) */
+    FTC_BASE_WEIGHTS = 2,      /* packed weight blob (caller-allocated, uploaded once) */
+    FTC_BASE_INPUT = 3,        /* image batch */
+    FTC_BASE_HEATMAP = 4,      /* [B,h,w,10] fp32 output */
+    FTC_BASE_FEATURES = 5,     /* [B,h,w,100] fp32 output */
+    FTC_NUM_BASES = 6
+} ftc_base;
+
+typedef struct ftc_ref {
+    int32_t base;              /* ftc_base */
+    int32_t reserved;
+    int64_t offset;            /* bytes from the base */
+} ftc_ref;
+
+typedef enum ftc_op_kind {
+    /* conv3x3 stride 2 on the 3-channel image with x*2-1 fused (CenterNetDetection.forward,
+       detector.py:218) + folded BN + SiLU  -- features[0] */
+    FTC_OP_STEM = 1,
+    /* dense 1x1 / 3x3 convolution as im2col-free implicit GEMM on MFMA, NHWC, with fused
+       per-channel bias (folded BN), activation, residual add, optional per-(image,channel)
+       SE scale on the input, channel-sliced input and output (free concat) */
+    FTC_OP_CONV = 2,
+    /* depthwise 3x3 (stride 1|2) + folded BN + SiLU, plus per-(image,channel) partial sums of
+       the output for the SE squeeze */
+    FTC_OP_DWCONV = 3,
+    /* SE excitation: mean of the partial sums -> fc1+bias -> SiLU -> fc2+bias -> sigmoid */
+    FTC_OP_SE = 4,
+    /* FPN level input: bilinear x2 (align_corners=True) of the previous level, concatenated with
+       the per-head BatchNorm of the backbone tap (Leafmap.forward, detector.py:192-201) */
+    FTC_OP_UPCAT = 5,
+    /* 3x3 max-pool NMS on heatmap channel 0 -> channel 1 (CenterNetDetector.forward,
+       detector.py:291-296) */
+    FTC_OP_NMS = 6
+} ftc_op_kind;
+
+enum {
+    FTC_ACT_NONE = 0, FTC_ACT_SILU = 1, FTC_ACT_GELU = 2
+};
+
+enum {
+    FTC_FLAG_RESIDUAL = 1,     /* out += in2 (after activation) */
+    FTC_FLAG_SE_SCALE = 2,     /* input multiplied by scale[b, cin] while staging (CONV) */
+    FTC_FLAG_IN_NCHW = 4       /* STEM: input is [B,3,H,W]-contiguous instead of NHWC */
+};
+
+/* One step of a plan.  Fields that an op kind does not use must be zero. */
+typedef struct ftc_op {
+    int32_t kind;              /* ftc_op_kind */
+    int32_t flags;
+    int32_t act;               /* FTC_ACT_* */
+    int32_t in_dtype;          /* ftc_dtype of `in` (and `in2` for UPCAT) */
+    int32_t out_dtype;         /* ftc_dtype of `out` */
+    int32_t w_dtype;           /* ftc_dtype of `w` = MFMA compute type (CONV) */
+    int32_t B, H, W;           /* input batch / height / width */
+    int32_t Ho, Wo;            /* output height / width */
+    int32_t Cin;               /* input channels consumed */
+    int32_t Cin_total;         /* channel stride of the input buffer (>= cin_off + Cin) */
+    int32_t cin_off;
+    int32_t Cout;              /* output channels produced */
+    int32_t Cout_total;        /* channel stride of the output buffer */
+    int32_t cout_off;
+    int32_t ksize;             /* 1 or 3 */
+    int32_t stride;            /* 1 or 2 */
+    int32_t aux0;              /* DWCONV: number of row-strips P;  SE: squeeze channels;
+                                  UPCAT: channels of the upsampled part (0 = none) */
+    int32_t aux1;              /* SE: number of partial sums P;  UPCAT: tap channels */
+    int32_t res_dtype;         /* ftc_dtype of in2 (CONV residual / UPCAT tap) */
+    ftc_ref in;                /* main input */
+    ftc_ref in2;               /* CONV: residual [B,Ho,Wo,Cout];  UPCAT: backbone tap [B,Ho,Wo,aux1] */
+    ftc_ref out;
+    ftc_ref w;                 /* CONV: [Cout][k*k][Cin] (K-major);  DWCONV: [9][C] fp32;
+                                  STEM: [27][Cout] fp32;  SE: fc1 [S][C] fp32 */
+    ftc_ref w2;                /* SE: fc2 transposed [S][C] fp32 */
+    ftc_ref bias;              /* fp32 [Cout] (SE: fc1 bias [S]) */
+    ftc_ref bias2;             /* SE: fc2 bias [C] */
+    ftc_ref scale;             /* CONV+SE_SCALE: fp32 [B,Cin];  UPCAT: BN scale fp32 [aux1] */
+    ftc_ref shift;             /* UPCAT: BN shift fp32 [aux1] */
+    ftc_ref aux;               /* DWCONV: partial sums out fp32 [B,P,C];  SE: partial sums in */
+} ftc_op;
+
+typedef struct ftc_plan ftc_plan;
+
+/* Library / device ------------------------------------------------------------------------- */
+int ftc_abi_version(void);
+/* Thread-local message of the last failing call ("" if none). */
+const char* ftc_last_error(void);
+/* FTC_OK iff the current HIP device is a gfx950 part; writes CU count and name when non-NULL. */
+int ftc_device_info(int* n_cu, char* name, int name_len);
+
+/* Plan ------------------------------------------------------------------------------------- */
+/* Validates and copies `ops`; `workspace_bytes` is recorded for bounds checks of workspace refs. */
+int ftc_plan_create(const ftc_op* ops, int n_ops, int64_t workspace_bytes, int64_t weights_bytes,
+                    ftc_plan** out);
+void ftc_plan_destroy(ftc_plan* plan);
+int ftc_plan_num_ops(const ftc_plan* plan);
+/* Enqueues every op on `stream` (a hipStream_t; NULL = the default stream).  `bases[i]` is the
+   device address for ftc_base i (bases[0] ignored).  `first_op..last_op` (inclusive, -1 = end)
+   selects a sub-range, used by the per-op parity tests and the profiler harness. */
+int ftc_plan_run(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], void* stream,
+                 int first_op, int last_op);
+/* Same as ftc_plan_run, bracketing every op with HIP events on `stream` and returning the
+   per-op elapsed milliseconds in ms_out[n_ops] (synchronises; measurement only). */
+int ftc_plan_profile(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], void* stream,
+                     float* ms_out);
+
+/* Peak decode ------------------------------------------------------------------------------ */
+/* Per-image geometry of the tile being decoded (process_ocr_base.py:487-503). */
+typedef struct ftc_tile {
+    int32_t offset_x, offset_y;        /* tile origin on the page, input pixels */
+    int32_t page_w, page_h;            /* page size, input pixels (boxes wider/taller are dropped) */
+    int32_t x_min, x_max, y_min, y_max;/* trusted rectangle in map pixels, max exclusive */
+} ftc_tile;
+
+/*
+ * GPU replacement of the per-tile host loop (process_ocr_base.py:518-538 == test_image1_torch.py:
+ * 123-143): keeps pixels of heatmap channel 1 (NMS'd key logit) inside the tile's trusted
+ * rectangle whose logit >= logit_cut, drops boxes with w,h <= 0 or larger than the page, orders
+ * them by (score desc, pixel index asc) and writes for the first `max_boxes` of them
+ *   boxes[b, i, 0:9]  = p, ix, iy, w, h, code1, code2, code4, code8   (fp32)
+ *   feats[b, i, 0:C]  = features[b, y, x, :]                           (fp32)
+ *   index[b, i]       = y * w + x                                      (int32)
+ * counts[b] receives the TOTAL number of kept peaks (may exceed max_boxes: caller detects
+ * truncation).  heatmap [B,h,w,10] fp32 NHWC, features [B,h,w,C] fp32 NHWC, tiles_dev = B
+ * ftc_tile records in DEVICE memory, scratch_dev >= ftc_decode_scratch_bytes(B,h,w) bytes.
+ */
+int64_t ftc_decode_scratch_bytes(int B, int h, int w);
+int ftc_decode(const float* heatmap, const float* features, int B, int h, int w, int C,
+               const ftc_tile* tiles_dev, float logit_cut, int scale, int max_boxes,
+               float* boxes, float* feats, int32_t* index, int32_t* counts,
+               void* scratch_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FTC_H_ */

@@ -1,0 +1,85 @@
+"""Helpers for the -m gpu parity tests: run single ftc_op plans through the C ABI on real tensors."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from findtextcenternet_amd import _lib as L
+
+REF_FIELDS = ("in_", "in2", "out", "w", "w2", "bias", "bias2", "scale", "shift", "aux")
+
+
+def to_dev_bytes(t: torch.Tensor, dtype: int) -> torch.Tensor:
+    """CPU fp32 tensor -> contiguous CPU tensor in the storage dtype."""
+    t = t.contiguous()
+    return t.to(torch.bfloat16) if dtype == L.BF16 else t.float()
+
+
+def bf16_round(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).float()
+
+
+class Arena:
+    """One device byte buffer holding every operand of a test op (all refs use FTC_BASE_WORKSPACE)."""
+
+    def __init__(self, device="cuda"):
+        self.device = torch.device(device)
+        self.items = []      # (offset, cpu tensor or None, nbytes)
+        self.size = 0
+
+    def put(self, t: torch.Tensor) -> int:
+        t = t.contiguous()
+        off = self.size
+        self.items.append((off, t))
+        self.size = (self.size + t.numel() * t.element_size() + 255) // 256 * 256
+        return off
+
+    def reserve(self, nbytes: int) -> int:
+        off = self.size
+        self.items.append((off, None))
+        self.size = (self.size + nbytes + 255) // 256 * 256
+        return off
+
+    def materialize(self, fill: int = 0xCD) -> torch.Tensor:
+        buf = torch.full((self.size + 256,), fill, dtype=torch.uint8, device=self.device)
+        for off, t in self.items:
+            if t is not None:
+                raw = t.view(torch.uint8).reshape(-1) if t.dtype != torch.bfloat16 else t.view(torch.int16).view(torch.uint8).reshape(-1)
+                buf[off:off + raw.numel()] = raw.to(self.device)
+        self.buf = buf
+        return buf
+
+    def read(self, off: int, shape, dtype: torch.dtype) -> torch.Tensor:
+        n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        raw = self.buf[off:off + n].cpu()
+        return raw.view(dtype).reshape(shape).clone()
+
+
+def run_op(fields: Dict, arena: Arena) -> None:
+    """fields: ftc_op int fields + ref fields given as arena offsets (or None)."""
+    lib = L.load()
+    op = (L.Op * 1)()
+    for k, v in fields.items():
+        if k in REF_FIELDS:
+            if v is None:
+                continue
+            r = getattr(op[0], k)
+            r.base, r.offset = L.BASE_WORKSPACE, int(v)
+        else:
+            setattr(op[0], k, int(v))
+    h = C.c_void_p()
+    L.check(lib.ftc_plan_create(op, 1, arena.size + 256, 0, C.byref(h)), "ftc_plan_create")
+    try:
+        bases = (C.c_void_p * L.NUM_BASES)(None, arena.buf.data_ptr(), None, None, None, None)
+        stream = torch.cuda.current_stream().cuda_stream
+        L.check(lib.ftc_plan_run(h, bases, C.c_void_p(stream), 0, -1), "ftc_plan_run")
+        torch.cuda.synchronize()
+    finally:
+        lib.ftc_plan_destroy(h)
+
+
+def tdtype(d: int) -> torch.dtype:
+    return torch.float32 if d == L.F32 else torch.bfloat16

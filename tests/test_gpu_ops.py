@@ -1,0 +1,233 @@
+"""-m gpu: every HIP kernel, called through the C ABI (single-op plans), against the same op
+computed by PyTorch on the CPU in fp32 -- the floating-point reference for one kernel; the
+end-to-end oracle/golden comparison is in test_gpu_detector.py.
+
+Tolerances: fp32 kernels 2e-4 * max|ref| (summation order only: exact-f32 MFMA vs MKL-DNN);
+bf16 kernels are compared with the CPU result on bf16-ROUNDED operands (so only accumulation
+order / output rounding differ): 1.5e-2 * max|ref|.
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from findtextcenternet_amd import _lib as L
+from gpu_harness import Arena, bf16_round, run_op, tdtype, to_dev_bytes
+
+pytestmark = pytest.mark.gpu
+
+ACT = {L.ACT_NONE: lambda v: v, L.ACT_SILU: F.silu, L.ACT_GELU: F.gelu}
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def _log(msg):
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/test_ops.log", "a") as f:
+        f.write(msg + "\n")
+
+
+# (name, B,H,W, Cin,CinT,cin_off, Cout,CoutT,cout_off, k, stride, act, residual, se)
+CONV_CASES = [
+    ("pw_128tile", 2, 24, 24, 64, 64, 0, 256, 256, 0, 1, 1, L.ACT_SILU, False, False),
+    ("pw_project_se_res", 2, 12, 12, 384, 384, 0, 64, 64, 0, 1, 1, L.ACT_NONE, True, True),
+    ("pw_bigtile", 4, 48, 48, 96, 96, 0, 384, 384, 0, 1, 1, L.ACT_SILU, False, False),
+    ("pw_n640", 1, 24, 24, 128, 128, 0, 640, 640, 0, 1, 1, L.ACT_NONE, True, False),
+    ("c3_s1_32", 1, 40, 36, 32, 32, 0, 32, 32, 0, 3, 1, L.ACT_SILU, True, False),
+    ("c3_s2_32_128", 2, 32, 32, 32, 32, 0, 128, 128, 0, 3, 2, L.ACT_SILU, False, False),
+    ("c3_s1_64_256", 1, 24, 28, 64, 64, 0, 256, 256, 0, 3, 1, L.ACT_SILU, False, False),
+    ("c3_96", 1, 20, 20, 96, 96, 0, 96, 96, 0, 3, 1, L.ACT_NONE, True, False),
+    ("fpn_192_gelu", 1, 24, 24, 288, 288, 0, 192, 192, 0, 3, 1, L.ACT_GELU, False, False),
+    ("fpn_slice_in", 1, 16, 16, 64, 256, 192, 192, 192, 0, 3, 1, L.ACT_GELU, False, False),
+    ("top_1ch_into10", 2, 16, 24, 192, 192, 0, 1, 10, 4, 3, 1, L.ACT_NONE, False, False),
+    ("top_2ch_into10", 1, 16, 16, 192, 192, 0, 2, 10, 2, 3, 1, L.ACT_NONE, False, False),
+    ("top_100ch", 1, 24, 24, 192, 192, 0, 100, 100, 0, 3, 1, L.ACT_NONE, False, False),
+    ("odd_hw_s2", 1, 15, 17, 64, 64, 0, 64, 64, 0, 3, 2, L.ACT_SILU, False, False),
+    ("cin_not_mult32", 1, 12, 12, 24, 24, 0, 48, 48, 0, 3, 1, L.ACT_SILU, False, False),
+    ("k_deep", 1, 8, 8, 1280, 1280, 0, 192, 192, 0, 3, 1, L.ACT_GELU, False, False),
+]
+# (mode name, w_dtype, in_dtype, out_dtype)
+CONV_MODES = [("f32", L.F32, L.F32, L.F32), ("bf16", L.BF16, L.BF16, L.BF16), ("bf16_f32in", L.BF16, L.F32, L.BF16),
+              ("bf16_f32out", L.BF16, L.BF16, L.F32), ("bf16_f32io", L.BF16, L.F32, L.F32)]
+
+
+@pytest.mark.parametrize("mode", CONV_MODES, ids=[m[0] for m in CONV_MODES])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv(case, mode):
+    name, B, H, W, Cin, CinT, cin_off, Cout, CoutT, cout_off, k, stride, act, residual, se = case
+    mname, wdt, idt, odt = mode
+    if wdt == L.BF16 and Cin % 8:
+        pytest.skip("bf16 needs Cin % 8 == 0")
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    x_full = torch.randn(B, H, W, CinT, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.3
+    pad = (k - 1) // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = torch.randn(B, Ho, Wo, Cout, generator=g) if residual else None
+    sc = torch.rand(B, Cin, generator=g) + 0.25 if se else None
+    if idt == L.BF16:
+        x_full = bf16_round(x_full)
+    wq = bf16_round(w) if wdt == L.BF16 else w
+    x = x_full[..., cin_off:cin_off + Cin]
+    xin = x * sc[:, None, None, :] if se else x
+    if se and wdt == L.BF16:
+        xin = bf16_round(xin)                      # the kernel narrows the scaled activation to bf16
+    elif wdt == L.BF16 and idt == L.F32:
+        xin = bf16_round(xin)
+    ref = F.conv2d(xin.permute(0, 3, 1, 2), wq, None, stride, pad).permute(0, 2, 3, 1) + bias
+    ref = ACT[act](ref)
+    if residual:
+        ref = ref + res
+    ar = Arena()
+    o_in = ar.put(to_dev_bytes(x_full, idt))
+    o_w = ar.put(to_dev_bytes(w.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin), wdt))
+    o_b = ar.put(bias)
+    o_res = ar.put(res) if residual else None
+    o_sc = ar.put(sc) if se else None
+    esz = 4 if odt == L.F32 else 2
+    o_out = ar.reserve(B * Ho * Wo * CoutT * esz)
+    ar.materialize()
+    run_op(dict(kind=L.OP_CONV, flags=(L.FLAG_RESIDUAL if residual else 0) | (L.FLAG_SE_SCALE if se else 0), act=act,
+                in_dtype=idt, out_dtype=odt, w_dtype=wdt, B=B, H=H, W=W, Ho=Ho, Wo=Wo, Cin=Cin, Cin_total=CinT, cin_off=cin_off,
+                Cout=Cout, Cout_total=CoutT, cout_off=cout_off, ksize=k, stride=stride, res_dtype=L.F32,
+                in_=o_in, in2=o_res, out=o_out, w=o_w, bias=o_b, scale=o_sc), ar)
+    full = ar.read(o_out, (B, Ho, Wo, CoutT), tdtype(odt))
+    out = full[..., cout_off:cout_off + Cout].float()
+    err = _rel(out, ref)
+    _log(f"conv {name:18s} {mname:12s} rel_err {err:.3e}")
+    tol = 2e-4 if wdt == L.F32 else 1.5e-2
+    assert err < tol, (name, mname, err)
+    if CoutT != Cout:      # untouched channels keep the 0xCD fill: the kernel wrote only its slice
+        raw = ar.buf[o_out:o_out + B * Ho * Wo * CoutT * esz].cpu().view(B * Ho * Wo, CoutT * esz)
+        keep = torch.ones(CoutT * esz, dtype=torch.bool)
+        keep[cout_off * esz:(cout_off + Cout) * esz] = False
+        assert (raw[:, keep] == 0xCD).all()
+
+
+@pytest.mark.parametrize("odt", [L.F32, L.BF16])
+@pytest.mark.parametrize("nchw", [False, True])
+def test_stem(nchw, odt):
+    g = torch.Generator().manual_seed(3)
+    B, H, W, C0 = 2, 64, 96, 32
+    x = torch.rand(B, H, W, 3, generator=g)
+    w = torch.randn(C0, 3, 3, 3, generator=g) * 0.3
+    bias = torch.randn(C0, generator=g) * 0.2
+    ref = F.silu(F.conv2d((x * 2 - 1).permute(0, 3, 1, 2), w, bias, 2, 1)).permute(0, 2, 3, 1)
+    ar = Arena()
+    o_in = ar.put(x.permute(0, 3, 1, 2).contiguous() if nchw else x)
+    o_w = ar.put(w.permute(2, 3, 1, 0).reshape(27, C0).contiguous())
+    o_b = ar.put(bias)
+    o_out = ar.reserve(B * (H // 2) * (W // 2) * C0 * 4)
+    ar.materialize()
+    run_op(dict(kind=L.OP_STEM, flags=L.FLAG_IN_NCHW if nchw else 0, act=L.ACT_SILU, in_dtype=L.F32, out_dtype=odt, B=B, H=H, W=W,
+                Ho=H // 2, Wo=W // 2, Cin=3, Cout=C0, ksize=3, stride=2, in_=o_in, out=o_out, w=o_w, bias=o_b), ar)
+    out = ar.read(o_out, (B, H // 2, W // 2, C0), tdtype(odt)).float()
+    err = _rel(out, ref)
+    _log(f"stem nchw={nchw} odt={odt} rel_err {err:.3e}")
+    assert err < (1e-5 if odt == L.F32 else 6e-3)
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+@pytest.mark.parametrize("shape", [(2, 48, 48, 192, 1), (2, 48, 48, 128, 2), (1, 21, 13, 72, 1), (1, 21, 13, 72, 2), (3, 24, 24, 3840, 1)])
+def test_dwconv_and_se(shape, dt):
+    B, H, W, Cc, stride = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, H, W, Cc, generator=g)
+    if dt == L.BF16:
+        x = bf16_round(x)
+    w = torch.randn(Cc, 1, 3, 3, generator=g) * 0.4
+    bias = torch.randn(Cc, generator=g) * 0.2
+    ref = F.silu(F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride, 1, 1, Cc)).permute(0, 2, 3, 1)
+    Ho, Wo = ref.shape[1:3]
+    th = 8 if stride == 1 else 4
+    P = ((Ho + th - 1) // th) * ((Wo + 7) // 8)
+    S = max(1, Cc // 24)
+    w1 = torch.randn(S, Cc, generator=g) / Cc ** 0.5
+    b1 = torch.randn(S, generator=g) * 0.3
+    w2 = torch.randn(Cc, S, generator=g) / S ** 0.5
+    b2 = torch.randn(Cc, generator=g) * 0.3
+    ar = Arena()
+    o_in = ar.put(to_dev_bytes(x, dt))
+    o_w = ar.put(w.reshape(Cc, 9).t().contiguous())
+    o_b = ar.put(bias)
+    esz = 4 if dt == L.F32 else 2
+    o_out = ar.reserve(B * Ho * Wo * Cc * esz)
+    o_part = ar.reserve(B * P * Cc * 4)
+    o_w1, o_b1, o_w2t, o_b2 = ar.put(w1), ar.put(b1), ar.put(w2.t().contiguous()), ar.put(b2)
+    o_scale = ar.reserve(B * Cc * 4)
+    ar.materialize()
+    run_op(dict(kind=L.OP_DWCONV, act=L.ACT_SILU, in_dtype=dt, out_dtype=dt, B=B, H=H, W=W, Ho=Ho, Wo=Wo, Cin=Cc, Cout=Cc, ksize=3,
+                stride=stride, aux0=P, in_=o_in, out=o_out, w=o_w, bias=o_b, aux=o_part), ar)
+    out = ar.read(o_out, (B, Ho, Wo, Cc), tdtype(dt)).float()
+    err = _rel(out, ref)
+    part = ar.read(o_part, (B, P, Cc), torch.float32)
+    mean = part.sum(1) / (Ho * Wo)
+    # the kernel sums its fp32 results BEFORE narrowing to the storage dtype
+    err_mean = float((mean - ref.mean((1, 2))).abs().max())
+    _log(f"dwconv {shape} dt={dt} rel_err {err:.3e} mean_err {err_mean:.3e}")
+    assert err < (1e-5 if dt == L.F32 else 6e-3)
+    assert err_mean < (1e-5 if dt == L.F32 else 2e-3)
+    run_op(dict(kind=L.OP_SE, B=B, H=Ho, W=Wo, Cin=Cc, Cout=Cc, aux0=S, aux1=P, aux=o_part, out=o_scale, w=o_w1, w2=o_w2t,
+                bias=o_b1, bias2=o_b2), ar)
+    sc = ar.read(o_scale, (B, Cc), torch.float32)
+    ref_sc = torch.sigmoid(F.silu(mean @ w1.t() + b1) @ w2.t() + b2)
+    err_se = float((sc - ref_sc).abs().max())
+    _log(f"se {shape} abs_err {err_se:.3e}")
+    assert err_se < 2e-6
+
+
+@pytest.mark.parametrize("cfg", [("f32", L.F32, L.F32), ("bf16_f32tap", L.BF16, L.F32), ("bf16", L.BF16, L.BF16)], ids=lambda c: c[0])
+@pytest.mark.parametrize("with_y", [True, False])
+def test_upcat(with_y, cfg):
+    _, dt, tdt = cfg
+    g = torch.Generator().manual_seed(5)
+    B, Hi, Wi, Cy, Ct = 2, 12, 10, 192, 96
+    Ho, Wo = (2 * Hi, 2 * Wi) if with_y else (Hi, Wi)
+    y = torch.randn(B, Hi, Wi, Cy, generator=g)
+    tap = torch.randn(B, Ho, Wo, Ct, generator=g)
+    if dt == L.BF16:
+        y = bf16_round(y)
+    if tdt == L.BF16:
+        tap = bf16_round(tap)
+    sc, sh = torch.rand(Ct, generator=g) + 0.5, torch.randn(Ct, generator=g)
+    parts = []
+    if with_y:
+        parts.append(F.interpolate(y.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1))
+    parts.append(tap * sc + sh)
+    ref = torch.cat(parts, -1)
+    ar = Arena()
+    o_y = ar.put(to_dev_bytes(y, dt)) if with_y else None
+    o_tap = ar.put(to_dev_bytes(tap, tdt))
+    o_sc, o_sh = ar.put(sc), ar.put(sh)
+    Ctot = (Cy if with_y else 0) + Ct
+    o_out = ar.reserve(B * Ho * Wo * Ctot * (4 if dt == L.F32 else 2))
+    ar.materialize()
+    run_op(dict(kind=L.OP_UPCAT, in_dtype=dt, out_dtype=dt, res_dtype=tdt, B=B, H=Hi, W=Wi, Ho=Ho, Wo=Wo, Cin=Ctot, Cout=Ctot,
+                aux0=Cy if with_y else 0, aux1=Ct, in_=o_y, in2=o_tap, out=o_out, scale=o_sc, shift=o_sh), ar)
+    out = ar.read(o_out, (B, Ho, Wo, Ctot), tdtype(dt)).float()
+    err = _rel(out, ref)
+    _log(f"upcat with_y={with_y} {cfg[0]} rel_err {err:.3e}")
+    assert err < (2e-6 if dt == L.F32 else 5e-3)
+
+
+def test_nms_ties_golden(golden_dir):
+    """Bit-exact against the reference's own CenterNetDetector.forward on a map with ties,
+    plateaus, -inf and border maxima (tests/golden/g4_nms_ties.npz)."""
+    g = np.load(os.path.join(golden_dir, "g4_nms_ties.npz"))
+    maps = torch.from_numpy(g["maps"])                      # [2,9,16,20]
+    B, _, h, w = maps.shape
+    heat = torch.full((B, h, w, 10), 123.0)
+    heat[..., 0] = maps[:, 0]
+    heat[..., 2:] = maps[:, 1:].permute(0, 2, 3, 1)
+    ar = Arena()
+    o = ar.put(heat)
+    ar.materialize()
+    run_op(dict(kind=L.OP_NMS, B=B, H=h, W=w, Ho=h, Wo=w, Cout_total=10, out=o), ar)
+    out = ar.read(o, (B, h, w, 10), torch.float32).permute(0, 3, 1, 2).numpy()
+    assert np.array_equal(out, g["heatmap"])

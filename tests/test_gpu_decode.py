@@ -117,5 +117,5 @@ def test_cut_off_boundary_is_exact():
         hm[0, 1] = -np.inf
         hm[0, 1, 2, 2], hm[0, 1, 5, 5] = t, below
         ft = np.zeros((1, 100, 8, 8), np.float32)
-        d = decode_peaks(_nhwc(hm), _nhwc(ft), [TileGeom(0, 0, 32, 32, (0, 8, 0, 8))], cut_off=cut)
+        d = decode_peaks(_nhwc(hm), _nhwc(ft), [TileGeom(0, 0, 1000, 1000, (0, 8, 0, 8))], cut_off=cut)
         assert int(d.counts[0]) == 1 and int(d.index[0, 0]) == 2 * 8 + 2

@@ -62,19 +62,26 @@ def _nms_margin(hm_ref, b, y, x):
 
 
 def _compare_maps(tag, hm, ft, g_hm, g_ft=None, tol=TOL):
+    """L-inf on finite entries < tol; the -inf (suppressed) pattern of the NMS channel must be
+    identical wherever the reference's own keep/suppress call had a margin above MARGIN = 1e-4
+    (20x the fp32 summation-order noise we measure, 10x below tol): in flat background regions
+    (white page padding) neighbouring key logits differ by ~1e-6, so which of them "wins" the 3x3
+    window is decided by the last fp32 bit in the reference itself (3e-5
+    between 4 and 8 CPU threads)."""
+    MARGIN = 1e-4
     fin_ref, fin = np.isfinite(g_hm), np.isfinite(hm)
     both = fin & fin_ref
     e_hm = float(np.abs(hm[both] - g_hm[both]).max())
     mism = np.argwhere(fin != fin_ref)
     assert (mism[:, 1] == 1).all() if len(mism) else True          # only the NMS channel can hold -inf
-    margins = [_nms_margin(g_hm, b, y, x) for b, c, y, x in mism]
+    margins = np.array([_nms_margin(g_hm, b, y, x) for b, c, y, x in mism])
+    above = sum(1 for b, c, y, x in mism if g_hm[b, 0, y, x] > np.log(0.4 / 0.6))
     e_ft = float(np.abs(ft - g_ft).max()) if g_ft is not None else None
-    _log(f"{tag}: heatmap Linf {e_hm:.3e}  features Linf {e_ft if e_ft is None else round(e_ft, 7)}  "
-         f"NMS-mask mismatches {len(mism)} (ref margins {['%.1e' % m for m in margins]})  range hm [{g_hm[fin_ref].min():.2f},{g_hm[fin_ref].max():.2f}]")
+    _log(f"{tag}: heatmap Linf {e_hm:.3e}  features Linf {e_ft}  NMS-mask flips {len(mism)} of {int(fin_ref[:, 1].size)} px "
+         f"(max ref margin {margins.max() if len(mism) else 0:.1e}, {above} of them above the 0.4 cut-off)  "
+         f"hm range [{g_hm[fin_ref].min():.2f},{g_hm[fin_ref].max():.2f}]")
     assert e_hm < tol
-    # suppressed positions must be identical; a flip is tolerated only where the reference's own
-    # keep/suppress margin is below the numeric tolerance (an fp32 summation-order tie)
-    assert len(mism) <= 2 and all(m < 2 * tol for m in margins)
+    assert len(mism) == 0 or margins.max() < MARGIN
     return e_hm
 
 
@@ -122,12 +129,20 @@ def test_forward_768_fp32_golden_and_decode(det_fp32, golden_dir, name):
     loc, _, idx_ref = decode_oracle.decode_tile(g["heatmap"], np.zeros((1, 100, 192, 192), np.float32), 0, 0, 768, 768, 0.4, rect)
     only_gpu, only_ref = set(idx_gpu) - set(idx_ref), set(idx_ref) - set(idx_gpu)
     _log(f"g2 768 {name}: peaks gpu {n} ref {len(idx_ref)} only_gpu {len(only_gpu)} only_ref {len(only_ref)}")
-    # a difference is tolerated only for peaks whose score is within TOL of the cut-off or whose NMS margin is a tie
+    # a difference is tolerated only where the reference's own decision was an fp32 tie: score within
+    # 2*TOL of the cut-off, or 3x3 keep/suppress margin below 1e-4 (test1.png is mostly white padding:
+    # its flat background sits above the cut-off with random weights and neighbouring logits differ
+    # by ~1e-6, so the reference's own peak list there depends on its thread count)
+    hard = []
     for i in only_gpu | only_ref:
         y, x = divmod(int(i), 192)
         near_cut = abs(float(g["heatmap"][0, 0, y, x]) - np.log(0.4 / 0.6)) < 2 * TOL
-        assert near_cut or _nms_margin(g["heatmap"], 0, y, x) < 2 * TOL
-    assert len(only_gpu) + len(only_ref) <= 2 and n > 20
+        if not (near_cut or _nms_margin(g["heatmap"], 0, y, x) < 1e-4):
+            hard.append((y, x))
+    _log(f"g2 768 {name}: differing peaks that are NOT reference-side ties: {len(hard)}")
+    assert not hard and n > 20
+    if name == "page":
+        assert not only_gpu and not only_ref                           # realistic page: index set bit-exact
 
 
 def test_matches_oracle_on_fresh_input(det_fp32, sd):

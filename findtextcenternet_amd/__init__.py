@@ -3,9 +3,9 @@
 Public names mirror the reference (``/root/reference/models/detector.py``, ``util_func.py:5-9``)."""
 from .schema import feature_dim, height, modulo_list, scale, width          # noqa: F401
 from .detector import CenterNetDetection, CenterNetDetector, SimpleDecoder, TextDetectorModel   # noqa: F401
-from .decode import Decoded, HipDetectorBackend, TileGeom, decode_peaks, exact_logit_cut, tile_keep_rect   # noqa: F401
+from .decode import Decoded, HipDetectorBackend, TileGeom, decode_peaks, exact_logit_cut, tile_keep_rect, tiles_to_device   # noqa: F401
 from .weights import deterministic_state_dict                               # noqa: F401
 
 __all__ = ["TextDetectorModel", "CenterNetDetection", "CenterNetDetector", "SimpleDecoder", "HipDetectorBackend",
-           "TileGeom", "Decoded", "decode_peaks", "exact_logit_cut", "tile_keep_rect", "deterministic_state_dict",
+           "TileGeom", "Decoded", "decode_peaks", "tiles_to_device", "exact_logit_cut", "tile_keep_rect", "deterministic_state_dict",
            "width", "height", "scale", "feature_dim", "modulo_list"]

@@ -17,7 +17,7 @@ ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 FLAG_RESIDUAL, FLAG_SE_SCALE, FLAG_IN_NCHW = 1, 2, 4
 
 EXPORTS = ["ftc_abi_version", "ftc_last_error", "ftc_device_info", "ftc_plan_create", "ftc_plan_destroy",
-           "ftc_plan_num_ops", "ftc_plan_run", "ftc_plan_profile", "ftc_decode_scratch_bytes", "ftc_decode"]
+           "ftc_plan_num_ops", "ftc_plan_run", "ftc_plan_profile", "ftc_op_kernel_label", "ftc_decode_scratch_bytes", "ftc_decode"]
 
 
 class FtcLibraryError(RuntimeError):
@@ -69,6 +69,7 @@ def load():
     lib.ftc_plan_num_ops.argtypes = [vp]
     lib.ftc_plan_run.argtypes = [vp, C.POINTER(vp), vp, i32, i32]
     lib.ftc_plan_profile.argtypes = [vp, C.POINTER(vp), vp, C.POINTER(C.c_float)]
+    lib.ftc_op_kernel_label.argtypes = [C.POINTER(Op), C.c_char_p, i32]
     lib.ftc_decode_scratch_bytes.argtypes = [i32, i32, i32]
     lib.ftc_decode_scratch_bytes.restype = i64
     lib.ftc_decode.argtypes = [vp, vp, i32, i32, i32, i32, vp, C.c_float, i32, i32, vp, vp, vp, vp, vp, vp]

@@ -18,6 +18,8 @@
 // the MBConv project conv is applied on the fly and fp32 trunk activations can be narrowed to
 // bf16), double-buffered in LDS with one barrier per 32-deep K step; LDS rows are padded by one
 // 16-byte chunk which makes both the ds_write_b128 and the fragment ds_read_b128 conflict-free.
+#include <cstdio>
+
 #include "ftc_common.h"
 
 namespace {
@@ -306,20 +308,39 @@ hipError_t launch_cfg(ConvP p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Tile configuration by output-channel count and problem size (channels x pixels per workgroup).
+enum { CFG_32x256 = 0, CFG_64x128, CFG_96x128, CFG_192x128, CFG_128x64, CFG_128x128 };
+const char* const kCfgName[] = {"32x256", "64x128", "96x128", "192x128", "128x64", "128x128"};
+
+int select_cfg(int n, int M) {
+    if (n <= 32) return CFG_32x256;
+    if (n <= 64) return CFG_64x128;
+    if (n <= 96) return CFG_96x128;
+    if (n % 192 == 0 && n % 128 != 0) return CFG_192x128;
+    // 128-channel tiles; shrink the pixel tile when the grid would not fill the 256 CUs twice
+    const long tiles128 = (long)((n + 127) / 128) * ((M + 127) / 128);
+    return tiles128 < 512 ? CFG_128x64 : CFG_128x128;
+}
+
 template <typename WT, typename InT, typename OutT>
 hipError_t launch_types(const ConvP& p, hipStream_t s) {
-    const int n = p.Cout;
-    if (n <= 32) return launch_cfg<WT, InT, OutT, 1, 4, 1, 2>(p, s);        //  32 ch x 256 px
-    if (n <= 64) return launch_cfg<WT, InT, OutT, 2, 2, 1, 2>(p, s);        //  64 ch x 128 px
-    if (n <= 96) return launch_cfg<WT, InT, OutT, 1, 4, 3, 1>(p, s);        //  96 ch x 128 px
-    if (n % 192 == 0 && n % 128 != 0) return launch_cfg<WT, InT, OutT, 2, 2, 3, 2>(p, s);   // 192 ch x 128 px
-    // 128 ch tiles; shrink the pixel tile when the grid would not fill the 256 CUs twice
-    const long tiles128 = (long)((n + 127) / 128) * ((p.M + 127) / 128);
-    if (tiles128 < 512) return launch_cfg<WT, InT, OutT, 2, 2, 2, 1>(p, s); // 128 ch x  64 px
-    return launch_cfg<WT, InT, OutT, 2, 2, 2, 2>(p, s);                     // 128 ch x 128 px
+    switch (select_cfg(p.Cout, p.M)) {
+    case CFG_32x256: return launch_cfg<WT, InT, OutT, 1, 4, 1, 2>(p, s);
+    case CFG_64x128: return launch_cfg<WT, InT, OutT, 2, 2, 1, 2>(p, s);
+    case CFG_96x128: return launch_cfg<WT, InT, OutT, 1, 4, 3, 1>(p, s);
+    case CFG_192x128: return launch_cfg<WT, InT, OutT, 2, 2, 3, 2>(p, s);
+    case CFG_128x64: return launch_cfg<WT, InT, OutT, 2, 2, 2, 1>(p, s);
+    default: return launch_cfg<WT, InT, OutT, 2, 2, 2, 2>(p, s);
+    }
 }
 
 }  // namespace
+
+void conv_kernel_label(const ftc_op& op, char* buf, int len) {
+    const char* dt[] = {"f32", "bf16"};
+    snprintf(buf, len, "conv_igemm<%s,in=%s,out=%s,tile=%s>", dt[op.w_dtype & 1], dt[op.in_dtype & 1], dt[op.out_dtype & 1],
+             kCfgName[select_cfg(op.Cout, op.B * op.Ho * op.Wo)]);
+}
 
 const char* conv_validate(const ftc_op& op) {
     if (op.ksize != 1 && op.ksize != 3) return "conv: ksize must be 1 or 3";

@@ -195,6 +195,20 @@ int ftc_plan_run(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], void* s
     return FTC_OK;
 }
 
+int ftc_op_kernel_label(const ftc_op* op, char* buf, int len) {
+    if (!op || !buf || len <= 0) return fail(FTC_ERR_INVALID, "ftc_op_kernel_label: null arguments");
+    switch (op->kind) {
+    case FTC_OP_STEM: std::snprintf(buf, len, "stem_kernel"); break;
+    case FTC_OP_CONV: conv_kernel_label(*op, buf, len); break;
+    case FTC_OP_DWCONV: std::snprintf(buf, len, "dwconv_kernel<%s,s%d>", op->in_dtype == FTC_F32 ? "f32" : "bf16", op->stride); break;
+    case FTC_OP_SE: std::snprintf(buf, len, "se_kernel"); break;
+    case FTC_OP_UPCAT: std::snprintf(buf, len, "upcat_kernel<%s>", op->in_dtype == FTC_F32 ? "f32" : "bf16"); break;
+    case FTC_OP_NMS: std::snprintf(buf, len, "nms_kernel"); break;
+    default: return fail(FTC_ERR_INVALID, "ftc_op_kernel_label: unknown op kind");
+    }
+    return FTC_OK;
+}
+
 int ftc_plan_profile(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], void* stream, float* ms_out) {
     if (!plan || !bases || !ms_out) return fail(FTC_ERR_INVALID, "ftc_plan_profile: null arguments");
     const int n = (int)plan->ops.size();

@@ -83,9 +83,19 @@ class Decoded:
     counts: torch.Tensor     # [B] int32 number of peaks found (may exceed max_boxes)
 
 
-def decode_peaks(heat_nhwc: torch.Tensor, feat_nhwc: torch.Tensor, tiles: Sequence[TileGeom], cut_off: float = 0.4,
+def tiles_to_device(tiles: Sequence[TileGeom], device, h: int, w: int) -> torch.Tensor:
+    """[B,8] int32 ftc_tile records on the GPU (upload once when the geometry repeats)."""
+    tl = np.array([[t.offset_x, t.offset_y, t.page_w, t.page_h, *t.rect] for t in tiles], np.int32)
+    for r in tl:
+        if not (0 <= r[4] <= r[5] <= w and 0 <= r[6] <= r[7] <= h):
+            raise ValueError("tile rectangle outside the map")
+    return torch.from_numpy(tl).to(device)
+
+
+def decode_peaks(heat_nhwc: torch.Tensor, feat_nhwc: torch.Tensor, tiles, cut_off: float = 0.4,
                  max_boxes: int = 4096, logit_cut: Optional[float] = None) -> Decoded:
-    """heat_nhwc [B,h,w,10] fp32, feat_nhwc [B,h,w,C] fp32 (NHWC memory, on the GPU)."""
+    """heat_nhwc [B,h,w,10] fp32, feat_nhwc [B,h,w,C] fp32 (NHWC memory, on the GPU); ``tiles`` is a
+    sequence of TileGeom or the [B,8] int32 device tensor from ``tiles_to_device``."""
     if not (heat_nhwc.is_cuda and feat_nhwc.is_cuda):
         raise RuntimeError("decode_peaks runs on the GPU only (no CPU fallback)")
     lib = L.load()
@@ -95,12 +105,12 @@ def decode_peaks(heat_nhwc: torch.Tensor, feat_nhwc: torch.Tensor, tiles: Sequen
     assert ch == 10 and heat_nhwc.dtype == torch.float32 and feat_nhwc.dtype == torch.float32
     assert len(tiles) == B and feat_nhwc.shape[:3] == heat_nhwc.shape[:3]
     dev = heat_nhwc.device
-    tl = np.array([[t.offset_x, t.offset_y, t.page_w, t.page_h, *t.rect] for t in tiles], np.int32)
-    for r in tl:
-        if not (0 <= r[4] <= r[5] <= w and 0 <= r[6] <= r[7] <= h):
-            raise ValueError("tile rectangle outside the map")
     with torch.cuda.device(dev):
-        tl_dev = torch.from_numpy(tl).to(dev)
+        if isinstance(tiles, torch.Tensor):
+            tl_dev = tiles
+            assert tl_dev.shape == (B, 8) and tl_dev.dtype == torch.int32 and tl_dev.device == dev and tl_dev.is_contiguous()
+        else:
+            tl_dev = tiles_to_device(tiles, dev, h, w)
         boxes = torch.zeros((B, max_boxes, 9), dtype=torch.float32, device=dev)
         feats = torch.zeros((B, max_boxes, Cf), dtype=torch.float32, device=dev)
         index = torch.full((B, max_boxes), -1, dtype=torch.int32, device=dev)

@@ -150,6 +150,10 @@ int ftc_plan_run(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], void* s
 int ftc_plan_profile(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], void* stream,
                      float* ms_out);
 
+/* Label of the kernel instantiation an op dispatches to (dtype + tile configuration), e.g.
+   "conv_igemm<bf16,in=bf16,out=bf16,tile=192x128>"; used to attribute rocprof / HIP-event time. */
+int ftc_op_kernel_label(const ftc_op* op, char* buf, int len);
+
 /* Peak decode ------------------------------------------------------------------------------ */
 /* Per-image geometry of the tile being decoded (process_ocr_base.py:487-503). */
 typedef struct ftc_tile {

@@ -36,7 +36,7 @@ class Op(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "kind", "flags", "act", "in_dtype", "out_dtype", "w_dtype", "B", "H", "W", "Ho", "Wo", "Cin", "Cin_total",
         "cin_off", "Cout", "Cout_total", "cout_off", "ksize", "stride", "aux0", "aux1", "res_dtype")] + [
-        (n, Ref) for n in ("in_", "in2", "out", "w", "w2", "bias", "bias2", "scale", "shift", "aux")]
+        (n, Ref) for n in ("in_", "in2", "out", "w", "w2", "bias", "bias2", "scale", "shift", "aux", "out2")]
 
 
 class Tile(C.Structure):

@@ -9,9 +9,10 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libftc_hip.so")
-SOURCES = ["conv_igemm.hip", "backbone_ops.hip", "fpn_ops.hip", "decode.hip", "ftc_api.hip"]
-HEADERS = [os.path.join(CSRC, "ftc_common.h"), os.path.join(os.path.dirname(HERE), "include", "ftc.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+SOURCES = ["conv_igemm_bf16_bb.hip", "conv_igemm_bf16_fb.hip", "conv_igemm_bf16_bf.hip", "conv_igemm_bf16_ff.hip",
+           "conv_igemm_f32.hip", "conv_igemm.hip", "backbone_ops.hip", "fpn_ops.hip", "decode.hip", "ftc_api.hip"]
+HEADERS = [os.path.join(CSRC, "ftc_common.h"), os.path.join(CSRC, "conv_igemm_impl.h"), os.path.join(os.path.dirname(HERE), "include", "ftc.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
 def _hipcc() -> str:
@@ -52,7 +53,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     if jobs:
         if verbose:
             print(f"[ftc build] compiling {len(jobs)} HIP source(s) for gfx950 ...", flush=True)
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(cc, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):

@@ -14,7 +14,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 template <typename OutT>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                   const float* __restrict__ bias, OutT* __restrict__ out,
+                                                   const float* __restrict__ bias, OutT* __restrict__ out, __bf16* __restrict__ out2,
                                                    int B, int H, int W, int Ho, int Wo, int C0, int nchw) {
     extern __shared__ __attribute__((aligned(16))) float sw[];   // [27][C0]
     for (int i = threadIdx.x; i < 27 * C0; i += blockDim.x) sw[i] = w[i];
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = act_silu_precise(acc[e]);
         store4<OutT>(out + pix * C0 + cq * 4, acc);
+        if (out2) store4<__bf16>(out2 + pix * C0 + cq * 4, acc);
     }
 }
 
@@ -133,42 +134,53 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, c
 }
 
 // ------------------------------------------------------------------------------------------
-// SE excitation: scale[b,c] = sigmoid(fc2(SiLU(fc1(mean_hw(x))))).  grid = (NSPLIT, B); every
-// workgroup of an image recomputes the tiny squeeze + fc1 (wave-per-hidden-unit dot products,
-// wave64 shuffle reductions) and then produces its slice of the C outputs.
+// SE excitation: scale[b,c] = sigmoid(fc2(SiLU(fc1(mean_hw(x))))), as two short kernels that
+// keep every load independent (the first version chained ~1200 dependent L2 round trips per
+// wave and cost 200-450 us per layer):
+//   se_fc1: grid (ceil(S/8), B), 8 waves: the workgroup reduces the P per-tile partial sums to
+//           mean[C] in LDS (float4, fixed order -> deterministic), then each wave computes ONE
+//           hidden unit as a float4 dot product + wave64 shuffle reduction.
+//   se_fc2: grid (ceil(C/256), B): one lane per output channel, fc2 stored transposed [S][C]
+//           so the S loads of a lane are coalesced across the wave and independent of each other.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void se_kernel(const float* __restrict__ partial, const float* __restrict__ w1,
-                                                 const float* __restrict__ b1, const float* __restrict__ w2t,
-                                                 const float* __restrict__ b2, float* __restrict__ scale,
-                                                 int C, int S, int P, float inv_hw) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // mean[C] | hidden[S]
-    float* mean = sm;
-    float* hidden = sm + C;
+__global__ __launch_bounds__(512) void se_fc1_kernel(const float* __restrict__ partial, const float* __restrict__ w1,
+                                                     const float* __restrict__ b1, float* __restrict__ hidden,
+                                                     int C, int S, int P, float inv_hw) {
+    extern __shared__ __attribute__((aligned(16))) float mean[];   // [C]
     const int b = blockIdx.y;
     const int t = threadIdx.x;
-    for (int c = t; c < C; c += blockDim.x) {
-        float s = 0.f;
-        for (int p = 0; p < P; ++p) s += partial[((long)b * P + p) * C + c];
-        mean[c] = s * inv_hw;
+    const int CQ = C >> 2;
+    const f32x4* pb = reinterpret_cast<const f32x4*>(partial + (long)b * P * C);
+    for (int q = t; q < CQ; q += 512) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int p = 0; p < P; ++p) s += pb[(long)p * CQ + q];
+        reinterpret_cast<f32x4*>(mean)[q] = s * inv_hw;
     }
     __syncthreads();
-    const int lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
-    for (int s = wave; s < S; s += nw) {
-        const float* wr = w1 + (long)s * C;
-        float acc = 0.f;
-        for (int c = lane; c < C; c += 64) acc += wr[c] * mean[c];
-        acc = wave_sum(acc);
-        if (lane == 0) hidden[s] = act_silu_precise(acc + b1[s]);
-    }
+    const int lane = t & 63, wave = t >> 6;
+    const int sidx = blockIdx.x * 8 + wave;
+    if (sidx >= S) return;
+    const f32x4* wr = reinterpret_cast<const f32x4*>(w1 + (long)sidx * C);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int q = lane; q < CQ; q += 64) acc += wr[q] * reinterpret_cast<const f32x4*>(mean)[q];
+    float a = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+    if (lane == 0) hidden[(long)b * S + sidx] = act_silu_precise(a + b1[sidx]);
+}
+
+__global__ __launch_bounds__(256) void se_fc2_kernel(const float* __restrict__ hidden, const float* __restrict__ w2t,
+                                                     const float* __restrict__ b2, float* __restrict__ scale, int C, int S) {
+    extern __shared__ __attribute__((aligned(16))) float hid[];    // [S]
+    const int b = blockIdx.y;
+    for (int s = threadIdx.x; s < S; s += 256) hid[s] = hidden[(long)b * S + s];
     __syncthreads();
-    const int per = (C + gridDim.x - 1) / gridDim.x;
-    const int c0 = blockIdx.x * per;
-    const int c1 = min(C, c0 + per);
-    for (int c = c0 + t; c < c1; c += blockDim.x) {
-        float acc = b2[c];
-        for (int s = 0; s < S; ++s) acc += hidden[s] * w2t[(long)s * C + c];
-        scale[(long)b * C + c] = sigmoid_precise(acc);
-    }
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float acc = b2[c];
+#pragma unroll 8
+    for (int s = 0; s < S; ++s) acc += hid[s] * w2t[(long)s * C + c];
+    scale[(long)b * C + c] = sigmoid_precise(acc);
 }
 
 }  // namespace
@@ -181,10 +193,10 @@ hipError_t launch_stem(const OpArgs& a, hipStream_t s) {
     const int nchw = (o.flags & FTC_FLAG_IN_NCHW) ? 1 : 0;
     if (o.out_dtype == FTC_F32)
         hipLaunchKernelGGL(stem_kernel<float>, dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
-                           a.bias, (float*)a.out, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw);
+                           a.bias, (float*)a.out, (__bf16*)a.out2, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw);
     else
         hipLaunchKernelGGL(stem_kernel<__bf16>, dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
-                           a.bias, (__bf16*)a.out, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw);
+                           a.bias, (__bf16*)a.out, (__bf16*)nullptr, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw);
     return hipGetLastError();
 }
 
@@ -207,11 +219,12 @@ hipError_t launch_dwconv(const OpArgs& a, hipStream_t s) {
 hipError_t launch_se(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
     const int C = o.Cin, S = o.aux0, P = o.aux1;
-    int nsplit = 64 / (o.B > 0 ? o.B : 1);
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > 16) nsplit = 16;
-    const size_t lds = (size_t)(C + S) * sizeof(float);
-    hipLaunchKernelGGL(se_kernel, dim3(nsplit, o.B), dim3(512), lds, s, (const float*)a.aux, (const float*)a.w, a.bias,
-                       (const float*)a.w2, a.bias2, (float*)a.out, C, S, P, 1.0f / (float)(o.H * o.W));
+    float* hidden = const_cast<float*>(static_cast<const float*>(a.in2));      // [B,S] scratch
+    hipLaunchKernelGGL(se_fc1_kernel, dim3((S + 7) / 8, o.B), dim3(512), (size_t)C * sizeof(float), s, (const float*)a.aux,
+                       (const float*)a.w, a.bias, hidden, C, S, P, 1.0f / (float)(o.H * o.W));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(se_fc2_kernel, dim3((C + 255) / 256, o.B), dim3(256), (size_t)S * sizeof(float), s, hidden,
+                       (const float*)a.w2, a.bias2, (float*)a.out, C, S);
     return hipGetLastError();
 }

@@ -1,0 +1,403 @@
+// Dense 1x1 / 3x3 convolution as an im2col-free implicit GEMM on the gfx950 matrix cores.
+//
+// Covers every dense convolution on the detector path: the Fused-MBConv
+// 3x3 and 1x1 convs, the MBConv expand / project 1x1 convs, the backbone head conv, the FPN 3x3
+// convs and the `top_conv`s (reference: torchvision blocks instantiated by
+// /root/reference/models/detector.py:12-28, Leafmap layers :164-190).
+//
+//   D[n][m] = sum_{tap,c} W[n][tap][c] * X[pixel(m) shifted by tap][c]
+//
+// GEMM view: rows n = output channels (MFMA "A" operand = weights, K-major [Cout][k*k][Cin]),
+// columns m = output pixels (MFMA "B" operand = NHWC activations, K-contiguous per pixel), so the
+// MFMA C/D layout gives every lane 4 CONSECUTIVE output channels of one pixel per register quad:
+// the NHWC epilogue (bias, activation, residual, store) is vectorised 4 wide with no shuffles.
+//
+// fp32 mode  : v_mfma_f32_32x32x2_f32  (exact f32 FMA chain, 157 TF peak) -- the parity mode.
+// bf16 mode  : v_mfma_f32_32x32x16_bf16 (fp32 accumulate, 2.5 PF peak)    -- the speed mode.
+//
+// Staging is global -> registers -> LDS (out-of-image taps zero-filled, the SE scale of the MBConv
+// project conv applied on the fly, fp32 trunk activations narrowed to bf16 on the way).  All
+// global reads are raw buffer loads: the per-row byte offset lives in one VGPR, the K position
+// (tap, channel block) is wave-uniform and goes in the SGPR offset / one scalar add, and rows or
+// taps outside the image are redirected to an out-of-range offset which the buffer unit answers
+// with zeros -- about 4 VALU instructions per 16-byte load instead of a 64-bit address chain
+// (the first version of this kernel issued 13.7 VALU per MFMA; PMC in profiles/).
+// LDS rows are padded by one 16-byte chunk: conflict-free ds_read_b128 fragments.
+#pragma once
+#include <cstdio>
+
+#include "ftc_common.h"
+
+namespace convimpl {
+
+struct ConvP {
+    const void* in;
+    const void* w;
+    const float* bias;
+    const void* res;
+    void* out;
+    void* out2;
+    const float* se;
+    unsigned in_bytes, w_bytes, se_bytes;
+    int B, H, W, Ho, Wo;
+    int Cin, CinT, cin_off;
+    int Cout, CoutT, cout_off;
+    int KS, stride, pad;
+    int act, flags, res_dtype;
+    int M;      // B*Ho*Wo
+    int ncb;    // ceil(Cin / BK)
+    int nk;     // KS*KS*ncb
+    int nN;     // channel tiles
+    int nblk;   // total workgroups
+};
+
+template <typename WT> struct Frag;
+template <> struct Frag<float> { using type = f32x4; };
+template <> struct Frag<__bf16> { using type = bf16x8; };
+
+constexpr int OOB = 0x7ffffff0;      // byte offset beyond any buffer: the load returns zeros
+
+__device__ __forceinline__ u32x4 bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+// One 16-byte LDS chunk worth of K (E elements of WT) of an activation row, read as InT.
+template <typename WT, typename InT>
+__device__ __forceinline__ u32x4 load_act(__amdgpu_buffer_rsrc_t rin, int voff, bool use_se, __amdgpu_buffer_rsrc_t rse, int seoff) {
+    if constexpr (sizeof(WT) == 4) {
+        static_assert(sizeof(InT) == 4, "fp32 compute takes fp32 activations");
+        u32x4 raw = bload(rin, voff, 0);
+        if (use_se) {
+            f32x4 v = __builtin_bit_cast(f32x4, raw) * __builtin_bit_cast(f32x4, bload(rse, seoff, 0));
+            raw = __builtin_bit_cast(u32x4, v);
+        }
+        return raw;
+    } else {
+        float f[8];
+        if constexpr (sizeof(InT) == 4) {
+            const f32x4 lo = __builtin_bit_cast(f32x4, bload(rin, voff, 0));
+            const f32x4 hi = __builtin_bit_cast(f32x4, bload(rin, voff + 16, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
+        } else {
+            const u32x4 raw = bload(rin, voff, 0);
+            if (!use_se) return raw;
+            const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+        }
+        if (use_se) {
+            const f32x4 s0 = __builtin_bit_cast(f32x4, bload(rse, seoff, 0));
+            const f32x4 s1 = __builtin_bit_cast(f32x4, bload(rse, seoff + 16, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f[e] *= s0[e]; f[4 + e] *= s1[e]; }
+        }
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (__bf16)f[e];
+        return __builtin_bit_cast(u32x4, r);
+    }
+}
+
+template <typename WT, typename InT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF, bool SE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
+    constexpr int E = 16 / (int)sizeof(WT);      // elements per 16-byte chunk (4 fp32 | 8 bf16)
+    constexpr int CPR = BK / E;                  // chunks per LDS row
+    constexpr int ROW = BK + E;                  // padded LDS row, elements
+    constexpr int TN = WN * SN * 32;             // output channels per workgroup
+    constexpr int TM = WM * SM * 32;             // output pixels per workgroup
+    constexpr int NA = (TN * CPR + 255) / 256;
+    constexpr int NB = (TM * CPR + 255) / 256;
+    constexpr int RPP = 256 / CPR;               // rows covered per staging pass
+    constexpr int BUF = (TN + TM) * ROW;         // elements per LDS buffer
+    static_assert(WN * WM == 4, "4 waves per workgroup");
+    static_assert(NBUF == 1 || NBUF == 2, "");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    WT* lds = reinterpret_cast<WT*>(smem_raw);
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wn = wave / WM, wm = wave % WM;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // XCD-aware remap (block b runs on XCD b % 8): give each XCD a contiguous run of tiles so
+    // that the 9 taps / the channel tiles of neighbouring pixel tiles hit the same private L2.
+    int bid = blockIdx.x;
+    {
+        const int q = p.nblk >> 3, r = p.nblk & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int mt = bid / p.nN, nt = bid - mt * p.nN;
+    const int m0 = mt * TM, n0 = nt * TN;
+
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rse = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.se), 0, p.se_bytes, 0x00020000);
+    constexpr bool use_se = SE;
+
+    const int kc = t % CPR;                      // this thread's 16-byte chunk inside a K row
+    const int row0 = t / CPR;
+    const int HoWo = p.Ho * p.Wo;
+    const int KK = p.KS * p.KS;
+
+    // per-row byte offsets (one VGPR each) and the 9-bit "tap lands inside the image" masks
+    int a_off[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = row0 + i * RPP;
+        const int n = n0 + row;
+        a_off[i] = (row < TN && n < p.Cout) ? (n * KK * p.Cin + kc * E) * (int)sizeof(WT) : OOB;
+    }
+    int b_off[NB], b_mask[NB], b_se[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int row = row0 + i * RPP;
+        const int m = m0 + row;
+        const bool ok = (row < TM) && (m < p.M);
+        const int mm = ok ? m : 0;
+        const int img = mm / HoWo;
+        const int rem = mm - img * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        b_off[i] = (((img * p.H + iy0) * p.W + ix0) * p.CinT + p.cin_off + kc * E) * (int)sizeof(InT);
+        int mask = 0;
+        for (int r = 0; r < p.KS; ++r)
+            for (int s = 0; s < p.KS; ++s)
+                if (ok && (unsigned)(iy0 + r) < (unsigned)p.H && (unsigned)(ix0 + s) < (unsigned)p.W) mask |= 1 << (r * p.KS + s);
+        b_mask[i] = mask;
+        b_se[i] = (img * p.Cin + kc * E) * 4;
+    }
+
+    u32x4 ra[NA], rb[NB];
+    // K position of the NEXT tile to fetch (all wave-uniform -> SALU)
+    int ld_tap = 0, ld_r = 0, ld_s = 0, ld_cb = 0;
+
+    auto gload = [&]() {
+        const int c0 = ld_cb * BK;
+        const int w_soff = (ld_tap * p.Cin + c0) * (int)sizeof(WT);
+        const int in_toff = ((ld_r * p.W + ld_s) * p.CinT + c0) * (int)sizeof(InT);
+        // partial last channel block: only possible when Cin % BK != 0 (never for BK = 64, see select_bk)
+        const bool cok = BK == 64 ? true : (c0 + kc * E) < p.Cin;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = bload(rw, cok ? a_off[i] : OOB, w_soff);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const bool ok = cok && ((b_mask[i] >> ld_tap) & 1);
+            rb[i] = load_act<WT, InT>(rin, ok ? b_off[i] + in_toff : OOB, use_se, rse, b_se[i] + c0 * 4);
+        }
+        if (++ld_cb == p.ncb) {
+            ld_cb = 0;
+            ++ld_tap;
+            if (++ld_s == p.KS) { ld_s = 0; ++ld_r; }
+        }
+    };
+
+    WT* const wA = lds + row0 * ROW + kc * E;                     // staging write base (weights)
+    WT* const wB = lds + (TN + row0) * ROW + kc * E;              //                     (pixels)
+    auto lds_write = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            if ((TN * CPR) % 256 == 0 || row0 + i * RPP < TN) *reinterpret_cast<u32x4*>(wA + buf * BUF + i * RPP * ROW) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if ((TM * CPR) % 256 == 0 || row0 + i * RPP < TM) *reinterpret_cast<u32x4*>(wB + buf * BUF + i * RPP * ROW) = rb[i];
+    };
+
+    f32x16 acc[SN][SM];
+#pragma unroll
+    for (int i = 0; i < SN; ++i)
+#pragma unroll
+        for (int j = 0; j < SM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    using FragT = typename Frag<WT>::type;
+    const WT* const fA = lds + (wn * SN * 32 + l31) * ROW + half * E;
+    const WT* const fB = lds + (TN + wm * SM * 32 + l31) * ROW + half * E;
+    auto compute = [&](int buf) {
+        const WT* A = fA + buf * BUF;
+        const WT* Bm = fB + buf * BUF;
+        if constexpr (sizeof(WT) == 4) {
+            // 8 k per group: lanes 0-31 hold k = 0..3, lanes 32-63 hold k = 4..7 of the group;
+            // step tt feeds A[:,k=tt | 4+tt], B likewise -- same permutation on both operands.
+#pragma unroll
+            for (int g = 0; g < BK / 8; ++g) {
+                FragT af[SN], bf[SM];
+#pragma unroll
+                for (int i = 0; i < SN; ++i) af[i] = *reinterpret_cast<const FragT*>(A + i * 32 * ROW + g * 8);
+#pragma unroll
+                for (int j = 0; j < SM; ++j) bf[j] = *reinterpret_cast<const FragT*>(Bm + j * 32 * ROW + g * 8);
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int i = 0; i < SN; ++i)
+#pragma unroll
+                        for (int j = 0; j < SM; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < BK / 16; ++g) {
+                FragT af[SN], bf[SM];
+#pragma unroll
+                for (int i = 0; i < SN; ++i) af[i] = *reinterpret_cast<const FragT*>(A + i * 32 * ROW + g * 16);
+#pragma unroll
+                for (int j = 0; j < SM; ++j) bf[j] = *reinterpret_cast<const FragT*>(Bm + j * 32 * ROW + g * 16);
+#pragma unroll
+                for (int i = 0; i < SN; ++i)
+#pragma unroll
+                    for (int j = 0; j < SM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    gload();
+    if constexpr (NBUF == 2) {
+        lds_write(0);
+        __syncthreads();
+        for (int it = 0; it < p.nk; it += 2) {
+            if (it + 1 < p.nk) gload();
+            compute(0);
+            if (it + 1 < p.nk) lds_write(1);
+            __syncthreads();
+            if (it + 1 >= p.nk) break;
+            if (it + 2 < p.nk) gload();
+            compute(1);
+            if (it + 2 < p.nk) lds_write(0);
+            __syncthreads();
+        }
+    } else {
+        for (int it = 0; it < p.nk; ++it) {
+            lds_write(0);
+            __syncthreads();
+            if (it + 1 < p.nk) gload();          // in flight while this tile is multiplied
+            compute(0);
+            __syncthreads();
+        }
+    }
+
+    // Epilogue: lane owns pixel (l31) of each 32-pixel sub-tile and, per register quad q,
+    // channels 8q + 4*half .. +3 of each 32-channel sub-tile (C/D layout of the 32x32 MFMA).
+    OutT* __restrict__ outp = reinterpret_cast<OutT*>(p.out);
+    const bool has_res = (p.flags & FTC_FLAG_RESIDUAL) != 0;
+    const bool vec_ok = ((p.Cout | p.CoutT | p.cout_off) & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < SM; ++j) {
+        const int m = m0 + wm * SM * 32 + j * 32 + l31;
+        if (m >= p.M) continue;
+        OutT* orow = outp + (size_t)m * p.CoutT + p.cout_off;
+#pragma unroll
+        for (int i = 0; i < SN; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * SN * 32 + i * 32 + 8 * q + 4 * half;
+                if (n >= p.Cout) continue;
+                if (vec_ok) {
+                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    v += *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act_sel<sizeof(WT) == 2>(v[e], p.act);
+                    if (has_res) {
+                        if (p.res_dtype == FTC_F32) v += load4<float>(reinterpret_cast<const float*>(p.res) + (size_t)m * p.Cout + n);
+                        else v += load4<__bf16>(reinterpret_cast<const __bf16*>(p.res) + (size_t)m * p.Cout + n);
+                    }
+                    store4<OutT>(orow + n, v);
+                    if constexpr (sizeof(OutT) == 4) {
+                        if (p.out2) store4<__bf16>(reinterpret_cast<__bf16*>(p.out2) + (size_t)m * p.Cout + n, v);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e >= p.Cout) continue;
+                        float v = acc[i][j][4 * q + e] + p.bias[n + e];
+                        v = apply_act_sel<sizeof(WT) == 2>(v, p.act);
+                        if (has_res) {
+                            if (p.res_dtype == FTC_F32) v += reinterpret_cast<const float*>(p.res)[(size_t)m * p.Cout + n + e];
+                            else v += (float)reinterpret_cast<const __bf16*>(p.res)[(size_t)m * p.Cout + n + e];
+                        }
+                        orow[n + e] = from_f32<OutT>(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename WT, typename InT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF, bool SE>
+hipError_t launch_cfg2(ConvP p, hipStream_t s) {
+    constexpr int E = 16 / (int)sizeof(WT);
+    constexpr int ROW = BK + E;
+    constexpr int TN = WN * SN * 32, TM = WM * SM * 32;
+    constexpr size_t lds_bytes = (size_t)NBUF * (TN + TM) * ROW * sizeof(WT);
+    auto kern = conv_igemm_kernel<WT, InT, OutT, BK, WN, WM, SN, SM, NBUF, SE>;
+    static bool attr_set = false;     // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    p.ncb = (p.Cin + BK - 1) / BK;
+    p.nk = p.KS * p.KS * p.ncb;
+    p.nN = (p.Cout + TN - 1) / TN;
+    const int nM = (p.M + TM - 1) / TM;
+    p.nblk = p.nN * nM;
+    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(256), lds_bytes, s, p);
+    return hipGetLastError();
+}
+
+template <typename WT, typename InT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF>
+hipError_t launch_cfg(const ConvP& p, hipStream_t s) {
+    // the SE-scaled variant exists only where the network uses it: 1x1 project convs
+    if (p.flags & FTC_FLAG_SE_SCALE) return launch_cfg2<WT, InT, OutT, BK, WN, WM, SN, SM, NBUF, true>(p, s);
+    return launch_cfg2<WT, InT, OutT, BK, WN, WM, SN, SM, NBUF, false>(p, s);
+}
+
+// Tile configuration (channels x pixels per workgroup) by output-channel count and problem size.
+enum { CFG_32x256 = 0, CFG_64x128, CFG_96x128, CFG_192x128, CFG_128x64, CFG_128x128, CFG_COUNT };
+static const char* const kCfgName[] = {"32x256", "64x128", "96x128", "192x128", "128x64", "128x128"};
+
+inline int select_cfg(int n, int M) {
+    if (n <= 32) return CFG_32x256;
+    if (n <= 64) return CFG_64x128;
+    if (n <= 96) return CFG_96x128;
+    if (n % 192 == 0 && n % 128 != 0) return CFG_192x128;
+    // 128-channel tiles; shrink the pixel tile when the grid would not fill the 256 CUs twice
+    const long tiles128 = (long)((n + 127) / 128) * ((M + 127) / 128);
+    return tiles128 < 512 ? CFG_128x64 : CFG_128x128;
+}
+
+// K step: 64 for bf16 when the channel count allows it (half the barriers), else 32.
+inline int select_bk(const ftc_op& o) { return (o.w_dtype == FTC_BF16 && o.Cin % 64 == 0) ? 64 : 32; }
+// LDS buffering: tuning hint in ftc_op.aux0 (0 = default, 1 = single buffer, 2 = double buffer).
+// Measured (tools/conv_bench.py): bf16 wants the single buffer (2-3 workgroups per CU hide the two
+// barriers better than one double-buffered workgroup: FPN L3 689 vs 391 TF).
+inline int select_nbuf(const ftc_op& o) { return o.aux0 == 1 ? 1 : (o.aux0 == 2 ? 2 : 1); }
+
+template <typename WT, typename InT, typename OutT, int BK, int NBUF>
+hipError_t launch_tiles(const ConvP& p, int cfg, hipStream_t s) {
+    switch (cfg) {
+    case CFG_32x256: return launch_cfg<WT, InT, OutT, BK, 1, 4, 1, 2, NBUF>(p, s);
+    case CFG_64x128: return launch_cfg<WT, InT, OutT, BK, 2, 2, 1, 2, NBUF>(p, s);
+    case CFG_96x128: return launch_cfg<WT, InT, OutT, BK, 1, 4, 3, 1, NBUF>(p, s);
+    case CFG_192x128: return launch_cfg<WT, InT, OutT, BK, 2, 2, 3, 2, NBUF>(p, s);
+    case CFG_128x64: return launch_cfg<WT, InT, OutT, BK, 2, 2, 2, 1, NBUF>(p, s);
+    default: return launch_cfg<WT, InT, OutT, BK, 2, 2, 2, 2, NBUF>(p, s);
+    }
+}
+
+template <typename WT, typename InT, typename OutT>
+hipError_t launch_types(const ConvP& p, const ftc_op& o, hipStream_t s) {
+    const int cfg = select_cfg(p.Cout, p.M);
+    const int nbuf = select_nbuf(o);
+    if constexpr (sizeof(WT) == 2) {
+        if (select_bk(o) == 64)
+            return nbuf == 1 ? launch_tiles<WT, InT, OutT, 64, 1>(p, cfg, s) : launch_tiles<WT, InT, OutT, 64, 2>(p, cfg, s);
+    }
+    return nbuf == 1 ? launch_tiles<WT, InT, OutT, 32, 1>(p, cfg, s) : launch_tiles<WT, InT, OutT, 32, 2>(p, cfg, s);
+}
+
+}  // namespace convimpl

@@ -54,11 +54,15 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
     case FTC_OP_STEM:
         if (!need(o.in, true, "in") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.bias, true, "bias")) return why->c_str();
         if (o.Cout % 4 || o.Cout > 256) return "stem: Cout must be a multiple of 4 (<= 256)";
+        if (!need(o.out2, false, "out2")) return why->c_str();
+        if (o.out2.base != FTC_BASE_NULL && o.out_dtype != FTC_F32) return "stem: out2 (bf16 copy) needs an fp32 primary output";
         if (o.Ho != (o.H - 1) / 2 + 1 || o.Wo != (o.W - 1) / 2 + 1) return "stem: Ho/Wo inconsistent";
         return nullptr;
     case FTC_OP_CONV: {
         if (!need(o.in, true, "in") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.bias, true, "bias")) return why->c_str();
         if (!need(o.in2, (o.flags & FTC_FLAG_RESIDUAL) != 0, "in2") || !need(o.scale, (o.flags & FTC_FLAG_SE_SCALE) != 0, "scale")) return why->c_str();
+        if (!need(o.out2, false, "out2")) return why->c_str();
+        if (o.out2.base != FTC_BASE_NULL && (o.out_dtype != FTC_F32 || o.Cout % 4)) return "conv: out2 (bf16 copy) needs an fp32 primary output and Cout % 4 == 0";
         return conv_validate(o);
     }
     case FTC_OP_DWCONV:
@@ -69,10 +73,11 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if (o.in_dtype != o.out_dtype) return "dwconv: in/out dtype must match";
         return nullptr;
     case FTC_OP_SE:
-        if (!need(o.aux, true, "aux") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.w2, true, "w2") ||
+        if (!need(o.aux, true, "aux") || !need(o.out, true, "out") || !need(o.in2, true, "in2") || !need(o.w, true, "w") || !need(o.w2, true, "w2") ||
             !need(o.bias, true, "bias") || !need(o.bias2, true, "bias2")) return why->c_str();
         if (o.aux0 <= 0 || o.aux1 <= 0 || o.Cin <= 0) return "se: C, S, P must be positive";
-        if ((size_t)(o.Cin + o.aux0) * 4 > 60000) return "se: C + S too large for LDS";
+        if (o.Cin % 4) return "se: C must be a multiple of 4";
+        if ((size_t)o.Cin * 4 > 64000 || (size_t)o.aux0 * 4 > 64000) return "se: C or S too large for LDS";
         return nullptr;
     case FTC_OP_UPCAT:
         if (!need(o.in, o.aux0 > 0, "in") || !need(o.in2, true, "in2") || !need(o.out, true, "out") || !need(o.scale, true, "scale") ||
@@ -107,6 +112,7 @@ hipError_t run_one(const ftc_op& o, void* const bases[FTC_NUM_BASES], hipStream_
     a.scale = static_cast<const float*>(resolve(o.scale, bases));
     a.shift = static_cast<const float*>(resolve(o.shift, bases));
     a.aux = static_cast<float*>(resolve(o.aux, bases));
+    a.out2 = resolve(o.out2, bases);
     switch (o.kind) {
     case FTC_OP_STEM: return launch_stem(a, s);
     case FTC_OP_CONV: return launch_conv(a, s);
@@ -121,7 +127,7 @@ hipError_t run_one(const ftc_op& o, void* const bases[FTC_NUM_BASES], hipStream_
 int check_bases(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], int first, int last) {
     for (int i = first; i <= last; ++i) {
         const ftc_op& o = plan->ops[i];
-        const ftc_ref* refs[] = {&o.in, &o.in2, &o.out, &o.w, &o.w2, &o.bias, &o.bias2, &o.scale, &o.shift, &o.aux};
+        const ftc_ref* refs[] = {&o.in, &o.in2, &o.out, &o.w, &o.w2, &o.bias, &o.bias2, &o.scale, &o.shift, &o.aux, &o.out2};
         for (const ftc_ref* r : refs)
             if (r->base != FTC_BASE_NULL && bases[r->base] == nullptr)
                 return fail(FTC_ERR_INVALID, "ftc_plan_run: op " + std::to_string(i) + " needs base " + std::to_string(r->base) + " which is NULL");
@@ -201,7 +207,7 @@ int ftc_op_kernel_label(const ftc_op* op, char* buf, int len) {
     case FTC_OP_STEM: std::snprintf(buf, len, "stem_kernel"); break;
     case FTC_OP_CONV: conv_kernel_label(*op, buf, len); break;
     case FTC_OP_DWCONV: std::snprintf(buf, len, "dwconv_kernel<%s,s%d>", op->in_dtype == FTC_F32 ? "f32" : "bf16", op->stride); break;
-    case FTC_OP_SE: std::snprintf(buf, len, "se_kernel"); break;
+    case FTC_OP_SE: std::snprintf(buf, len, "se_fc1+se_fc2"); break;
     case FTC_OP_UPCAT: std::snprintf(buf, len, "upcat_kernel<%s>", op->in_dtype == FTC_F32 ? "f32" : "bf16"); break;
     case FTC_OP_NMS: std::snprintf(buf, len, "nms_kernel"); break;
     default: return fail(FTC_ERR_INVALID, "ftc_op_kernel_label: unknown op kind");

@@ -26,6 +26,7 @@ struct OpArgs {
     const float* scale;
     const float* shift;
     float* aux;
+    void* out2;
 };
 
 __device__ __forceinline__ float bf16_to_f32(__bf16 v) { return (float)v; }
@@ -58,6 +59,30 @@ __device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-
 __device__ __forceinline__ float act_silu_precise(float x) { return x / (1.0f + expf(-x)); }
 __device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float sigmoid_precise(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Fast forms for the bf16 speed mode (a conv epilogue applies the activation to 64-96 values per
+// lane; libm expf/erff made the epilogue cost as much VALU time as ~200 MFMAs):
+//   SiLU  = x * rcp(1 + exp2(-x*log2 e))                       (v_exp_f32 + v_rcp_f32, ~3e-7 rel)
+//   GELU  = 0.5 x (1 + erf(x/sqrt2)), erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7 abs)
+__device__ __forceinline__ float act_silu_fast(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float act_gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    float poly = 1.061405429f;
+    poly = poly * t - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const float e = 1.0f - poly * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // erf(|x|/sqrt2)
+    return 0.5f * x + 0.5f * fabsf(x) * e;                     // x*erf(x/sqrt2) = |x|*erf(|x|/sqrt2)
+}
+template <bool FAST> __device__ __forceinline__ float apply_act_sel(float x, int act) {
+    if (act == FTC_ACT_SILU) return FAST ? act_silu_fast(x) : act_silu_precise(x);
+    if (act == FTC_ACT_GELU) return FAST ? act_gelu_fast(x) : act_gelu(x);
+    return x;
+}
 
 template <int ACT> __device__ __forceinline__ float apply_act(float x) {
     if constexpr (ACT == FTC_ACT_SILU) return act_silu_precise(x);

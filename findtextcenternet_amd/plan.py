@@ -209,7 +209,7 @@ class _Builder:
 
     def emit(self, meta: OpMeta, **f) -> None:
         idx = len(self.ops)
-        for k in ("in_", "in2", "out", "aux", "scale"):
+        for k in ("in_", "in2", "out", "aux", "scale", "out2"):
             r = f.get(k)
             if isinstance(r, tuple) and r[0] == "buf":
                 b = self.bufs[r[1]]
@@ -219,18 +219,20 @@ class _Builder:
 
     # --- op helpers ---------------------------------------------------------------------------
     def conv(self, name, x, xdt, H, W, cin, cin_total, cin_off, wname, cout, k, stride, act, out, odt, cout_total=None,
-             cout_off=0, residual=None, res_dt=0, se=None):
+             cout_off=0, residual=None, res_dt=0, se=None, out2=None):
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         flags = (L.FLAG_RESIDUAL if residual is not None else 0) | (L.FLAG_SE_SCALE if se is not None else 0)
         macs = self.B * Ho * Wo * cout * cin * k * k
         byt = self.B * H * W * cin * self.esize(xdt) + self.B * Ho * Wo * cout * self.esize(odt) + cout * cin * k * k * self.esize(self.cdt)
         if residual is not None:
             byt += self.B * Ho * Wo * cout * self.esize(res_dt)
+        if out2 is not None:
+            byt += self.B * Ho * Wo * cout * 2
         self.emit(OpMeta(name, f"conv{k}x{k}", 2.0 * macs, byt), kind=L.OP_CONV, flags=flags, act=act, in_dtype=xdt,
                   out_dtype=odt, w_dtype=self.cdt, B=self.B, H=H, W=W, Ho=Ho, Wo=Wo, Cin=cin, Cin_total=cin_total,
                   cin_off=cin_off, Cout=cout, Cout_total=cout_total or cout, cout_off=cout_off, ksize=k, stride=stride,
                   res_dtype=res_dt, in_=x, in2=residual, out=out, w=self.wref(wname + ".w"), bias=self.wref(wname + ".b"),
-                  scale=se)
+                  scale=se, out2=out2)
         return Ho, Wo
 
     def build(self) -> Plan:
@@ -239,12 +241,21 @@ class _Builder:
         stages = backbone_blocks(ms)
         c0 = STAGES[ms][0][4]
         T, A = self.trunk, self.act
+        # In bf16 mode every trunk tensor (fp32, feeds the residual adds and the FPN taps) is written
+        # together with a bf16 copy by the producing epilogue; the next GEMM reads the copy.
+        dual = self.mode == "bf16"
+        G = A if dual else T                      # dtype the GEMMs read the trunk in
+
+        def trunk(nelem):
+            return ("buf", self.buf(nelem, T)), (("buf", self.buf(nelem, L.BF16)) if dual else None)
+
         # stem
         h, w = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        x = ("buf", self.buf(B * h * w * c0, T))
-        self.emit(OpMeta("backbone.features.0", "stem", 2.0 * B * h * w * c0 * 27, B * H * W * 3 * 4 + B * h * w * c0 * self.esize(T)),
+        x, xb = trunk(B * h * w * c0)
+        self.emit(OpMeta("backbone.features.0", "stem", 2.0 * B * h * w * c0 * 27,
+                         B * H * W * 3 * 4 + B * h * w * c0 * (self.esize(T) + (2 if dual else 0))),
                   kind=L.OP_STEM, flags=L.FLAG_IN_NCHW if self.nchw else 0, act=L.ACT_SILU, in_dtype=L.F32, out_dtype=T,
-                  B=B, H=H, W=W, Ho=h, Wo=w, Cin=3, Cout=c0, ksize=3, stride=2, in_=("input", 0), out=x,
+                  B=B, H=H, W=W, Ho=h, Wo=w, Cin=3, Cout=c0, ksize=3, stride=2, in_=("input", 0), out=x, out2=xb,
                   w=self.wref("stem.w"), bias=self.wref("stem.b"))
         taps = []
         for si, stage in enumerate(stages):
@@ -252,19 +263,19 @@ class _Builder:
                 p = blk.prefix + ".block"
                 ho, wo = (h - 1) // blk.stride + 1, (w - 1) // blk.stride + 1
                 res = x if blk.residual else None
+                gin = xb if dual else x           # GEMM-side view of the block input
+                y, yb = trunk(B * ho * wo * blk.cout)
                 if blk.kind == "fused" and blk.exp == blk.cin:
-                    y = ("buf", self.buf(B * ho * wo * blk.cout, T))
-                    self.conv(p + ".0", x, T, h, w, blk.cin, blk.cin, 0, p + ".0", blk.cout, 3, blk.stride, L.ACT_SILU, y, T,
-                              residual=res, res_dt=T)
+                    self.conv(p + ".0", gin, G, h, w, blk.cin, blk.cin, 0, p + ".0", blk.cout, 3, blk.stride, L.ACT_SILU, y, T,
+                              residual=res, res_dt=T, out2=yb)
                 elif blk.kind == "fused":
                     e = ("buf", self.buf(B * ho * wo * blk.exp, A))
-                    self.conv(p + ".0", x, T, h, w, blk.cin, blk.cin, 0, p + ".0", blk.exp, 3, blk.stride, L.ACT_SILU, e, A)
-                    y = ("buf", self.buf(B * ho * wo * blk.cout, T))
+                    self.conv(p + ".0", gin, G, h, w, blk.cin, blk.cin, 0, p + ".0", blk.exp, 3, blk.stride, L.ACT_SILU, e, A)
                     self.conv(p + ".1", e, A, ho, wo, blk.exp, blk.exp, 0, p + ".1", blk.cout, 1, 1, L.ACT_NONE, y, T,
-                              residual=res, res_dt=T)
+                              residual=res, res_dt=T, out2=yb)
                 else:
                     e = ("buf", self.buf(B * h * w * blk.exp, A))
-                    self.conv(p + ".0", x, T, h, w, blk.cin, blk.cin, 0, p + ".0", blk.exp, 1, 1, L.ACT_SILU, e, A)
+                    self.conv(p + ".0", gin, G, h, w, blk.cin, blk.cin, 0, p + ".0", blk.exp, 1, 1, L.ACT_SILU, e, A)
                     th = 8 if blk.stride == 1 else 4
                     P = ((ho + th - 1) // th) * ((wo + 7) // 8)
                     d = ("buf", self.buf(B * ho * wo * blk.exp, A))
@@ -275,20 +286,20 @@ class _Builder:
                               Cin=blk.exp, Cout=blk.exp, ksize=3, stride=blk.stride, aux0=P, in_=e, out=d,
                               w=self.wref(p + ".1.w"), bias=self.wref(p + ".1.b"), aux=part)
                     sc = ("buf", self.buf(B * blk.exp, L.F32))
+                    hid = ("buf", self.buf(B * blk.squeeze, L.F32))
                     self.emit(OpMeta(p + ".2", "se", 4.0 * B * blk.exp * blk.squeeze, 8.0 * blk.exp * blk.squeeze + B * P * blk.exp * 4),
                               kind=L.OP_SE, B=B, H=ho, W=wo, Cin=blk.exp, Cout=blk.exp, aux0=blk.squeeze, aux1=P, aux=part,
-                              out=sc, w=self.wref(p + ".2.w1"), w2=self.wref(p + ".2.w2t"), bias=self.wref(p + ".2.b1"),
+                              out=sc, in2=hid, w=self.wref(p + ".2.w1"), w2=self.wref(p + ".2.w2t"), bias=self.wref(p + ".2.b1"),
                               bias2=self.wref(p + ".2.b2"))
-                    y = ("buf", self.buf(B * ho * wo * blk.cout, T))
                     self.conv(p + ".3", d, A, ho, wo, blk.exp, blk.exp, 0, p + ".3", blk.cout, 1, 1, L.ACT_NONE, y, T,
-                              residual=res, res_dt=T, se=sc)
-                x, h, w = y, ho, wo
+                              residual=res, res_dt=T, se=sc, out2=yb)
+                x, xb, h, w = y, yb, ho, wo
             if (si + 1) in (2, 3, 5):
                 taps.append((x, stage[-1].cout, h, w, T))
         nfeat = len(stages) + 1
         hp = f"backbone.features.{nfeat}"
         x4 = ("buf", self.buf(B * h * w * LAST_CHANNEL, A))
-        self.conv(hp, x, T, h, w, stages[-1][-1].cout, stages[-1][-1].cout, 0, hp, LAST_CHANNEL, 1, 1, L.ACT_SILU, x4, A)
+        self.conv(hp, xb if dual else x, G, h, w, stages[-1][-1].cout, stages[-1][-1].cout, 0, hp, LAST_CHANNEL, 1, 1, L.ACT_SILU, x4, A)
         taps.append((x4, LAST_CHANNEL, h, w, A))
         mh, mw = taps[0][2], taps[0][3]
         # heads
@@ -347,7 +358,7 @@ class _Builder:
         for i, f in enumerate(self.ops):
             o = arr[i]
             for k, v in f.items():
-                if k in ("in_", "in2", "out", "w", "w2", "bias", "bias2", "scale", "shift", "aux"):
+                if k in ("in_", "in2", "out", "w", "w2", "bias", "bias2", "scale", "shift", "aux", "out2"):
                     if v is None:
                         continue
                     r = getattr(o, k)

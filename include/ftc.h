@@ -113,7 +113,8 @@ typedef struct ftc_op {
     int32_t aux1;              /* SE: number of partial sums P;  UPCAT: tap channels */
     int32_t res_dtype;         /* ftc_dtype of in2 (CONV residual / UPCAT tap) */
     ftc_ref in;                /* main input */
-    ftc_ref in2;               /* CONV: residual [B,Ho,Wo,Cout];  UPCAT: backbone tap [B,Ho,Wo,aux1] */
+    ftc_ref in2;               /* CONV: residual [B,Ho,Wo,Cout];  UPCAT: backbone tap [B,Ho,Wo,aux1];
+                                  SE: hidden-unit scratch fp32 [B,aux0] */
     ftc_ref out;
     ftc_ref w;                 /* CONV: [Cout][k*k][Cin] (K-major);  DWCONV: [9][C] fp32;
                                   STEM: [27][Cout] fp32;  SE: fc1 [S][C] fp32 */
@@ -123,6 +124,9 @@ typedef struct ftc_op {
     ftc_ref scale;             /* CONV+SE_SCALE: fp32 [B,Cin];  UPCAT: BN scale fp32 [aux1] */
     ftc_ref shift;             /* UPCAT: BN shift fp32 [aux1] */
     ftc_ref aux;               /* DWCONV: partial sums out fp32 [B,P,C];  SE: partial sums in */
+    ftc_ref out2;              /* CONV / STEM with fp32 `out`: optional bf16 copy [B,Ho,Wo,Cout] of the same
+                                  values (the fp32 tensor feeds the residual adds, the copy feeds the
+                                  next bf16 GEMM without a conversion pass) */
 } ftc_op;
 
 typedef struct ftc_plan ftc_plan;

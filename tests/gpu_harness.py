@@ -9,7 +9,7 @@ import torch
 
 from findtextcenternet_amd import _lib as L
 
-REF_FIELDS = ("in_", "in2", "out", "w", "w2", "bias", "bias2", "scale", "shift", "aux")
+REF_FIELDS = ("in_", "in2", "out", "w", "w2", "bias", "bias2", "scale", "shift", "aux", "out2")
 
 
 def to_dev_bytes(t: torch.Tensor, dtype: int) -> torch.Tensor:

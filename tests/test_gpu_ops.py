@@ -110,6 +110,28 @@ def test_conv(case, mode):
         assert (raw[:, keep] == 0xCD).all()
 
 
+def test_conv_dual_output_bf16_copy():
+    """fp32 trunk output + bf16 copy (ftc_op.out2) written by the same epilogue."""
+    g = torch.Generator().manual_seed(77)
+    B, H, W, Cin, Cout = 2, 12, 12, 384, 64
+    x = bf16_round(torch.randn(B, H, W, Cin, generator=g))
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.3
+    res = torch.randn(B, H, W, Cout, generator=g)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), bf16_round(w), None).permute(0, 2, 3, 1) + bias + res
+    ar = Arena()
+    o_in, o_w, o_b, o_res = ar.put(to_dev_bytes(x, L.BF16)), ar.put(to_dev_bytes(w.reshape(Cout, 1, Cin), L.BF16)), ar.put(bias), ar.put(res)
+    o_out, o_out2 = ar.reserve(B * H * W * Cout * 4), ar.reserve(B * H * W * Cout * 2)
+    ar.materialize()
+    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_RESIDUAL, act=L.ACT_NONE, in_dtype=L.BF16, out_dtype=L.F32, w_dtype=L.BF16, B=B, H=H, W=W,
+                Ho=H, Wo=W, Cin=Cin, Cin_total=Cin, Cout=Cout, Cout_total=Cout, ksize=1, stride=1, res_dtype=L.F32,
+                in_=o_in, in2=o_res, out=o_out, out2=o_out2, w=o_w, bias=o_b), ar)
+    out = ar.read(o_out, (B, H, W, Cout), torch.float32)
+    out2 = ar.read(o_out2, (B, H, W, Cout), torch.bfloat16)
+    assert _rel(out, ref) < 1.5e-2
+    assert torch.equal(out2, out.to(torch.bfloat16))            # the copy is the RNE rounding of the fp32 value
+
+
 @pytest.mark.parametrize("odt", [L.F32, L.BF16])
 @pytest.mark.parametrize("nchw", [False, True])
 def test_stem(nchw, odt):
@@ -161,6 +183,7 @@ def test_dwconv_and_se(shape, dt):
     o_part = ar.reserve(B * P * Cc * 4)
     o_w1, o_b1, o_w2t, o_b2 = ar.put(w1), ar.put(b1), ar.put(w2.t().contiguous()), ar.put(b2)
     o_scale = ar.reserve(B * Cc * 4)
+    o_hid = ar.reserve(B * S * 4)
     ar.materialize()
     run_op(dict(kind=L.OP_DWCONV, act=L.ACT_SILU, in_dtype=dt, out_dtype=dt, B=B, H=H, W=W, Ho=Ho, Wo=Wo, Cin=Cc, Cout=Cc, ksize=3,
                 stride=stride, aux0=P, in_=o_in, out=o_out, w=o_w, bias=o_b, aux=o_part), ar)
@@ -173,7 +196,7 @@ def test_dwconv_and_se(shape, dt):
     _log(f"dwconv {shape} dt={dt} rel_err {err:.3e} mean_err {err_mean:.3e}")
     assert err < (1e-5 if dt == L.F32 else 6e-3)
     assert err_mean < (1e-5 if dt == L.F32 else 2e-3)
-    run_op(dict(kind=L.OP_SE, B=B, H=Ho, W=Wo, Cin=Cc, Cout=Cc, aux0=S, aux1=P, aux=o_part, out=o_scale, w=o_w1, w2=o_w2t,
+    run_op(dict(kind=L.OP_SE, B=B, H=Ho, W=Wo, Cin=Cc, Cout=Cc, aux0=S, aux1=P, aux=o_part, out=o_scale, in2=o_hid, w=o_w1, w2=o_w2t,
                 bias=o_b1, bias2=o_b2), ar)
     sc = ar.read(o_scale, (B, Cc), torch.float32)
     ref_sc = torch.sigmoid(F.silu(mean @ w1.t() + b1) @ w2.t() + b2)

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the implicit-GEMM conv kernel on representative detector layers (GPU box).
+
+    python tools/conv_bench.py [--mode bf16|fp32] [--batch 8] [--reps 20] [--only NAME_SUBSTR]
+
+Each shape is run as a single-op plan through the C ABI; time = HIP events (ftc_plan_profile)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from findtextcenternet_amd import _lib as L  # noqa: E402
+
+# name, H, W, Cin, Cout, k, stride, act, residual, se, in_trunk(f32 in bf16 mode), out_trunk
+SHAPES = [
+    ("stage1 3x3 32->32", 384, 384, 32, 32, 3, 1, 1, True, False, True, True),
+    ("stage2 3x3 64->256", 192, 192, 64, 256, 3, 1, 1, False, False, True, False),
+    ("stage2 1x1 256->64", 192, 192, 256, 64, 1, 1, 0, True, False, False, True),
+    ("stage3 3x3 96->384", 96, 96, 96, 384, 3, 1, 1, False, False, True, False),
+    ("stage3 1x1 384->96", 96, 96, 384, 96, 1, 1, 0, True, False, False, True),
+    ("stage5 exp 256->1536", 48, 48, 256, 1536, 1, 1, 1, False, False, True, False),
+    ("stage5 proj 1536->256", 48, 48, 1536, 256, 1, 1, 0, True, True, False, True),
+    ("stage6 exp 512->3072", 24, 24, 512, 3072, 1, 1, 1, False, False, True, False),
+    ("stage6 proj 3072->512", 24, 24, 3072, 512, 1, 1, 0, True, True, False, True),
+    ("fpn L0 1280->192", 24, 24, 1280, 192, 3, 1, 2, False, False, False, False),
+    ("fpn L1 448->192", 48, 48, 448, 192, 3, 1, 2, False, False, False, False),
+    ("fpn L2 288->192", 96, 96, 288, 192, 3, 1, 2, False, False, False, False),
+    ("fpn L3 256->192", 192, 192, 256, 192, 3, 1, 2, False, False, False, False),
+    ("top 192->100", 192, 192, 192, 100, 3, 1, 0, False, False, False, True),
+    ("top 192->1", 192, 192, 192, 1, 3, 1, 0, False, False, False, True),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="bf16")
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--nbuf", type=int, default=0, help="buffering hint (ftc_op.aux0): 0 auto, 1 single, 2 double")
+    a = ap.parse_args()
+    lib = L.load()
+    dev = torch.device("cuda")
+    cdt = L.F32 if a.mode == "fp32" else L.BF16
+    peak = 157.3 if a.mode == "fp32" else 2500.0
+    print(f"{'layer':26s} {'M':>8s} {'N':>5s} {'K':>6s} {'us':>9s} {'TFLOP/s':>8s} {'%peak':>6s}  kernel")
+    for (name, H, W, Cin, Cout, k, stride, act, res, se, in_tr, out_tr) in SHAPES:
+        if a.only and a.only not in name:
+            continue
+        B = a.batch
+        idt = L.F32 if a.mode == "fp32" else L.BF16      # bf16 mode: GEMMs read the bf16 trunk copy
+        odt = L.F32 if (a.mode == "fp32" or out_tr) else L.BF16
+        Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+        es = lambda d: 4 if d == L.F32 else 2  # noqa: E731
+        sizes = {"in": B * H * W * Cin * es(idt), "w": Cout * k * k * Cin * es(cdt), "bias": Cout * 4,
+                 "res": B * Ho * Wo * Cout * 4 if res else 0, "se": B * Cin * 4 if se else 0, "out": B * Ho * Wo * Cout * es(odt)}
+        off, cur = {}, 0
+        for key, n in sizes.items():
+            off[key] = cur
+            cur = (cur + n + 255) // 256 * 256
+        ws = torch.empty(cur + 256, dtype=torch.uint8, device=dev)
+        # random contents (bench on random data, not zeros: DVFS)
+        nfl = (cur + 256) // 4
+        ws.view(torch.float32)[:nfl].normal_(0, 0.5)
+        if idt == L.BF16:
+            ws[off["in"]:off["in"] + sizes["in"]].view(torch.bfloat16).normal_(0, 0.5)
+        if cdt == L.BF16:
+            ws[off["w"]:off["w"] + sizes["w"]].view(torch.bfloat16).normal_(0, 0.05)
+        op = (L.Op * 1)()
+        o = op[0]
+        o.kind, o.flags, o.act = L.OP_CONV, (L.FLAG_RESIDUAL if res else 0) | (L.FLAG_SE_SCALE if se else 0), act
+        o.in_dtype, o.out_dtype, o.w_dtype, o.res_dtype = idt, odt, cdt, L.F32
+        o.B, o.H, o.W, o.Ho, o.Wo = B, H, W, Ho, Wo
+        o.Cin = o.Cin_total = Cin
+        o.Cout = o.Cout_total = Cout
+        o.ksize, o.stride = k, stride
+        o.aux0 = a.nbuf
+        for fld, key in (("in_", "in"), ("w", "w"), ("bias", "bias"), ("out", "out")):
+            r = getattr(o, fld); r.base, r.offset = L.BASE_WORKSPACE, off[key]
+        if res:
+            o.in2.base, o.in2.offset = L.BASE_WORKSPACE, off["res"]
+        if se:
+            o.scale.base, o.scale.offset = L.BASE_WORKSPACE, off["se"]
+        h = C.c_void_p()
+        L.check(lib.ftc_plan_create(op, 1, cur + 256, 0, C.byref(h)), "create")
+        bases = (C.c_void_p * L.NUM_BASES)(None, ws.data_ptr(), None, None, None, None)
+        ms = (C.c_float * 1)()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for _ in range(3):
+            lib.ftc_plan_run(h, bases, st, 0, -1)
+        ts = []
+        for _ in range(a.reps):
+            L.check(lib.ftc_plan_profile(h, bases, st, ms), "profile")
+            ts.append(ms[0])
+        t = float(np.median(ts))
+        fl = 2.0 * B * Ho * Wo * Cout * Cin * k * k
+        buf = C.create_string_buffer(128)
+        lib.ftc_op_kernel_label(C.byref(o), buf, 128)
+        tf = fl / (t * 1e-3) / 1e12
+        print(f"{name:26s} {B * Ho * Wo:8d} {Cout:5d} {Cin * k * k:6d} {t * 1e3:9.1f} {tf:8.1f} {100 * tf / peak:6.1f}  {buf.value.decode()}")
+        lib.ftc_plan_destroy(h)
+        del ws
+
+
+if __name__ == "__main__":
+    main()

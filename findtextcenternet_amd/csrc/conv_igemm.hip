@@ -12,8 +12,10 @@ hipError_t launch_conv_bf16_ff(const ConvP& p, const ftc_op& o, hipStream_t s);
 
 void conv_kernel_label(const ftc_op& op, char* buf, int len) {
     const char* dt[] = {"f32", "bf16"};
-    snprintf(buf, len, "conv_igemm<%s,in=%s,out=%s,tile=%s,bk=%d,nbuf=%d>", dt[op.w_dtype & 1], dt[op.in_dtype & 1], dt[op.out_dtype & 1],
-             kCfgName[select_cfg(op.Cout, op.B * op.Ho * op.Wo)], select_bk(op), select_nbuf(op));
+    const bool dma = uses_glds(op);
+    snprintf(buf, len, "conv_igemm%s<%s,in=%s,out=%s,tile=%s,bk=%d,nbuf=%d>", dma ? "_glds" : "", dt[op.w_dtype & 1], dt[op.in_dtype & 1],
+             dt[op.out_dtype & 1], kCfgName[select_cfg(op.Cout, op.B * op.Ho * op.Wo)], select_bk(op),
+             dma ? ((op.aux0 & 8) ? 3 : 2) : select_nbuf(op));
 }
 
 const char* conv_validate(const ftc_op& op) {
@@ -31,12 +33,13 @@ const char* conv_validate(const ftc_op& op) {
     if (op.Ho != (op.H + 2 * pad - op.ksize) / op.stride + 1 || op.Wo != (op.W + 2 * pad - op.ksize) / op.stride + 1)
         return "conv: Ho/Wo inconsistent with H/W/ksize/stride";
     if ((op.flags & FTC_FLAG_SE_SCALE) && op.ksize != 1) return "conv: SE scale only on 1x1";
+    if ((op.flags & FTC_FLAG_BORDER_BIAS) && (op.ksize != 3 || op.stride != 1)) return "conv: border-bias table only for 3x3 stride 1";
     if ((long)op.B * op.Ho * op.Wo > 0x7fffffffL / 4) return "conv: too many output pixels";
     // buffer addressing is 32-bit: keep every operand below 2 GiB
     const long in_bytes = (long)op.B * op.H * op.W * op.Cin_total * (op.in_dtype == FTC_F32 ? 4 : 2);
     const long w_bytes = (long)op.Cout * op.ksize * op.ksize * op.Cin * (op.w_dtype == FTC_F32 ? 4 : 2);
     if (in_bytes >= 0x7ff00000L || w_bytes >= 0x7ff00000L) return "conv: operand larger than 2 GiB (split the batch)";
-    if (op.aux0 < 0 || op.aux0 > 2) return "conv: aux0 (buffering hint) must be 0, 1 or 2";
+    if (op.aux0 < 0 || op.aux0 > 31) return "conv: aux0 (tuning hints) out of range";
     return nullptr;
 }
 
@@ -54,6 +57,8 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
     p.act = o.act; p.flags = o.flags; p.res_dtype = o.res_dtype;
     p.M = o.B * o.Ho * o.Wo;
     p.ncb = p.nk = p.nN = p.nblk = 0;
+    p.use_glds = uses_glds(o) ? 1 : 0;
+    p.glds_nbuf = (o.aux0 & 8) ? 3 : 2;
     if (o.w_dtype == FTC_F32) return launch_conv_f32(p, o, s);
     if (o.in_dtype == FTC_BF16 && o.out_dtype == FTC_BF16) return launch_conv_bf16_bb(p, o, s);
     if (o.in_dtype == FTC_F32 && o.out_dtype == FTC_BF16) return launch_conv_bf16_fb(p, o, s);

@@ -25,6 +25,7 @@
 // LDS rows are padded by one 16-byte chunk: conflict-free ds_read_b128 fragments.
 #pragma once
 #include <cstdio>
+#include <type_traits>
 
 #include "ftc_common.h"
 
@@ -49,6 +50,8 @@ struct ConvP {
     int nk;     // KS*KS*ncb
     int nN;     // channel tiles
     int nblk;   // total workgroups
+    int use_glds;   // direct-to-LDS kernel selected (uses_glds)
+    int glds_nbuf;  // tuning: LDS ring depth of the DMA kernel (2 | 3)
 };
 
 template <typename WT> struct Frag;
@@ -96,6 +99,62 @@ __device__ __forceinline__ u32x4 load_act(__amdgpu_buffer_rsrc_t rin, int voff, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) r[e] = (__bf16)f[e];
         return __builtin_bit_cast(u32x4, r);
+    }
+}
+
+// Epilogue shared by both kernels: lane owns pixel (l31) of each 32-pixel sub-tile and, per register
+// quad q, channels 8q + 4*half .. +3 of each 32-channel sub-tile (C/D layout of the 32x32 MFMA).
+template <typename WT, typename OutT, int SN, int SM>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[SN][SM], int m0, int n0, int wn, int wm, int half, int l31) {
+    OutT* __restrict__ outp = reinterpret_cast<OutT*>(p.out);
+    const bool has_res = (p.flags & FTC_FLAG_RESIDUAL) != 0;
+    const bool vec_ok = ((p.Cout | p.CoutT | p.cout_off) & 3) == 0;
+#pragma unroll
+    for (int j = 0; j < SM; ++j) {
+        const int m = m0 + wm * SM * 32 + j * 32 + l31;
+        if (m >= p.M) continue;
+        OutT* orow = outp + (size_t)m * p.CoutT + p.cout_off;
+        const float* brow = p.bias;
+        if (p.flags & FTC_FLAG_BORDER_BIAS) {
+            const int rem = m % (p.Ho * p.Wo);
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int idx = (oy == 0 ? 1 : 0) | (oy == p.Ho - 1 ? 2 : 0) | (ox == 0 ? 4 : 0) | (ox == p.Wo - 1 ? 8 : 0);
+            brow += idx * p.Cout;
+        }
+#pragma unroll
+        for (int i = 0; i < SN; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * SN * 32 + i * 32 + 8 * q + 4 * half;
+                if (n >= p.Cout) continue;
+                if (vec_ok) {
+                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    v += *reinterpret_cast<const f32x4*>(brow + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = apply_act_sel<sizeof(WT) == 2>(v[e], p.act);
+                    if (has_res) {
+                        if (p.res_dtype == FTC_F32) v += load4<float>(reinterpret_cast<const float*>(p.res) + (size_t)m * p.Cout + n);
+                        else v += load4<__bf16>(reinterpret_cast<const __bf16*>(p.res) + (size_t)m * p.Cout + n);
+                    }
+                    store4<OutT>(orow + n, v);
+                    if constexpr (sizeof(OutT) == 4) {
+                        if (p.out2) store4<__bf16>(reinterpret_cast<__bf16*>(p.out2) + (size_t)m * p.Cout + n, v);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e >= p.Cout) continue;
+                        float v = acc[i][j][4 * q + e] + brow[n + e];
+                        v = apply_act_sel<sizeof(WT) == 2>(v, p.act);
+                        if (has_res) {
+                            if (p.res_dtype == FTC_F32) v += reinterpret_cast<const float*>(p.res)[(size_t)m * p.Cout + n + e];
+                            else v += (float)reinterpret_cast<const __bf16*>(p.res)[(size_t)m * p.Cout + n + e];
+                        }
+                        orow[n + e] = from_f32<OutT>(v);
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -279,51 +338,185 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         }
     }
 
-    // Epilogue: lane owns pixel (l31) of each 32-pixel sub-tile and, per register quad q,
-    // channels 8q + 4*half .. +3 of each 32-channel sub-tile (C/D layout of the 32x32 MFMA).
-    OutT* __restrict__ outp = reinterpret_cast<OutT*>(p.out);
-    const bool has_res = (p.flags & FTC_FLAG_RESIDUAL) != 0;
-    const bool vec_ok = ((p.Cout | p.CoutT | p.cout_off) & 3) == 0;
+    conv_epilogue<WT, OutT, SN, SM>(p, acc, m0, n0, wn, wm, half, l31);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Direct-to-LDS variant (buffer_load ... lds): used whenever the activation dtype equals the MFMA
+// compute dtype and no SE scale is applied, i.e. for ~95 % of the FLOPs.  The staging pass of the
+// register kernel (ds_write_b128 at ~79 B/clk/CU) made the LDS pipe as busy as the MFMA pipe; here
+// the tiles go HBM/L2 -> LDS by DMA: no staging VGPRs, no ds_write, and NBUF-1 tiles stay in
+// flight across the single barrier per K step (counted s_waitcnt vmcnt).
+// LDS image: unpadded rows of CPR 16-byte chunks; a wave-level DMA writes 64 consecutive chunks,
+// so the bank-conflict-avoiding XOR swizzle is applied on the SOURCE side (lane -> which global
+// chunk it fetches) and again on the fragment read: slot = chunk ^ f(row), f(row) = (row>>1)&7 for
+// 128-byte rows, (row>>2)&3 for 64-byte rows (conflict-free ds_read_b128).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// (kept in a __device__ function: called straight from a lambda the builtin makes the host pass drop the kernel stub)
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, lds_void_t* dst, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void wg_barrier() { __builtin_amdgcn_s_barrier(); }
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename WT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF>
+__global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p) {
+    constexpr int E = 16 / (int)sizeof(WT);
+    constexpr int CPR = BK / E;                  // 16-byte chunks per row: 8 (128-byte rows) or 4
+    constexpr int ROWB = CPR * 16;
+    constexpr int TN = WN * SN * 32, TM = WM * SM * 32;
+    constexpr int NCH = (TN + TM) * CPR;         // chunks per tile
+    constexpr int NL = NCH / 256;                // DMA instructions per thread per tile
+    constexpr int ACH = TN * CPR;                // chunks of the weight part
+    constexpr int BUFB = NCH * 16;               // bytes per LDS buffer
+    constexpr int D = NBUF - 1;                  // tiles in flight
+    static_assert(CPR == 8 || CPR == 4, "");
+    static_assert(NCH % 256 == 0 && ACH % 64 == 0, "tile must be a whole number of wave-level DMAs");
+    static_assert(WN * WM == 4 && (NBUF == 2 || NBUF == 3), "");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wn = wave / WM, wm = wave % WM;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    int bid = blockIdx.x;
+    {
+        const int q = p.nblk >> 3, r = p.nblk & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int mt = bid / p.nN, nt = bid - mt * p.nN;
+    const int m0 = mt * TM, n0 = nt * TN;
+
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+    const int HoWo = p.Ho * p.Wo;
+    const int KK = p.KS * p.KS;
+
+    // DMA slot q = i*256 + t of a tile: LDS byte q*16; rows of the weight part first, pixels after.
+    int s_off[NL], s_mask[NL];                   // byte offset (global), tap mask | (chunk index << 16)
 #pragma unroll
-    for (int j = 0; j < SM; ++j) {
-        const int m = m0 + wm * SM * 32 + j * 32 + l31;
-        if (m >= p.M) continue;
-        OutT* orow = outp + (size_t)m * p.CoutT + p.cout_off;
-#pragma unroll
-        for (int i = 0; i < SN; ++i) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * SN * 32 + i * 32 + 8 * q + 4 * half;
-                if (n >= p.Cout) continue;
-                if (vec_ok) {
-                    f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                    v += *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act_sel<sizeof(WT) == 2>(v[e], p.act);
-                    if (has_res) {
-                        if (p.res_dtype == FTC_F32) v += load4<float>(reinterpret_cast<const float*>(p.res) + (size_t)m * p.Cout + n);
-                        else v += load4<__bf16>(reinterpret_cast<const __bf16*>(p.res) + (size_t)m * p.Cout + n);
-                    }
-                    store4<OutT>(orow + n, v);
-                    if constexpr (sizeof(OutT) == 4) {
-                        if (p.out2) store4<__bf16>(reinterpret_cast<__bf16*>(p.out2) + (size_t)m * p.Cout + n, v);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (n + e >= p.Cout) continue;
-                        float v = acc[i][j][4 * q + e] + p.bias[n + e];
-                        v = apply_act_sel<sizeof(WT) == 2>(v, p.act);
-                        if (has_res) {
-                            if (p.res_dtype == FTC_F32) v += reinterpret_cast<const float*>(p.res)[(size_t)m * p.Cout + n + e];
-                            else v += (float)reinterpret_cast<const __bf16*>(p.res)[(size_t)m * p.Cout + n + e];
-                        }
-                        orow[n + e] = from_f32<OutT>(v);
-                    }
-                }
-            }
+    for (int i = 0; i < NL; ++i) {
+        const int q = i * 256 + t;
+        const bool isA = (ACH % 256 == 0) ? (i < ACH / 256) : (i * 256 + wave * 64 < ACH);
+        const int qq = isA ? q : q - ACH;
+        const int row = qq / CPR, slot = qq % CPR;
+        const int kc = slot ^ (CPR == 8 ? (row >> 1) & 7 : (row >> 2) & 3);
+        if (isA) {
+            const int n = n0 + row;
+            s_off[i] = n < p.Cout ? (n * KK * p.Cin + kc * E) * (int)sizeof(WT) : OOB;
+            s_mask[i] = 0x1ff | (kc << 16);
+        } else {
+            const int m = m0 + row;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
+            const int img = mm / HoWo;
+            const int rem = mm - img * HoWo;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+            s_off[i] = (((img * p.H + iy0) * p.W + ix0) * p.CinT + p.cin_off + kc * E) * (int)sizeof(WT);
+            int mask = 0;
+            for (int r = 0; r < p.KS; ++r)
+                for (int s = 0; s < p.KS; ++s)
+                    if (ok && (unsigned)(iy0 + r) < (unsigned)p.H && (unsigned)(ix0 + s) < (unsigned)p.W) mask |= 1 << (r * p.KS + s);
+            s_mask[i] = mask | (kc << 16);
         }
     }
+
+    int ld_tap = 0, ld_r = 0, ld_s = 0, ld_cb = 0;
+    // `bufoff` = byte offset of the ring slot (wave-uniform, lives in an SGPR): one straight-line loop
+    // body, so the accumulators stay in AGPRs (an unrolled-by-NBUF body made hipcc shuttle all 96 of
+    // them through VGPRs every K step).
+    auto issue = [&](int bufoff) {
+        const int c0 = ld_cb * BK;
+        const int w_soff = (ld_tap * p.Cin + c0) * (int)sizeof(WT);
+        const int in_toff = ((ld_r * p.W + ld_s) * p.CinT + c0) * (int)sizeof(WT);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const bool isA = (ACH % 256 == 0) ? (i < ACH / 256) : (i * 256 + wave * 64 < ACH);
+            const bool cok = BK == 64 ? true : (c0 + (s_mask[i] >> 16) * E) < p.Cin;
+            lds_void_t* dst = (lds_void_t*)(smem_raw + bufoff + (i * 256 + wave * 64) * 16);
+            if (isA) {
+                glds16(rw, dst, cok ? s_off[i] : OOB, w_soff);
+            } else {
+                const bool ok = cok && ((s_mask[i] >> ld_tap) & 1);
+                glds16(rin, dst, ok ? s_off[i] + in_toff : OOB, 0);
+            }
+        }
+        if (++ld_cb == p.ncb) {
+            ld_cb = 0;
+            ++ld_tap;
+            if (++ld_s == p.KS) { ld_s = 0; ++ld_r; }
+        }
+    };
+
+    f32x16 acc[SN][SM];
+#pragma unroll
+    for (int i = 0; i < SN; ++i)
+#pragma unroll
+        for (int j = 0; j < SM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    using FragT = typename Frag<WT>::type;
+    constexpr int G = CPR / 2;                   // MFMA K groups per tile (two chunks each: lower / upper half-wave)
+    const int fr = CPR == 8 ? (l31 >> 1) & 7 : (l31 >> 2) & 3;
+    int offA[G], offB[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int sl = ((g * 2 + half) ^ fr) * 16;
+        offA[g] = (wn * SN * 32 + l31) * ROWB + sl;
+        offB[g] = (TN + wm * SM * 32 + l31) * ROWB + sl;
+    }
+    auto compute = [&](int bufoff) {
+        const unsigned char* base = smem_raw + bufoff;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            FragT af[SN], bf[SM];
+#pragma unroll
+            for (int i = 0; i < SN; ++i) af[i] = *reinterpret_cast<const FragT*>(base + offA[g] + i * 32 * ROWB);
+#pragma unroll
+            for (int j = 0; j < SM; ++j) bf[j] = *reinterpret_cast<const FragT*>(base + offB[g] + j * 32 * ROWB);
+            if constexpr (sizeof(WT) == 4) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int i = 0; i < SN; ++i)
+#pragma unroll
+                        for (int j = 0; j < SM; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < SN; ++i)
+#pragma unroll
+                    for (int j = 0; j < SM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    // prologue: D tiles in flight
+    int iss_off = 0, cur_off = 0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        if (j < p.nk) issue(iss_off);
+        iss_off += BUFB;
+    }
+    for (int it = 0; it < p.nk; ++it) {
+        // tile `it` has landed once at most the later-issued tiles remain outstanding
+        if (D == 1 || it + 1 >= p.nk) wait_vmcnt<0>(); else wait_vmcnt<NL>();
+        wg_barrier();
+        if (it + D < p.nk) issue(iss_off);                   // that slot was consumed in step it-1
+        iss_off = iss_off + BUFB == NBUF * BUFB ? 0 : iss_off + BUFB;
+        compute(cur_off);
+        cur_off = cur_off + BUFB == NBUF * BUFB ? 0 : cur_off + BUFB;
+    }
+    conv_epilogue<WT, OutT, SN, SM>(p, acc, m0, n0, wn, wm, half, l31);
 }
 
 template <typename WT, typename InT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF, bool SE>
@@ -349,8 +542,37 @@ hipError_t launch_cfg2(ConvP p, hipStream_t s) {
     return hipGetLastError();
 }
 
+template <typename WT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF>
+hipError_t launch_glds(ConvP p, hipStream_t s) {
+    constexpr int E = 16 / (int)sizeof(WT);
+    constexpr int TN = WN * SN * 32, TM = WM * SM * 32;
+    constexpr size_t lds_bytes = (size_t)NBUF * (TN + TM) * (BK / E) * 16;
+    auto kern = conv_igemm_glds_kernel<WT, OutT, BK, WN, WM, SN, SM, NBUF>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    p.ncb = (p.Cin + BK - 1) / BK;
+    p.nk = p.KS * p.KS * p.ncb;
+    p.nN = (p.Cout + TN - 1) / TN;
+    p.nblk = p.nN * ((p.M + TM - 1) / TM);
+    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(256), lds_bytes, s, p);
+    return hipGetLastError();
+}
+
 template <typename WT, typename InT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF>
 hipError_t launch_cfg(const ConvP& p, hipStream_t s) {
+    constexpr int E = 16 / (int)sizeof(WT);
+    constexpr bool glds_ok = sizeof(WT) == sizeof(InT) && (((WN * SN + WM * SM) * 32 * (BK / E)) % 256 == 0) &&
+                             ((WN * SN * 32 * (BK / E)) % 64 == 0);
+    if constexpr (glds_ok) {
+        if (p.use_glds) {
+            if (p.glds_nbuf == 3) return launch_glds<WT, OutT, BK, WN, WM, SN, SM, 3>(p, s);
+            return launch_glds<WT, OutT, BK, WN, WM, SN, SM, 2>(p, s);
+        }
+    }
     // the SE-scaled variant exists only where the network uses it: 1x1 project convs
     if (p.flags & FTC_FLAG_SE_SCALE) return launch_cfg2<WT, InT, OutT, BK, WN, WM, SN, SM, NBUF, true>(p, s);
     return launch_cfg2<WT, InT, OutT, BK, WN, WM, SN, SM, NBUF, false>(p, s);
@@ -372,10 +594,26 @@ inline int select_cfg(int n, int M) {
 
 // K step: 64 for bf16 when the channel count allows it (half the barriers), else 32.
 inline int select_bk(const ftc_op& o) { return (o.w_dtype == FTC_BF16 && o.Cin % 64 == 0) ? 64 : 32; }
-// LDS buffering: tuning hint in ftc_op.aux0 (0 = default, 1 = single buffer, 2 = double buffer).
+// Tuning hints in ftc_op.aux0 (0 = defaults): bits 0-1 LDS buffering of the register-staged kernel
+// (1 single, 2 double), bit 2 (4) = never use the direct-to-LDS kernel, bit 3 (8) = 3-deep DMA ring,
+// bit 4 (16) = use the direct-to-LDS kernel wherever it is legal.
 // Measured (tools/conv_bench.py): bf16 wants the single buffer (2-3 workgroups per CU hide the two
 // barriers better than one double-buffered workgroup: FPN L3 689 vs 391 TF).
-inline int select_nbuf(const ftc_op& o) { return o.aux0 == 1 ? 1 : (o.aux0 == 2 ? 2 : 1); }
+inline int select_nbuf(const ftc_op& o) { return (o.aux0 & 3) == 2 ? 2 : 1; }
+inline bool uses_glds(const ftc_op& o) {
+    if ((o.aux0 & 4) || (o.flags & FTC_FLAG_SE_SCALE) || o.in_dtype != o.w_dtype) return false;
+    const int cpr = (o.w_dtype == FTC_BF16 && o.Cin % 64 == 0) ? 8 : (o.w_dtype == FTC_BF16 ? 4 : 8);
+    const int cfg = select_cfg(o.Cout, o.B * o.Ho * o.Wo);
+    const int tn[] = {32, 64, 96, 192, 128, 128}, tm[] = {256, 128, 128, 128, 64, 128};
+    // tiles must be a whole number of workgroup-level DMA passes
+    if (((tn[cfg] + tm[cfg]) * cpr) % 256 != 0 || (tn[cfg] * cpr) % 64 != 0) return false;
+    if (o.aux0 & 16) return true;                       // tuning: force the DMA kernel where legal
+    // Measured (tools/conv_bench.py, MI355X): the 2-slot DMA ring wins on the 192x128 and 64x128 tiles
+    // (FPN: 819 vs 746 TF); on 128-channel tiles the register-staged kernel keeps 3-4 workgroups per
+    // CU with its single 36 KB buffer and is faster (stage2 3x3: 504 vs 439 TF).  fp32: DMA everywhere.
+    if (o.w_dtype == FTC_F32) return true;
+    return cfg == CFG_192x128 || cfg == CFG_64x128;
+}
 
 template <typename WT, typename InT, typename OutT, int BK, int NBUF>
 hipError_t launch_tiles(const ConvP& p, int cfg, hipStream_t s) {

@@ -15,7 +15,7 @@ template <typename T, typename TapT>
 __global__ __launch_bounds__(256) void upcat_kernel(const T* __restrict__ prev, const TapT* __restrict__ tap,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                     T* __restrict__ out, int B, int Hi, int Wi, int Ho, int Wo,
-                                                    int Cy, int Ct, float ry, float rx) {
+                                                    int Cy, int Ct, int CyT, float ry, float rx) {
     const int Ctot = Cy + Ct;
     const int Q = Ctot >> 2;
     const long total = (long)B * Ho * Wo * Q;
@@ -34,11 +34,11 @@ __global__ __launch_bounds__(256) void upcat_kernel(const T* __restrict__ prev, 
             const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
             const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
             const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
-            const T* base = prev + (long)b * Hi * Wi * Cy + c;
-            const f32x4 v00 = load4<T>(base + ((long)y0 * Wi + x0) * Cy);
-            const f32x4 v01 = load4<T>(base + ((long)y0 * Wi + x1) * Cy);
-            const f32x4 v10 = load4<T>(base + ((long)y1 * Wi + x0) * Cy);
-            const f32x4 v11 = load4<T>(base + ((long)y1 * Wi + x1) * Cy);
+            const T* base = prev + (long)b * Hi * Wi * CyT + c;      // prev already points at its channel slice
+            const f32x4 v00 = load4<T>(base + ((long)y0 * Wi + x0) * CyT);
+            const f32x4 v01 = load4<T>(base + ((long)y0 * Wi + x1) * CyT);
+            const f32x4 v10 = load4<T>(base + ((long)y1 * Wi + x0) * CyT);
+            const f32x4 v11 = load4<T>(base + ((long)y1 * Wi + x1) * CyT);
             v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
         } else {
             const int ct = c - Cy;
@@ -84,14 +84,15 @@ __global__ __launch_bounds__(256) void nms_kernel(float* __restrict__ heat, int 
 hipError_t launch_upcat(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
     const int Cy = o.aux0, Ct = o.aux1;
+    const int CyT = o.Cin_total > 0 ? o.Cin_total : Cy;     // channel stride of the upsampled tensor
     const long total = (long)o.B * o.Ho * o.Wo * ((Cy + Ct) / 4);
     long nb = (total + 255) / 256;
     if (nb > 16384) nb = 16384;
     const float ry = o.Ho > 1 ? (float)(o.H - 1) / (float)(o.Ho - 1) : 0.f;
     const float rx = o.Wo > 1 ? (float)(o.W - 1) / (float)(o.Wo - 1) : 0.f;
 #define UPCAT_LAUNCH(T, TT)                                                                                       \
-    hipLaunchKernelGGL((upcat_kernel<T, TT>), dim3((unsigned)nb), dim3(256), 0, s, (const T*)a.in, (const TT*)a.in2, \
-                       a.scale, a.shift, (T*)a.out, o.B, o.H, o.W, o.Ho, o.Wo, Cy, Ct, ry, rx)
+    hipLaunchKernelGGL((upcat_kernel<T, TT>), dim3((unsigned)nb), dim3(256), 0, s, (const T*)a.in + o.cin_off, (const TT*)a.in2, \
+                       a.scale, a.shift, (T*)a.out, o.B, o.H, o.W, o.Ho, o.Wo, Cy, Ct, CyT, ry, rx)
     // res_dtype = dtype of the backbone tap (the trunk stays fp32 in bf16 mode)
     if (o.in_dtype == FTC_F32) UPCAT_LAUNCH(float, float);
     else if (o.res_dtype == FTC_F32) UPCAT_LAUNCH(__bf16, float);

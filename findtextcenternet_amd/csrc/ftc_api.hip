@@ -83,6 +83,7 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if (!need(o.in, o.aux0 > 0, "in") || !need(o.in2, true, "in2") || !need(o.out, true, "out") || !need(o.scale, true, "scale") ||
             !need(o.shift, true, "shift")) return why->c_str();
         if (o.aux0 % 4 || o.aux1 % 4 || o.aux1 <= 0) return "upcat: channel counts must be multiples of 4";
+        if (o.aux0 > 0 && o.Cin_total > 0 && (o.Cin_total % 4 || o.cin_off % 4 || o.cin_off + o.aux0 > o.Cin_total)) return "upcat: bad channel slice of the upsampled tensor";
         if (o.in_dtype != o.out_dtype) return "upcat: in/out dtype must match";
         return nullptr;
     case FTC_OP_NMS:

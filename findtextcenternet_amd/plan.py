@@ -133,6 +133,27 @@ def pack_weights(sd: Dict[str, torch.Tensor], mode: str = "fp32", model_size: st
     hp = f"backbone.features.{nfeat}"
     conv_bn(hp, hp + ".0.weight", hp + ".1", BACKBONE_BN_EPS)
     ntap = len(TAP_DIMS[model_size])
+    # FPN level 0 of all nine heads as ONE convolution over the shared 1/32 tap: each head's input
+    # BatchNorm is folded in exactly -- scale into the weights, shift into a 16-entry border-case bias
+    # table (the shift does not see the zero padding ring, so its contribution depends on which taps of
+    # the 3x3 window fall inside the image).  Leafmap.forward i=0, models/detector.py:194-197.
+    wm_all, bias16_all = [], []
+    for name, out_dim, _ in HEADS:
+        q = f"{name}.in_bn.{ntap - 1}"
+        g = sd[q + ".weight"].detach().cpu().double().numpy()
+        si = g / np.sqrt(sd[q + ".running_var"].detach().cpu().double().numpy() + HEAD_BN_EPS)
+        ti = sd[q + ".bias"].detach().cpu().double().numpy() - sd[q + ".running_mean"].detach().cpu().double().numpy() * si
+        wf, bo = _fold(sd, f"{name}.upsamplers.0.0.weight", f"{name}.upsamplers.0.1", HEAD_BN_EPS)      # [192,C,3,3]
+        wm_all.append(_kmajor(wf * si[None, :, None, None]))
+        tmap = np.einsum("ncrs,c->nrs", wf, ti)                                                      # [192,3,3]
+        b16 = np.zeros((16, wf.shape[0]))
+        for idx in range(16):
+            rows = [r for r in range(3) if not (r == 0 and idx & 1) and not (r == 2 and idx & 2)]
+            cols = [c for c in range(3) if not (c == 0 and idx & 4) and not (c == 2 and idx & 8)]
+            b16[idx] = bo + tmap[np.ix_(range(wf.shape[0]), rows, cols)].sum(axis=(1, 2))
+        bias16_all.append(b16)
+    bl.add("heads.L0.w", _to_compute(np.concatenate(wm_all, axis=0), mode))
+    bl.add("heads.L0.b", np.concatenate(bias16_all, axis=1).astype(np.float32))                      # [16][9*192]
     for name, out_dim, _ in HEADS:
         for i in range(ntap):
             q = f"{name}.in_bn.{i}"
@@ -141,7 +162,7 @@ def pack_weights(sd: Dict[str, torch.Tensor], mode: str = "fp32", model_size: st
             t = sd[q + ".bias"].detach().cpu().double().numpy() - sd[q + ".running_mean"].detach().cpu().double().numpy() * s
             bl.add(q + ".scale", s.astype(np.float32))
             bl.add(q + ".shift", t.astype(np.float32))
-        for i in range(ntap):
+        for i in range(1, ntap):
             q = f"{name}.upsamplers.{i}"
             conv_bn(q, q + ".0.weight", q + ".1", HEAD_BN_EPS)
         w = sd[f"{name}.top_conv.0.weight"].detach().cpu().double().numpy()
@@ -219,9 +240,9 @@ class _Builder:
 
     # --- op helpers ---------------------------------------------------------------------------
     def conv(self, name, x, xdt, H, W, cin, cin_total, cin_off, wname, cout, k, stride, act, out, odt, cout_total=None,
-             cout_off=0, residual=None, res_dt=0, se=None, out2=None):
+             cout_off=0, residual=None, res_dt=0, se=None, out2=None, extra_flags=0):
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-        flags = (L.FLAG_RESIDUAL if residual is not None else 0) | (L.FLAG_SE_SCALE if se is not None else 0)
+        flags = (L.FLAG_RESIDUAL if residual is not None else 0) | (L.FLAG_SE_SCALE if se is not None else 0) | extra_flags
         macs = self.B * Ho * Wo * cout * cin * k * k
         byt = self.B * H * W * cin * self.esize(xdt) + self.B * Ho * Wo * cout * self.esize(odt) + cout * cin * k * k * self.esize(self.cdt)
         if residual is not None:
@@ -302,24 +323,29 @@ class _Builder:
         self.conv(hp, xb if dual else x, G, h, w, stages[-1][-1].cout, stages[-1][-1].cout, 0, hp, LAST_CHANNEL, 1, 1, L.ACT_SILU, x4, A)
         taps.append((x4, LAST_CHANNEL, h, w, A))
         mh, mw = taps[0][2], taps[0][3]
-        # heads
+        # heads.  Level 0 of all nine heads is one convolution (see pack_weights); levels 1.. per head.
         ntap = len(taps)
-        for name, out_dim, ch0 in HEADS:
-            y, yh, yw = None, 0, 0
-            for i in range(ntap):
+        nh = len(HEADS)
+        t4, c4, h4, w4, dt4 = taps[ntap - 1]
+        y0 = ("buf", self.buf(B * h4 * w4 * nh * FPN_DIM, A))
+        self.conv("heads.upsamplers.0", t4, dt4, h4, w4, c4, c4, 0, "heads.L0", nh * FPN_DIM, 3, 1, L.ACT_GELU, y0, A,
+                  extra_flags=L.FLAG_BORDER_BIAS)
+        for hi, (name, out_dim, ch0) in enumerate(HEADS):
+            y, yh, yw, ystride, yoff = y0, h4, w4, nh * FPN_DIM, hi * FPN_DIM
+            for i in range(1, ntap):
                 tbuf, tc, th_, tw_, tdt = taps[ntap - 1 - i]
-                cy = FPN_DIM if y is not None else 0
+                cy = FPN_DIM
                 cat = ("buf", self.buf(B * th_ * tw_ * (cy + tc), A))
                 q = f"{name}.in_bn.{ntap - 1 - i}"
                 self.emit(OpMeta(f"{name}.cat{i}", "upcat", 0.0,
                                  B * th_ * tw_ * ((cy + tc) * self.esize(A) + tc * self.esize(tdt)) + B * yh * yw * cy * self.esize(A)),
-                          kind=L.OP_UPCAT, in_dtype=A, out_dtype=A, res_dtype=tdt, B=B, H=yh if y is not None else th_,
-                          W=yw if y is not None else tw_, Ho=th_, Wo=tw_, Cin=cy + tc, Cout=cy + tc, aux0=cy, aux1=tc,
+                          kind=L.OP_UPCAT, in_dtype=A, out_dtype=A, res_dtype=tdt, B=B, H=yh, W=yw, Ho=th_, Wo=tw_, Cin=cy + tc,
+                          Cin_total=ystride, cin_off=yoff, Cout=cy + tc, aux0=cy, aux1=tc,
                           in_=y, in2=tbuf, out=cat, scale=self.wref(q + ".scale"), shift=self.wref(q + ".shift"))
                 y = ("buf", self.buf(B * th_ * tw_ * FPN_DIM, A))
                 self.conv(f"{name}.upsamplers.{i}", cat, A, th_, tw_, cy + tc, cy + tc, 0, f"{name}.upsamplers.{i}", FPN_DIM, 3, 1,
                           L.ACT_GELU, y, A)
-                yh, yw = th_, tw_
+                yh, yw, ystride, yoff = th_, tw_, FPN_DIM, 0
             if ch0 >= 0:       # map heads write straight into their channel slice; channel 1 is the NMS slot
                 off = 0 if ch0 == 0 else ch0 + 1
                 self.conv(f"{name}.top_conv", y, A, yh, yw, FPN_DIM, FPN_DIM, 0, f"{name}.top_conv", out_dim, 3, 1, L.ACT_NONE,

@@ -87,7 +87,10 @@ enum {
 enum {
     FTC_FLAG_RESIDUAL = 1,     /* out += in2 (after activation) */
     FTC_FLAG_SE_SCALE = 2,     /* input multiplied by scale[b, cin] while staging (CONV) */
-    FTC_FLAG_IN_NCHW = 4       /* STEM: input is [B,3,H,W]-contiguous instead of NHWC */
+    FTC_FLAG_IN_NCHW = 4,      /* STEM: input is [B,3,H,W]-contiguous instead of NHWC */
+    FTC_FLAG_BORDER_BIAS = 8   /* CONV 3x3 s1: `bias` is a [16][Cout] table indexed by which image borders the
+                                  output pixel touches (top | bottom<<1 | left<<2 | right<<3): lets a per-channel
+                                  affine (BatchNorm) that PRECEDES a zero-padded conv be folded into it exactly */
 };
 
 /* One step of a plan.  Fields that an op kind does not use must be zero. */
@@ -101,7 +104,8 @@ typedef struct ftc_op {
     int32_t B, H, W;           /* input batch / height / width */
     int32_t Ho, Wo;            /* output height / width */
     int32_t Cin;               /* input channels consumed */
-    int32_t Cin_total;         /* channel stride of the input buffer (>= cin_off + Cin) */
+    int32_t Cin_total;         /* channel stride of the input buffer (>= cin_off + Cin);
+                                  UPCAT: channel stride of `in` (the tensor being upsampled) */
     int32_t cin_off;
     int32_t Cout;              /* output channels produced */
     int32_t Cout_total;        /* channel stride of the output buffer */

@@ -110,6 +110,40 @@ def test_conv(case, mode):
         assert (raw[:, keep] == 0xCD).all()
 
 
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+def test_conv_border_bias_folds_preceding_batchnorm(dt):
+    """conv3x3(zero_pad(x*s + t)) == conv3x3_{W*s}(zero_pad(x)) + bias_table[border case]: how the
+    per-head input BatchNorm of FPN level 0 is folded (Leafmap.forward, detector.py:194-197)."""
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cin, Cout = 2, 6, 7, 64, 192
+    x = torch.randn(B, H, W, Cin, generator=g)
+    if dt == L.BF16:
+        x = bf16_round(x)
+    si, ti = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bo = torch.randn(Cout, generator=g) * 0.2
+    ref = F.gelu(F.conv2d((x * si + ti).permute(0, 3, 1, 2), w, bo, 1, 1)).permute(0, 2, 3, 1)
+    wm = w * si[None, :, None, None]
+    tmap = torch.einsum("ncrs,c->nrs", w.double(), ti.double())
+    b16 = torch.zeros(16, Cout, dtype=torch.float64)
+    for idx in range(16):
+        rows = [r for r in range(3) if not (r == 0 and idx & 1) and not (r == 2 and idx & 2)]
+        cols = [c for c in range(3) if not (c == 0 and idx & 4) and not (c == 2 and idx & 8)]
+        b16[idx] = bo.double() + tmap[:, rows][:, :, cols].sum((1, 2))
+    ar = Arena()
+    o_in = ar.put(to_dev_bytes(x, dt))
+    o_w = ar.put(to_dev_bytes(wm.permute(0, 2, 3, 1).reshape(Cout, 9, Cin), dt))
+    o_b = ar.put(b16.float())
+    o_out = ar.reserve(B * H * W * Cout * (4 if dt == L.F32 else 2))
+    ar.materialize()
+    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_BORDER_BIAS, act=L.ACT_GELU, in_dtype=dt, out_dtype=dt, w_dtype=dt, B=B, H=H, W=W, Ho=H, Wo=W,
+                Cin=Cin, Cin_total=Cin, Cout=Cout, Cout_total=Cout, ksize=3, stride=1, in_=o_in, out=o_out, w=o_w, bias=o_b), ar)
+    out = ar.read(o_out, (B, H, W, Cout), tdtype(dt)).float()
+    err = _rel(out, ref)
+    _log(f"conv border-bias dt={dt} rel_err {err:.3e}")
+    assert err < (1e-5 if dt == L.F32 else 2e-2)
+
+
 def test_conv_dual_output_bf16_copy():
     """fp32 trunk output + bf16 copy (ftc_op.out2) written by the same epilogue."""
     g = torch.Generator().manual_seed(77)
@@ -237,6 +271,25 @@ def test_upcat(with_y, cfg):
     err = _rel(out, ref)
     _log(f"upcat with_y={with_y} {cfg[0]} rel_err {err:.3e}")
     assert err < (2e-6 if dt == L.F32 else 5e-3)
+
+
+def test_upcat_reads_channel_slice_of_wider_tensor():
+    g = torch.Generator().manual_seed(8)
+    B, Hi, Wi, Cy, Ct, CyT, off = 1, 6, 5, 192, 64, 576, 192
+    wide = torch.randn(B, Hi, Wi, CyT, generator=g)
+    tap = torch.randn(B, 2 * Hi, 2 * Wi, Ct, generator=g)
+    sc, sh = torch.rand(Ct, generator=g) + 0.5, torch.randn(Ct, generator=g)
+    y = wide[..., off:off + Cy]
+    ref = torch.cat([F.interpolate(y.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1),
+                     tap * sc + sh], -1)
+    ar = Arena()
+    o_y, o_tap, o_sc, o_sh = ar.put(wide), ar.put(tap), ar.put(sc), ar.put(sh)
+    o_out = ar.reserve(B * 4 * Hi * Wi * (Cy + Ct) * 4)
+    ar.materialize()
+    run_op(dict(kind=L.OP_UPCAT, in_dtype=L.F32, out_dtype=L.F32, res_dtype=L.F32, B=B, H=Hi, W=Wi, Ho=2 * Hi, Wo=2 * Wi, Cin=Cy + Ct,
+                Cin_total=CyT, cin_off=off, Cout=Cy + Ct, aux0=Cy, aux1=Ct, in_=o_y, in2=o_tap, out=o_out, scale=o_sc, shift=o_sh), ar)
+    out = ar.read(o_out, (B, 2 * Hi, 2 * Wi, Cy + Ct), torch.float32)
+    assert _rel(out, ref) < 2e-6
 
 
 def test_nms_ties_golden(golden_dir):

@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
-    ap.add_argument("--nbuf", type=int, default=0, help="buffering hint (ftc_op.aux0): 0 auto, 1 single, 2 double")
+    ap.add_argument("--nbuf", type=int, default=0, help="tuning hints (ftc_op.aux0): bits0-1 register-kernel buffering, 4 = no direct-to-LDS, 8 = 3-deep DMA ring")
     a = ap.parse_args()
     lib = L.load()
     dev = torch.device("cuda")

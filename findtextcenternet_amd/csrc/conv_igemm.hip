@@ -14,8 +14,7 @@ void conv_kernel_label(const ftc_op& op, char* buf, int len) {
     const char* dt[] = {"f32", "bf16"};
     const bool dma = uses_glds(op);
     snprintf(buf, len, "conv_igemm%s<%s,in=%s,out=%s,tile=%s,bk=%d,nbuf=%d>", dma ? "_glds" : "", dt[op.w_dtype & 1], dt[op.in_dtype & 1],
-             dt[op.out_dtype & 1], kCfgName[select_cfg(op.Cout, op.B * op.Ho * op.Wo)], select_bk(op),
-             dma ? ((op.aux0 & 8) ? 3 : 2) : select_nbuf(op));
+             dt[op.out_dtype & 1], kCfgName[select_cfg(op)], select_bk(op), dma ? glds_ring(op) : 1);
 }
 
 const char* conv_validate(const ftc_op& op) {
@@ -39,7 +38,10 @@ const char* conv_validate(const ftc_op& op) {
     const long in_bytes = (long)op.B * op.H * op.W * op.Cin_total * (op.in_dtype == FTC_F32 ? 4 : 2);
     const long w_bytes = (long)op.Cout * op.ksize * op.ksize * op.Cin * (op.w_dtype == FTC_F32 ? 4 : 2);
     if (in_bytes >= 0x7ff00000L || w_bytes >= 0x7ff00000L) return "conv: operand larger than 2 GiB (split the batch)";
-    if (op.aux0 < 0 || op.aux0 > 31) return "conv: aux0 (tuning hints) out of range";
+    if (op.aux0 < 0 || op.aux0 > 0x3ff || hint_cfg(op) >= CFG_COUNT) return "conv: aux0 (tuned kernel choice) out of range";
+    if (hint_bk(op) && op.w_dtype == FTC_BF16 && (op.Cin % hint_bk(op)) && hint_bk(op) != 32) return "conv: tuned K step does not divide Cin";
+    if (hint_bk(op) == 128 && op.in_dtype != FTC_BF16) return "conv: K step 128 needs bf16 activations";
+    if (hint_stage(op) >= 2 && !glds_legal(op)) return "conv: direct-to-LDS kernel is not legal for this op/tile";
     return nullptr;
 }
 
@@ -58,7 +60,7 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
     p.M = o.B * o.Ho * o.Wo;
     p.ncb = p.nk = p.nN = p.nblk = 0;
     p.use_glds = uses_glds(o) ? 1 : 0;
-    p.glds_nbuf = (o.aux0 & 8) ? 3 : 2;
+    p.glds_nbuf = glds_ring(o);
     if (o.w_dtype == FTC_F32) return launch_conv_f32(p, o, s);
     if (o.in_dtype == FTC_BF16 && o.out_dtype == FTC_BF16) return launch_conv_bf16_bb(p, o, s);
     if (o.in_dtype == FTC_F32 && o.out_dtype == FTC_BF16) return launch_conv_bf16_fb(p, o, s);

@@ -237,8 +237,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         const int c0 = ld_cb * BK;
         const int w_soff = (ld_tap * p.Cin + c0) * (int)sizeof(WT);
         const int in_toff = ((ld_r * p.W + ld_s) * p.CinT + c0) * (int)sizeof(InT);
-        // partial last channel block: only possible when Cin % BK != 0 (never for BK = 64, see select_bk)
-        const bool cok = BK == 64 ? true : (c0 + kc * E) < p.Cin;
+        // partial last channel block: only possible when Cin % BK != 0 (never for BK >= 64, see select_bk)
+        const bool cok = BK >= 64 ? true : (c0 + kc * E) < p.Cin;
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = bload(rw, cok ? a_off[i] : OOB, w_soff);
 #pragma unroll
@@ -565,8 +565,8 @@ hipError_t launch_glds(ConvP p, hipStream_t s) {
 template <typename WT, typename InT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF>
 hipError_t launch_cfg(const ConvP& p, hipStream_t s) {
     constexpr int E = 16 / (int)sizeof(WT);
-    constexpr bool glds_ok = sizeof(WT) == sizeof(InT) && (((WN * SN + WM * SM) * 32 * (BK / E)) % 256 == 0) &&
-                             ((WN * SN * 32 * (BK / E)) % 64 == 0);
+    constexpr bool glds_ok = sizeof(WT) == sizeof(InT) && (BK / E == 8 || BK / E == 4) &&
+                             (((WN * SN + WM * SM) * 32 * (BK / E)) % 256 == 0) && ((WN * SN * 32 * (BK / E)) % 64 == 0);
     if constexpr (glds_ok) {
         if (p.use_glds) {
             if (p.glds_nbuf == 3) return launch_glds<WT, OutT, BK, WN, WM, SN, SM, 3>(p, s);
@@ -578,64 +578,88 @@ hipError_t launch_cfg(const ConvP& p, hipStream_t s) {
     return launch_cfg2<WT, InT, OutT, BK, WN, WM, SN, SM, NBUF, false>(p, s);
 }
 
-// Tile configuration (channels x pixels per workgroup) by output-channel count and problem size.
-enum { CFG_32x256 = 0, CFG_64x128, CFG_96x128, CFG_192x128, CFG_128x64, CFG_128x128, CFG_COUNT };
-static const char* const kCfgName[] = {"32x256", "64x128", "96x128", "192x128", "128x64", "128x128"};
+// Tile configurations (output channels x output pixels per workgroup), in order of preference.
+enum { CFG_192x128 = 0, CFG_128x128, CFG_96x128, CFG_64x128, CFG_128x64, CFG_32x256, CFG_64x64, CFG_COUNT };
+static const char* const kCfgName[] = {"192x128", "128x128", "96x128", "64x128", "128x64", "32x256", "64x64"};
+static const int kCfgTN[] = {192, 128, 96, 64, 128, 32, 64};
+static const int kCfgTM[] = {128, 128, 128, 128, 64, 256, 64};
 
-inline int select_cfg(int n, int M) {
+// ftc_op.aux0 carries the tuned kernel choice (0 = heuristics below): bits 0-3 tile config + 1,
+// bits 4-5 staging (1 = register-staged, 2 = direct-to-LDS 2-slot ring, 3 = 3-slot ring), bits 8-9 K step
+// (1 = 32, 2 = 64, 3 = 128).  The Python side fills it from a table measured on MI355X
+// (findtextcenternet_amd/tuning.py); every choice gives bit-identical results (same K order).
+inline int hint_cfg(const ftc_op& o) { return (o.aux0 & 15) - 1; }
+inline int hint_stage(const ftc_op& o) { return (o.aux0 >> 4) & 3; }
+inline int hint_bk(const ftc_op& o) { const int b = (o.aux0 >> 8) & 3; return b == 1 ? 32 : b == 2 ? 64 : b == 3 ? 128 : 0; }
+
+inline int default_cfg(int n, int M) {
     if (n <= 32) return CFG_32x256;
     if (n <= 64) return CFG_64x128;
     if (n <= 96) return CFG_96x128;
-    if (n % 192 == 0 && n % 128 != 0) return CFG_192x128;
+    const long t192 = (long)((n + 191) / 192) * ((M + 127) / 128);
+    if (n % 192 == 0 && n % 128 != 0) return t192 >= 256 ? CFG_192x128 : CFG_64x64;
     // 128-channel tiles; shrink the pixel tile when the grid would not fill the 256 CUs twice
     const long tiles128 = (long)((n + 127) / 128) * ((M + 127) / 128);
     return tiles128 < 512 ? CFG_128x64 : CFG_128x128;
 }
-
-// K step: 64 for bf16 when the channel count allows it (half the barriers), else 32.
-inline int select_bk(const ftc_op& o) { return (o.w_dtype == FTC_BF16 && o.Cin % 64 == 0) ? 64 : 32; }
-// Tuning hints in ftc_op.aux0 (0 = defaults): bits 0-1 LDS buffering of the register-staged kernel
-// (1 single, 2 double), bit 2 (4) = never use the direct-to-LDS kernel, bit 3 (8) = 3-deep DMA ring,
-// bit 4 (16) = use the direct-to-LDS kernel wherever it is legal.
-// Measured (tools/conv_bench.py): bf16 wants the single buffer (2-3 workgroups per CU hide the two
-// barriers better than one double-buffered workgroup: FPN L3 689 vs 391 TF).
-inline int select_nbuf(const ftc_op& o) { return (o.aux0 & 3) == 2 ? 2 : 1; }
-inline bool uses_glds(const ftc_op& o) {
-    if ((o.aux0 & 4) || (o.flags & FTC_FLAG_SE_SCALE) || o.in_dtype != o.w_dtype) return false;
-    const int cpr = (o.w_dtype == FTC_BF16 && o.Cin % 64 == 0) ? 8 : (o.w_dtype == FTC_BF16 ? 4 : 8);
-    const int cfg = select_cfg(o.Cout, o.B * o.Ho * o.Wo);
-    const int tn[] = {32, 64, 96, 192, 128, 128}, tm[] = {256, 128, 128, 128, 64, 128};
-    // tiles must be a whole number of workgroup-level DMA passes
-    if (((tn[cfg] + tm[cfg]) * cpr) % 256 != 0 || (tn[cfg] * cpr) % 64 != 0) return false;
-    if (o.aux0 & 16) return true;                       // tuning: force the DMA kernel where legal
-    // Measured (tools/conv_bench.py, MI355X): the 2-slot DMA ring wins on the 192x128 and 64x128 tiles
-    // (FPN: 819 vs 746 TF); on 128-channel tiles the register-staged kernel keeps 3-4 workgroups per
-    // CU with its single 36 KB buffer and is faster (stage2 3x3: 504 vs 439 TF).  fp32: DMA everywhere.
-    if (o.w_dtype == FTC_F32) return true;
-    return cfg == CFG_192x128 || cfg == CFG_64x128;
+inline int select_cfg(const ftc_op& o) {
+    const int h = hint_cfg(o);
+    return h >= 0 && h < CFG_COUNT ? h : default_cfg(o.Cout, o.B * o.Ho * o.Wo);
 }
 
-template <typename WT, typename InT, typename OutT, int BK, int NBUF>
+// K step: 64 for bf16 when the channel count allows (half the barriers per FLOP), else 32; 128 only by hint.
+inline int select_bk(const ftc_op& o) {
+    if (o.w_dtype != FTC_BF16) return 32;
+    const int h = hint_bk(o);
+    if (h) return h;
+    return o.Cin % 64 == 0 ? 64 : 32;
+}
+inline bool glds_legal(const ftc_op& o) {
+    if ((o.flags & FTC_FLAG_SE_SCALE) || o.in_dtype != o.w_dtype) return false;
+    const int bk = select_bk(o);
+    if (bk == 128) return false;
+    const int cpr = bk / (o.w_dtype == FTC_BF16 ? 8 : 4);
+    const int cfg = select_cfg(o);
+    // tiles must be a whole number of workgroup-level DMA passes
+    return ((kCfgTN[cfg] + kCfgTM[cfg]) * cpr) % 256 == 0 && (kCfgTN[cfg] * cpr) % 64 == 0;
+}
+inline bool uses_glds(const ftc_op& o) {
+    if (!glds_legal(o)) return false;
+    const int st = hint_stage(o);
+    if (st) return st >= 2;
+    // Untuned default (tools/conv_bench.py, MI355X): the 2-slot DMA ring wins on the 192x128 and 64x128
+    // tiles (FPN: 819 vs 746 TF); on 128-channel tiles the register-staged kernel keeps 3-4 workgroups
+    // per CU with its single 36 KB buffer and is faster (stage2 3x3: 504 vs 439 TF).  fp32: DMA everywhere.
+    if (o.w_dtype == FTC_F32) return true;
+    const int cfg = select_cfg(o);
+    return cfg == CFG_192x128 || cfg == CFG_64x128;
+}
+inline int glds_ring(const ftc_op& o) { return hint_stage(o) == 3 ? 3 : 2; }
+
+template <typename WT, typename InT, typename OutT, int BK>
 hipError_t launch_tiles(const ConvP& p, int cfg, hipStream_t s) {
     switch (cfg) {
-    case CFG_32x256: return launch_cfg<WT, InT, OutT, BK, 1, 4, 1, 2, NBUF>(p, s);
-    case CFG_64x128: return launch_cfg<WT, InT, OutT, BK, 2, 2, 1, 2, NBUF>(p, s);
-    case CFG_96x128: return launch_cfg<WT, InT, OutT, BK, 1, 4, 3, 1, NBUF>(p, s);
-    case CFG_192x128: return launch_cfg<WT, InT, OutT, BK, 2, 2, 3, 2, NBUF>(p, s);
-    case CFG_128x64: return launch_cfg<WT, InT, OutT, BK, 2, 2, 2, 1, NBUF>(p, s);
-    default: return launch_cfg<WT, InT, OutT, BK, 2, 2, 2, 2, NBUF>(p, s);
+    case CFG_192x128: return launch_cfg<WT, InT, OutT, BK, 2, 2, 3, 2, 1>(p, s);
+    case CFG_128x128: return launch_cfg<WT, InT, OutT, BK, 2, 2, 2, 2, 1>(p, s);
+    case CFG_96x128: return launch_cfg<WT, InT, OutT, BK, 1, 4, 3, 1, 1>(p, s);
+    case CFG_64x128: return launch_cfg<WT, InT, OutT, BK, 2, 2, 1, 2, 1>(p, s);
+    case CFG_128x64: return launch_cfg<WT, InT, OutT, BK, 2, 2, 2, 1, 1>(p, s);
+    case CFG_32x256: return launch_cfg<WT, InT, OutT, BK, 1, 4, 1, 2, 1>(p, s);
+    default: return launch_cfg<WT, InT, OutT, BK, 2, 2, 1, 1, 1>(p, s);
     }
 }
 
 template <typename WT, typename InT, typename OutT>
 hipError_t launch_types(const ConvP& p, const ftc_op& o, hipStream_t s) {
-    const int cfg = select_cfg(p.Cout, p.M);
-    const int nbuf = select_nbuf(o);
+    const int cfg = select_cfg(o);
     if constexpr (sizeof(WT) == 2) {
-        if (select_bk(o) == 64)
-            return nbuf == 1 ? launch_tiles<WT, InT, OutT, 64, 1>(p, cfg, s) : launch_tiles<WT, InT, OutT, 64, 2>(p, cfg, s);
+        const int bk = select_bk(o);
+        if constexpr (sizeof(InT) == 2) {
+            if (bk == 128) return launch_tiles<WT, InT, OutT, 128>(p, cfg, s);
+        }
+        if (bk >= 64) return launch_tiles<WT, InT, OutT, 64>(p, cfg, s);
     }
-    return nbuf == 1 ? launch_tiles<WT, InT, OutT, 32, 1>(p, cfg, s) : launch_tiles<WT, InT, OutT, 32, 2>(p, cfg, s);
+    return launch_tiles<WT, InT, OutT, 32>(p, cfg, s);
 }
 
 }  // namespace convimpl

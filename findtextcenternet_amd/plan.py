@@ -392,6 +392,8 @@ class _Builder:
                     r.offset = self.bufs[v[1]].offset if v[0] == "buf" else v[1]
                 else:
                     setattr(o, k, int(v))
+        from . import tuning
+        tuning.apply(arr)                       # measured kernel choice per conv shape (ftc_op.aux0)
         return Plan(arr, self.meta, ws, self.B, self.H, self.W, mh, mw, self.mode, None, peak,
                     sum(b.nbytes for b in self.bufs))
 

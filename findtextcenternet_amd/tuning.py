@@ -1,0 +1,167 @@
+"""Measured kernel selection for the implicit-GEMM convolution ("measure, don't guess").
+
+Every dense conv of the plan can run on several variants of the same kernel -- 7 tile shapes x
+{register-staged, direct-to-LDS 2/3-slot ring} x K step {32, 64, 128} -- which all produce
+bit-identical results (same K summation order) but differ up to 2x in speed depending on how many
+workgroups the layer yields and how long its K loop is.  ``tune_plan`` times every legal variant of
+every distinct conv shape of a plan on the GPU (single-op plans over the real operand buffers, HIP
+events through ``ftc_plan_profile``) and records the fastest in a table keyed by the layer signature;
+``apply`` writes the choice into ``ftc_op.aux0``.  The table measured on MI355X is committed as
+``tuning_gfx950.json``; shapes missing from it fall back to the heuristics in conv_igemm_impl.h.
+
+    python -m findtextcenternet_amd.tuning --batch 8 --precision bf16 [--out path.json]
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import Dict, List, Optional
+
+from . import _lib as L
+
+TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_gfx950.json")
+CFG_NAMES = ["192x128", "128x128", "96x128", "64x128", "128x64", "32x256", "64x64"]
+_table: Optional[Dict[str, int]] = None
+
+
+def signature(o) -> str:
+    return (f"w{o.w_dtype}i{o.in_dtype}o{o.out_dtype}_B{o.B}_{o.H}x{o.W}_c{o.Cin}of{o.Cin_total}_n{o.Cout}of{o.Cout_total}"
+            f"_k{o.ksize}s{o.stride}_f{o.flags}_a{o.act}")
+
+
+def encode(cfg: int, stage: int, bk: int) -> int:
+    return (cfg + 1) | (stage << 4) | ({0: 0, 32: 1, 64: 2, 128: 3}[bk] << 8)
+
+
+def describe(aux0: int) -> str:
+    if aux0 == 0:
+        return "default"
+    return f"tile={CFG_NAMES[(aux0 & 15) - 1]},stage={['auto', 'reg', 'dma2', 'dma3'][(aux0 >> 4) & 3]},bk={[0, 32, 64, 128][(aux0 >> 8) & 3]}"
+
+
+def load_table(path: str = TABLE_PATH) -> Dict[str, int]:
+    global _table
+    if _table is None:
+        _table = {}
+        if os.path.exists(path) and os.environ.get("FTC_NO_TUNING", "0") != "1":
+            with open(path) as f:
+                _table = {k: int(v) for k, v in json.load(f).get("choices", {}).items()}
+    return _table
+
+
+def apply(ops, table: Optional[Dict[str, int]] = None) -> int:
+    """Writes tuned choices into ops[i].aux0 for the conv ops found in the table; returns how many."""
+    table = load_table() if table is None else table
+    n = 0
+    for o in ops:
+        if o.kind == L.OP_CONV:
+            v = table.get(signature(o))
+            if v:
+                o.aux0 = v
+                n += 1
+    return n
+
+
+def candidates(o) -> List[int]:
+    bks = [32] if o.w_dtype == L.F32 else [b for b in (32, 64, 128) if o.Cin % b == 0 or b == 32]
+    if o.w_dtype == L.BF16 and o.Cin % 64 == 0:
+        bks = [b for b in bks if b != 32]                 # 32 never wins when 64 is legal
+    out = []
+    for cfg in range(len(CFG_NAMES)):
+        tn = int(CFG_NAMES[cfg].split("x")[0])
+        if tn > 2 * max(32, o.Cout):                      # more than half the tile rows would be padding
+            continue
+        for bk in bks:
+            for stage in (1, 2, 3):
+                out.append(encode(cfg, stage, bk))
+    return out
+
+
+def tune_plan(engine, plan, reps: int = 5, verbose: bool = False) -> Dict[str, int]:
+    """engine: detector._HipEngine with weights + workspace resident and one forward already run."""
+    import numpy as np
+    import torch
+    lib = L.load()
+    dev = engine.wdev.device
+    heat = torch.empty((plan.B, plan.h, plan.w, 10), dtype=torch.float32, device=dev)
+    feat = torch.empty((plan.B, plan.h, plan.w, 100), dtype=torch.float32, device=dev)
+    x = torch.rand((plan.B, plan.H, plan.W, 3), dtype=torch.float32, device=dev)
+    bases = (C.c_void_p * L.NUM_BASES)(None, engine.workspace.data_ptr(), engine.wdev.data_ptr(), x.data_ptr(), heat.data_ptr(), feat.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    L.check(lib.ftc_plan_run(plan.handle, bases, stream, 0, -1), "forward (fills the activation buffers)")
+    torch.cuda.synchronize()
+    choices: Dict[str, int] = {}
+    ms = (C.c_float * 1)()
+    for i in range(len(plan.ops)):
+        o = plan.ops[i]
+        if o.kind != L.OP_CONV:
+            continue
+        key = signature(o)
+        if key in choices:
+            continue
+        best, best_t, base_t = 0, 1e30, None
+        one = (L.Op * 1)()
+        for aux in [0] + candidates(o):
+            C.memmove(C.byref(one[0]), C.byref(o), C.sizeof(L.Op))
+            one[0].aux0 = aux
+            h = C.c_void_p()
+            if lib.ftc_plan_create(one, 1, plan.workspace_bytes, engine.pw.nbytes, C.byref(h)) != 0:
+                continue                                     # not legal for this op
+            ts = []
+            lib.ftc_plan_run(h, bases, stream, 0, -1)
+            for _ in range(reps):
+                L.check(lib.ftc_plan_profile(h, bases, stream, ms), "profile")
+                ts.append(ms[0])
+            lib.ftc_plan_destroy(h)
+            t = float(np.median(ts))
+            if aux == 0:
+                base_t = t
+            if t < best_t * 0.98:                            # keep the earlier (simpler) choice on ties
+                best, best_t = aux, t
+        choices[key] = best
+        if verbose:
+            print(f"{key:70s} default {base_t * 1e3:8.1f} us -> {best_t * 1e3:8.1f} us  {describe(best)}", flush=True)
+    return choices
+
+
+def main():
+    import argparse
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from findtextcenternet_amd import CenterNetDetector, TextDetectorModel, deterministic_state_dict
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, nargs="+", default=[8])
+    ap.add_argument("--precision", nargs="+", default=["bf16"])
+    ap.add_argument("--size", type=int, default=768)
+    ap.add_argument("--out", default=TABLE_PATH)
+    ap.add_argument("--merge", action="store_true", help="keep existing entries of --out")
+    a = ap.parse_args()
+    os.environ["FTC_NO_TUNING"] = "1"
+    allc: Dict[str, int] = {}
+    if a.merge and os.path.exists(a.out):
+        allc = {k: int(v) for k, v in json.load(open(a.out)).get("choices", {}).items()}
+    sd = deterministic_state_dict(0)
+    for prec in a.precision:
+        model = TextDetectorModel(pre_weights=False, precision=prec)
+        model.load_state_dict(sd)
+        det = CenterNetDetector(model.detector).to("cuda").eval()
+        for B in a.batch:
+            x = torch.rand((B, a.size, a.size, 3), device="cuda").permute(0, 3, 1, 2)
+            with torch.no_grad():
+                det(x)
+            eng = model.detector._engine
+            plan = eng.get_plan(B, a.size, a.size, False)
+            ch = tune_plan(eng, plan, verbose=True)
+            allc.update(ch)
+        del det, model
+        torch.cuda.empty_cache()
+    with open(a.out, "w") as f:
+        json.dump({"device": "MI355X gfx950", "note": "aux0 per conv signature, measured by findtextcenternet_amd.tuning",
+                   "choices": dict(sorted(allc.items()))}, f, indent=0)
+    print("wrote", a.out, len(allc), "entries")
+
+
+if __name__ == "__main__":
+    main()

@@ -23,11 +23,14 @@ SHAPES = [
     ("stage2 1x1 256->64", 192, 192, 256, 64, 1, 1, 0, True, False, False, True),
     ("stage3 3x3 96->384", 96, 96, 96, 384, 3, 1, 1, False, False, True, False),
     ("stage3 1x1 384->96", 96, 96, 384, 96, 1, 1, 0, True, False, False, True),
+    ("stage4 exp 192->768", 48, 48, 192, 768, 1, 1, 1, False, False, True, False),
+    ("stage4 proj 768->192", 48, 48, 768, 192, 1, 1, 0, True, True, False, True),
     ("stage5 exp 256->1536", 48, 48, 256, 1536, 1, 1, 1, False, False, True, False),
     ("stage5 proj 1536->256", 48, 48, 1536, 256, 1, 1, 0, True, True, False, True),
     ("stage6 exp 512->3072", 24, 24, 512, 3072, 1, 1, 1, False, False, True, False),
     ("stage6 proj 3072->512", 24, 24, 3072, 512, 1, 1, 0, True, True, False, True),
-    ("fpn L0 1280->192", 24, 24, 1280, 192, 3, 1, 2, False, False, False, False),
+    ("stage7 proj 3840->640", 24, 24, 3840, 640, 1, 1, 0, True, True, False, True),
+    ("fpn L0 1280->1728", 24, 24, 1280, 1728, 3, 1, 2, False, False, False, False),
     ("fpn L1 448->192", 48, 48, 448, 192, 3, 1, 2, False, False, False, False),
     ("fpn L2 288->192", 96, 96, 288, 192, 3, 1, 2, False, False, False, False),
     ("fpn L3 256->192", 192, 192, 256, 192, 3, 1, 2, False, False, False, False),
@@ -42,7 +45,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
-    ap.add_argument("--nbuf", type=int, default=0, help="tuning hints (ftc_op.aux0): bits0-1 register-kernel buffering, 4 = no direct-to-LDS, 8 = 3-deep DMA ring")
+    ap.add_argument("--nbuf", type=int, default=0, help="tuning hints (ftc_op.aux0): 4 = no direct-to-LDS, 8 = 3-deep DMA ring, 16 = force direct-to-LDS")
     a = ap.parse_args()
     lib = L.load()
     dev = torch.device("cuda")

@@ -174,6 +174,18 @@ def main():
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s"}
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
         roof["traffic"] = None
+        # HBM-side traffic of this kernel from the committed PMC passes (profiles/*_pmc_traffic.json: rocprofv3
+        # FETCH_SIZE / WRITE_SIZE collected separately, gfx950 correction applied); null if not profiled.
+        try:
+            import glob
+            for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+                tab = json.load(open(pth)).get("by_label", {})
+                for lab, rec in tab.items():
+                    if lab.split("|")[0] == name and args.precision == "bf16" and B == 8:
+                        roof["traffic"] = rec["traffic_bytes"]
+                        roof["traffic_note"] = f"bytes/launch for the M={lab.split('M=')[1]} launches, {os.path.basename(pth)}"
+        except Exception:
+            pass
         roof["kernel"] = name
         roof["launches_per_step"] = d["launches"]
         roof["avg_launch_ms"] = round(d["ms"] / d["launches"], 4)

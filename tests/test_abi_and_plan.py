@@ -1,0 +1,162 @@
+"""CPU (no GPU): the C-ABI library loads and exports every symbol include/ftc.h declares, plan
+validation works through ftc_plan_create, and the host-side plan / weight-packing logic is sound."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from findtextcenternet_amd import _lib as L
+from findtextcenternet_amd import plan as P
+from findtextcenternet_amd import tuning
+from findtextcenternet_amd.weights import deterministic_state_dict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    hdr = open(os.path.join(ROOT, "include", "ftc.h")).read()
+    declared = sorted(set(re.findall(r"\b(ftc_[a-z_0-9]+)\s*\(", hdr)))
+    assert set(declared) == set(L.EXPORTS), (declared, L.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.ftc_abi_version() == L.FTC_ABI_VERSION
+    assert C.sizeof(L.Op) == 22 * 4 + 11 * 16 and C.sizeof(L.Ref) == 16 and C.sizeof(L.Tile) == 32
+
+
+def test_device_info_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = L.load()
+    n = C.c_int()
+    buf = C.create_string_buffer(64)
+    assert lib.ftc_device_info(C.byref(n), buf, 64) == -3           # FTC_ERR_NO_DEVICE
+    assert b"device" in lib.ftc_last_error().lower() or b"hip" in lib.ftc_last_error().lower()
+
+
+def _op(**f):
+    op = (L.Op * 1)()
+    for k, v in f.items():
+        if k in ("in_", "in2", "out", "w", "w2", "bias", "bias2", "scale", "shift", "aux", "out2"):
+            r = getattr(op[0], k)
+            r.base, r.offset = L.BASE_WORKSPACE, v
+        else:
+            setattr(op[0], k, v)
+    return op
+
+
+def test_plan_create_validates_ops():
+    lib = L.load()
+    h = C.c_void_p()
+    good = dict(kind=L.OP_CONV, in_dtype=L.F32, out_dtype=L.F32, w_dtype=L.F32, B=1, H=8, W=8, Ho=8, Wo=8, Cin=32, Cin_total=32,
+                Cout=64, Cout_total=64, ksize=3, stride=1, in_=0, out=65536, w=131072, bias=262144)
+    assert lib.ftc_plan_create(_op(**good), 1, 1 << 20, 0, C.byref(h)) == 0
+    assert lib.ftc_plan_num_ops(h) == 1
+    lib.ftc_plan_destroy(h)
+    for bad, msg in [(dict(good, Cin=30), b"Cin"), (dict(good, Ho=7), b"Ho/Wo"), (dict(good, ksize=5), b"ksize"),
+                     (dict(good, in_=8), b"16-byte"), (dict(good, out=1 << 21), b"out of range"),
+                     (dict(good, kind=99), b"unknown op"), (dict(good, flags=L.FLAG_RESIDUAL), b"in2")]:
+        assert lib.ftc_plan_create(_op(**bad), 1, 1 << 20, 0, C.byref(h)) == -1
+        assert msg in lib.ftc_last_error(), (msg, lib.ftc_last_error())
+    # running without a device / with NULL bases is an error, not a crash
+    assert lib.ftc_plan_create(_op(**good), 1, 1 << 20, 0, C.byref(h)) == 0
+    bases = (C.c_void_p * L.NUM_BASES)()
+    assert lib.ftc_plan_run(h, bases, None, 0, -1) == -1 and b"NULL" in lib.ftc_last_error()
+    lib.ftc_plan_destroy(h)
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return deterministic_state_dict(0, prefix_detector=False)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_plan_structure_flops_and_arena(sd, mode):
+    pw = P.pack_weights(sd, mode)
+    pl = P.build_plan(pw, 2, 768, 768)
+    P.create_handle(pl, pw.nbytes)                       # every op passes the C-side validation
+    L.load().ftc_plan_destroy(pl.handle)
+    # forward work of the reference network: 432.50 GMAC = 865.0 GFLOP per image
+    assert abs(sum(m.flops for m in pl.meta) / 2 / 1e9 - 865.0006) < 0.01
+    kinds = [m.kind for m in pl.meta]
+    assert kinds.count("dwconv3x3") == 80 and kinds.count("se") == 80 and kinds.count("stem") == 1 and kinds[-1] == "nms"
+    assert kinds.count("upcat") == 27 and sum(k.startswith("conv") for k in kinds) == 20 + 16 + 160 + 1 + 1 + 27 + 9
+    # arena: no two simultaneously-live buffers overlap
+    live = {}
+    ops = pl.ops
+    spans = {}
+    for i in range(len(ops)):
+        for fld in ("in_", "in2", "out", "aux", "scale", "out2"):
+            r = getattr(ops[i], fld)
+            if r.base == L.BASE_WORKSPACE:
+                s = spans.setdefault(r.offset, [i, i])
+                s[1] = i
+    assert max(spans) < pl.workspace_bytes and pl.workspace_bytes < 0.5 * pl.total_buffer_bytes
+    assert pl.h == 192 and pl.w == 192
+
+
+def test_bn_fold_and_kmajor_layout_match_torch(sd):
+    """pack_weights: conv + eval BatchNorm == conv with folded weights + bias, in the K-major layout."""
+    pw = P.pack_weights(sd, "fp32")
+    name = "backbone.features.2.1.block.0"
+    w = sd[name + ".0.weight"]
+    cout, cin, k, _ = w.shape
+    off_w, off_b = pw.table[name + ".w"], pw.table[name + ".b"]
+    wk = torch.from_numpy(pw.blob[off_w:off_w + cout * cin * k * k * 4].view(np.float32).reshape(cout, k * k, cin).copy())
+    b = torch.from_numpy(pw.blob[off_b:off_b + cout * 4].view(np.float32).copy())
+    x = torch.randn(1, cin, 9, 9)
+    ref = F.batch_norm(F.conv2d(x, w, None, 1, 1), sd[name + ".1.running_mean"], sd[name + ".1.running_var"], sd[name + ".1.weight"],
+                       sd[name + ".1.bias"], False, 0.0, 1e-3)
+    mine = F.conv2d(x, wk.reshape(cout, k, k, cin).permute(0, 3, 1, 2), b, 1, 1)
+    assert float((ref - mine).abs().max()) < 1e-5
+
+
+def test_merged_fpn_level0_border_bias_is_exact(sd):
+    """The nine per-head (in_bn -> conv3x3 -> BN) at the 1/32 tap packed as ONE conv with a
+    16-case border bias equals the reference composition (Leafmap.forward i=0, detector.py:194-197)."""
+    pw = P.pack_weights(sd, "fp32")
+    C4, N = 1280, 9 * 192
+    ow, ob = pw.table["heads.L0.w"], pw.table["heads.L0.b"]
+    wk = torch.from_numpy(pw.blob[ow:ow + N * 9 * C4 * 4].view(np.float32).reshape(N, 3, 3, C4).copy()).permute(0, 3, 1, 2)
+    b16 = torch.from_numpy(pw.blob[ob:ob + 16 * N * 4].view(np.float32).reshape(16, N).copy())
+    x = torch.randn(1, C4, 4, 5)
+    y = F.conv2d(x, wk, None, 1, 1)
+    H, W = 4, 5
+    for oy in range(H):
+        for ox in range(W):
+            idx = (oy == 0) | ((oy == H - 1) << 1) | ((ox == 0) << 2) | ((ox == W - 1) << 3)
+            y[0, :, oy, ox] += b16[idx]
+    for hi, name in enumerate(["keyheatmap", "feature"]):
+        h = {"keyheatmap": 0, "feature": 8}[name]
+        xin = F.batch_norm(x, sd[f"{name}.in_bn.3.running_mean"], sd[f"{name}.in_bn.3.running_var"], sd[f"{name}.in_bn.3.weight"],
+                           sd[f"{name}.in_bn.3.bias"], False, 0.0, 1e-5)
+        ref = F.batch_norm(F.conv2d(xin, sd[f"{name}.upsamplers.0.0.weight"], None, 1, 1), sd[f"{name}.upsamplers.0.1.running_mean"],
+                           sd[f"{name}.upsamplers.0.1.running_var"], sd[f"{name}.upsamplers.0.1.weight"],
+                           sd[f"{name}.upsamplers.0.1.bias"], False, 0.0, 1e-5)
+        assert float((ref - y[:, h * 192:(h + 1) * 192]).abs().max()) < 2e-4
+
+
+def test_tuning_table_entries_are_legal():
+    tab = tuning.load_table()
+    assert isinstance(tab, dict)
+    for k, v in tab.items():
+        assert 0 <= v <= 0x3ff and (v & 15) - 1 < len(tuning.CFG_NAMES), (k, v)
+        assert tuning.describe(v)
+
+
+def test_drop_in_module_schema_and_loud_failures():
+    from findtextcenternet_amd import CenterNetDetector, TextDetectorModel
+    from findtextcenternet_amd.schema import text_detector_schema
+    m = TextDetectorModel(pre_weights=False)
+    keys = list(m.state_dict().keys())
+    assert keys == list(text_detector_schema("xl").keys()) and len(keys) == 2444
+    m.load_state_dict(deterministic_state_dict(0))               # strict load of the reference key set
+    det = CenterNetDetector(m.detector).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        det(torch.zeros(1, 3, 64, 64))
+    with pytest.raises(TypeError):
+        CenterNetDetector(torch.nn.Identity())

@@ -65,69 +65,95 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, c
                                                      const float* __restrict__ bias, T* __restrict__ out,
                                                      float* __restrict__ partial, int H, int W, int Ho, int Wo,
                                                      int C, int tilesX, int P) {
+    constexpr int V = 16 / (int)sizeof(T);      // channels per lane = one 16-byte access (4 fp32 | 8 bf16)
+    constexpr int LPP = 64 / V;                 // lanes per pixel of the 64-channel slab (16 | 8)
+    constexpr int SLOTS = 256 / LPP;            // pixel slots per workgroup (16 | 32)
     constexpr int TH = STRIDE == 1 ? 8 : 4;
     constexpr int TW = 8;
     constexpr int IH = (TH - 1) * STRIDE + 3;
     constexpr int IW = (TW - 1) * STRIDE + 3;
-    __shared__ __attribute__((aligned(16))) float tile[IH * IW * 64];
-    __shared__ __attribute__((aligned(16))) float red[16 * 64];
+    __shared__ __attribute__((aligned(16))) T tile[IH * IW * 64];        // halo tile in the storage dtype
+    __shared__ __attribute__((aligned(16))) float red[SLOTS * 64];
 
     const int t = threadIdx.x;
-    const int cq = t & 15;          // channel quad inside the 64-channel slab
-    const int pt = t >> 4;          // pixel slot 0..15
-    const int c = blockIdx.x * 64 + cq * 4;
+    const int cq = t % LPP;         // channel group inside the 64-channel slab
+    const int pt = t / LPP;         // pixel slot
+    const int c = blockIdx.x * 64 + cq * V;
     const int tileId = blockIdx.y;
     const int ty = tileId / tilesX, tx = tileId - ty * tilesX;
     const int b = blockIdx.z;
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
-    const bool cok = c < C;
+    const bool cok = c < C;         // C % V == 0 (validated), so a lane is entirely in or out
 
-    for (int i = pt; i < IH * IW; i += 16) {
+    for (int i = pt; i < IH * IW; i += SLOTS) {
         const int ry = i / IW, rx = i - ry * IW;
         const int iy = iy0 + ry, ix = ix0 + rx;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        u32x4 v = {0u, 0u, 0u, 0u};
         if (cok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-            v = load4<T>(in + (((long)b * H + iy) * W + ix) * C + c);
-        *reinterpret_cast<f32x4*>(tile + i * 64 + cq * 4) = v;
+            v = *reinterpret_cast<const u32x4*>(in + (((long)b * H + iy) * W + ix) * C + c);
+        *reinterpret_cast<u32x4*>(tile + i * 64 + cq * V) = v;
     }
-    f32x4 wv[9];
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    float wv[9][V], bv[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) bv[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < V; ++e) wv[k][e] = 0.f;
     if (cok) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const f32x4*>(w + (long)k * C + c);
-        bv = *reinterpret_cast<const f32x4*>(bias + c);
-    } else {
+        for (int k = 0; k < 9; ++k)
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wv[k] = bv;
+            for (int q = 0; q < V / 4; ++q) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(w + (long)k * C + c + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wv[k][4 * q + e] = x[e];
+            }
+#pragma unroll
+        for (int q = 0; q < V / 4; ++q) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(bias + c + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[4 * q + e] = x[e];
+        }
     }
     __syncthreads();
 
-    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    float sum[V];
 #pragma unroll
-    for (int k = 0; k < TH * TW / 16; ++k) {
-        const int o = pt + 16 * k;
+    for (int e = 0; e < V; ++e) sum[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < TH * TW / SLOTS; ++k) {
+        const int o = pt + SLOTS * k;
         const int ly = o / TW, lx = o - ly * TW;
         const int oy = oy0 + ly, ox = ox0 + lx;
-        f32x4 acc = bv;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = bv[e];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int s = 0; s < 3; ++s)
-                acc += wv[r * 3 + s] * *reinterpret_cast<const f32x4*>(tile + ((ly * STRIDE + r) * IW + lx * STRIDE + s) * 64 + cq * 4);
+            for (int s = 0; s < 3; ++s) {
+                float x[V];
+                load16<T>(tile + ((ly * STRIDE + r) * IW + lx * STRIDE + s) * 64 + cq * V, x);
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] = fmaf(wv[r * 3 + s][e], x[e], acc[e]);
+            }
         if (cok && oy < Ho && ox < Wo) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = act_silu_precise(acc[e]);
-            store4<T>(out + (((long)b * Ho + oy) * Wo + ox) * C + c, acc);
-            sum += acc;
+            for (int e = 0; e < V; ++e) acc[e] = sizeof(T) == 2 ? act_silu_fast(acc[e]) : act_silu_precise(acc[e]);
+            store16<T>(out + (((long)b * Ho + oy) * Wo + ox) * C + c, acc);
+#pragma unroll
+            for (int e = 0; e < V; ++e) sum[e] += acc[e];
         }
     }
-    *reinterpret_cast<f32x4*>(red + pt * 64 + cq * 4) = sum;
+#pragma unroll
+    for (int e = 0; e < V; ++e) red[pt * 64 + cq * V + e] = sum[e];
     __syncthreads();
     if (t < 64) {
         float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) s += red[k * 64 + t];
+        for (int k = 0; k < SLOTS; ++k) s += red[k * 64 + t];
         const int cc = blockIdx.x * 64 + t;
         if (cc < C) partial[((long)b * P + tileId) * C + cc] = s;
     }

@@ -16,14 +16,15 @@ __global__ __launch_bounds__(256) void upcat_kernel(const T* __restrict__ prev, 
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                     T* __restrict__ out, int B, int Hi, int Wi, int Ho, int Wo,
                                                     int Cy, int Ct, int CyT, float ry, float rx) {
+    constexpr int V = 16 / (int)sizeof(T);         // channels per lane = one 16-byte store (4 fp32 | 8 bf16)
     const int Ctot = Cy + Ct;
-    const int Q = Ctot >> 2;
+    const int Q = Ctot / V;
     const long total = (long)B * Ho * Wo * Q;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int q = (int)(idx % Q);
         const long pix = idx / Q;
-        const int c = q * 4;
-        f32x4 v;
+        const int c = q * V;
+        float v[V];
         if (c < Cy) {
             const int x = (int)(pix % Wo);
             const int y = (int)((pix / Wo) % Ho);
@@ -35,19 +36,25 @@ __global__ __launch_bounds__(256) void upcat_kernel(const T* __restrict__ prev, 
             const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
             const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
             const T* base = prev + (long)b * Hi * Wi * CyT + c;      // prev already points at its channel slice
-            const f32x4 v00 = load4<T>(base + ((long)y0 * Wi + x0) * CyT);
-            const f32x4 v01 = load4<T>(base + ((long)y0 * Wi + x1) * CyT);
-            const f32x4 v10 = load4<T>(base + ((long)y1 * Wi + x0) * CyT);
-            const f32x4 v11 = load4<T>(base + ((long)y1 * Wi + x1) * CyT);
-            v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+            float v00[V], v01[V], v10[V], v11[V];
+            load16<T>(base + ((long)y0 * Wi + x0) * CyT, v00);
+            load16<T>(base + ((long)y0 * Wi + x1) * CyT, v01);
+            load16<T>(base + ((long)y1 * Wi + x0) * CyT, v10);
+            load16<T>(base + ((long)y1 * Wi + x1) * CyT, v11);
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] = ly0 * (lx0 * v00[e] + lx1 * v01[e]) + ly1 * (lx0 * v10[e] + lx1 * v11[e]);
         } else {
             const int ct = c - Cy;
-            const f32x4 xv = load4<TapT>(tap + pix * Ct + ct);
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + ct);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + ct);
-            v = xv * sc + sh;
+#pragma unroll
+            for (int h = 0; h < V / 4; ++h) {
+                const f32x4 xv = load4<TapT>(tap + pix * Ct + ct + 4 * h);
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + ct + 4 * h);
+                const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + ct + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[4 * h + e] = xv[e] * sc[e] + sh[e];
+            }
         }
-        store4<T>(out + pix * Ctot + c, v);
+        store16<T>(out + pix * Ctot + c, v);
     }
 }
 
@@ -85,7 +92,8 @@ hipError_t launch_upcat(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
     const int Cy = o.aux0, Ct = o.aux1;
     const int CyT = o.Cin_total > 0 ? o.Cin_total : Cy;     // channel stride of the upsampled tensor
-    const long total = (long)o.B * o.Ho * o.Wo * ((Cy + Ct) / 4);
+    const int V = o.in_dtype == FTC_F32 ? 4 : 8;
+    const long total = (long)o.B * o.Ho * o.Wo * ((Cy + Ct) / V);
     long nb = (total + 255) / 256;
     if (nb > 16384) nb = 16384;
     const float ry = o.Ho > 1 ? (float)(o.H - 1) / (float)(o.Ho - 1) : 0.f;

@@ -67,7 +67,7 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
     }
     case FTC_OP_DWCONV:
         if (!need(o.in, true, "in") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.bias, true, "bias") || !need(o.aux, true, "aux")) return why->c_str();
-        if (o.Cin % 4 || o.Cin != o.Cout) return "dwconv: C must be a multiple of 4 and Cin == Cout";
+        if (o.Cin % (o.in_dtype == FTC_F32 ? 4 : 8) || o.Cin != o.Cout) return "dwconv: C must be a multiple of one 16-byte access (4 fp32 / 8 bf16) and Cin == Cout";
         if (o.stride != 1 && o.stride != 2) return "dwconv: stride must be 1 or 2";
         if (o.Ho != (o.H - 1) / o.stride + 1 || o.Wo != (o.W - 1) / o.stride + 1) return "dwconv: Ho/Wo inconsistent";
         if (o.in_dtype != o.out_dtype) return "dwconv: in/out dtype must match";
@@ -82,7 +82,7 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
     case FTC_OP_UPCAT:
         if (!need(o.in, o.aux0 > 0, "in") || !need(o.in2, true, "in2") || !need(o.out, true, "out") || !need(o.scale, true, "scale") ||
             !need(o.shift, true, "shift")) return why->c_str();
-        if (o.aux0 % 4 || o.aux1 % 4 || o.aux1 <= 0) return "upcat: channel counts must be multiples of 4";
+        if (o.aux0 % (o.in_dtype == FTC_F32 ? 4 : 8) || o.aux1 % (o.in_dtype == FTC_F32 ? 4 : 8) || o.aux1 <= 0) return "upcat: channel counts must be multiples of one 16-byte access (4 fp32 / 8 bf16)";
         if (o.aux0 > 0 && o.Cin_total > 0 && (o.Cin_total % 4 || o.cin_off % 4 || o.cin_off + o.aux0 > o.Cin_total)) return "upcat: bad channel slice of the upsampled tensor";
         if (o.in_dtype != o.out_dtype) return "upcat: in/out dtype must match";
         return nullptr;

@@ -54,6 +54,34 @@ template <> __device__ __forceinline__ void store4<__bf16>(__bf16* p, f32x4 v) {
     *reinterpret_cast<bf16x4*>(p) = r;
 }
 
+// V consecutive elements (16 bytes of storage: V = 4 fp32 | 8 bf16) <-> V floats
+template <typename T> struct vec16 { static constexpr int V = 16 / (int)sizeof(T); };
+template <typename T> __device__ __forceinline__ void load16(const T* p, float (&f)[16 / sizeof(T)]);
+template <> __device__ __forceinline__ void load16<float>(const float* p, float (&f)[4]) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = v[e];
+}
+template <> __device__ __forceinline__ void load16<__bf16>(const __bf16* p, float (&f)[8]) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f[2 * e] = __uint_as_float(v[e] << 16);
+        f[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u);
+    }
+}
+template <typename T> __device__ __forceinline__ void store16(T* p, const float (&f)[16 / sizeof(T)]);
+template <> __device__ __forceinline__ void store16<float>(float* p, const float (&f)[4]) {
+    f32x4 v = {f[0], f[1], f[2], f[3]};
+    *reinterpret_cast<f32x4*>(p) = v;
+}
+template <> __device__ __forceinline__ void store16<__bf16>(__bf16* p, const float (&f)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (__bf16)f[e];
+    *reinterpret_cast<bf16x8*>(p) = v;
+}
+
 // Activations.  SiLU = x*sigmoid(x); GELU = exact erf form (nn.GELU default, detector.py:169).
 __device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float act_silu_precise(float x) { return x / (1.0f + expf(-x)); }

@@ -64,7 +64,7 @@ template <typename T, int STRIDE>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w,
                                                      const float* __restrict__ bias, T* __restrict__ out,
                                                      float* __restrict__ partial, int H, int W, int Ho, int Wo,
-                                                     int C, int tilesX, int P) {
+                                                     int C, int tilesX, int P, int tiles_per_wg) {
     constexpr int V = 16 / (int)sizeof(T);      // channels per lane = one 16-byte access (4 fp32 | 8 bf16)
     constexpr int LPP = 64 / V;                 // lanes per pixel of the 64-channel slab (16 | 8)
     constexpr int SLOTS = 256 / LPP;            // pixel slots per workgroup (16 | 32)
@@ -72,28 +72,48 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, c
     constexpr int TW = 8;
     constexpr int IH = (TH - 1) * STRIDE + 3;
     constexpr int IW = (TW - 1) * STRIDE + 3;
-    __shared__ __attribute__((aligned(16))) T tile[IH * IW * 64];        // halo tile in the storage dtype
+    constexpr int NPX = IH * IW;
+    constexpr int NLD = (NPX + SLOTS - 1) / SLOTS;                       // halo pixels fetched per lane per tile
+    __shared__ __attribute__((aligned(16))) T tile[2][NPX * 64];         // double-buffered halo tile (storage dtype;
+                                                                         // widening it to fp32 at staging measured slower)
     __shared__ __attribute__((aligned(16))) float red[SLOTS * 64];
 
     const int t = threadIdx.x;
     const int cq = t % LPP;         // channel group inside the 64-channel slab
     const int pt = t / LPP;         // pixel slot
     const int c = blockIdx.x * 64 + cq * V;
-    const int tileId = blockIdx.y;
-    const int ty = tileId / tilesX, tx = tileId - ty * tilesX;
     const int b = blockIdx.z;
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
     const bool cok = c < C;         // C % V == 0 (validated), so a lane is entirely in or out
+    const int tile0 = blockIdx.y * tiles_per_wg;
+    const int ntile = min(tiles_per_wg, P - tile0);
 
-    for (int i = pt; i < IH * IW; i += SLOTS) {
-        const int ry = i / IW, rx = i - ry * IW;
-        const int iy = iy0 + ry, ix = ix0 + rx;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (cok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-            v = *reinterpret_cast<const u32x4*>(in + (((long)b * H + iy) * W + ix) * C + c);
-        *reinterpret_cast<u32x4*>(tile + i * 64 + cq * V) = v;
-    }
+    // The workgroup walks `tiles_per_wg` consecutive spatial tiles of its 64-channel slab: the halo of
+    // tile k+1 is fetched into registers while tile k is convolved out of LDS, and the 9x(4|8) filter
+    // taps are loaded once.
+    u32x4 stage[NLD];
+    auto fetch = [&](int tileId) {
+        const int ty = tileId / tilesX, tx = tileId - ty * tilesX;
+        const int iy0 = ty * TH * STRIDE - 1, ix0 = tx * TW * STRIDE - 1;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = pt + j * SLOTS;
+            const int ry = i / IW, rx = i - ry * IW;
+            const int iy = iy0 + ry, ix = ix0 + rx;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (cok && i < NPX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                v = *reinterpret_cast<const u32x4*>(in + (((long)b * H + iy) * W + ix) * C + c);
+            stage[j] = v;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = pt + j * SLOTS;
+            if (i < NPX) *reinterpret_cast<u32x4*>(&tile[buf][i * 64 + cq * V]) = stage[j];
+        }
+    };
+
+    fetch(tile0);
     float wv[9][V], bv[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) bv[e] = 0.f;
@@ -117,45 +137,55 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, c
             for (int e = 0; e < 4; ++e) bv[4 * q + e] = x[e];
         }
     }
+    commit(0);
     __syncthreads();
 
-    float sum[V];
+    for (int kt = 0; kt < ntile; ++kt) {
+        const int tileId = tile0 + kt;
+        const int buf = kt & 1;
+        if (kt + 1 < ntile) fetch(tileId + 1);                 // in flight during the convolution below
+        const int ty = tileId / tilesX, tx = tileId - ty * tilesX;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        float sum[V];
 #pragma unroll
-    for (int e = 0; e < V; ++e) sum[e] = 0.f;
+        for (int e = 0; e < V; ++e) sum[e] = 0.f;
 #pragma unroll
-    for (int k = 0; k < TH * TW / SLOTS; ++k) {
-        const int o = pt + SLOTS * k;
-        const int ly = o / TW, lx = o - ly * TW;
-        const int oy = oy0 + ly, ox = ox0 + lx;
-        float acc[V];
+        for (int k = 0; k < TH * TW / SLOTS; ++k) {
+            const int o = pt + SLOTS * k;
+            const int ly = o / TW, lx = o - ly * TW;
+            const int oy = oy0 + ly, ox = ox0 + lx;
+            float acc[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) acc[e] = bv[e];
+            for (int e = 0; e < V; ++e) acc[e] = bv[e];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                float x[V];
-                load16<T>(tile + ((ly * STRIDE + r) * IW + lx * STRIDE + s) * 64 + cq * V, x);
+                for (int s = 0; s < 3; ++s) {
+                    float x[V];
+                    load16<T>(&tile[buf][((ly * STRIDE + r) * IW + lx * STRIDE + s) * 64 + cq * V], x);
 #pragma unroll
-                for (int e = 0; e < V; ++e) acc[e] = fmaf(wv[r * 3 + s][e], x[e], acc[e]);
+                    for (int e = 0; e < V; ++e) acc[e] = fmaf(wv[r * 3 + s][e], x[e], acc[e]);
+                }
+            if (cok && oy < Ho && ox < Wo) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] = sizeof(T) == 2 ? act_silu_fast(acc[e]) : act_silu_precise(acc[e]);
+                store16<T>(out + (((long)b * Ho + oy) * Wo + ox) * C + c, acc);
+#pragma unroll
+                for (int e = 0; e < V; ++e) sum[e] += acc[e];
             }
-        if (cok && oy < Ho && ox < Wo) {
-#pragma unroll
-            for (int e = 0; e < V; ++e) acc[e] = sizeof(T) == 2 ? act_silu_fast(acc[e]) : act_silu_precise(acc[e]);
-            store16<T>(out + (((long)b * Ho + oy) * Wo + ox) * C + c, acc);
-#pragma unroll
-            for (int e = 0; e < V; ++e) sum[e] += acc[e];
         }
-    }
 #pragma unroll
-    for (int e = 0; e < V; ++e) red[pt * 64 + cq * V + e] = sum[e];
-    __syncthreads();
-    if (t < 64) {
-        float s = 0.f;
+        for (int e = 0; e < V; ++e) red[pt * 64 + cq * V + e] = sum[e];
+        if (kt + 1 < ntile) commit(buf ^ 1);                    // the other buffer was last read one iteration ago
+        __syncthreads();
+        if (t < 64) {
+            float s = 0.f;
 #pragma unroll
-        for (int k = 0; k < SLOTS; ++k) s += red[k * 64 + t];
-        const int cc = blockIdx.x * 64 + t;
-        if (cc < C) partial[((long)b * P + tileId) * C + cc] = s;
+            for (int k = 0; k < SLOTS; ++k) s += red[k * 64 + t];
+            const int cc = blockIdx.x * 64 + t;
+            if (cc < C) partial[((long)b * P + tileId) * C + cc] = s;
+        }
+        __syncthreads();                                         // red[] is reused by the next tile
     }
 }
 
@@ -232,10 +262,15 @@ hipError_t launch_dwconv(const OpArgs& a, hipStream_t s) {
     const int tilesX = (o.Wo + TW - 1) / TW, tilesY = (o.Ho + TH - 1) / TH;
     const int P = tilesX * tilesY;
     if (P != o.aux0) return hipErrorInvalidValue;
-    dim3 grid((o.Cin + 63) / 64, P, o.B);
+    // consecutive tiles per workgroup: as many as still leave >= 4 workgroups per CU
+    const long slabs = (long)((o.Cin + 63) / 64) * o.B;
+    int tpw = (int)((slabs * P) / 1024);
+    if (tpw < 1) tpw = 1;
+    if (tpw > 8) tpw = 8;
+    dim3 grid((o.Cin + 63) / 64, (P + tpw - 1) / tpw, o.B);
 #define DW_LAUNCH(T, ST)                                                                                      \
     hipLaunchKernelGGL((dwconv_kernel<T, ST>), grid, dim3(256), 0, s, (const T*)a.in, (const float*)a.w, a.bias, \
-                       (T*)a.out, a.aux, o.H, o.W, o.Ho, o.Wo, o.Cin, tilesX, P)
+                       (T*)a.out, a.aux, o.H, o.W, o.Ho, o.Wo, o.Cin, tilesX, P, tpw)
     if (o.in_dtype == FTC_F32) { if (o.stride == 1) DW_LAUNCH(float, 1); else DW_LAUNCH(float, 2); }
     else { if (o.stride == 1) DW_LAUNCH(__bf16, 1); else DW_LAUNCH(__bf16, 2); }
 #undef DW_LAUNCH

@@ -17,7 +17,7 @@ ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 FLAG_RESIDUAL, FLAG_SE_SCALE, FLAG_IN_NCHW, FLAG_BORDER_BIAS = 1, 2, 4, 8
 
 EXPORTS = ["ftc_abi_version", "ftc_last_error", "ftc_device_info", "ftc_plan_create", "ftc_plan_destroy",
-           "ftc_plan_num_ops", "ftc_plan_run", "ftc_plan_profile", "ftc_op_kernel_label", "ftc_decode_scratch_bytes", "ftc_decode"]
+           "ftc_plan_num_ops", "ftc_plan_run", "ftc_plan_profile", "ftc_op_kernel_label", "ftc_decode_scratch_bytes", "ftc_decode", "ftc_tile_gather", "ftc_paste_maps"]
 
 
 class FtcLibraryError(RuntimeError):
@@ -73,6 +73,8 @@ def load():
     lib.ftc_decode_scratch_bytes.argtypes = [i32, i32, i32]
     lib.ftc_decode_scratch_bytes.restype = i64
     lib.ftc_decode.argtypes = [vp, vp, i32, i32, i32, i32, vp, C.c_float, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.ftc_tile_gather.argtypes = [vp, i32, i32, vp, i32, i32, i32, vp, vp]
+    lib.ftc_paste_maps.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]
     if lib.ftc_abi_version() != FTC_ABI_VERSION:
         raise FtcLibraryError(f"ABI mismatch: library {lib.ftc_abi_version()} vs binding {FTC_ABI_VERSION}")
     _lib = lib

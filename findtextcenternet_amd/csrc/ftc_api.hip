@@ -11,6 +11,11 @@ hipError_t launch_decode(const float* heat, const float* feat, int B, int h, int
                          float logit_cut, int scale, int max_boxes, float* boxes, float* feats, int32_t* index,
                          int32_t* counts, void* scratch, hipStream_t s);
 
+hipError_t launch_tile_gather(const unsigned char* page, int PH, int PW, const int* origins, int B, int th, int tw, float* out,
+                              hipStream_t s);
+hipError_t launch_paste_maps(const float* heat, const ftc_tile* tiles, int B, int h, int w, int scale, float* canv, int ph, int pw,
+                             hipStream_t s);
+
 struct ftc_plan {
     std::vector<ftc_op> ops;
     int64_t workspace_bytes;
@@ -251,6 +256,24 @@ int ftc_decode(const float* heatmap, const float* features, int B, int h, int w,
     hipError_t e = launch_decode(heatmap, features, B, h, w, C, tiles_dev, logit_cut, scale, max_boxes, boxes, feats, index,
                                  counts, scratch_dev, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(e, "ftc_decode");
+    return FTC_OK;
+}
+
+int ftc_tile_gather(const unsigned char* page_u8, int page_h, int page_w, const int32_t* origins_yx_dev, int B, int tile_h,
+                    int tile_w, float* tiles_out, void* stream) {
+    if (!page_u8 || !origins_yx_dev || !tiles_out) return fail(FTC_ERR_INVALID, "ftc_tile_gather: null pointer argument");
+    if (page_h <= 0 || page_w <= 0 || B <= 0 || tile_h <= 0 || tile_w <= 0) return fail(FTC_ERR_INVALID, "ftc_tile_gather: bad sizes");
+    hipError_t e = launch_tile_gather(page_u8, page_h, page_w, origins_yx_dev, B, tile_h, tile_w, tiles_out, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "ftc_tile_gather");
+    return FTC_OK;
+}
+
+int ftc_paste_maps(const float* heatmap, const ftc_tile* tiles_dev, int B, int h, int w, int scale, float* canvases, int page_mh,
+                   int page_mw, void* stream) {
+    if (!heatmap || !tiles_dev || !canvases) return fail(FTC_ERR_INVALID, "ftc_paste_maps: null pointer argument");
+    if (B <= 0 || h <= 0 || w <= 0 || scale <= 0 || page_mh <= 0 || page_mw <= 0) return fail(FTC_ERR_INVALID, "ftc_paste_maps: bad sizes");
+    hipError_t e = launch_paste_maps(heatmap, tiles_dev, B, h, w, scale, canvases, page_mh, page_mw, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "ftc_paste_maps");
     return FTC_OK;
 }
 

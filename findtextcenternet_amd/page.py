@@ -1,0 +1,241 @@
+"""Page-level detector pipeline on the MI355X path: tiling front-end, batched tiles through the HIP
+detector, GPU peak decode, GPU paste of the page maps, host-side page merge.
+
+Drop-in for ``OCR_Processer.run_detector`` (``/root/reference/process_ocr_base.py:474-650``) and for the
+tiling part of ``call_OCR`` (``:57-78``): same arguments, same four return values
+``(locations float32 [M,9], glyphfeatures float32 [M,100], lines_all, seps_all)``.
+
+What runs where
+* GPU (HIP): tile gather from the uint8 page (``ftc_tile_gather``), detector forward + NMS for batches of
+  tiles (the reference runs them one by one), peak decode + feature gather (``ftc_decode``), the
+  ``np.maximum`` paste of the masked sigmoid maps (``ftc_paste_maps``).  Only the decoded peaks and the
+  page-sized canvases come back over PCIe -- not 16 MB of maps per tile.
+* Host (numpy, as in the reference): the page-level selection -- 2-means contrast filter, greedy
+  overlap suppression with the coverage rule, separator filter, 3x3 code maximum
+  (``process_ocr_base.py:540-648``).  It is a sequential greedy over ~10^3 boxes; SURVEY.md 8(a) row 11
+  keeps it on the host ("next" row 8f-1 is its GPU version).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .decode import TileGeom, decode_peaks, tile_keep_rect, tiles_to_device
+from .schema import feature_dim, height, scale, width
+
+
+# ------------------------------------------------------------------------------------------------
+# tiling (process_ocr_base.py:63-76)
+# ------------------------------------------------------------------------------------------------
+def padded_page_size(h: int, w: int, stepx: int, stepy: int) -> Tuple[int, int]:
+    padx = max(0, (width - w) % stepx, width - w)
+    pady = max(0, (height - h) % stepy, height - h)
+    return h + pady, w + padx
+
+
+def tile_origins(page_h: int, page_w: int, stepx: int, stepy: int) -> List[Tuple[int, int]]:
+    return [(y, x) for y in range(0, page_h - height + 1, stepy) for x in range(0, page_w - width + 1, stepx)]
+
+
+# ------------------------------------------------------------------------------------------------
+# host page merge (process_ocr_base.py:540-648)
+# ------------------------------------------------------------------------------------------------
+def _two_means_distance(hist: np.ndarray) -> float:
+    """Distance between the centres of a 1-D 2-means clustering of a 256-bin histogram
+    (``imageHist.cluster_dist``, process_ocr_base.py:654-684)."""
+    total = hist.sum()
+    if total == 0:
+        return 0
+    idx = np.arange(hist.shape[0])
+    weighted = hist * idx
+    cut = int(weighted.sum() / total + 0.5)
+    n_lo, n_hi = hist[:cut].sum(), hist[cut:].sum()
+    if n_lo == 0 or n_hi == 0:
+        return 0
+    c_lo, c_hi = weighted[:cut].sum() / n_lo, weighted[cut:].sum() / n_hi
+    last, dist = 256.0, abs(c_lo - c_hi)
+    while last != dist:
+        last = dist
+        lo = np.abs(idx - c_lo) < np.abs(idx - c_hi)
+        n_lo, n_hi = hist[lo].sum(), hist[~lo].sum()
+        if n_lo == 0 or n_hi == 0:
+            return 0
+        c_lo, c_hi = weighted[lo].sum() / n_lo, weighted[~lo].sum() / n_hi
+        dist = abs(c_lo - c_hi)
+    return last
+
+
+def image_contrast(patch: np.ndarray) -> float:
+    """``OCR_Processer.imageHist`` (process_ocr_base.py:652-693)."""
+    best = -1
+    for ch in range(3):
+        best = max(best, _two_means_distance(np.histogram(patch[:, :, ch], bins=256, range=(0, 256))[0]))
+    return best
+
+
+def page_merge(locations: np.ndarray, glyphfeatures: np.ndarray, org_img: np.ndarray, seps_all: np.ndarray,
+               code_all: Sequence[np.ndarray], cut_off: float):
+    """locations float64 [N,9] in page coordinates (any order), glyphfeatures [N,100]."""
+    page_h, page_w = org_img.shape[:2]
+    mh, mw = page_h // scale, page_w // scale
+    n = locations.shape[0]
+    above = locations[:, 0] >= cut_off
+    # contrast threshold: median of the per-box contrast / 5 (:543-557); crop bounds as in the reference,
+    # including its use of possibly negative slice starts
+    hists = []
+    for i in np.nonzero(above)[0]:
+        _, cx, cy, w, h = locations[i, :5]
+        hists.append(image_contrast(org_img[int(cy - h / 2) - 1:int(cy + h / 2) + 2, int(cx - w / 2) - 1:int(cx + w / 2) + 2, :]))
+    th_hist = np.median(hists) / 5 if hists else np.nan
+
+    kept_boxes = np.zeros([0, 4])
+    kept: List[int] = []
+    for i in np.argsort(-locations[:, 0], kind="stable"):
+        p, cx, cy, w, h = locations[i, :5]
+        if p < cut_off:
+            break
+        x0, x1 = max(0, int(cx - w / 2)), min(page_w - 1, int(cx + w / 2) + 1)
+        y0, y1 = max(0, int(cy - h / 2)), min(page_h - 1, int(cy + h / 2) + 1)
+        if image_contrast(org_img[y0:y1, x0:x1, :]) < th_hist:
+            continue
+        if kept_boxes.shape[0] > 0:
+            area = w * h
+            ix0 = np.maximum(cx - w / 2, kept_boxes[:, 0] - kept_boxes[:, 2] / 2)
+            iy0 = np.maximum(cy - h / 2, kept_boxes[:, 1] - kept_boxes[:, 3] / 2)
+            ix1 = np.minimum(cx + w / 2, kept_boxes[:, 0] + kept_boxes[:, 2] / 2)
+            iy1 = np.minimum(cy + h / 2, kept_boxes[:, 1] + kept_boxes[:, 3] / 2)
+            inter = np.maximum(ix1 - ix0, 0.) * np.maximum(iy1 - iy0, 0.)
+            union = area + kept_boxes[:, 2] * kept_boxes[:, 3] - inter
+            iou = np.where(union > 0., inter / union, 0.)
+            if iou.max() > 0.5 or inter.max() > area * 0.75:
+                continue
+            covered = np.zeros([int(w), int(h)], dtype=bool)
+            for j in np.nonzero(iou > 0)[0]:
+                kx, ky, kw, kh = kept_boxes[j]
+                a0 = int(max(kx - kw / 2, cx - w / 2) - (cx - w / 2))
+                a1 = int(min(kx + kw / 2, cx + w / 2) - (cx - w / 2)) + 1
+                b0 = int(max(ky - kh / 2, cy - h / 2) - (cy - h / 2))
+                b1 = int(min(ky + kh / 2, cy + h / 2) - (cy - h / 2)) + 1
+                covered[a0:a1, b0:b1] = True
+            if np.mean(covered) > 0.5:
+                continue
+        kept_boxes = np.vstack([kept_boxes, np.array([cx, cy, w, h])])
+        kept.append(i)
+
+    final = []
+    for i in kept:
+        x, y = int(locations[i, 1] / scale), int(locations[i, 2] / scale)
+        if 0 <= x < mw and 0 <= y < mh and seps_all[y, x] > 0.5:
+            continue
+        final.append(i)
+    if final:
+        sel = np.array(final)
+        locations, glyphfeatures = locations[sel, :].copy(), glyphfeatures[sel, :]
+    else:
+        locations, glyphfeatures = np.zeros([0, 9]), np.zeros([0, feature_dim], dtype=np.float32)
+    for i in range(locations.shape[0]):
+        cx, cy = locations[i, 1], locations[i, 2]
+        x, y = int(cx / scale), int(cy / scale)
+        if 0 <= x < mw and 0 <= y < mh:
+            xs = slice(max(0, int(cx / scale - 1)), min(mw, int(cx / scale + 1) + 1))
+            ys = slice(max(0, int(cy / scale - 1)), min(mh, int(cy / scale + 1) + 1))
+            for k in range(4):
+                locations[i, 5 + k] = max(np.max(code_all[k][ys, xs]), locations[i, 5 + k])
+    return locations.astype(np.float32), glyphfeatures
+
+
+# ------------------------------------------------------------------------------------------------
+# the pipeline
+# ------------------------------------------------------------------------------------------------
+class PageDetector:
+    """``run_detector`` / tiling of ``OCR_Processer`` on top of a HIP ``CenterNetDetector``."""
+
+    def __init__(self, detector, step_ratio: float = 0.6, cut_off: float = 0.4, batch: int = 8, max_boxes: int = 4096,
+                 device: str = "cuda"):
+        self.device = torch.device(device)
+        detector.to(device=self.device)
+        detector.eval()
+        self.detector = detector
+        self.step_ratio, self.cut_off, self.batch, self.max_boxes = step_ratio, cut_off, batch, max_boxes
+        self.stepx, self.stepy = int(width * step_ratio), int(height * step_ratio)      # process_ocr_base.py:43-45
+
+    # -- reference signature -----------------------------------------------------------------
+    def run_detector(self, ds: Sequence[dict], org_img: np.ndarray):
+        """ds: list of {'input': [1,768,768,3] float32 0..255, 'offsetx', 'offsety'}; org_img float32 page."""
+        tiles = np.concatenate([np.asarray(d["input"], dtype=np.float32) for d in ds], axis=0)
+        origins = [(d["offsety"], d["offsetx"]) for d in ds]
+        x_all = torch.from_numpy(tiles / np.float32(255.)).to(self.device)
+        return self._run(lambda lo, hi: x_all[lo:hi], origins, org_img)
+
+    def detect_page(self, im_u8: np.ndarray):
+        """uint8 RGB page [H,W,3] -> same outputs; pads with white and tiles like call_OCR (:63-76)."""
+        lib = L.load()
+        h0, w0 = im_u8.shape[:2]
+        ph, pw = padded_page_size(h0, w0, self.stepx, self.stepy)
+        origins = tile_origins(ph, pw, self.stepx, self.stepy)
+        page_dev = torch.from_numpy(np.ascontiguousarray(im_u8[:, :, :3])).to(self.device)
+        org = np.full((ph, pw, 3), 255, np.uint8)
+        org[:h0, :w0] = im_u8[:, :, :3]
+        org_img = org.astype(np.float32)
+
+        def gather(lo, hi):
+            o = torch.tensor(origins[lo:hi], dtype=torch.int32, device=self.device)
+            out = torch.empty((hi - lo, height, width, 3), dtype=torch.float32, device=self.device)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            L.check(lib.ftc_tile_gather(page_dev.data_ptr(), h0, w0, o.data_ptr(), hi - lo, height, width, out.data_ptr(),
+                                        C.c_void_p(stream)), "ftc_tile_gather")
+            return out
+        return self._run(gather, origins, org_img)
+
+    # -- shared ------------------------------------------------------------------------------------
+    def _run(self, get_tiles, origins, org_img):
+        lib = L.load()
+        page_h, page_w = org_img.shape[:2]
+        mh, mw = page_h // scale, page_w // scale
+        canv = torch.zeros((7, mh, mw), dtype=torch.float32, device=self.device)
+        parts = []
+        with torch.cuda.device(self.device), torch.no_grad():
+            for lo in range(0, len(origins), self.batch):
+                hi = min(len(origins), lo + self.batch)
+                x = get_tiles(lo, hi).permute(0, 3, 1, 2)
+                heat, feat = self.detector.forward_nhwc(x)
+                geoms = [TileGeom(ox, oy, page_w, page_h, tile_keep_rect(ox, oy, page_w, page_h, self.step_ratio)) for (oy, ox) in origins[lo:hi]]
+                tl = tiles_to_device(geoms, self.device, heat.shape[1], heat.shape[2])
+                stream = torch.cuda.current_stream(self.device).cuda_stream
+                L.check(lib.ftc_paste_maps(heat.data_ptr(), tl.data_ptr(), hi - lo, heat.shape[1], heat.shape[2], scale, canv.data_ptr(),
+                                           mh, mw, C.c_void_p(stream)), "ftc_paste_maps")
+                dec = decode_peaks(heat, feat, tl, cut_off=self.cut_off, max_boxes=self.max_boxes)
+                parts.append((dec.counts.cpu().numpy(), dec.boxes, dec.feats))
+        locs, feats = [np.zeros([1, 9])], [np.zeros([1, feature_dim], np.float32)]      # the reference's dummy first row (:478-479)
+        for counts, boxes, fts in parts:
+            if (counts > self.max_boxes).any():
+                raise RuntimeError(f"a tile produced {int(counts.max())} peaks > max_boxes={self.max_boxes}; raise max_boxes")
+            for b, n in enumerate(counts):
+                locs.append(boxes[b, :n].cpu().numpy().astype(np.float64))
+                feats.append(fts[b, :n].cpu().numpy())
+        canv_h = canv.cpu().numpy()
+        locations, glyph = page_merge(np.concatenate(locs), np.concatenate(feats), org_img, canv_h[2], list(canv_h[3:7]), self.cut_off)
+        return locations, glyph, canv_h[1], canv_h[2]
+
+
+def linedetect_request(locations: np.ndarray, lines: np.ndarray, seps: np.ndarray) -> bytes:
+    """Binary request of the reference's ``linedetect`` CLI (``process_ocr_base.py:80-88``; parser
+    ``textline_detect/src/main.cpp:100-180``): u32 mode=0, u32 w, u32 h, f32 lines[h*w], f32 seps[h*w],
+    u32 n, n x 8 f32 (cx, cy, w, h, code1, code2, code4, code8)."""
+    h, w = lines.shape
+    out = int(0).to_bytes(4, "little") + int(w).to_bytes(4, "little") + int(h).to_bytes(4, "little")
+    out += np.ascontiguousarray(lines, dtype=np.float32).tobytes() + np.ascontiguousarray(seps, dtype=np.float32).tobytes()
+    out += int(locations.shape[0]).to_bytes(4, "little")
+    out += np.ascontiguousarray(locations[:, 1:], dtype=np.float32).tobytes()
+    return out
+
+
+def linedetect_parse(result: bytes):
+    """i32 n, n x 7 i32 (id, block, idx, subidx, subtype, page, section) -- process_ocr_base.py:91-112."""
+    n = int.from_bytes(result[:4], "little")
+    a = np.frombuffer(result, dtype="<i4", count=7 * n, offset=4).reshape(n, 7)
+    return [tuple(int(v) for v in row) for row in a]

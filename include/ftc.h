@@ -188,6 +188,24 @@ int ftc_decode(const float* heatmap, const float* features, int B, int h, int w,
                float* boxes, float* feats, int32_t* index, int32_t* counts,
                void* scratch_dev, void* stream);
 
+/* Page front / back end ("next" rows of SURVEY.md 8f) ----------------------------------------- */
+/*
+ * Tiling front-end of OCR_Processer.call_OCR (process_ocr_base.py:67-76): cuts B tiles of
+ * tile_h x tile_w out of a uint8 RGB page resident in device memory and writes them as
+ * [B,tile_h,tile_w,3] fp32 = pixel / 255 (process_ocr_torch.py:44).  origins_yx_dev = B (y, x) int32
+ * pairs in device memory; pixels beyond the page read as 255 (the reference's white padding, :63-65).
+ */
+int ftc_tile_gather(const unsigned char* page_u8, int page_h, int page_w, const int32_t* origins_yx_dev, int B, int tile_h,
+                    int tile_w, float* tiles_out, void* stream);
+/*
+ * np.maximum paste of the masked sigmoid maps of B tiles into page canvases (process_ocr_base.py:505-516).
+ * canvases = [7][page_mh][page_mw] fp32 (key, textline, separator, code1, code2, code4, code8), zeroed by
+ * the caller before the first batch of a page; merges with atomic max (values >= 0), so the result does
+ * not depend on tile order.
+ */
+int ftc_paste_maps(const float* heatmap, const ftc_tile* tiles_dev, int B, int h, int w, int scale, float* canvases, int page_mh,
+                   int page_mw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

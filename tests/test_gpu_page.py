@@ -1,0 +1,102 @@
+"""-m gpu: tiling front-end, GPU paste of the page maps and the whole PageDetector.run_detector /
+detect_page against the numpy oracle of OCR_Processer.run_detector (oracle/decode_oracle.py, pinned
+by the reference's own outputs)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from findtextcenternet_amd import CenterNetDetector, TextDetectorModel, TileGeom, deterministic_state_dict, tile_keep_rect, tiles_to_device
+from findtextcenternet_amd import _lib as L
+from findtextcenternet_amd import page
+from oracle import decode_oracle, detector_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_tile_gather_matches_numpy_padding_and_scaling():
+    lib = L.load()
+    rng = np.random.Generator(np.random.PCG64(1))
+    im = rng.integers(0, 256, (900, 1000, 3), dtype=np.uint8)
+    ph, pw = page.padded_page_size(900, 1000, 460, 460)
+    padded = np.full((ph, pw, 3), 255, np.uint8)
+    padded[:900, :1000] = im
+    origins = page.tile_origins(ph, pw, 460, 460)
+    assert len(origins) == 4
+    dev = torch.device("cuda")
+    pg = torch.from_numpy(im).to(dev)
+    o = torch.tensor(origins, dtype=torch.int32, device=dev)
+    out = torch.empty((len(origins), 768, 768, 3), dtype=torch.float32, device=dev)
+    L.check(lib.ftc_tile_gather(pg.data_ptr(), 900, 1000, o.data_ptr(), len(origins), 768, 768, out.data_ptr(),
+                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gather")
+    ref = np.stack([padded[y:y + 768, x:x + 768].astype(np.float32) / np.float32(255.) for (y, x) in origins])
+    assert np.array_equal(out.cpu().numpy(), ref)                       # bit-exact: IEEE division, white padding
+
+
+def test_paste_maps_matches_oracle():
+    lib = L.load()
+    step = int(768 * 0.6)
+    P = 768 + step
+    origins = [(0, 0), (0, step), (step, 0), (step, step)]
+    maps = [synth.detector_maps(300 + n) for n in range(4)]
+    hm = np.concatenate([m[0] for m in maps])
+    canv_ref = [np.zeros([P // 4, P // 4], np.float32) for _ in range(7)]
+    geoms = []
+    for (y, x), (h1, _) in zip(origins, maps):
+        rect = decode_oracle.tile_keep_rect(x, y, P, P, 0.6)
+        decode_oracle.paste_maps(canv_ref, h1, x, y, rect)
+        geoms.append(TileGeom(x, y, P, P, rect))
+    dev = torch.device("cuda")
+    heat = torch.from_numpy(np.ascontiguousarray(hm.transpose(0, 2, 3, 1))).to(dev)
+    canv = torch.zeros((7, P // 4, P // 4), dtype=torch.float32, device=dev)
+    tl = tiles_to_device(geoms, dev, 192, 192)
+    L.check(lib.ftc_paste_maps(heat.data_ptr(), tl.data_ptr(), 4, 192, 192, 4, canv.data_ptr(), P // 4, P // 4,
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), "paste")
+    got = canv.cpu().numpy()
+    for k in range(7):
+        assert np.abs(got[k] - canv_ref[k]).max() < 3e-7               # GPU tanhf vs numpy tanh, values in [0,1]
+
+
+@pytest.fixture(scope="module")
+def detector():
+    m = TextDetectorModel(pre_weights=False, precision="fp32")
+    m.load_state_dict(deterministic_state_dict(0))
+    return CenterNetDetector(m.detector).to("cuda").eval()
+
+
+def test_run_detector_two_tiles_vs_oracle(detector):
+    """Whole pipeline (forward, NMS, decode, paste, page merge) on a 2-tile page against the CPU oracle
+    fed by the CPU oracle detector: same boxes, features and page maps."""
+    step = int(768 * 0.6)
+    ph, pw = 768, 768 + step
+    img_u8 = synth.page_uint8(55, ph, pw)
+    img = img_u8.astype(np.float32)
+    ds = [{"input": img[None, :, x:x + 768], "offsetx": x, "offsety": 0} for x in (0, step)]
+    sd = deterministic_state_dict(0)
+
+    def cpu_call_detector(image_input):
+        x = torch.from_numpy(image_input / np.float32(255.)).permute(0, 3, 1, 2)
+        h, f = detector_oracle.detector_forward(sd, x)
+        return h.numpy(), f.numpy()
+    o_loc, o_gf, o_lines, o_seps, _ = decode_oracle.run_detector(ds, img, cpu_call_detector, 0.6, 0.4)
+    pd = page.PageDetector(detector, step_ratio=0.6, cut_off=0.4, batch=2)
+    loc, gf, lines, seps = pd.run_detector(ds, img)
+    assert np.abs(lines - o_lines).max() < 1e-4 and np.abs(seps - o_seps).max() < 1e-4
+    # the greedy page merge is discontinuous in its inputs: require the same boxes up to fp32-tie effects
+    key = lambda a: {(int(r[1]), int(r[2])) for r in a}                      # noqa: E731
+    common = key(loc) & key(o_loc)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/test_detector.log", "a") as f:
+        f.write(f"run_detector 2 tiles: gpu {len(loc)} boxes, oracle {len(o_loc)}, common {len(common)}\\n")
+    assert len(common) >= 0.98 * max(len(loc), len(o_loc)) and len(o_loc) > 50
+    idx = {(int(r[1]), int(r[2])): i for i, r in enumerate(o_loc)}
+    sel = [(i, idx[(int(r[1]), int(r[2]))]) for i, r in enumerate(loc) if (int(r[1]), int(r[2])) in idx]
+    a, b = np.array([s[0] for s in sel]), np.array([s[1] for s in sel])
+    np.testing.assert_allclose(loc[a], o_loc[b], rtol=2e-4, atol=2e-4)
+    assert np.abs(gf[a] - o_gf[b]).max() < 1e-3
+    # tiling front-end from the uint8 page gives the same result as the reference-style ds list
+    loc2, gf2, lines2, seps2 = pd.detect_page(img_u8)
+    assert np.array_equal(loc2, loc) and np.array_equal(gf2, gf) and np.array_equal(lines2, lines)

@@ -95,3 +95,68 @@ def deterministic_state_dict(seed: int = 0, model_size: str = "xl", with_decoder
         for k, (shape, kind) in detector_schema(model_size).items():
             out[k] = fill_tensor(seed, k, shape, kind)
     return out
+
+
+def tf_efficientnetv2_npz_names(model_size: str = "xl"):
+    """(state_dict key of the backbone, npz array name, permutation or None) for every tensor the
+    reference's TF-checkpoint importer touches (``load_weight``, ``/root/reference/models/detector.py:30-121``):
+    conv kernels are HWIO in the npz (-> ``permute(3,2,0,1)``), depthwise kernels HWC1-like (-> ``permute(2,3,0,1)``),
+    BatchNorm gamma/beta/moving_mean/moving_variance map to weight/bias/running_mean/running_var.  As in
+    the reference, the SE ``fc1``/``fc2`` *biases* are NOT imported (``apply_weights`` only assigns ``weight``)."""
+    from .schema import STAGES, backbone_blocks
+    root = f"efficientnetv2-{model_size}/"
+    bn = [("weight", "gamma"), ("bias", "beta"), ("running_mean", "moving_mean"), ("running_var", "moving_variance")]
+    out = []
+
+    def conv(key, name):
+        out.append((key, name + "kernel", (3, 2, 0, 1)))
+
+    def norm(prefix, name):
+        for a, b in bn:
+            out.append((f"{prefix}.{a}", name + b, None))
+
+    conv("backbone.features.0.0.weight", root + "stem/conv2d/")
+    norm("backbone.features.0.1", root + "stem/tpu_batch_normalization/")
+    idx = 0
+    for stage in backbone_blocks(model_size):
+        for blk in stage:
+            p, t = blk.prefix + ".block", f"{root}blocks_{idx}/"
+            if blk.kind == "fused" and blk.exp == blk.cin:
+                conv(p + ".0.0.weight", t + "conv2d/")
+                norm(p + ".0.1", t + "tpu_batch_normalization/")
+            elif blk.kind == "fused":
+                conv(p + ".0.0.weight", t + "conv2d/")
+                norm(p + ".0.1", t + "tpu_batch_normalization/")
+                conv(p + ".1.0.weight", t + "conv2d_1/")
+                norm(p + ".1.1", t + "tpu_batch_normalization_1/")
+            else:
+                conv(p + ".0.0.weight", t + "conv2d/")
+                norm(p + ".0.1", t + "tpu_batch_normalization/")
+                out.append((p + ".1.0.weight", t + "depthwise_conv2d/depthwise_kernel", (2, 3, 0, 1)))
+                norm(p + ".1.1", t + "tpu_batch_normalization_1/")
+                conv(p + ".2.fc1.weight", t + "se/conv2d/")
+                conv(p + ".2.fc2.weight", t + "se/conv2d_1/")
+                conv(p + ".3.0.weight", t + "conv2d_1/")
+                norm(p + ".3.1", t + "tpu_batch_normalization_2/")
+            idx += 1
+    n = len(STAGES[model_size]) + 1
+    conv(f"backbone.features.{n}.0.weight", root + "head/conv2d/")
+    norm(f"backbone.features.{n}.1", root + "head/tpu_batch_normalization/")
+    return out
+
+
+def load_tf_efficientnetv2_npz(detection_module, weight_path: str, model_size: str = "xl") -> bool:
+    """Import a TF EfficientNetV2 ``.npz`` into the backbone of a ``CenterNetDetection`` (mirror of the
+    reference's ``load_weight``; returns False and prints ``not found`` when the file is absent, as the
+    reference does at ``models/detector.py:34-36``)."""
+    import os
+    if not os.path.exists(weight_path):
+        print("not found:", weight_path)
+        return False
+    sd = detection_module.state_dict()
+    with np.load(weight_path) as w:
+        for key, name, perm in tf_efficientnetv2_npz_names(model_size):
+            t = torch.from_numpy(w[name])
+            sd[key] = t.permute(*perm).contiguous() if perm is not None else t
+    detection_module.load_state_dict(sd)
+    return True

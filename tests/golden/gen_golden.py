@@ -176,10 +176,48 @@ def gen_decode():
     save("g3_sigmoid.npz", x=xs, y=ref_util.sigmoid(xs))
 
 
+def gen_tf_import(model):
+    """Reference load_weight (models/detector.py:30-121) on a synthetic TF-style npz whose array names come
+    from OUR name table: if a name or a layout were wrong the reference would raise or produce other bytes."""
+    import hashlib
+    import tempfile
+    from findtextcenternet_amd.weights import tf_efficientnetv2_npz_names
+    sd = model.detector.state_dict()
+    rng = np.random.Generator(np.random.PCG64(77))
+    arrs = {}
+    for key, name, perm in tf_efficientnetv2_npz_names("xl"):
+        shape = tuple(sd[key].shape)
+        if perm is not None:                      # inverse permutation gives the npz-side shape
+            inv = np.argsort(perm)
+            shape = tuple(np.array(shape)[inv])
+        arrs[name] = rng.standard_normal(shape).astype(np.float32)
+    path = os.path.join(tempfile.mkdtemp(), "synthetic-xl.npz")
+    np.savez(path, **arrs)
+    eff = model.detector.backbone
+    import torchvision.models.efficientnet as tve         # the restated stand-in
+
+    class _M(torch.nn.Module):                              # load_weight wants an object with .features
+        def __init__(self, f):
+            super().__init__()
+            self.features = f
+    m = _M(eff.features)
+    before_bias = m.features[4][0].block[2].fc1.bias.detach().clone()
+    ref_detector.load_weight(m, path)
+    after = model.detector.state_dict()
+    digest = {}
+    for key, name, perm in tf_efficientnetv2_npz_names("xl"):
+        digest[key] = hashlib.sha1(after[key].contiguous().numpy().tobytes()).hexdigest()[:16]
+    assert torch.equal(before_bias, m.features[4][0].block[2].fc1.bias)       # SE biases untouched by the reference
+    with gzip.open(os.path.join(HERE, "g5_tf_import_digest.json.gz"), "wt") as f:
+        json.dump({"seed": 77, "digest": digest}, f)
+    print("wrote g5_tf_import_digest.json.gz", len(digest), "tensors")
+
+
 def main():
     torch.manual_seed(0)
     model = ref_detector.TextDetectorModel(pre_weights=False)
     gen_schema(model)
+    gen_tf_import(model)
     model.load_state_dict(deterministic_state_dict(SEED_W))
     det = ref_detector.CenterNetDetector(model.detector)
     det.eval()

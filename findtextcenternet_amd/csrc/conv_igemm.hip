@@ -12,6 +12,11 @@ hipError_t launch_conv_bf16_ff(const ConvP& p, const ftc_op& o, hipStream_t s);
 
 void conv_kernel_label(const ftc_op& op, char* buf, int len) {
     const char* dt[] = {"f32", "bf16"};
+    if (uses_halo(op)) {
+        snprintf(buf, len, "conv3x3_halo<%s,out=%s,tile=%dx16x16,bk=%d>", dt[op.w_dtype & 1], dt[op.out_dtype & 1], halo_sn(op) * 64,
+                 halo_cpr(op) * (op.w_dtype == FTC_BF16 ? 8 : 4));
+        return;
+    }
     const bool dma = uses_glds(op);
     snprintf(buf, len, "conv_igemm%s<%s,in=%s,out=%s,tile=%s,bk=%d,nbuf=%d>", dma ? "_glds" : "", dt[op.w_dtype & 1], dt[op.in_dtype & 1],
              dt[op.out_dtype & 1], kCfgName[select_cfg(op)], select_bk(op), dma ? glds_ring(op) : 1);
@@ -38,6 +43,7 @@ const char* conv_validate(const ftc_op& op) {
     const long in_bytes = (long)op.B * op.H * op.W * op.Cin_total * (op.in_dtype == FTC_F32 ? 4 : 2);
     const long w_bytes = (long)op.Cout * op.ksize * op.ksize * op.Cin * (op.w_dtype == FTC_F32 ? 4 : 2);
     if (in_bytes >= 0x7ff00000L || w_bytes >= 0x7ff00000L) return "conv: operand larger than 2 GiB (split the batch)";
+    if (hint_halo(op) && !halo_legal(op)) return "conv: LDS-halo kernel is not legal for this op/tile";
     if (op.aux0 < 0 || op.aux0 > 0x3ff || hint_cfg(op) >= CFG_COUNT) return "conv: aux0 (tuned kernel choice) out of range";
     if (hint_bk(op) && op.w_dtype == FTC_BF16 && (op.Cin % hint_bk(op)) && hint_bk(op) != 32) return "conv: tuned K step does not divide Cin";
     if (hint_bk(op) == 128 && op.in_dtype != FTC_BF16) return "conv: K step 128 needs bf16 activations";

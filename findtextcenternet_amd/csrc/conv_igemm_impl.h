@@ -105,14 +105,29 @@ __device__ __forceinline__ u32x4 load_act(__amdgpu_buffer_rsrc_t rin, int voff, 
 // Epilogue shared by both kernels: lane owns pixel (l31) of each 32-pixel sub-tile and, per register
 // quad q, channels 8q + 4*half .. +3 of each 32-channel sub-tile (C/D layout of the 32x32 MFMA).
 template <typename WT, typename OutT, int SN, int SM>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvP& p, f32x16 (&acc)[SN][SM], const int (&mrow)[SM], int nbase, int half);
+
+template <typename WT, typename OutT, int SN, int SM>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[SN][SM], int m0, int n0, int wn, int wm, int half, int l31) {
+    int mrow[SM];
+#pragma unroll
+    for (int j = 0; j < SM; ++j) {
+        const int m = m0 + wm * SM * 32 + j * 32 + l31;
+        mrow[j] = m < p.M ? m : -1;
+    }
+    conv_epilogue_rows<WT, OutT, SN, SM>(p, acc, mrow, n0 + wn * SN * 32, half);
+}
+
+// mrow[j] = flat output pixel index (b*Ho*Wo + oy*Wo + ox) this lane owns in sub-tile j, or -1.
+template <typename WT, typename OutT, int SN, int SM>
+__device__ __forceinline__ void conv_epilogue_rows(const ConvP& p, f32x16 (&acc)[SN][SM], const int (&mrow)[SM], int nbase, int half) {
     OutT* __restrict__ outp = reinterpret_cast<OutT*>(p.out);
     const bool has_res = (p.flags & FTC_FLAG_RESIDUAL) != 0;
     const bool vec_ok = ((p.Cout | p.CoutT | p.cout_off) & 3) == 0;
 #pragma unroll
     for (int j = 0; j < SM; ++j) {
-        const int m = m0 + wm * SM * 32 + j * 32 + l31;
-        if (m >= p.M) continue;
+        const int m = mrow[j];
+        if (m < 0) continue;
         OutT* orow = outp + (size_t)m * p.CoutT + p.cout_off;
         const float* brow = p.bias;
         if (p.flags & FTC_FLAG_BORDER_BIAS) {
@@ -125,7 +140,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[SN][
         for (int i = 0; i < SN; ++i) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * SN * 32 + i * 32 + 8 * q + 4 * half;
+                const int n = nbase + i * 32 + 8 * q + 4 * half;
                 if (n >= p.Cout) continue;
                 if (vec_ok) {
                     f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
@@ -153,6 +168,108 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[SN][
                         orow[n + e] = from_f32<OutT>(v);
                     }
                 }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-staged epilogue.  The MFMA C/D layout hands every lane 4-channel quads of 32 DIFFERENT pixels, so
+// storing straight from the accumulators issues 64 scattered 8-byte (bf16) writes per instruction: the
+// s_memtime timeline of a 192x256 tile showed 23k of 131k cycles spent in that store tail (store-issue
+// bound, nothing overlaps it).  Instead each lane drops its biased/activated quads into an LDS image
+// of the output tile ([pixel][channel], 16-byte chunks XOR-swizzled by pixel&7, free of the operand
+// buffers after the K loop) and the workgroup then writes whole NHWC rows with 16-byte lanes; the
+// residual add and the bf16 trunk copy ride on the same coalesced pass.
+// Used when rows are 16-byte aligned in the output (else the direct path below).
+// ------------------------------------------------------------------------------------------------
+template <typename OutT> __host__ __device__ constexpr int epi_pitch(int tn) { return (tn * (int)sizeof(OutT) + 127) / 128 * 128; }
+
+template <typename OutT> __device__ __forceinline__ bool epi_lds_ok(const ConvP& p) {
+    constexpr int V = 16 / (int)sizeof(OutT);
+    return ((p.Cout | p.CoutT | p.cout_off) % V) == 0 && (p.Cout % 8) == 0;
+}
+
+template <typename WT, typename OutT, int SN, int SM, int NTHREADS, int TN, int TM, typename RowFn>
+__device__ __forceinline__ void conv_epilogue_lds(const ConvP& p, f32x16 (&acc)[SN][SM], unsigned char* smem, int n0, int nw0, int pw0,
+                                                  int half, int l31, RowFn row_to_m) {
+    constexpr int PITCH = epi_pitch<OutT>(TN);
+    constexpr int V = 16 / (int)sizeof(OutT);               // channels per 16-byte chunk (4 fp32 | 8 bf16)
+    constexpr int CH = TN / V;                              // chunks per pixel row
+    __syncthreads();                                        // every wave is done with the operand buffers
+    // bias rows of this channel tile -> LDS behind the output image (1 row, or the 16 border cases):
+    // read from global lane by lane they were 4*SN serialized L1 round trips per pixel sub-tile.
+    float* lbias = reinterpret_cast<float*>(smem + TM * PITCH);
+    const int nrows = (p.flags & FTC_FLAG_BORDER_BIAS) ? 16 : 1;
+    for (int c = threadIdx.x; c < nrows * (TN / 4); c += NTHREADS) {
+        const int r = c / (TN / 4), q = c - r * (TN / 4);
+        const int n = n0 + 4 * q;
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (n < p.Cout) b = *reinterpret_cast<const f32x4*>(p.bias + (size_t)r * p.Cout + n);
+        *reinterpret_cast<f32x4*>(lbias + r * TN + 4 * q) = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SM; ++j) {
+        const int prow = pw0 + j * 32 + l31;                // pixel row inside the tile
+        const float* brow = lbias;
+        if (p.flags & FTC_FLAG_BORDER_BIAS) {
+            const int m = row_to_m(prow);
+            if (m >= 0) {
+                const int rem = m % (p.Ho * p.Wo);
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                brow += ((oy == 0 ? 1 : 0) | (oy == p.Ho - 1 ? 2 : 0) | (ox == 0 ? 4 : 0) | (ox == p.Wo - 1 ? 8 : 0)) * TN;
+            }
+        }
+        unsigned char* lrow = smem + prow * PITCH;
+#pragma unroll
+        for (int i = 0; i < SN; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = nw0 + i * 32 + 8 * q + 4 * half;          // channel inside the tile
+                f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                v += *reinterpret_cast<const f32x4*>(brow + nl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act_sel<sizeof(WT) == 2>(v[e], p.act);
+                const int chunk = (nl / V) ^ (prow & 7);
+                store4<OutT>(reinterpret_cast<OutT*>(lrow + chunk * 16) + (nl % V), v);
+            }
+        }
+    }
+    __syncthreads();
+    OutT* __restrict__ outp = reinterpret_cast<OutT*>(p.out);
+    const bool has_res = (p.flags & FTC_FLAG_RESIDUAL) != 0;
+    for (int c = threadIdx.x; c < TM * CH; c += NTHREADS) {
+        const int prow = c / CH, cc = c - prow * CH;
+        const int m = row_to_m(prow);
+        const int n = n0 + cc * V;
+        if (m < 0 || n >= p.Cout) continue;
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(smem + prow * PITCH + ((cc ^ (prow & 7)) * 16));
+        if constexpr (sizeof(OutT) == 4) {
+            f32x4 v = __builtin_bit_cast(f32x4, raw);
+            if (has_res) {
+                if (p.res_dtype == FTC_F32) v += load4<float>(reinterpret_cast<const float*>(p.res) + (size_t)m * p.Cout + n);
+                else v += load4<__bf16>(reinterpret_cast<const __bf16*>(p.res) + (size_t)m * p.Cout + n);
+            }
+            *reinterpret_cast<f32x4*>(outp + (size_t)m * p.CoutT + p.cout_off + n) = v;
+            if (p.out2) store4<__bf16>(reinterpret_cast<__bf16*>(p.out2) + (size_t)m * p.Cout + n, v);
+        } else {
+            if (has_res) {
+                float f[8], r[8];
+                load16<__bf16>(reinterpret_cast<const __bf16*>(&raw), f);
+                if (p.res_dtype == FTC_F32) {
+                    const f32x4 r0 = load4<float>(reinterpret_cast<const float*>(p.res) + (size_t)m * p.Cout + n);
+                    const f32x4 r1 = load4<float>(reinterpret_cast<const float*>(p.res) + (size_t)m * p.Cout + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { r[e] = r0[e]; r[4 + e] = r1[e]; }
+                } else {
+                    load16<__bf16>(reinterpret_cast<const __bf16*>(p.res) + (size_t)m * p.Cout + n, r);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] += r[e];
+                store16<__bf16>(reinterpret_cast<__bf16*>(outp) + (size_t)m * p.CoutT + p.cout_off + n, f);
+            } else {
+                *reinterpret_cast<u32x4*>(outp + (size_t)m * p.CoutT + p.cout_off + n) = raw;
             }
         }
     }
@@ -338,7 +455,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
         }
     }
 
-    conv_epilogue<WT, OutT, SN, SM>(p, acc, m0, n0, wn, wm, half, l31);
+    if (epi_lds_ok<OutT>(p)) {
+        conv_epilogue_lds<WT, OutT, SN, SM, 256, TN, TM>(p, acc, smem_raw, n0, wn * SN * 32, wm * SM * 32, half, l31,
+                                                         [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; });
+    } else {
+        conv_epilogue<WT, OutT, SN, SM>(p, acc, m0, n0, wn, wm, half, l31);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -516,7 +638,254 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p) {
         compute(cur_off);
         cur_off = cur_off + BUFB == NBUF * BUFB ? 0 : cur_off + BUFB;
     }
-    conv_epilogue<WT, OutT, SN, SM>(p, acc, m0, n0, wn, wm, half, l31);
+    if (epi_lds_ok<OutT>(p)) {
+        conv_epilogue_lds<WT, OutT, SN, SM, 256, TN, TM>(p, acc, smem_raw, n0, wn * SN * 32, wm * SM * 32, half, l31,
+                                                         [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; });
+    } else {
+        conv_epilogue<WT, OutT, SN, SM>(p, acc, m0, n0, wn, wm, half, l31);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution with the activation HALO resident in LDS (8 waves, 2-D pixel tiles).
+//
+// The per-tap kernels above re-fetch every activation row 9 times and every weight row once per
+// 128-pixel tile: 78 FLOP per byte moved L2 -> LDS, which (PMC + Little's law) caps
+// the matrix pipe near 40 %.  Here a workgroup owns a 16x16-pixel output tile of one image:
+//   * per 64-(or 32-)channel block the 18x18 halo of input pixels is DMA'd ONCE (double buffered) and
+//     all nine taps read their shifted windows out of it;
+//   * the weights of one (tap, channel block) form a K step and stream through a 3-slot DMA ring;
+//   * 8 waves (2 channel halves x 4 pixel quarters) share both, so a 192-channel tile moves
+//     ~14 KB per 192x128x64 MACs instead of 40 KB.
+// LDS: 3 x TN x ROWB (weights) + 2 x 324 x ROWB (halo) = 153 KB for TN = 192: one workgroup per CU.
+// Same swizzled, unpadded row image and counted-vmcnt protocol as conv_igemm_glds_kernel; the number of
+// DMA instructions a wave issues per step depends on the wave (partial last pass), so the wait counts
+// are per-wave values.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wait_vmcnt_n(int n) {
+    switch (n) {
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<1>(); break;
+    case 2: wait_vmcnt<2>(); break;
+    case 3: wait_vmcnt<3>(); break;
+    case 4: wait_vmcnt<4>(); break;
+    case 5: wait_vmcnt<5>(); break;
+    case 6: wait_vmcnt<6>(); break;
+    case 7: wait_vmcnt<7>(); break;
+    case 8: wait_vmcnt<8>(); break;
+    default: wait_vmcnt<9>(); break;
+    }
+}
+
+template <typename WT, typename OutT, int CPR, int SN>
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
+    constexpr int E = 16 / (int)sizeof(WT);
+    constexpr int BK = CPR * E;
+    constexpr int ROWB = CPR * 16;
+    constexpr int WN = 2, WM = 4, SM = 2;
+    constexpr int TN = WN * SN * 32;
+    constexpr int TY = 16, TX = 16, HW = TX + 2, NH = (TY + 2) * HW;        // 324 halo pixels
+    constexpr int WCH = TN * CPR, HCH = NH * CPR;                            // 16-byte chunks per weight step / halo block
+    constexpr int NLW = (WCH + 511) / 512, NLH = (HCH + 511) / 512;          // DMA passes of the 512 threads
+    constexpr int WSLOT = TN * ROWB, HBUF = NH * ROWB;
+    static_assert(CPR == 8 || CPR == 4, "");
+    static_assert(NLW + NLH <= 9, "");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char* const wbase = smem_raw;                   // 3 weight slots
+    unsigned char* const hbase = smem_raw + 3 * WSLOT;       // 2 halo buffers
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wn = wave / WM, wm = wave % WM;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    int bid = blockIdx.x;
+    {
+        const int q = p.nblk >> 3, r = p.nblk & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int nt = bid % p.nN;
+    int sp = bid / p.nN;
+    const int tilesX = (p.Wo + TX - 1) / TX, tilesY = (p.Ho + TY - 1) / TY;
+    const int img = sp / (tilesX * tilesY);
+    sp -= img * tilesX * tilesY;
+    const int ty0 = (sp / tilesX) * TY, tx0 = (sp % tilesX) * TX;
+    const int n0 = nt * TN;
+
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+
+    // per-lane global byte offsets of the DMA slots (fixed for the whole tile)
+    int w_off[NLW], h_off[NLH];
+#pragma unroll
+    for (int i = 0; i < NLW; ++i) {
+        const int q = i * 512 + t;
+        const int row = q / CPR, kc = (q % CPR) ^ (CPR == 8 ? (row >> 1) & 7 : (row >> 2) & 3);
+        const int n = n0 + row;
+        w_off[i] = (q < WCH && n < p.Cout) ? (n * 9 * p.Cin + kc * E) * (int)sizeof(WT) : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < NLH; ++i) {
+        const int q = i * 512 + t;
+        const int hr = q / CPR, kc = (q % CPR) ^ (CPR == 8 ? (hr >> 1) & 7 : (hr >> 2) & 3);
+        const int iy = ty0 - 1 + hr / HW, ix = tx0 - 1 + hr % HW;
+        const bool ok = q < HCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        h_off[i] = ok ? (((img * p.H + iy) * p.W + ix) * p.CinT + p.cin_off + kc * E) * (int)sizeof(WT) : OOB;
+    }
+    // DMA instructions THIS wave issues per weight step / halo block (the last pass may cover fewer waves)
+    int nlw = 0, nlh = 0;
+#pragma unroll
+    for (int i = 0; i < NLW; ++i) nlw += (i * 512 + wave * 64 < WCH) ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < NLH; ++i) nlh += (i * 512 + wave * 64 < HCH) ? 1 : 0;
+
+    auto issue_w = [&](int k) {                              // weights of K step k -> ring slot k % 3
+        const int cb = k / 9, tap = k - cb * 9;
+        const int soff = (tap * p.Cin + cb * BK) * (int)sizeof(WT);
+        unsigned char* slot = wbase + (k % 3) * WSLOT;
+#pragma unroll
+        for (int i = 0; i < NLW; ++i) {
+            if (i * 512 + wave * 64 < WCH) {                 // wave-uniform
+                lds_void_t* dst = (lds_void_t*)(slot + (i * 512 + wave * 64) * 16);
+                if (i * 512 + t < WCH) glds16(rw, dst, w_off[i], soff);
+            }
+        }
+    };
+    auto issue_h = [&](int cb) {                             // halo of channel block cb -> buffer cb & 1
+        const int soff = cb * BK * (int)sizeof(WT);
+        unsigned char* buf = hbase + (cb & 1) * HBUF;
+#pragma unroll
+        for (int i = 0; i < NLH; ++i) {
+            if (i * 512 + wave * 64 < HCH) {
+                lds_void_t* dst = (lds_void_t*)(buf + (i * 512 + wave * 64) * 16);
+                if (i * 512 + t < HCH) glds16(rin, dst, h_off[i], soff);
+            }
+        }
+    };
+
+    f32x16 acc[SN][SM];
+#pragma unroll
+    for (int i = 0; i < SN; ++i)
+#pragma unroll
+        for (int j = 0; j < SM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    using FragT = typename Frag<WT>::type;
+    constexpr int G = CPR / 2;
+    const int frA = CPR == 8 ? (l31 >> 1) & 7 : (l31 >> 2) & 3;
+    int offA[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) offA[g] = (wn * SN * 32 + l31) * ROWB + (((g * 2 + half) ^ frA) << 4);
+    int hr0[SM];                                             // halo row of this lane's pixel (tap 0,0) per sub-tile
+#pragma unroll
+    for (int j = 0; j < SM; ++j) hr0[j] = (wm * 4 + j * 2 + (l31 >> 4)) * HW + (l31 & 15);
+
+    auto compute = [&](int k) {
+        const int cb = k / 9, tap = k - cb * 9;
+        const int d = (tap / 3) * HW + (tap % 3);
+        const unsigned char* wa = wbase + (k % 3) * WSLOT;
+        const unsigned char* hb = hbase + (cb & 1) * HBUF;
+        int rowB[SM], f4[SM];
+#pragma unroll
+        for (int j = 0; j < SM; ++j) {
+            const int hr = hr0[j] + d;
+            rowB[j] = hr * ROWB;
+            f4[j] = (CPR == 8 ? (hr >> 1) & 7 : (hr >> 2) & 3) << 4;
+        }
+        // fragments of K group g+1 are requested from LDS before the MFMAs of group g are issued
+        FragT af[2][SN], bf[2][SM];
+        auto ldfrag = [&](int g, int s) {
+#pragma unroll
+            for (int i = 0; i < SN; ++i) af[s][i] = *reinterpret_cast<const FragT*>(wa + offA[g] + i * 32 * ROWB);
+#pragma unroll
+            for (int j = 0; j < SM; ++j) bf[s][j] = *reinterpret_cast<const FragT*>(hb + rowB[j] + ((((g * 2 + half) << 4)) ^ f4[j]));
+        };
+        ldfrag(0, 0);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int s = g & 1;
+            if (g + 1 < G) ldfrag(g + 1, s ^ 1);
+            if constexpr (sizeof(WT) == 4) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int i = 0; i < SN; ++i)
+#pragma unroll
+                        for (int j = 0; j < SM; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s][i][tt], bf[s][j][tt], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < SN; ++i)
+#pragma unroll
+                    for (int j = 0; j < SM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nk = 9 * p.ncb;
+    // 0x1000: timeline of wave 0 of the first 512 workgroups into p.res (tools/conv_bench.py --timeline)
+    const bool tl_on = (p.flags & 0x1000) && blockIdx.x < 512 && t == 0;
+    unsigned long long* tl = reinterpret_cast<unsigned long long*>(const_cast<void*>(p.res)) + (size_t)blockIdx.x * 64;
+    if (tl_on) tl[0] = __builtin_amdgcn_s_memtime();
+    issue_h(0);
+    issue_w(0);
+    if (nk > 1) issue_w(1);
+    if (tl_on) tl[1] = __builtin_amdgcn_s_memtime();
+    for (int k = 0; k < nk; ++k) {
+        if (tl_on && k < 40) tl[2 + k] = __builtin_amdgcn_s_memtime();
+        // weights(k) (and, at tap 0, halo(cb)) have landed once only the later-issued DMAs remain outstanding:
+        // weights(k+1), and the halo prefetch issued in step k-1 when that step was a tap 0
+        const int kp = k - 1;
+        const bool halo_prev = kp >= 0 && (kp % 9) == 0 && (kp / 9 + 1) < p.ncb;
+        if (p.flags & 0x100) wait_vmcnt<0>(); else wait_vmcnt_n((k + 1 < nk ? nlw : 0) + (halo_prev ? nlh : 0));
+        if (!(p.flags & 0x800)) wg_barrier();                        // 0x800: ablation, no barrier
+        if (!(p.flags & 0x100)) {                                    // 0x100/0x200: ablation switches of tools/conv_bench.py
+            if ((k % 9) == 0 && k / 9 + 1 < p.ncb) issue_h(k / 9 + 1);   // other halo buffer: last read 9 steps ago
+            if (k + 2 < nk) issue_w(k + 2);                              // slot (k+2)%3 was read in step k-1
+        }
+        if (!(p.flags & 0x200)) compute(k);
+    }
+
+    if (tl_on) tl[42] = __builtin_amdgcn_s_memtime();
+    int mrow[SM];
+#pragma unroll
+    for (int j = 0; j < SM; ++j) {
+        const int oy = ty0 + wm * 4 + j * 2 + (l31 >> 4), ox = tx0 + (l31 & 15);
+        mrow[j] = (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
+    }
+    if (epi_lds_ok<OutT>(p) && (size_t)TY * TX * epi_pitch<OutT>(TN) + (size_t)16 * TN * 4 <= (size_t)3 * WSLOT + 2 * HBUF) {
+        conv_epilogue_lds<WT, OutT, SN, SM, 512, TN, TY * TX>(p, acc, smem_raw, n0, wn * SN * 32, wm * SM * 32, half, l31, [&](int row) {
+            const int oy = ty0 + (row >> 4), ox = tx0 + (row & 15);
+            return (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
+        });
+    } else {
+        conv_epilogue_rows<WT, OutT, SN, SM>(p, acc, mrow, n0 + wn * SN * 32, half);
+    }
+    if (tl_on) tl[43] = __builtin_amdgcn_s_memtime();
+}
+
+template <typename WT, typename OutT, int CPR, int SN>
+hipError_t launch_halo(ConvP p, hipStream_t s) {
+    constexpr int E = 16 / (int)sizeof(WT);
+    constexpr int TN = 2 * SN * 32;
+    constexpr size_t lds_bytes = (size_t)3 * TN * CPR * 16 + (size_t)2 * 324 * CPR * 16;
+    auto kern = conv3x3_halo_kernel<WT, OutT, CPR, SN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    p.ncb = p.Cin / (CPR * E);
+    p.nk = 9 * p.ncb;
+    p.nN = (p.Cout + TN - 1) / TN;
+    p.nblk = p.nN * p.B * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16);
+    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(512), lds_bytes, s, p);
+    return hipGetLastError();
 }
 
 template <typename WT, typename InT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF, bool SE>
@@ -524,7 +893,9 @@ hipError_t launch_cfg2(ConvP p, hipStream_t s) {
     constexpr int E = 16 / (int)sizeof(WT);
     constexpr int ROW = BK + E;
     constexpr int TN = WN * SN * 32, TM = WM * SM * 32;
-    constexpr size_t lds_bytes = (size_t)NBUF * (TN + TM) * ROW * sizeof(WT);
+    constexpr size_t lds_stage = (size_t)NBUF * (TN + TM) * ROW * sizeof(WT);
+    constexpr size_t lds_epi = (size_t)TM * epi_pitch<OutT>(TN) + (size_t)16 * TN * 4;
+    constexpr size_t lds_bytes = lds_stage > lds_epi ? lds_stage : lds_epi;
     auto kern = conv_igemm_kernel<WT, InT, OutT, BK, WN, WM, SN, SM, NBUF, SE>;
     static bool attr_set = false;     // per instantiation
     if (!attr_set) {
@@ -546,7 +917,9 @@ template <typename WT, typename OutT, int BK, int WN, int WM, int SN, int SM, in
 hipError_t launch_glds(ConvP p, hipStream_t s) {
     constexpr int E = 16 / (int)sizeof(WT);
     constexpr int TN = WN * SN * 32, TM = WM * SM * 32;
-    constexpr size_t lds_bytes = (size_t)NBUF * (TN + TM) * (BK / E) * 16;
+    constexpr size_t lds_stage = (size_t)NBUF * (TN + TM) * (BK / E) * 16;
+    constexpr size_t lds_epi = (size_t)TM * epi_pitch<OutT>(TN) + (size_t)16 * TN * 4;
+    constexpr size_t lds_bytes = lds_stage > lds_epi ? lds_stage : lds_epi;
     auto kern = conv_igemm_glds_kernel<WT, OutT, BK, WN, WM, SN, SM, NBUF>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -589,6 +962,7 @@ static const int kCfgTM[] = {128, 128, 128, 128, 64, 256, 64};
 // (1 = 32, 2 = 64, 3 = 128).  The Python side fills it from a table measured on MI355X
 // (findtextcenternet_amd/tuning.py); every choice gives bit-identical results (same K order).
 inline int hint_cfg(const ftc_op& o) { return (o.aux0 & 15) - 1; }
+inline bool hint_halo(const ftc_op& o) { return (o.aux0 & 64) != 0; }         // bit 6: LDS-halo 3x3 kernel
 inline int hint_stage(const ftc_op& o) { return (o.aux0 >> 4) & 3; }
 inline int hint_bk(const ftc_op& o) { const int b = (o.aux0 >> 8) & 3; return b == 1 ? 32 : b == 2 ? 64 : b == 3 ? 128 : 0; }
 
@@ -635,6 +1009,16 @@ inline bool uses_glds(const ftc_op& o) {
     return cfg == CFG_192x128 || cfg == CFG_64x128;
 }
 inline int glds_ring(const ftc_op& o) { return hint_stage(o) == 3 ? 3 : 2; }
+// LDS-halo kernel: 3x3 stride 1, activations in the compute dtype, whole channel blocks, tile = 64/128/192 channels
+inline int halo_sn(const ftc_op& o) { const int c = select_cfg(o); return c == CFG_192x128 ? 3 : c == CFG_128x128 ? 2 : c == CFG_64x128 ? 1 : 0; }
+inline int halo_cpr(const ftc_op& o) {
+    if (o.w_dtype == FTC_F32) return o.Cin % 32 == 0 ? 8 : 0;
+    return o.Cin % 64 == 0 ? 8 : (o.Cin % 32 == 0 ? 4 : 0);
+}
+inline bool halo_legal(const ftc_op& o) {
+    return o.ksize == 3 && o.stride == 1 && o.in_dtype == o.w_dtype && !(o.flags & FTC_FLAG_SE_SCALE) && halo_sn(o) > 0 && halo_cpr(o) > 0;
+}
+inline bool uses_halo(const ftc_op& o) { return hint_halo(o) && halo_legal(o); }
 
 template <typename WT, typename InT, typename OutT, int BK>
 hipError_t launch_tiles(const ConvP& p, int cfg, hipStream_t s) {
@@ -649,8 +1033,27 @@ hipError_t launch_tiles(const ConvP& p, int cfg, hipStream_t s) {
     }
 }
 
+template <typename WT, typename OutT>
+hipError_t launch_halo_dispatch(const ConvP& p, const ftc_op& o, hipStream_t s) {
+    const int sn = halo_sn(o), cpr = halo_cpr(o);
+    if (cpr == 8) {
+        if (sn == 3) return launch_halo<WT, OutT, 8, 3>(p, s);
+        if (sn == 2) return launch_halo<WT, OutT, 8, 2>(p, s);
+        return launch_halo<WT, OutT, 8, 1>(p, s);
+    }
+    if constexpr (sizeof(WT) == 2) {
+        if (sn == 3) return launch_halo<WT, OutT, 4, 3>(p, s);
+        if (sn == 2) return launch_halo<WT, OutT, 4, 2>(p, s);
+        return launch_halo<WT, OutT, 4, 1>(p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 template <typename WT, typename InT, typename OutT>
 hipError_t launch_types(const ConvP& p, const ftc_op& o, hipStream_t s) {
+    if constexpr (sizeof(WT) == sizeof(InT)) {
+        if (uses_halo(o)) return launch_halo_dispatch<WT, OutT>(p, o, s);
+    }
     const int cfg = select_cfg(o);
     if constexpr (sizeof(WT) == 2) {
         const int bk = select_bk(o);

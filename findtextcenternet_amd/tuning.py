@@ -30,13 +30,15 @@ def signature(o) -> str:
             f"_k{o.ksize}s{o.stride}_f{o.flags}_a{o.act}")
 
 
-def encode(cfg: int, stage: int, bk: int) -> int:
-    return (cfg + 1) | (stage << 4) | ({0: 0, 32: 1, 64: 2, 128: 3}[bk] << 8)
+def encode(cfg: int, stage: int, bk: int, halo: bool = False) -> int:
+    return (cfg + 1) | (stage << 4) | ({0: 0, 32: 1, 64: 2, 128: 3}[bk] << 8) | (64 if halo else 0)
 
 
 def describe(aux0: int) -> str:
     if aux0 == 0:
         return "default"
+    if aux0 & 64:
+        return f"halo,channels={CFG_NAMES[(aux0 & 15) - 1].split('x')[0]}"
     return f"tile={CFG_NAMES[(aux0 & 15) - 1]},stage={['auto', 'reg', 'dma2', 'dma3'][(aux0 >> 4) & 3]},bk={[0, 32, 64, 128][(aux0 >> 8) & 3]}"
 
 
@@ -75,6 +77,9 @@ def candidates(o) -> List[int]:
         for bk in bks:
             for stage in (1, 2, 3):
                 out.append(encode(cfg, stage, bk))
+    if o.ksize == 3 and o.stride == 1:
+        for cfg in (0, 1, 3):                             # LDS-halo kernel with 192 / 128 / 64 channel tiles
+            out.append(encode(cfg, 0, 0, halo=True))
     return out
 
 

@@ -56,9 +56,31 @@ CONV_MODES = [("f32", L.F32, L.F32, L.F32), ("bf16", L.BF16, L.BF16, L.BF16), ("
               ("bf16_f32out", L.BF16, L.BF16, L.F32), ("bf16_f32io", L.BF16, L.F32, L.F32)]
 
 
+HALO_CASES = [c for c in CONV_CASES if c[10] == 3 and c[11] == 1] + [
+    ("halo_2tiles_edge", 2, 40, 24, 64, 64, 0, 192, 192, 0, 3, 1, L.ACT_GELU, False, False),
+    ("halo_288", 1, 32, 32, 288, 288, 0, 192, 192, 0, 3, 1, L.ACT_GELU, False, False),
+]
+
+
+@pytest.mark.parametrize("tile", [65, 66, 68], ids=["halo192", "halo128", "halo64"])
+@pytest.mark.parametrize("mode", [CONV_MODES[0], CONV_MODES[1], CONV_MODES[3]], ids=["f32", "bf16", "bf16_f32out"])
+@pytest.mark.parametrize("case", HALO_CASES, ids=[c[0] for c in HALO_CASES])
+def test_conv_halo_kernel(case, mode, tile):
+    """The LDS-halo 3x3 kernel (ftc_op.aux0 bit 6) on every stride-1 3x3 case, all three channel tiles."""
+    if case[4] % (8 if mode[1] == L.F32 else 32):
+        pytest.skip("halo kernel needs whole 32-element channel blocks")
+    if mode[1] == L.F32 and case[4] % 32:
+        pytest.skip("fp32 halo kernel needs Cin % 32 == 0")
+    _run_conv_case(case, mode, aux0=tile)
+
+
 @pytest.mark.parametrize("mode", CONV_MODES, ids=[m[0] for m in CONV_MODES])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv(case, mode):
+    _run_conv_case(case, mode, aux0=0)
+
+
+def _run_conv_case(case, mode, aux0):
     name, B, H, W, Cin, CinT, cin_off, Cout, CoutT, cout_off, k, stride, act, residual, se = case
     mname, wdt, idt, odt = mode
     if wdt == L.BF16 and Cin % 8:
@@ -95,12 +117,12 @@ def test_conv(case, mode):
     ar.materialize()
     run_op(dict(kind=L.OP_CONV, flags=(L.FLAG_RESIDUAL if residual else 0) | (L.FLAG_SE_SCALE if se else 0), act=act,
                 in_dtype=idt, out_dtype=odt, w_dtype=wdt, B=B, H=H, W=W, Ho=Ho, Wo=Wo, Cin=Cin, Cin_total=CinT, cin_off=cin_off,
-                Cout=Cout, Cout_total=CoutT, cout_off=cout_off, ksize=k, stride=stride, res_dtype=L.F32,
+                Cout=Cout, Cout_total=CoutT, cout_off=cout_off, ksize=k, stride=stride, res_dtype=L.F32, aux0=aux0,
                 in_=o_in, in2=o_res, out=o_out, w=o_w, bias=o_b, scale=o_sc), ar)
     full = ar.read(o_out, (B, Ho, Wo, CoutT), tdtype(odt))
     out = full[..., cout_off:cout_off + Cout].float()
     err = _rel(out, ref)
-    _log(f"conv {name:18s} {mname:12s} rel_err {err:.3e}")
+    _log(f"conv {name:18s} {mname:12s} aux0={aux0} rel_err {err:.3e}")
     tol = 2e-4 if wdt == L.F32 else 1.5e-2
     assert err < tol, (name, mname, err)
     if CoutT != Cout:      # untouched channels keep the 0xCD fill: the kernel wrote only its slice

@@ -34,6 +34,8 @@ SHAPES = [
     ("fpn L1 448->192", 48, 48, 448, 192, 3, 1, 2, False, False, False, False),
     ("fpn L2 288->192", 96, 96, 288, 192, 3, 1, 2, False, False, False, False),
     ("fpn L3 256->192", 192, 192, 256, 192, 3, 1, 2, False, False, False, False),
+    ("fpn L3 noact 256->192", 192, 192, 256, 192, 3, 1, 0, False, False, False, False),
+    ("fpn L3 silu 256->192", 192, 192, 256, 192, 3, 1, 1, False, False, False, False),
     ("top 192->100", 192, 192, 192, 100, 3, 1, 0, False, False, False, True),
     ("top 192->1", 192, 192, 192, 1, 3, 1, 0, False, False, False, True),
 ]
@@ -45,6 +47,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--timeline", action="store_true", help="halo kernel: dump the s_memtime timeline of wave 0 of the first workgroups")
+    ap.add_argument("--ablate", type=int, default=0, help="halo kernel ablation: 1 = no DMA in the K loop, 2 = no MFMA/LDS reads (wrong results; timing only)")
     ap.add_argument("--nbuf", type=int, default=0, help="tuning hints (ftc_op.aux0): 4 = no direct-to-LDS, 8 = 3-deep DMA ring, 16 = force direct-to-LDS")
     a = ap.parse_args()
     lib = L.load()
@@ -61,7 +65,7 @@ def main():
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         es = lambda d: 4 if d == L.F32 else 2  # noqa: E731
         sizes = {"in": B * H * W * Cin * es(idt), "w": Cout * k * k * Cin * es(cdt), "bias": Cout * 4,
-                 "res": B * Ho * Wo * Cout * 4 if res else 0, "se": B * Cin * 4 if se else 0, "out": B * Ho * Wo * Cout * es(odt)}
+                 "res": B * Ho * Wo * Cout * 4 if (res or a.timeline) else 0, "se": B * Cin * 4 if se else 0, "out": B * Ho * Wo * Cout * es(odt)}
         off, cur = {}, 0
         for key, n in sizes.items():
             off[key] = cur
@@ -76,7 +80,7 @@ def main():
             ws[off["w"]:off["w"] + sizes["w"]].view(torch.bfloat16).normal_(0, 0.05)
         op = (L.Op * 1)()
         o = op[0]
-        o.kind, o.flags, o.act = L.OP_CONV, (L.FLAG_RESIDUAL if res else 0) | (L.FLAG_SE_SCALE if se else 0), act
+        o.kind, o.flags, o.act = L.OP_CONV, (L.FLAG_RESIDUAL if res else 0) | (L.FLAG_SE_SCALE if se else 0) | (a.ablate << 8) | (0x1000 if a.timeline else 0), act
         o.in_dtype, o.out_dtype, o.w_dtype, o.res_dtype = idt, odt, cdt, L.F32
         o.B, o.H, o.W, o.Ho, o.Wo = B, H, W, Ho, Wo
         o.Cin = o.Cin_total = Cin
@@ -85,7 +89,7 @@ def main():
         o.aux0 = a.nbuf
         for fld, key in (("in_", "in"), ("w", "w"), ("bias", "bias"), ("out", "out")):
             r = getattr(o, fld); r.base, r.offset = L.BASE_WORKSPACE, off[key]
-        if res:
+        if res or a.timeline:
             o.in2.base, o.in2.offset = L.BASE_WORKSPACE, off["res"]
         if se:
             o.scale.base, o.scale.offset = L.BASE_WORKSPACE, off["se"]
@@ -106,6 +110,15 @@ def main():
         lib.ftc_op_kernel_label(C.byref(o), buf, 128)
         tf = fl / (t * 1e-3) / 1e12
         print(f"{name:26s} {B * Ho * Wo:8d} {Cout:5d} {Cin * k * k:6d} {t * 1e3:9.1f} {tf:8.1f} {100 * tf / peak:6.1f}  {buf.value.decode()}")
+        if a.timeline:
+            torch.cuda.synchronize()
+            tl = ws[off["res"]:off["res"] + 512 * 64 * 8].view(torch.int64).reshape(512, 64).cpu().numpy()
+            import numpy as _np
+            for blk in (0, 1, 100, 255, 256, 300, 511):
+                r = tl[blk]
+                steps = _np.diff(r[2:42])
+                print(f"  wg {blk:3d}: setup+prologue issue {r[1]-r[0]:6d}  first-step wait {r[3]-r[2]:6d}  steps 1..35 mean {steps[1:35].mean():7.0f} (min {steps[1:35].min()}, max {steps[1:35].max()})  "
+                      f"loop {r[42]-r[2]:7d}  epilogue {r[43]-r[42]:6d}  total {r[43]-r[0]:7d}  start_rel {r[0]-tl[0][0]:8d}")
         lib.ftc_plan_destroy(h)
         del ws
 

@@ -1,5 +1,7 @@
 // Dispatcher of the implicit-GEMM convolution (kernel in conv_igemm_impl.h, one translation unit per
 // type combination): validation, kernel label and the ftc_op -> ConvP lowering.
+#include <cstring>
+
 #include "conv_igemm_impl.h"
 
 using namespace convimpl;
@@ -20,6 +22,7 @@ void conv_kernel_label(const ftc_op& op, char* buf, int len) {
     const bool dma = uses_glds(op);
     snprintf(buf, len, "conv_igemm%s<%s,in=%s,out=%s,tile=%s,bk=%d,nbuf=%d>", dma ? "_glds" : "", dt[op.w_dtype & 1], dt[op.in_dtype & 1],
              dt[op.out_dtype & 1], kCfgName[select_cfg(op)], select_bk(op), dma ? glds_ring(op) : 1);
+    if (!dma && hint_splitk(op) > 1) snprintf(buf + strlen(buf) - 1, len - strlen(buf) + 1, ",splitk=%d>", hint_splitk(op));
 }
 
 const char* conv_validate(const ftc_op& op) {
@@ -44,7 +47,8 @@ const char* conv_validate(const ftc_op& op) {
     const long w_bytes = (long)op.Cout * op.ksize * op.ksize * op.Cin * (op.w_dtype == FTC_F32 ? 4 : 2);
     if (in_bytes >= 0x7ff00000L || w_bytes >= 0x7ff00000L) return "conv: operand larger than 2 GiB (split the batch)";
     if (hint_halo(op) && !halo_legal(op)) return "conv: LDS-halo kernel is not legal for this op/tile";
-    if (op.aux0 < 0 || op.aux0 > 0x3ff || hint_cfg(op) >= CFG_COUNT) return "conv: aux0 (tuned kernel choice) out of range";
+    if (hint_splitk(op) > 1 && !splitk_legal(op, hint_splitk(op))) return "conv: split-K variant is not legal for this op/tile";
+    if (op.aux0 < 0 || op.aux0 > 0xfff || hint_cfg(op) >= CFG_COUNT) return "conv: aux0 (tuned kernel choice) out of range";
     if (hint_bk(op) && op.w_dtype == FTC_BF16 && (op.Cin % hint_bk(op)) && hint_bk(op) != 32) return "conv: tuned K step does not divide Cin";
     if (hint_bk(op) == 128 && op.in_dtype != FTC_BF16) return "conv: K step 128 needs bf16 activations";
     if (hint_stage(op) >= 2 && !glds_legal(op)) return "conv: direct-to-LDS kernel is not legal for this op/tile";
@@ -67,6 +71,7 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
     p.ncb = p.nk = p.nN = p.nblk = 0;
     p.use_glds = uses_glds(o) ? 1 : 0;
     p.glds_nbuf = glds_ring(o);
+    p.split_k = (!uses_halo(o) && !uses_glds(o)) ? hint_splitk(o) : 1;
     if (o.w_dtype == FTC_F32) return launch_conv_f32(p, o, s);
     if (o.in_dtype == FTC_BF16 && o.out_dtype == FTC_BF16) return launch_conv_bf16_bb(p, o, s);
     if (o.in_dtype == FTC_F32 && o.out_dtype == FTC_BF16) return launch_conv_bf16_fb(p, o, s);

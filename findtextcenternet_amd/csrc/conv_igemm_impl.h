@@ -52,6 +52,7 @@ struct ConvP {
     int nblk;   // total workgroups
     int use_glds;   // direct-to-LDS kernel selected (uses_glds)
     int glds_nbuf;  // tuning: LDS ring depth of the DMA kernel (2 | 3)
+    int split_k;    // tuning: K groups per workgroup of the register-staged kernel (1 | 2 | 4)
 };
 
 template <typename WT> struct Frag;
@@ -275,8 +276,81 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvP& p, f32x16 (&acc)[
     }
 }
 
-template <typename WT, typename InT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF, bool SE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
+// Epilogue of the intra-workgroup split-K variant: every K group parks its raw fp32 partial tile in its own
+// LDS image, then all 256*KG threads sum the KG images chunk by chunk (group 0 first: fixed order) and
+// apply bias / activation / residual / bf16 copy on the way out.
+template <typename WT, typename OutT, int SN, int SM, int KG, int TN, int TM, typename RowFn>
+__device__ __forceinline__ void conv_epilogue_splitk(const ConvP& p, f32x16 (&acc)[SN][SM], unsigned char* smem, int kg, int n0, int nw0,
+                                                     int pw0, int half, int l31, RowFn row_to_m) {
+    constexpr int PITCH = epi_pitch<float>(TN);
+    constexpr int CH = TN / 4;
+    __syncthreads();
+    unsigned char* img = smem + (size_t)kg * TM * PITCH;
+#pragma unroll
+    for (int j = 0; j < SM; ++j) {
+        const int prow = pw0 + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < SN; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = nw0 + i * 32 + 8 * q + 4 * half;
+                const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(img + prow * PITCH + (((nl >> 2) ^ (prow & 7)) << 4)) = v;
+            }
+    }
+    __syncthreads();
+    OutT* __restrict__ outp = reinterpret_cast<OutT*>(p.out);
+    const bool has_res = (p.flags & FTC_FLAG_RESIDUAL) != 0;
+    const bool vec_ok = ((p.Cout | p.CoutT | p.cout_off) & 3) == 0;
+    for (int c = threadIdx.x; c < TM * CH; c += 256 * KG) {
+        const int prow = c / CH, cc = c - prow * CH;
+        const int m = row_to_m(prow);
+        const int n = n0 + cc * 4;
+        if (m < 0 || n >= p.Cout) continue;
+        const int loff = prow * PITCH + ((cc ^ (prow & 7)) << 4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(smem + loff);
+#pragma unroll
+        for (int g = 1; g < KG; ++g) v += *reinterpret_cast<const f32x4*>(smem + (size_t)g * TM * PITCH + loff);
+        const float* brow = p.bias;
+        if (p.flags & FTC_FLAG_BORDER_BIAS) {
+            const int rem = m % (p.Ho * p.Wo);
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            brow += ((oy == 0 ? 1 : 0) | (oy == p.Ho - 1 ? 2 : 0) | (ox == 0 ? 4 : 0) | (ox == p.Wo - 1 ? 8 : 0)) * p.Cout;
+        }
+        if (vec_ok) {
+            v += *reinterpret_cast<const f32x4*>(brow + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act_sel<sizeof(WT) == 2>(v[e], p.act);
+            if (has_res) {
+                if (p.res_dtype == FTC_F32) v += load4<float>(reinterpret_cast<const float*>(p.res) + (size_t)m * p.Cout + n);
+                else v += load4<__bf16>(reinterpret_cast<const __bf16*>(p.res) + (size_t)m * p.Cout + n);
+            }
+            store4<OutT>(outp + (size_t)m * p.CoutT + p.cout_off + n, v);
+            if constexpr (sizeof(OutT) == 4) {
+                if (p.out2) store4<__bf16>(reinterpret_cast<__bf16*>(p.out2) + (size_t)m * p.Cout + n, v);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n + e >= p.Cout) continue;
+                float x = apply_act_sel<sizeof(WT) == 2>(v[e] + brow[n + e], p.act);
+                if (has_res) {
+                    if (p.res_dtype == FTC_F32) x += reinterpret_cast<const float*>(p.res)[(size_t)m * p.Cout + n + e];
+                    else x += (float)reinterpret_cast<const __bf16*>(p.res)[(size_t)m * p.Cout + n + e];
+                }
+                outp[(size_t)m * p.CoutT + p.cout_off + n + e] = from_f32<OutT>(x);
+            }
+        }
+    }
+}
+
+// KG > 1 = intra-workgroup split-K: KG groups of 4 waves each stage and multiply their own 1/KG of the K
+// range of the SAME output tile (own LDS buffers), and the partial tiles are summed in fixed group order
+// during the coalesced copy-out.  It multiplies the loads in flight per CU for the long-K, small-M MBConv
+// project convs (M = 4608 at batch 8 gives only 2 workgroups of 64x64 per CU) without any inter-workgroup
+// protocol and stays deterministic.
+template <typename WT, typename InT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF, bool SE, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(const ConvP p) {
     constexpr int E = 16 / (int)sizeof(WT);      // elements per 16-byte chunk (4 fp32 | 8 bf16)
     constexpr int CPR = BK / E;                  // chunks per LDS row
     constexpr int ROW = BK + E;                  // padded LDS row, elements
@@ -290,9 +364,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     static_assert(NBUF == 1 || NBUF == 2, "");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    WT* lds = reinterpret_cast<WT*>(smem_raw);
+    const int kg = KG == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);     // K group of this wave
+    WT* lds = reinterpret_cast<WT*>(smem_raw) + kg * NBUF * BUF;
 
-    const int t = threadIdx.x;
+    const int t = threadIdx.x & 255;
     const int lane = t & 63;
     const int wave = t >> 6;
     const int wn = wave / WM, wm = wave % WM;
@@ -347,8 +422,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     }
 
     u32x4 ra[NA], rb[NB];
-    // K position of the NEXT tile to fetch (all wave-uniform -> SALU)
-    int ld_tap = 0, ld_r = 0, ld_s = 0, ld_cb = 0;
+    // K position of the NEXT tile to fetch (all wave-uniform -> SALU); K group kg starts at step kg*nk/KG
+    const int nk_g = p.nk / KG;
+    int ld_tap = (kg * nk_g) / p.ncb, ld_cb = (kg * nk_g) % p.ncb;
+    int ld_r = ld_tap / p.KS, ld_s = ld_tap % p.KS;
 
     auto gload = [&]() {
         const int c0 = ld_cb * BK;
@@ -434,25 +511,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvP p) {
     if constexpr (NBUF == 2) {
         lds_write(0);
         __syncthreads();
-        for (int it = 0; it < p.nk; it += 2) {
-            if (it + 1 < p.nk) gload();
+        for (int it = 0; it < nk_g; it += 2) {
+            if (it + 1 < nk_g) gload();
             compute(0);
-            if (it + 1 < p.nk) lds_write(1);
+            if (it + 1 < nk_g) lds_write(1);
             __syncthreads();
-            if (it + 1 >= p.nk) break;
-            if (it + 2 < p.nk) gload();
+            if (it + 1 >= nk_g) break;
+            if (it + 2 < nk_g) gload();
             compute(1);
-            if (it + 2 < p.nk) lds_write(0);
+            if (it + 2 < nk_g) lds_write(0);
             __syncthreads();
         }
     } else {
-        for (int it = 0; it < p.nk; ++it) {
+        for (int it = 0; it < nk_g; ++it) {
             lds_write(0);
             __syncthreads();
-            if (it + 1 < p.nk) gload();          // in flight while this tile is multiplied
+            if (it + 1 < nk_g) gload();          // in flight while this tile is multiplied
             compute(0);
             __syncthreads();
         }
+    }
+    if constexpr (KG > 1) {
+        conv_epilogue_splitk<WT, OutT, SN, SM, KG, TN, TM>(p, acc, smem_raw, kg, n0, wn * SN * 32, wm * SM * 32, half, l31,
+                                                           [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; });
+        return;
     }
 
     if (epi_lds_ok<OutT>(p)) {
@@ -888,15 +970,15 @@ hipError_t launch_halo(ConvP p, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <typename WT, typename InT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF, bool SE>
+template <typename WT, typename InT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF, bool SE, int KG = 1>
 hipError_t launch_cfg2(ConvP p, hipStream_t s) {
     constexpr int E = 16 / (int)sizeof(WT);
     constexpr int ROW = BK + E;
     constexpr int TN = WN * SN * 32, TM = WM * SM * 32;
-    constexpr size_t lds_stage = (size_t)NBUF * (TN + TM) * ROW * sizeof(WT);
-    constexpr size_t lds_epi = (size_t)TM * epi_pitch<OutT>(TN) + (size_t)16 * TN * 4;
+    constexpr size_t lds_stage = (size_t)KG * NBUF * (TN + TM) * ROW * sizeof(WT);
+    constexpr size_t lds_epi = KG == 1 ? (size_t)TM * epi_pitch<OutT>(TN) + (size_t)16 * TN * 4 : (size_t)KG * TM * epi_pitch<float>(TN);
     constexpr size_t lds_bytes = lds_stage > lds_epi ? lds_stage : lds_epi;
-    auto kern = conv_igemm_kernel<WT, InT, OutT, BK, WN, WM, SN, SM, NBUF, SE>;
+    auto kern = conv_igemm_kernel<WT, InT, OutT, BK, WN, WM, SN, SM, NBUF, SE, KG>;
     static bool attr_set = false;     // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -909,7 +991,7 @@ hipError_t launch_cfg2(ConvP p, hipStream_t s) {
     p.nN = (p.Cout + TN - 1) / TN;
     const int nM = (p.M + TM - 1) / TM;
     p.nblk = p.nN * nM;
-    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(256), lds_bytes, s, p);
+    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(256 * KG), lds_bytes, s, p);
     return hipGetLastError();
 }
 
@@ -946,6 +1028,17 @@ hipError_t launch_cfg(const ConvP& p, hipStream_t s) {
             return launch_glds<WT, OutT, BK, WN, WM, SN, SM, 2>(p, s);
         }
     }
+    // intra-workgroup split-K (tuned per layer): long-K 1x1 convs on small tiles
+    if constexpr (sizeof(WT) == 2 && sizeof(InT) == 2 && WN * SN * WM * SM <= 8 && BK >= 64) {
+        if (p.split_k == 2) {
+            if (p.flags & FTC_FLAG_SE_SCALE) return launch_cfg2<WT, InT, OutT, BK, WN, WM, SN, SM, NBUF, true, 2>(p, s);
+            return launch_cfg2<WT, InT, OutT, BK, WN, WM, SN, SM, NBUF, false, 2>(p, s);
+        }
+        if (p.split_k == 4) {
+            if (p.flags & FTC_FLAG_SE_SCALE) return launch_cfg2<WT, InT, OutT, BK, WN, WM, SN, SM, NBUF, true, 4>(p, s);
+            return launch_cfg2<WT, InT, OutT, BK, WN, WM, SN, SM, NBUF, false, 4>(p, s);
+        }
+    }
     // the SE-scaled variant exists only where the network uses it: 1x1 project convs
     if (p.flags & FTC_FLAG_SE_SCALE) return launch_cfg2<WT, InT, OutT, BK, WN, WM, SN, SM, NBUF, true>(p, s);
     return launch_cfg2<WT, InT, OutT, BK, WN, WM, SN, SM, NBUF, false>(p, s);
@@ -963,6 +1056,7 @@ static const int kCfgTM[] = {128, 128, 128, 128, 64, 256, 64};
 // (findtextcenternet_amd/tuning.py); every choice gives bit-identical results (same K order).
 inline int hint_cfg(const ftc_op& o) { return (o.aux0 & 15) - 1; }
 inline bool hint_halo(const ftc_op& o) { return (o.aux0 & 64) != 0; }         // bit 6: LDS-halo 3x3 kernel
+inline int hint_splitk(const ftc_op& o) { const int c = (o.aux0 >> 10) & 3; return c == 1 ? 2 : c == 2 ? 4 : 1; }   // bits 10-11
 inline int hint_stage(const ftc_op& o) { return (o.aux0 >> 4) & 3; }
 inline int hint_bk(const ftc_op& o) { const int b = (o.aux0 >> 8) & 3; return b == 1 ? 32 : b == 2 ? 64 : b == 3 ? 128 : 0; }
 
@@ -998,7 +1092,7 @@ inline bool glds_legal(const ftc_op& o) {
     return ((kCfgTN[cfg] + kCfgTM[cfg]) * cpr) % 256 == 0 && (kCfgTN[cfg] * cpr) % 64 == 0;
 }
 inline bool uses_glds(const ftc_op& o) {
-    if (!glds_legal(o)) return false;
+    if (!glds_legal(o) || hint_splitk(o) > 1) return false;
     const int st = hint_stage(o);
     if (st) return st >= 2;
     // Untuned default (tools/conv_bench.py, MI355X): the 2-slot DMA ring wins on the 192x128 and 64x128
@@ -1009,6 +1103,19 @@ inline bool uses_glds(const ftc_op& o) {
     return cfg == CFG_192x128 || cfg == CFG_64x128;
 }
 inline int glds_ring(const ftc_op& o) { return hint_stage(o) == 3 ? 3 : 2; }
+// intra-workgroup split-K: register-staged kernel, bf16 activations, K step >= 64, tiles of <= 8 MFMA sub-tiles
+// (64x64, 64x128, 128x64), and a K loop that divides evenly
+inline bool splitk_legal(const ftc_op& o, int kg) {
+    if (kg == 1) return true;
+    if (o.w_dtype != FTC_BF16 || o.in_dtype != FTC_BF16 || select_bk(o) < 64) return false;
+    const int cfg = select_cfg(o);
+    if (!(cfg == CFG_64x64 || cfg == CFG_64x128 || cfg == CFG_128x64)) return false;
+    const int bk = select_bk(o);
+    const long lds = (long)kg * (kCfgTN[cfg] + kCfgTM[cfg]) * (bk + 8) * 2;           // KG staging buffers (bf16, padded rows)
+    if (lds > 160 * 1024) return false;
+    const int nk = o.ksize * o.ksize * ((o.Cin + bk - 1) / bk);
+    return nk % kg == 0 && nk / kg >= 2;
+}
 // LDS-halo kernel: 3x3 stride 1, activations in the compute dtype, whole channel blocks, tile = 64/128/192 channels
 inline int halo_sn(const ftc_op& o) { const int c = select_cfg(o); return c == CFG_192x128 ? 3 : c == CFG_128x128 ? 2 : c == CFG_64x128 ? 1 : 0; }
 inline int halo_cpr(const ftc_op& o) {

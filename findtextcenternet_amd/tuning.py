@@ -30,8 +30,8 @@ def signature(o) -> str:
             f"_k{o.ksize}s{o.stride}_f{o.flags}_a{o.act}")
 
 
-def encode(cfg: int, stage: int, bk: int, halo: bool = False) -> int:
-    return (cfg + 1) | (stage << 4) | ({0: 0, 32: 1, 64: 2, 128: 3}[bk] << 8) | (64 if halo else 0)
+def encode(cfg: int, stage: int, bk: int, halo: bool = False, splitk: int = 1) -> int:
+    return (cfg + 1) | (stage << 4) | ({0: 0, 32: 1, 64: 2, 128: 3}[bk] << 8) | (64 if halo else 0) | ({1: 0, 2: 1, 4: 2}[splitk] << 10)
 
 
 def describe(aux0: int) -> str:
@@ -39,7 +39,9 @@ def describe(aux0: int) -> str:
         return "default"
     if aux0 & 64:
         return f"halo,channels={CFG_NAMES[(aux0 & 15) - 1].split('x')[0]}"
-    return f"tile={CFG_NAMES[(aux0 & 15) - 1]},stage={['auto', 'reg', 'dma2', 'dma3'][(aux0 >> 4) & 3]},bk={[0, 32, 64, 128][(aux0 >> 8) & 3]}"
+    sk = [1, 2, 4, 1][(aux0 >> 10) & 3]
+    return (f"tile={CFG_NAMES[(aux0 & 15) - 1]},stage={['auto', 'reg', 'dma2', 'dma3'][(aux0 >> 4) & 3]},bk={[0, 32, 64, 128][(aux0 >> 8) & 3]}"
+            + (f",splitk={sk}" if sk > 1 else ""))
 
 
 def load_table(path: str = TABLE_PATH) -> Dict[str, int]:
@@ -77,6 +79,11 @@ def candidates(o) -> List[int]:
         for bk in bks:
             for stage in (1, 2, 3):
                 out.append(encode(cfg, stage, bk))
+    if o.w_dtype == L.BF16 and o.in_dtype == L.BF16 and o.Cin * o.ksize * o.ksize >= 768:
+        for cfg in (3, 4, 6):                             # intra-workgroup split-K on the small tiles
+            for bk in [b for b in bks if b >= 64]:
+                for sk in (2, 4):
+                    out.append(encode(cfg, 1, bk, splitk=sk))
     if o.ksize == 3 and o.stride == 1:
         for cfg in (0, 1, 3):                             # LDS-halo kernel with 192 / 128 / 64 channel tiles
             out.append(encode(cfg, 0, 0, halo=True))
@@ -114,11 +121,15 @@ def tune_plan(engine, plan, reps: int = 5, verbose: bool = False) -> Dict[str, i
             if lib.ftc_plan_create(one, 1, plan.workspace_bytes, engine.pw.nbytes, C.byref(h)) != 0:
                 continue                                     # not legal for this op
             ts = []
-            lib.ftc_plan_run(h, bases, stream, 0, -1)
-            for _ in range(reps):
-                L.check(lib.ftc_plan_profile(h, bases, stream, ms), "profile")
+            ok = lib.ftc_plan_run(h, bases, stream, 0, -1) == 0
+            for _ in range(reps if ok else 0):
+                if lib.ftc_plan_profile(h, bases, stream, ms) != 0:
+                    ok = False
+                    break
                 ts.append(ms[0])
             lib.ftc_plan_destroy(h)
+            if not ok:                                       # variant refused by the runtime (e.g. resources): skip it
+                continue
             t = float(np.median(ts))
             if aux == 0:
                 base_t = t

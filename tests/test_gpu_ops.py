@@ -74,6 +74,26 @@ def test_conv_halo_kernel(case, mode, tile):
     _run_conv_case(case, mode, aux0=tile)
 
 
+SPLITK_CASES = [
+    ("sk_proj_se_res", 2, 24, 24, 1024, 1024, 0, 128, 128, 0, 1, 1, L.ACT_NONE, True, True),
+    ("sk_pw_silu", 1, 24, 24, 512, 512, 0, 192, 192, 0, 1, 1, L.ACT_SILU, False, False),
+    ("sk_3x3", 1, 12, 12, 128, 128, 0, 64, 64, 0, 3, 1, L.ACT_GELU, False, False),
+    ("sk_odd_n", 1, 16, 16, 768, 768, 0, 100, 100, 0, 1, 1, L.ACT_NONE, False, False),
+]
+
+
+@pytest.mark.parametrize("aux0", [1559, 2583, 1557, 1556 + 1024, 7 + 16 + 768 + 1024], ids=["64x64_sk2", "64x64_sk4", "128x64_sk2", "64x128_sk4", "64x64_bk128_sk2"])
+@pytest.mark.parametrize("mode", [CONV_MODES[1], CONV_MODES[3]], ids=["bf16", "bf16_f32out"])
+@pytest.mark.parametrize("case", SPLITK_CASES, ids=[c[0] for c in SPLITK_CASES])
+def test_conv_intra_workgroup_split_k(case, mode, aux0):
+    cin_k = case[4] * case[10] * case[10]
+    bk = 128 if (aux0 >> 8) & 3 == 3 else 64
+    kg = 2 if (aux0 >> 10) & 3 == 1 else 4
+    if case[4] % bk or (cin_k // bk) % kg or (cin_k // bk) // kg < 2:
+        pytest.skip("K loop does not split evenly")
+    _run_conv_case(case, mode, aux0=aux0)
+
+
 @pytest.mark.parametrize("mode", CONV_MODES, ids=[m[0] for m in CONV_MODES])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv(case, mode):

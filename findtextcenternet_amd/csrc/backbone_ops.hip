@@ -190,6 +190,121 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, c
 }
 
 // ------------------------------------------------------------------------------------------
+// bf16 stride-1 variant (every MBConv block but the first of stages 4 and 6).  Same tiling, LDS
+// image, partial-sum contract and tap order as dwconv_kernel, but a lane owns 4 channels and a
+// vertical strip of 4 outputs: the 6x3 input window is read and widened once for the 4 outputs
+// (18 ds_read_b64 instead of 36), and the 36 filter taps + 16 accumulators fit in < 128 VGPRs,
+// i.e. 4 waves per SIMD instead of the 2 the 8-channel kernel gets at 196 VGPRs.  The kernel is
+// VALU-bound (9 FMAs + widen + SiLU per output) before it is HBM-bound, so occupancy and the
+// shared window are what move it.
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, lds_ptr_t* dst, int voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, 0, 0, 0);     // LDS[dst + lane*16] = 16 bytes at r[voff]; zeros when voff is out of range
+}
+
+__global__ __launch_bounds__(256) void dwconv_strip_kernel(const __bf16* __restrict__ in, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, __bf16* __restrict__ out,
+                                                           float* __restrict__ partial, int H, int W, int C, int tilesX,
+                                                           int P, int tiles_per_wg) {
+    constexpr int TH = 8, TW = 8, IW = 10, NPX = 100;
+    constexpr int NLD = 4;                                               // DMA passes: 4 waves x 8 pixels x (8 lanes x 16 B) each
+    constexpr int OOB = 0x7ffffff0;
+    __shared__ __attribute__((aligned(16))) __bf16 tile[2][NLD * 32 * 64];
+    __shared__ __attribute__((aligned(16))) float red[16 * 64];
+
+    const int t = threadIdx.x;
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.x * 64;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(in + (long)b * H * W * C), 0,
+                                                                         H * W * C * 2, 0x00020000);
+    // staging role: pixel wave*8 + lane/8 of each 32-pixel pass, 8 channels (16 B)
+    const int s_px = wave * 8 + (lane >> 3);
+    const int s_coff = (c0 + (lane & 7) * 8 < C) ? (c0 + (lane & 7) * 8) * 2 : OOB;
+    // compute role: 4 channels, column t/16 % 8, rows (t/128)*4 .. +3
+    const int cq = t & 15, col = (t >> 4) & 7, rh = t >> 7;
+    const int c = c0 + cq * 4;
+    const bool cok = c < C;
+    const int tile0 = blockIdx.y * tiles_per_wg;
+    const int ntile = min(tiles_per_wg, P - tile0);
+
+    auto issue = [&](int tileId, int buf) {
+        const int ty = tileId / tilesX, tx = tileId - ty * tilesX;
+        const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = s_px + j * 32;
+            const int ry = i / IW, rx = i - ry * IW;
+            const int iy = iy0 + ry, ix = ix0 + rx;
+            const bool ok = i < NPX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            dma16(rin, (lds_ptr_t*)&tile[buf][(j * 32 + wave * 8) * 64], ok ? (iy * W + ix) * C * 2 + s_coff : OOB);
+        }
+    };
+
+    issue(tile0, 0);
+    f32x4 wv[9], bv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = bv;
+    if (cok) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const f32x4*>(w + (long)k * C + c);
+        bv = *reinterpret_cast<const f32x4*>(bias + c);
+    }
+
+    // Channel sums of the workgroup's outputs: accumulated in registers over all its tiles and reduced once;
+    // the total goes to the slot of the first tile, the other slots get 0 (se_fc1 sums the P slots of an image).
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < ntile; ++kt) {
+        const int tileId = tile0 + kt;
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this tile's halo has landed (and the taps, first time round)
+        __syncthreads();                                                // ... for every wave; buf^1 is free again
+        if (kt + 1 < ntile) issue(tileId + 1, buf ^ 1);
+        const int ty = tileId / tilesX, tx = tileId - ty * tilesX;
+        const int oy0 = ty * TH + rh * 4, ox = tx * TW + col;
+        f32x4 acc[4] = {bv, bv, bv, bv};
+        const __bf16* tp = &tile[buf][((rh * 4) * IW + col) * 64 + cq * 4];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            f32x4 x[3];
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) x[s2] = load4<__bf16>(tp + (r * IW + s2) * 64);
+#pragma unroll
+            for (int oo = 0; oo < 4; ++oo) {
+                const int kr = r - oo;
+                if (kr >= 0 && kr < 3) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 3; ++s2)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[oo][e] = fmaf(wv[kr * 3 + s2][e], x[s2][e], acc[oo][e]);
+                }
+            }
+        }
+#pragma unroll
+        for (int oo = 0; oo < 4; ++oo) {
+            const int oy = oy0 + oo;
+            if (cok && oy < H && ox < W) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[oo][e] = act_silu_fast(acc[oo][e]);
+                store4<__bf16>(out + (((long)b * H + oy) * W + ox) * C + c, acc[oo]);
+                sum += acc[oo];
+            }
+        }
+    }
+    *reinterpret_cast<f32x4*>(&red[(t >> 4) * 64 + cq * 4]) = sum;
+    __syncthreads();
+    if (t < 64 && c0 + t < C) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s2 += red[k * 64 + t];
+        float* pp = partial + ((long)b * P + tile0) * C + c0 + t;
+        pp[0] = s2;
+        for (int kt = 1; kt < ntile; ++kt) pp[(long)kt * C] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // SE excitation: scale[b,c] = sigmoid(fc2(SiLU(fc1(mean_hw(x))))), as two short kernels that
 // keep every load independent (the first version chained ~1200 dependent L2 round trips per
 // wave and cost 200-450 us per layer):
@@ -262,16 +377,26 @@ hipError_t launch_dwconv(const OpArgs& a, hipStream_t s) {
     const int tilesX = (o.Wo + TW - 1) / TW, tilesY = (o.Ho + TH - 1) / TH;
     const int P = tilesX * tilesY;
     if (P != o.aux0) return hipErrorInvalidValue;
-    // consecutive tiles per workgroup: as many as still leave >= 4 workgroups per CU
+    // Consecutive tiles per workgroup: the grid runs in ceil(workgroups / resident slots) rounds of `tpw` tile
+    // times each; take the tpw that minimises rounds * tpw (ties: the larger, it amortises the tap loads).
+    const bool strip = o.in_dtype == FTC_BF16 && o.stride == 1 && !(o.flags & 0x100);
     const long slabs = (long)((o.Cin + 63) / 64) * o.B;
-    int tpw = (int)((slabs * P) / 1024);
-    if (tpw < 1) tpw = 1;
-    if (tpw > 8) tpw = 8;
+    const long slots = 256L * (strip ? 4 : o.in_dtype == FTC_F32 ? 3 : 2);     // workgroups resident on 256 CUs (VGPR-limited)
+    int tpw = 1;
+    long best = -1;
+    for (int cand = 1; cand <= (P < 16 ? P : 16); ++cand) {
+        const long wgs = slabs * ((P + cand - 1) / cand);
+        const long cost = ((wgs + slots - 1) / slots) * cand;
+        if (best < 0 || cost <= best) { best = cost; tpw = cand; }
+    }
     dim3 grid((o.Cin + 63) / 64, (P + tpw - 1) / tpw, o.B);
 #define DW_LAUNCH(T, ST)                                                                                      \
     hipLaunchKernelGGL((dwconv_kernel<T, ST>), grid, dim3(256), 0, s, (const T*)a.in, (const float*)a.w, a.bias, \
                        (T*)a.out, a.aux, o.H, o.W, o.Ho, o.Wo, o.Cin, tilesX, P, tpw)
     if (o.in_dtype == FTC_F32) { if (o.stride == 1) DW_LAUNCH(float, 1); else DW_LAUNCH(float, 2); }
+    else if (o.stride == 1 && !(o.flags & 0x100))
+        hipLaunchKernelGGL(dwconv_strip_kernel, grid, dim3(256), 0, s, (const __bf16*)a.in, (const float*)a.w, a.bias,
+                           (__bf16*)a.out, a.aux, o.H, o.W, o.Cin, tilesX, P, tpw);
     else { if (o.stride == 1) DW_LAUNCH(__bf16, 1); else DW_LAUNCH(__bf16, 2); }
 #undef DW_LAUNCH
     return hipGetLastError();

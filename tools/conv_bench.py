@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--timeline", action="store_true", help="halo kernel: dump the s_memtime timeline of wave 0 of the first workgroups")
     ap.add_argument("--ablate", type=int, default=0, help="halo kernel ablation: 1 = no DMA in the K loop, 2 = no MFMA/LDS reads (wrong results; timing only)")
     ap.add_argument("--nbuf", type=int, default=0, help="tuning hints (ftc_op.aux0): 4 = no direct-to-LDS, 8 = 3-deep DMA ring, 16 = force direct-to-LDS")
+    ap.add_argument("--no-se", action="store_true", help="drop the SE-scale flag (what-if: scale folded into per-image weights)")
+    ap.add_argument("--sweep", action="store_true", help="try every tuner candidate for the layer and print the five fastest")
     a = ap.parse_args()
     lib = L.load()
     dev = torch.device("cuda")
@@ -60,6 +62,7 @@ def main():
         if a.only and a.only not in name:
             continue
         B = a.batch
+        se = se and not a.no_se
         idt = L.F32 if a.mode == "fp32" else L.BF16      # bf16 mode: GEMMs read the bf16 trunk copy
         odt = L.F32 if (a.mode == "fp32" or out_tr) else L.BF16
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -93,11 +96,34 @@ def main():
             o.in2.base, o.in2.offset = L.BASE_WORKSPACE, off["res"]
         if se:
             o.scale.base, o.scale.offset = L.BASE_WORKSPACE, off["se"]
-        h = C.c_void_p()
-        L.check(lib.ftc_plan_create(op, 1, cur + 256, 0, C.byref(h)), "create")
         bases = (C.c_void_p * L.NUM_BASES)(None, ws.data_ptr(), None, None, None, None)
         ms = (C.c_float * 1)()
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        fl = 2.0 * B * Ho * Wo * Cout * Cin * k * k
+        if a.sweep:
+            from findtextcenternet_amd import tuning as T
+            res_ = []
+            for aux in T.candidates(o):
+                o.aux0 = aux
+                h = C.c_void_p()
+                if lib.ftc_plan_create(op, 1, cur + 256, 0, C.byref(h)) != 0:
+                    continue
+                if lib.ftc_plan_run(h, bases, st, 0, -1) == 0:
+                    ts = []
+                    for _ in range(7):
+                        if lib.ftc_plan_profile(h, bases, st, ms) == 0:
+                            ts.append(ms[0])
+                    if ts:
+                        res_.append((float(np.median(ts)), aux))
+                lib.ftc_plan_destroy(h)
+            res_.sort()
+            print(f"{name:26s} M={B * Ho * Wo} N={Cout} K={Cin * k * k} se={se}")
+            for t, aux in res_[:5]:
+                print(f"    {t * 1e3:8.1f} us {fl / (t * 1e-3) / 1e12:7.1f} TF  {T.describe(aux)}")
+            del ws
+            continue
+        h = C.c_void_p()
+        L.check(lib.ftc_plan_create(op, 1, cur + 256, 0, C.byref(h)), "create")
         for _ in range(3):
             lib.ftc_plan_run(h, bases, st, 0, -1)
         ts = []
@@ -105,7 +131,6 @@ def main():
             L.check(lib.ftc_plan_profile(h, bases, st, ms), "profile")
             ts.append(ms[0])
         t = float(np.median(ts))
-        fl = 2.0 * B * Ho * Wo * Cout * Cin * k * k
         buf = C.create_string_buffer(128)
         lib.ftc_op_kernel_label(C.byref(o), buf, 128)
         tf = fl / (t * 1e-3) / 1e12

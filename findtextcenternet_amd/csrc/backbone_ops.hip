@@ -340,18 +340,48 @@ __global__ __launch_bounds__(512) void se_fc1_kernel(const float* __restrict__ p
     if (lane == 0) hidden[(long)b * S + sidx] = act_silu_precise(a + b1[sidx]);
 }
 
+// FOLD: additionally write the project weights scaled by this image's excitation, wb[b][n][c] = bf16(wp[n][c] * scale[b,c])
+// (FTC_FLAG_SE_FOLD).  The N rows are split over gridDim.z so that ~2 workgroups per CU share the copy; every z-slice
+// recomputes its 256 scale values (S coalesced loads per lane), slice 0 stores them.
+template <bool FOLD>
 __global__ __launch_bounds__(256) void se_fc2_kernel(const float* __restrict__ hidden, const float* __restrict__ w2t,
-                                                     const float* __restrict__ b2, float* __restrict__ scale, int C, int S) {
-    extern __shared__ __attribute__((aligned(16))) float hid[];    // [S]
+                                                     const float* __restrict__ b2, float* __restrict__ scale, int C, int S,
+                                                     const __bf16* __restrict__ wp, __bf16* __restrict__ wb, int N) {
+    extern __shared__ __attribute__((aligned(16))) float hid[];    // [S] (+ [256] scale values when FOLD)
     const int b = blockIdx.y;
     for (int s = threadIdx.x; s < S; s += 256) hid[s] = hidden[(long)b * S + s];
     __syncthreads();
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float acc = b2[c];
+    float sc = 0.f;
+    if (c < C) {
+        float acc = b2[c];
 #pragma unroll 8
-    for (int s = 0; s < S; ++s) acc += hid[s] * w2t[(long)s * C + c];
-    scale[(long)b * C + c] = sigmoid_precise(acc);
+        for (int s = 0; s < S; ++s) acc += hid[s] * w2t[(long)s * C + c];
+        sc = sigmoid_precise(acc);
+        if (!FOLD || blockIdx.z == 0) scale[(long)b * C + c] = sc;
+    }
+    if constexpr (FOLD) {
+        float* lsc = hid + S;
+        lsc[threadIdx.x] = sc;
+        __syncthreads();
+        const int chunk = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+        const int cc = blockIdx.x * 256 + chunk * 8;
+        if (cc >= C) return;                                       // C % 8 == 0 (validated)
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = lsc[chunk * 8 + e];
+        const int rows = (N + gridDim.z - 1) / gridDim.z;
+        const int n_lo = blockIdx.z * rows, n_hi = min(N, n_lo + rows);
+        __bf16* dst = wb + (long)b * N * C;
+#pragma unroll 4
+        for (int n = n_lo + r0; n < n_hi; n += 8) {
+            float x[8];
+            load16<__bf16>(wp + (long)n * C + cc, x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] *= f[e];
+            store16<__bf16>(dst + (long)n * C + cc, x);
+        }
+    }
 }
 
 }  // namespace
@@ -410,7 +440,15 @@ hipError_t launch_se(const OpArgs& a, hipStream_t s) {
                        (const float*)a.w, a.bias, hidden, C, S, P, 1.0f / (float)(o.H * o.W));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(se_fc2_kernel, dim3((C + 255) / 256, o.B), dim3(256), (size_t)S * sizeof(float), s, hidden,
-                       (const float*)a.w2, a.bias2, (float*)a.out, C, S);
+    if (o.flags & FTC_FLAG_SE_FOLD) {
+        const int cb = (C + 255) / 256;
+        int nz = 512 / (cb * o.B);
+        nz = nz < 1 ? 1 : nz > 8 ? 8 : nz;
+        hipLaunchKernelGGL(se_fc2_kernel<true>, dim3(cb, o.B, nz), dim3(256), (size_t)(S + 256) * sizeof(float), s, hidden,
+                           (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)a.in, (__bf16*)a.out2, o.Cout_total);
+    } else {
+        hipLaunchKernelGGL(se_fc2_kernel<false>, dim3((C + 255) / 256, o.B), dim3(256), (size_t)S * sizeof(float), s, hidden,
+                           (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)nullptr, (__bf16*)nullptr, 0);
+    }
     return hipGetLastError();
 }

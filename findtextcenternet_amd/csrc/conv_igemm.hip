@@ -46,6 +46,8 @@ const char* conv_validate(const ftc_op& op) {
     const long in_bytes = (long)op.B * op.H * op.W * op.Cin_total * (op.in_dtype == FTC_F32 ? 4 : 2);
     const long w_bytes = (long)op.Cout * op.ksize * op.ksize * op.Cin * (op.w_dtype == FTC_F32 ? 4 : 2);
     if (in_bytes >= 0x7ff00000L || w_bytes >= 0x7ff00000L) return "conv: operand larger than 2 GiB (split the batch)";
+    if ((op.flags & FTC_FLAG_W_PER_IMAGE) && (op.flags & (FTC_FLAG_SE_SCALE | FTC_FLAG_BORDER_BIAS))) return "conv: per-image weight sets exclude SE_SCALE / BORDER_BIAS";
+    if (!wset_legal(op)) return "conv: per-image weight sets need a pixel tile that divides Ho*Wo";
     if (hint_halo(op) && !halo_legal(op)) return "conv: LDS-halo kernel is not legal for this op/tile";
     if (hint_splitk(op) > 1 && !splitk_legal(op, hint_splitk(op))) return "conv: split-K variant is not legal for this op/tile";
     if (op.aux0 < 0 || op.aux0 > 0xfff || hint_cfg(op) >= CFG_COUNT) return "conv: aux0 (tuned kernel choice) out of range";
@@ -72,6 +74,7 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
     p.use_glds = uses_glds(o) ? 1 : 0;
     p.glds_nbuf = glds_ring(o);
     p.split_k = (!uses_halo(o) && !uses_glds(o)) ? hint_splitk(o) : 1;
+    p.wset_bytes = (o.flags & FTC_FLAG_W_PER_IMAGE) ? (int)p.w_bytes : 0;
     if (o.w_dtype == FTC_F32) return launch_conv_f32(p, o, s);
     if (o.in_dtype == FTC_BF16 && o.out_dtype == FTC_BF16) return launch_conv_bf16_bb(p, o, s);
     if (o.in_dtype == FTC_F32 && o.out_dtype == FTC_BF16) return launch_conv_bf16_fb(p, o, s);

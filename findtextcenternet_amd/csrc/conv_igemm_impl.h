@@ -53,7 +53,15 @@ struct ConvP {
     int use_glds;   // direct-to-LDS kernel selected (uses_glds)
     int glds_nbuf;  // tuning: LDS ring depth of the DMA kernel (2 | 3)
     int split_k;    // tuning: K groups per workgroup of the register-staged kernel (1 | 2 | 4)
+    int wset_bytes; // FTC_FLAG_W_PER_IMAGE: bytes between the weight sets of consecutive images (0 = one shared set)
 };
+
+// Weight descriptor of the workgroup whose first output row is m0 (all its rows are in one image when wset_bytes != 0).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const ConvP& p, int m0) {
+    const char* w = static_cast<const char*>(p.w);
+    if (p.wset_bytes) w += (long)(m0 / (p.Ho * p.Wo)) * p.wset_bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(w), 0, p.w_bytes, 0x00020000);
+}
 
 template <typename WT> struct Frag;
 template <> struct Frag<float> { using type = f32x4; };
@@ -383,7 +391,7 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(const ConvP p) {
     const int mt = bid / p.nN, nt = bid - mt * p.nN;
     const int m0 = mt * TM, n0 = nt * TN;
 
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = weight_rsrc(p, m0);
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rse = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.se), 0, p.se_bytes, 0x00020000);
     constexpr bool use_se = SE;
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p) {
     const int mt = bid / p.nN, nt = bid - mt * p.nN;
     const int m0 = mt * TM, n0 = nt * TN;
 
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = weight_rsrc(p, m0);
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
     const int HoWo = p.Ho * p.Wo;
     const int KK = p.KS * p.KS;
@@ -796,7 +804,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
     const int ty0 = (sp / tilesX) * TY, tx0 = (sp % tilesX) * TX;
     const int n0 = nt * TN;
 
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = weight_rsrc(p, img * p.Ho * p.Wo);
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
 
     // per-lane global byte offsets of the DMA slots (fixed for the whole tile)
@@ -1072,7 +1080,16 @@ inline int default_cfg(int n, int M) {
 }
 inline int select_cfg(const ftc_op& o) {
     const int h = hint_cfg(o);
-    return h >= 0 && h < CFG_COUNT ? h : default_cfg(o.Cout, o.B * o.Ho * o.Wo);
+    if (h >= 0 && h < CFG_COUNT) return h;
+    const int d = default_cfg(o.Cout, o.B * o.Ho * o.Wo);
+    // per-image weight sets: the pixel tile must divide the image
+    if ((o.flags & FTC_FLAG_W_PER_IMAGE) && (o.Ho * o.Wo) % kCfgTM[d]) return o.Cout > 64 ? CFG_128x64 : CFG_64x64;
+    return d;
+}
+inline bool wset_legal(const ftc_op& o) {
+    if (!(o.flags & FTC_FLAG_W_PER_IMAGE)) return true;
+    if (hint_halo(o)) return true;                                   // the halo kernel tiles each image separately
+    return (o.Ho * o.Wo) % kCfgTM[select_cfg(o)] == 0;
 }
 
 // K step: 64 for bf16 when the channel count allows (half the barriers per FLOP), else 32; 128 only by hint.

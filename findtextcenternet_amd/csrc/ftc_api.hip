@@ -83,6 +83,10 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if (o.aux0 <= 0 || o.aux1 <= 0 || o.Cin <= 0) return "se: C, S, P must be positive";
         if (o.Cin % 4) return "se: C must be a multiple of 4";
         if ((size_t)o.Cin * 4 > 64000 || (size_t)o.aux0 * 4 > 64000) return "se: C or S too large for LDS";
+        if (o.flags & FTC_FLAG_SE_FOLD) {
+            if (!need(o.in, true, "in") || !need(o.out2, true, "out2")) return why->c_str();
+            if (o.Cin % 8 || o.Cout_total <= 0 || o.w_dtype != FTC_BF16) return "se: SE_FOLD needs a bf16 [Cout_total][C] matrix with C % 8 == 0";
+        }
         return nullptr;
     case FTC_OP_UPCAT:
         if (!need(o.in, o.aux0 > 0, "in") || !need(o.in2, true, "in2") || !need(o.out, true, "out") || !need(o.scale, true, "scale") ||

@@ -100,9 +100,9 @@ class _HipEngine:
         except Exception:
             pass
 
-    def ensure_weights(self, state_dict, device) -> None:
-        if self.pw is None:
-            self.pw = P.pack_weights(state_dict, self.precision, self.model_size)
+    def ensure_weights(self, state_dict_fn, device) -> None:
+        if self.pw is None:                       # only then: enumerating the 2444-tensor state dict costs ~8 ms of host time
+            self.pw = P.pack_weights(state_dict_fn(), self.precision, self.model_size)
             self.wdev = None
         if self.wdev is None or self.wdev.device != device:
             self.wdev = torch.from_numpy(self.pw.blob).to(device)
@@ -134,7 +134,7 @@ class _HipEngine:
             x, nchw = x.contiguous(memory_format=torch.channels_last), False
         dev = x.device
         with torch.cuda.device(dev):
-            self.ensure_weights(state_dict_fn(), dev)
+            self.ensure_weights(state_dict_fn, dev)
             pl = self.get_plan(B, H, W, nchw)
             if self.workspace is None or self.workspace.device != dev or self.workspace.numel() < pl.workspace_bytes:
                 self.workspace = None

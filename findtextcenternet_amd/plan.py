@@ -230,7 +230,7 @@ class _Builder:
 
     def emit(self, meta: OpMeta, **f) -> None:
         idx = len(self.ops)
-        for k in ("in_", "in2", "out", "aux", "scale", "out2"):
+        for k in ("in_", "in2", "out", "aux", "scale", "out2", "w"):
             r = f.get(k)
             if isinstance(r, tuple) and r[0] == "buf":
                 b = self.bufs[r[1]]
@@ -240,7 +240,7 @@ class _Builder:
 
     # --- op helpers ---------------------------------------------------------------------------
     def conv(self, name, x, xdt, H, W, cin, cin_total, cin_off, wname, cout, k, stride, act, out, odt, cout_total=None,
-             cout_off=0, residual=None, res_dt=0, se=None, out2=None, extra_flags=0):
+             cout_off=0, residual=None, res_dt=0, se=None, out2=None, extra_flags=0, wsets=None):
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         flags = (L.FLAG_RESIDUAL if residual is not None else 0) | (L.FLAG_SE_SCALE if se is not None else 0) | extra_flags
         macs = self.B * Ho * Wo * cout * cin * k * k
@@ -249,11 +249,14 @@ class _Builder:
             byt += self.B * Ho * Wo * cout * self.esize(res_dt)
         if out2 is not None:
             byt += self.B * Ho * Wo * cout * 2
+        if wsets is not None:                     # one weight set per image (SE excitation folded in by the SE op)
+            flags |= L.FLAG_W_PER_IMAGE
+            byt += (self.B - 1) * cout * cin * k * k * self.esize(self.cdt)
         self.emit(OpMeta(name, f"conv{k}x{k}", 2.0 * macs, byt), kind=L.OP_CONV, flags=flags, act=act, in_dtype=xdt,
                   out_dtype=odt, w_dtype=self.cdt, B=self.B, H=H, W=W, Ho=Ho, Wo=Wo, Cin=cin, Cin_total=cin_total,
                   cin_off=cin_off, Cout=cout, Cout_total=cout_total or cout, cout_off=cout_off, ksize=k, stride=stride,
-                  res_dtype=res_dt, in_=x, in2=residual, out=out, w=self.wref(wname + ".w"), bias=self.wref(wname + ".b"),
-                  scale=se, out2=out2)
+                  res_dtype=res_dt, in_=x, in2=residual, out=out, w=wsets if wsets is not None else self.wref(wname + ".w"),
+                  bias=self.wref(wname + ".b"), scale=se, out2=out2)
         return Ho, Wo
 
     def build(self) -> Plan:
@@ -308,12 +311,19 @@ class _Builder:
                               w=self.wref(p + ".1.w"), bias=self.wref(p + ".1.b"), aux=part)
                     sc = ("buf", self.buf(B * blk.exp, L.F32))
                     hid = ("buf", self.buf(B * blk.squeeze, L.F32))
-                    self.emit(OpMeta(p + ".2", "se", 4.0 * B * blk.exp * blk.squeeze, 8.0 * blk.exp * blk.squeeze + B * P * blk.exp * 4),
-                              kind=L.OP_SE, B=B, H=ho, W=wo, Cin=blk.exp, Cout=blk.exp, aux0=blk.squeeze, aux1=P, aux=part,
+                    # bf16 mode: the SE op also writes the project weights scaled per image, so that the project
+                    # convolution streams both operands by DMA instead of rescaling activations while staging them.
+                    # Needs a 64-pixel tile that divides the image (true for every 768x768 stage).
+                    fold = dual and (ho * wo) % 64 == 0 and blk.exp % 8 == 0
+                    wb = ("buf", self.buf(B * blk.cout * blk.exp, L.BF16)) if fold else None
+                    se_bytes = 8.0 * blk.exp * blk.squeeze + B * P * blk.exp * 4 + ((B + 1) * blk.cout * blk.exp * 2 if fold else 0)
+                    self.emit(OpMeta(p + ".2", "se", 4.0 * B * blk.exp * blk.squeeze, se_bytes),
+                              kind=L.OP_SE, flags=L.FLAG_SE_FOLD if fold else 0, w_dtype=L.BF16 if fold else 0, B=B, H=ho, W=wo,
+                              Cin=blk.exp, Cout=blk.exp, Cout_total=blk.cout if fold else 0, aux0=blk.squeeze, aux1=P, aux=part,
                               out=sc, in2=hid, w=self.wref(p + ".2.w1"), w2=self.wref(p + ".2.w2t"), bias=self.wref(p + ".2.b1"),
-                              bias2=self.wref(p + ".2.b2"))
+                              bias2=self.wref(p + ".2.b2"), in_=self.wref(p + ".3.w") if fold else None, out2=wb)
                     self.conv(p + ".3", d, A, ho, wo, blk.exp, blk.exp, 0, p + ".3", blk.cout, 1, 1, L.ACT_NONE, y, T,
-                              residual=res, res_dt=T, se=sc, out2=yb)
+                              residual=res, res_dt=T, se=None if fold else sc, out2=yb, wsets=wb)
                 x, xb, h, w = y, yb, ho, wo
             if (si + 1) in (2, 3, 5):
                 taps.append((x, stage[-1].cout, h, w, T))

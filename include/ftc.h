@@ -88,9 +88,15 @@ enum {
     FTC_FLAG_RESIDUAL = 1,     /* out += in2 (after activation) */
     FTC_FLAG_SE_SCALE = 2,     /* input multiplied by scale[b, cin] while staging (CONV) */
     FTC_FLAG_IN_NCHW = 4,      /* STEM: input is [B,3,H,W]-contiguous instead of NHWC */
-    FTC_FLAG_BORDER_BIAS = 8   /* CONV 3x3 s1: `bias` is a [16][Cout] table indexed by which image borders the
+    FTC_FLAG_BORDER_BIAS = 8,  /* CONV 3x3 s1: `bias` is a [16][Cout] table indexed by which image borders the
                                   output pixel touches (top | bottom<<1 | left<<2 | right<<3): lets a per-channel
                                   affine (BatchNorm) that PRECEDES a zero-padded conv be folded into it exactly */
+    FTC_FLAG_W_PER_IMAGE = 16, /* CONV: `w` holds B weight sets [B][Cout][k*k][Cin], image b uses set b (the SE
+                                  excitation folded into the project weights, see FTC_FLAG_SE_FOLD).  The pixel
+                                  tile of a workgroup must not straddle images: Ho*Wo % tile rows == 0 */
+    FTC_FLAG_SE_FOLD = 32      /* SE: besides scale[b,c], write out2[b][n][c] = bf16(in[n][c] * scale[b,c]) for the
+                                  bf16 matrix `in` [Cout_total][C] -- the following 1x1 convolution then runs with
+                                  FTC_FLAG_W_PER_IMAGE on unscaled activations (both operands by DMA) */
 };
 
 /* One step of a plan.  Fields that an op kind does not use must be zero. */
@@ -130,7 +136,8 @@ typedef struct ftc_op {
     ftc_ref aux;               /* DWCONV: partial sums out fp32 [B,P,C];  SE: partial sums in */
     ftc_ref out2;              /* CONV / STEM with fp32 `out`: optional bf16 copy [B,Ho,Wo,Cout] of the same
                                   values (the fp32 tensor feeds the residual adds, the copy feeds the
-                                  next bf16 GEMM without a conversion pass) */
+                                  next bf16 GEMM without a conversion pass);  SE+SE_FOLD: the B scaled
+                                  weight sets bf16 [B][Cout_total][C] */
 } ftc_op;
 
 typedef struct ftc_plan ftc_plan;

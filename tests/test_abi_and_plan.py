@@ -144,7 +144,7 @@ def test_tuning_table_entries_are_legal():
     tab = tuning.load_table()
     assert isinstance(tab, dict)
     for k, v in tab.items():
-        assert 0 <= v <= 0x3ff and (v & 15) - 1 < len(tuning.CFG_NAMES), (k, v)
+        assert 0 <= v <= 0xfff and (v & 15) - 1 < len(tuning.CFG_NAMES), (k, v)
         assert tuning.describe(v)
 
 

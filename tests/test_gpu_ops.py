@@ -152,6 +152,54 @@ def _run_conv_case(case, mode, aux0):
         assert (raw[:, keep] == 0xCD).all()
 
 
+@pytest.mark.parametrize("aux0", [0, 5 + 32 + 512, 7 + 48 + 512, 7 + 16 + 512, 65], ids=["default", "128x64_dma2", "64x64_dma3", "64x64_reg", "halo"])
+@pytest.mark.parametrize("odt", [L.F32, L.BF16])
+def test_se_fold_then_per_image_weight_conv(odt, aux0):
+    """bf16 mode of an MBConv tail: the SE op writes W_b = bf16(W * scale[b]) (FTC_FLAG_SE_FOLD) and the project
+    convolution runs with one weight set per image (FTC_FLAG_W_PER_IMAGE) -- against project(x * scale) in fp32."""
+    g = torch.Generator().manual_seed(23)
+    B, H, W, Cc, N, S, P = 3, 8, 16, 256, 192, 16, 2
+    k = 3 if aux0 == 65 else 1
+    x = bf16_round(torch.randn(B, H, W, Cc, generator=g))
+    part = torch.randn(B, P, Cc, generator=g) * 30
+    w1 = torch.randn(S, Cc, generator=g) / Cc ** 0.5
+    b1 = torch.randn(S, generator=g) * 0.3
+    w2 = torch.randn(Cc, S, generator=g) / S ** 0.5
+    b2 = torch.randn(Cc, generator=g) * 0.3
+    wp = bf16_round(torch.randn(N, Cc, k, k, generator=g) / (Cc * k * k) ** 0.5)
+    bias = torch.randn(N, generator=g) * 0.2
+    res = torch.randn(B, H, W, N, generator=g)
+    mean = part.sum(1) / (H * W)
+    sc = torch.sigmoid(F.silu(mean @ w1.t() + b1) @ w2.t() + b2)                          # [B, C]
+    ref = torch.stack([F.conv2d((x[b] * sc[b]).permute(2, 0, 1)[None], wp, bias, 1, (k - 1) // 2)[0].permute(1, 2, 0) for b in range(B)]) + res
+    ar = Arena()
+    o_x = ar.put(to_dev_bytes(x, L.BF16))
+    o_part = ar.put(part)
+    o_w1, o_b1, o_w2t, o_b2 = ar.put(w1), ar.put(b1), ar.put(w2.t().contiguous()), ar.put(b2)
+    o_wp = ar.put(to_dev_bytes(wp.permute(0, 2, 3, 1).reshape(N, k * k * Cc), L.BF16))
+    o_bias, o_res = ar.put(bias), ar.put(res)
+    o_scale, o_hid = ar.reserve(B * Cc * 4), ar.reserve(B * S * 4)
+    o_wb = ar.reserve(B * N * k * k * Cc * 2)
+    esz = 4 if odt == L.F32 else 2
+    o_out = ar.reserve(B * H * W * N * esz)
+    ar.materialize()
+    # the fold treats the weight matrix as [rows][C]: for the 3x3 variant of this test rows = N*9 (K-major layout)
+    run_op(dict(kind=L.OP_SE, flags=L.FLAG_SE_FOLD, w_dtype=L.BF16, B=B, H=H, W=W, Cin=Cc, Cout=Cc, Cout_total=N * k * k, aux0=S, aux1=P,
+                aux=o_part, out=o_scale, in2=o_hid, w=o_w1, w2=o_w2t, bias=o_b1, bias2=o_b2, in_=o_wp, out2=o_wb), ar)
+    got_sc = ar.read(o_scale, (B, Cc), torch.float32)
+    assert float((got_sc - sc).abs().max()) < 2e-6
+    wb = ar.read(o_wb, (B, N, k * k, Cc), torch.bfloat16).float()
+    want = bf16_round(wp.permute(0, 2, 3, 1).reshape(1, N, k * k, Cc) * got_sc[:, None, None, :])
+    assert float((wb - want).abs().max()) <= float(want.abs().max()) * 2 ** -8       # same product, at most one bf16 ulp apart
+    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_RESIDUAL | L.FLAG_W_PER_IMAGE, act=L.ACT_NONE, in_dtype=L.BF16, out_dtype=odt, w_dtype=L.BF16,
+                B=B, H=H, W=W, Ho=H, Wo=W, Cin=Cc, Cin_total=Cc, Cout=N, Cout_total=N, ksize=k, stride=1, res_dtype=L.F32, aux0=aux0,
+                in_=o_x, in2=o_res, out=o_out, w=o_wb, bias=o_bias), ar)
+    out = ar.read(o_out, (B, H, W, N), tdtype(odt)).float()
+    err = _rel(out, ref)
+    _log(f"se_fold+per-image conv odt={odt} aux0={aux0} rel_err {err:.3e}")
+    assert err < 1.5e-2
+
+
 @pytest.mark.parametrize("dt", [L.F32, L.BF16])
 def test_conv_border_bias_folds_preceding_batchnorm(dt):
     """conv3x3(zero_pad(x*s + t)) == conv3x3_{W*s}(zero_pad(x)) + bias_table[border case]: how the

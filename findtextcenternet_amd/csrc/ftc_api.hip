@@ -216,7 +216,10 @@ int ftc_op_kernel_label(const ftc_op* op, char* buf, int len) {
     switch (op->kind) {
     case FTC_OP_STEM: std::snprintf(buf, len, "stem_kernel"); break;
     case FTC_OP_CONV: conv_kernel_label(*op, buf, len); break;
-    case FTC_OP_DWCONV: std::snprintf(buf, len, "dwconv_kernel<%s,s%d>", op->in_dtype == FTC_F32 ? "f32" : "bf16", op->stride); break;
+    case FTC_OP_DWCONV:
+        if (op->in_dtype == FTC_BF16 && op->stride == 1 && !(op->flags & 0x100)) std::snprintf(buf, len, "dwconv_strip_kernel<bf16,s1>");
+        else std::snprintf(buf, len, "dwconv_kernel<%s,s%d>", op->in_dtype == FTC_F32 ? "f32" : "bf16", op->stride);
+        break;
     case FTC_OP_SE: std::snprintf(buf, len, "se_fc1+se_fc2"); break;
     case FTC_OP_UPCAT: std::snprintf(buf, len, "upcat_kernel<%s>", op->in_dtype == FTC_F32 ? "f32" : "bf16"); break;
     case FTC_OP_NMS: std::snprintf(buf, len, "nms_kernel"); break;

@@ -169,7 +169,7 @@ def main():
         total_ms = float(acc.sum())
         dom = max(by.items(), key=lambda kv: kv[1]["ms"])
         name, d = dom
-        is_conv = name.startswith("conv_igemm")
+        is_conv = name.startswith("conv")
         if is_conv:
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK["bf16" if "<bf16" in name else "fp32"], "unit": "TFLOP/s"}
@@ -187,7 +187,7 @@ def main():
                 for lab, rec in tab.items():
                     if lab.split("|")[0] == name and args.precision == "bf16" and B == 8:
                         roof["traffic"] = rec["traffic_bytes"]
-                        roof["traffic_note"] = f"bytes/launch for the M={lab.split('M=')[1]} launches, {os.path.basename(pth)}"
+                        roof["traffic_note"] = f"bytes/launch, {os.path.basename(pth)}"
         except Exception:
             pass
         roof["kernel"] = name
@@ -196,8 +196,8 @@ def main():
         roof["algorithmic_gflop_per_launch"] = round(d["flops"] / d["launches"] / 1e9, 3)
         roof["share_of_forward_time"] = round(d["ms"] / total_ms, 3)
         result["roofline"] = roof
-        conv_ms = sum(v["ms"] for k, v in by.items() if k.startswith("conv_igemm"))
-        conv_fl = sum(v["flops"] for k, v in by.items() if k.startswith("conv_igemm"))
+        conv_ms = sum(v["ms"] for k, v in by.items() if k.startswith("conv"))
+        conv_fl = sum(v["flops"] for k, v in by.items() if k.startswith("conv"))
         result["all_conv_kernels"] = {"ms_per_step": round(conv_ms, 3), "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                                       "share_of_forward_time": round(conv_ms / total_ms, 3)}
         result["forward_ms_sum_of_kernels"] = round(total_ms, 3)

@@ -9,12 +9,13 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libftc_hip.so")
 
-FTC_ABI_VERSION = 1
+FTC_ABI_VERSION = 2
 F32, BF16 = 0, 1
 (BASE_NULL, BASE_WORKSPACE, BASE_WEIGHTS, BASE_INPUT, BASE_HEATMAP, BASE_FEATURES, NUM_BASES) = range(7)
 OP_STEM, OP_CONV, OP_DWCONV, OP_SE, OP_UPCAT, OP_NMS = 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 FLAG_RESIDUAL, FLAG_SE_SCALE, FLAG_IN_NCHW, FLAG_BORDER_BIAS, FLAG_W_PER_IMAGE, FLAG_SE_FOLD = 1, 2, 4, 8, 16, 32
+FLAG_GROUP_IN_SLICE, FLAG_GROUP_OUT_SLICE = 64, 128
 
 EXPORTS = ["ftc_abi_version", "ftc_last_error", "ftc_device_info", "ftc_plan_create", "ftc_plan_destroy",
            "ftc_plan_num_ops", "ftc_plan_run", "ftc_plan_profile", "ftc_op_kernel_label", "ftc_decode_scratch_bytes", "ftc_decode", "ftc_tile_gather", "ftc_paste_maps"]
@@ -35,7 +36,7 @@ class Ref(C.Structure):
 class Op(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "kind", "flags", "act", "in_dtype", "out_dtype", "w_dtype", "B", "H", "W", "Ho", "Wo", "Cin", "Cin_total",
-        "cin_off", "Cout", "Cout_total", "cout_off", "ksize", "stride", "aux0", "aux1", "res_dtype")] + [
+        "cin_off", "Cout", "Cout_total", "cout_off", "ksize", "stride", "aux0", "aux1", "res_dtype", "groups", "reserved0")] + [
         (n, Ref) for n in ("in_", "in2", "out", "w", "w2", "bias", "bias2", "scale", "shift", "aux", "out2")]
 
 

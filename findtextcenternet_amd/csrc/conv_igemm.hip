@@ -17,12 +17,14 @@ void conv_kernel_label(const ftc_op& op, char* buf, int len) {
     if (uses_halo(op)) {
         snprintf(buf, len, "conv3x3_halo<%s,out=%s,tile=%dx16x16,bk=%d>", dt[op.w_dtype & 1], dt[op.out_dtype & 1], halo_sn(op) * 64,
                  halo_cpr(op) * (op.w_dtype == FTC_BF16 ? 8 : 4));
+        if (op.groups > 1) snprintf(buf + strlen(buf) - 1, len - strlen(buf) + 1, ",groups=%d>", op.groups);
         return;
     }
     const bool dma = uses_glds(op);
     snprintf(buf, len, "conv_igemm%s<%s,in=%s,out=%s,tile=%s,bk=%d,nbuf=%d>", dma ? "_glds" : "", dt[op.w_dtype & 1], dt[op.in_dtype & 1],
              dt[op.out_dtype & 1], kCfgName[select_cfg(op)], select_bk(op), dma ? glds_ring(op) : 1);
     if (!dma && hint_splitk(op) > 1) snprintf(buf + strlen(buf) - 1, len - strlen(buf) + 1, ",splitk=%d>", hint_splitk(op));
+    if (op.groups > 1) snprintf(buf + strlen(buf) - 1, len - strlen(buf) + 1, ",groups=%d>", op.groups);
 }
 
 const char* conv_validate(const ftc_op& op) {
@@ -48,6 +50,10 @@ const char* conv_validate(const ftc_op& op) {
     if (in_bytes >= 0x7ff00000L || w_bytes >= 0x7ff00000L) return "conv: operand larger than 2 GiB (split the batch)";
     if ((op.flags & FTC_FLAG_W_PER_IMAGE) && (op.flags & (FTC_FLAG_SE_SCALE | FTC_FLAG_BORDER_BIAS))) return "conv: per-image weight sets exclude SE_SCALE / BORDER_BIAS";
     if (!wset_legal(op)) return "conv: per-image weight sets need a pixel tile that divides Ho*Wo";
+    if (op.groups < 0 || op.groups > 64 || op.reserved0 != 0) return "conv: groups must be in 0..64 and reserved0 zero";
+    if (op.groups > 1 && (op.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_SE_SCALE | FTC_FLAG_W_PER_IMAGE))) return "conv: grouped launches exclude RESIDUAL / SE_SCALE / W_PER_IMAGE";
+    if ((op.flags & FTC_FLAG_GROUP_OUT_SLICE) && (op.groups <= 1 || op.cout_off + op.groups * op.Cout > op.Cout_total)) return "conv: GROUP_OUT_SLICE channel slices out of range";
+    if (op.groups > 1 && (long)op.groups * op.B * op.Ho * op.Wo > 0x7fffffffL / 4) return "conv: too many output pixels over all groups";
     if (hint_halo(op) && !halo_legal(op)) return "conv: LDS-halo kernel is not legal for this op/tile";
     if (hint_splitk(op) > 1 && !splitk_legal(op, hint_splitk(op))) return "conv: split-K variant is not legal for this op/tile";
     if (op.aux0 < 0 || op.aux0 > 0xfff || hint_cfg(op) >= CFG_COUNT) return "conv: aux0 (tuned kernel choice) out of range";
@@ -75,6 +81,16 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
     p.glds_nbuf = glds_ring(o);
     p.split_k = (!uses_halo(o) && !uses_glds(o)) ? hint_splitk(o) : 1;
     p.wset_bytes = (o.flags & FTC_FLAG_W_PER_IMAGE) ? (int)p.w_bytes : 0;
+    p.groups = o.groups > 1 ? o.groups : 1;
+    p.nblk_g = 0;
+    const long osz = o.out_dtype == FTC_F32 ? 4 : 2;
+    const bool oslice = (o.flags & FTC_FLAG_GROUP_OUT_SLICE) != 0;
+    p.in_gs = (long)p.in_bytes;
+    p.w_gs = (long)p.w_bytes;
+    p.bias_gs = ((o.flags & FTC_FLAG_BORDER_BIAS) ? 16 : 1) * o.Cout;
+    p.out_gs = oslice ? 0 : (long)o.B * o.Ho * o.Wo * o.Cout_total * osz;
+    p.out2_gs = oslice ? 0 : (long)o.B * o.Ho * o.Wo * o.Cout_total * 2;
+    p.cout_gs = oslice ? o.Cout : 0;
     if (o.w_dtype == FTC_F32) return launch_conv_f32(p, o, s);
     if (o.in_dtype == FTC_BF16 && o.out_dtype == FTC_BF16) return launch_conv_bf16_bb(p, o, s);
     if (o.in_dtype == FTC_F32 && o.out_dtype == FTC_BF16) return launch_conv_bf16_fb(p, o, s);

@@ -54,7 +54,25 @@ struct ConvP {
     int glds_nbuf;  // tuning: LDS ring depth of the DMA kernel (2 | 3)
     int split_k;    // tuning: K groups per workgroup of the register-staged kernel (1 | 2 | 4)
     int wset_bytes; // FTC_FLAG_W_PER_IMAGE: bytes between the weight sets of consecutive images (0 = one shared set)
+    // grouped launch (ftc_op.groups): G independent instances, workgroups [g*nblk_g, (g+1)*nblk_g) belong to instance g
+    int groups, nblk_g;
+    long in_gs, w_gs, out_gs, out2_gs;   // bytes between the instances' operands
+    int bias_gs, cout_gs;                // floats between bias tables; channel-slice step of the output (OUT_SLICE)
 };
+
+// Turns the launch-wide parameter block into the one of the group that owns workgroup `bid`; returns the
+// workgroup index inside the group.
+__device__ __forceinline__ int enter_group(ConvP& p, int bid) {
+    if (p.groups <= 1) return bid;
+    const int g = bid / p.nblk_g;
+    p.in = static_cast<const char*>(p.in) + g * p.in_gs;
+    p.w = static_cast<const char*>(p.w) + g * p.w_gs;
+    p.bias += (long)g * p.bias_gs;
+    p.out = static_cast<char*>(p.out) + g * p.out_gs;
+    if (p.out2) p.out2 = static_cast<char*>(p.out2) + g * p.out2_gs;
+    p.cout_off += g * p.cout_gs;
+    return bid - g * p.nblk_g;
+}
 
 // Weight descriptor of the workgroup whose first output row is m0 (all its rows are in one image when wset_bytes != 0).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const ConvP& p, int m0) {
@@ -358,7 +376,8 @@ __device__ __forceinline__ void conv_epilogue_splitk(const ConvP& p, f32x16 (&ac
 // project convs (M = 4608 at batch 8 gives only 2 workgroups of 64x64 per CU) without any inter-workgroup
 // protocol and stays deterministic.
 template <typename WT, typename InT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF, bool SE, int KG = 1>
-__global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(const ConvP p) {
+__global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(const ConvP p_launch) {
+    ConvP p = p_launch;
     constexpr int E = 16 / (int)sizeof(WT);      // elements per 16-byte chunk (4 fp32 | 8 bf16)
     constexpr int CPR = BK / E;                  // chunks per LDS row
     constexpr int ROW = BK + E;                  // padded LDS row, elements
@@ -388,6 +407,7 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(const ConvP p) {
         const int q = p.nblk >> 3, r = p.nblk & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
+    bid = enter_group(p, bid);
     const int mt = bid / p.nN, nt = bid - mt * p.nN;
     const int m0 = mt * TM, n0 = nt * TN;
 
@@ -575,7 +595,8 @@ __device__ __forceinline__ void wg_barrier() { __builtin_amdgcn_s_barrier(); }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <typename WT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF>
-__global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p) {
+__global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p_launch) {
+    ConvP p = p_launch;
     constexpr int E = 16 / (int)sizeof(WT);
     constexpr int CPR = BK / E;                  // 16-byte chunks per row: 8 (128-byte rows) or 4
     constexpr int ROWB = CPR * 16;
@@ -602,6 +623,7 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p) {
         const int q = p.nblk >> 3, r = p.nblk & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
+    bid = enter_group(p, bid);
     const int mt = bid / p.nN, nt = bid - mt * p.nN;
     const int m0 = mt * TM, n0 = nt * TN;
 
@@ -768,7 +790,8 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
 }
 
 template <typename WT, typename OutT, int CPR, int SN>
-__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p_launch) {
+    ConvP p = p_launch;
     constexpr int E = 16 / (int)sizeof(WT);
     constexpr int BK = CPR * E;
     constexpr int ROWB = CPR * 16;
@@ -796,6 +819,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p) {
         const int q = p.nblk >> 3, r = p.nblk & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
+    bid = enter_group(p, bid);
     const int nt = bid % p.nN;
     int sp = bid / p.nN;
     const int tilesX = (p.Wo + TX - 1) / TX, tilesY = (p.Ho + TY - 1) / TY;
@@ -973,7 +997,8 @@ hipError_t launch_halo(ConvP p, hipStream_t s) {
     p.ncb = p.Cin / (CPR * E);
     p.nk = 9 * p.ncb;
     p.nN = (p.Cout + TN - 1) / TN;
-    p.nblk = p.nN * p.B * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16);
+    p.nblk_g = p.nN * p.B * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16);
+    p.nblk = p.nblk_g * (p.groups > 1 ? p.groups : 1);
     hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(512), lds_bytes, s, p);
     return hipGetLastError();
 }
@@ -998,7 +1023,8 @@ hipError_t launch_cfg2(ConvP p, hipStream_t s) {
     p.nk = p.KS * p.KS * p.ncb;
     p.nN = (p.Cout + TN - 1) / TN;
     const int nM = (p.M + TM - 1) / TM;
-    p.nblk = p.nN * nM;
+    p.nblk_g = p.nN * nM;
+    p.nblk = p.nblk_g * (p.groups > 1 ? p.groups : 1);
     hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(256 * KG), lds_bytes, s, p);
     return hipGetLastError();
 }
@@ -1020,7 +1046,8 @@ hipError_t launch_glds(ConvP p, hipStream_t s) {
     p.ncb = (p.Cin + BK - 1) / BK;
     p.nk = p.KS * p.KS * p.ncb;
     p.nN = (p.Cout + TN - 1) / TN;
-    p.nblk = p.nN * ((p.M + TM - 1) / TM);
+    p.nblk_g = p.nN * ((p.M + TM - 1) / TM);
+    p.nblk = p.nblk_g * (p.groups > 1 ? p.groups : 1);
     hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(256), lds_bytes, s, p);
     return hipGetLastError();
 }
@@ -1081,7 +1108,7 @@ inline int default_cfg(int n, int M) {
 inline int select_cfg(const ftc_op& o) {
     const int h = hint_cfg(o);
     if (h >= 0 && h < CFG_COUNT) return h;
-    const int d = default_cfg(o.Cout, o.B * o.Ho * o.Wo);
+    const int d = default_cfg(o.Cout, o.B * o.Ho * o.Wo * (o.groups > 1 ? o.groups : 1));
     // per-image weight sets: the pixel tile must divide the image
     if ((o.flags & FTC_FLAG_W_PER_IMAGE) && (o.Ho * o.Wo) % kCfgTM[d]) return o.Cout > 64 ? CFG_128x64 : CFG_64x64;
     return d;

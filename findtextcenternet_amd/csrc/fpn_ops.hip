@@ -15,9 +15,14 @@ template <typename T, typename TapT>
 __global__ __launch_bounds__(256) void upcat_kernel(const T* __restrict__ prev, const TapT* __restrict__ tap,
                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                     T* __restrict__ out, int B, int Hi, int Wi, int Ho, int Wo,
-                                                    int Cy, int Ct, int CyT, float ry, float rx) {
+                                                    int Cy, int Ct, int CyT, float ry, float rx, long prev_gs, long out_gs) {
     constexpr int V = 16 / (int)sizeof(T);         // channels per lane = one 16-byte store (4 fp32 | 8 bf16)
     const int Ctot = Cy + Ct;
+    // grouped launch (ftc_op.groups): blockIdx.y = instance; the backbone tap is shared, everything else is per instance
+    prev += blockIdx.y * prev_gs;
+    out += blockIdx.y * out_gs;
+    scale += blockIdx.y * Ct;
+    shift += blockIdx.y * Ct;
     const int Q = Ctot / V;
     const long total = (long)B * Ho * Wo * Q;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -96,11 +101,14 @@ hipError_t launch_upcat(const OpArgs& a, hipStream_t s) {
     const long total = (long)o.B * o.Ho * o.Wo * ((Cy + Ct) / V);
     long nb = (total + 255) / 256;
     if (nb > 16384) nb = 16384;
+    const int G = o.groups > 1 ? o.groups : 1;
+    const long prev_gs = G == 1 ? 0 : (o.flags & FTC_FLAG_GROUP_IN_SLICE) ? Cy : (long)o.B * o.H * o.W * CyT;
+    const long out_gs = G == 1 ? 0 : (long)o.B * o.Ho * o.Wo * (Cy + Ct);
     const float ry = o.Ho > 1 ? (float)(o.H - 1) / (float)(o.Ho - 1) : 0.f;
     const float rx = o.Wo > 1 ? (float)(o.W - 1) / (float)(o.Wo - 1) : 0.f;
 #define UPCAT_LAUNCH(T, TT)                                                                                       \
-    hipLaunchKernelGGL((upcat_kernel<T, TT>), dim3((unsigned)nb), dim3(256), 0, s, (const T*)a.in + o.cin_off, (const TT*)a.in2, \
-                       a.scale, a.shift, (T*)a.out, o.B, o.H, o.W, o.Ho, o.Wo, Cy, Ct, CyT, ry, rx)
+    hipLaunchKernelGGL((upcat_kernel<T, TT>), dim3((unsigned)nb, G), dim3(256), 0, s, (const T*)a.in + o.cin_off, (const TT*)a.in2, \
+                       a.scale, a.shift, (T*)a.out, o.B, o.H, o.W, o.Ho, o.Wo, Cy, Ct, CyT, ry, rx, prev_gs, out_gs)
     // res_dtype = dtype of the backbone tap (the trunk stays fp32 in bf16 mode)
     if (o.in_dtype == FTC_F32) UPCAT_LAUNCH(float, float);
     else if (o.res_dtype == FTC_F32) UPCAT_LAUNCH(__bf16, float);

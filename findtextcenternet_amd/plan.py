@@ -94,6 +94,9 @@ def _kmajor(w: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(w.transpose(0, 2, 3, 1)).reshape(o, kh * kw, i)
 
 
+TOP6 = ("textline", "sepatator", "code1", "code2", "code4", "code8")      # heads[2..7]: one output channel each, channels 4..9
+
+
 def pack_weights(sd: Dict[str, torch.Tensor], mode: str = "fp32", model_size: str = "xl") -> PackedWeights:
     """sd: ``CenterNetDetection`` state_dict (keys without the ``detector.`` prefix)."""
     assert mode in ("fp32", "bf16")
@@ -154,20 +157,35 @@ def pack_weights(sd: Dict[str, torch.Tensor], mode: str = "fp32", model_size: st
         bias16_all.append(b16)
     bl.add("heads.L0.w", _to_compute(np.concatenate(wm_all, axis=0), mode))
     bl.add("heads.L0.b", np.concatenate(bias16_all, axis=1).astype(np.float32))                      # [16][9*192]
-    for name, out_dim, _ in HEADS:
-        for i in range(ntap):
-            q = f"{name}.in_bn.{i}"
-            g = sd[q + ".weight"].detach().cpu().double().numpy()
-            s = g / np.sqrt(sd[q + ".running_var"].detach().cpu().double().numpy() + HEAD_BN_EPS)
-            t = sd[q + ".bias"].detach().cpu().double().numpy() - sd[q + ".running_mean"].detach().cpu().double().numpy() * s
-            bl.add(q + ".scale", s.astype(np.float32))
-            bl.add(q + ".shift", t.astype(np.float32))
-        for i in range(1, ntap):
-            q = f"{name}.upsamplers.{i}"
-            conv_bn(q, q + ".0.weight", q + ".1", HEAD_BN_EPS)
+    # FPN levels 1.. and the input BatchNorms of the nine heads are stored head-major ([9][...]) so that one grouped
+    # launch (ftc_op.groups = 9) covers all heads of a level; so are the six one-channel top convolutions whose heat-map
+    # channels are consecutive (textline, separator, code1/2/4/8 -> channels 4..9).
+    def bn_affine(q):
+        g = sd[q + ".weight"].detach().cpu().double().numpy()
+        s_ = g / np.sqrt(sd[q + ".running_var"].detach().cpu().double().numpy() + HEAD_BN_EPS)
+        t_ = sd[q + ".bias"].detach().cpu().double().numpy() - sd[q + ".running_mean"].detach().cpu().double().numpy() * s_
+        return s_.astype(np.float32), t_.astype(np.float32)
+
+    for i in range(ntap - 1):
+        st = [bn_affine(f"{name}.in_bn.{i}") for name, _, _ in HEADS]
+        bl.add(f"heads.in_bn.{i}.scale", np.stack([a for a, _ in st]))
+        bl.add(f"heads.in_bn.{i}.shift", np.stack([b for _, b in st]))
+    for i in range(1, ntap):
+        wb = [_fold(sd, f"{name}.upsamplers.{i}.0.weight", f"{name}.upsamplers.{i}.1", HEAD_BN_EPS) for name, _, _ in HEADS]
+        bl.add(f"heads.L{i}.w", _to_compute(np.stack([_kmajor(w) for w, _ in wb]), mode))
+        bl.add(f"heads.L{i}.b", np.stack([b for _, b in wb]).astype(np.float32))
+
+    def top(name):
         w = sd[f"{name}.top_conv.0.weight"].detach().cpu().double().numpy()
-        bl.add(f"{name}.top_conv.w", _to_compute(_kmajor(w), mode))
-        bl.add(f"{name}.top_conv.b", sd[f"{name}.top_conv.0.bias"].detach().cpu().float().numpy())
+        return _kmajor(w), sd[f"{name}.top_conv.0.bias"].detach().cpu().float().numpy()
+
+    for name in ("keyheatmap", "sizes", "feature"):
+        w, b = top(name)
+        bl.add(f"{name}.top_conv.w", _to_compute(w, mode))
+        bl.add(f"{name}.top_conv.b", b)
+    tops = [top(name) for name in TOP6]
+    bl.add("heads.top6.w", _to_compute(np.stack([w for w, _ in tops]), mode))
+    bl.add("heads.top6.b", np.stack([b for _, b in tops]).astype(np.float32))
     return PackedWeights(bl.finish(), bl.table, mode, model_size)
 
 
@@ -240,11 +258,12 @@ class _Builder:
 
     # --- op helpers ---------------------------------------------------------------------------
     def conv(self, name, x, xdt, H, W, cin, cin_total, cin_off, wname, cout, k, stride, act, out, odt, cout_total=None,
-             cout_off=0, residual=None, res_dt=0, se=None, out2=None, extra_flags=0, wsets=None):
+             cout_off=0, residual=None, res_dt=0, se=None, out2=None, extra_flags=0, wsets=None, groups=1):
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         flags = (L.FLAG_RESIDUAL if residual is not None else 0) | (L.FLAG_SE_SCALE if se is not None else 0) | extra_flags
-        macs = self.B * Ho * Wo * cout * cin * k * k
-        byt = self.B * H * W * cin * self.esize(xdt) + self.B * Ho * Wo * cout * self.esize(odt) + cout * cin * k * k * self.esize(self.cdt)
+        macs = groups * self.B * Ho * Wo * cout * cin * k * k
+        byt = groups * (self.B * H * W * cin * self.esize(xdt) + self.B * Ho * Wo * cout * self.esize(odt)
+                        + cout * cin * k * k * self.esize(self.cdt))
         if residual is not None:
             byt += self.B * Ho * Wo * cout * self.esize(res_dt)
         if out2 is not None:
@@ -256,7 +275,7 @@ class _Builder:
                   out_dtype=odt, w_dtype=self.cdt, B=self.B, H=H, W=W, Ho=Ho, Wo=Wo, Cin=cin, Cin_total=cin_total,
                   cin_off=cin_off, Cout=cout, Cout_total=cout_total or cout, cout_off=cout_off, ksize=k, stride=stride,
                   res_dtype=res_dt, in_=x, in2=residual, out=out, w=wsets if wsets is not None else self.wref(wname + ".w"),
-                  bias=self.wref(wname + ".b"), scale=se, out2=out2)
+                  bias=self.wref(wname + ".b"), scale=se, out2=out2, groups=groups if groups > 1 else 0)
         return Ho, Wo
 
     def build(self) -> Plan:
@@ -340,28 +359,38 @@ class _Builder:
         y0 = ("buf", self.buf(B * h4 * w4 * nh * FPN_DIM, A))
         self.conv("heads.upsamplers.0", t4, dt4, h4, w4, c4, c4, 0, "heads.L0", nh * FPN_DIM, 3, 1, L.ACT_GELU, y0, A,
                   extra_flags=L.FLAG_BORDER_BIAS)
+        # Levels 1.. : the nine heads have identical shapes, so each level is ONE grouped launch (upsample+concat, then the
+        # 3x3 convolution) over head-major stacked tensors [9][B,h,w,C] -- 2592 instead of 288 workgroups for the 96x96
+        # level, no 1.1-round tails on 256 CUs.
+        y, yh, yw = y0, h4, w4
+        for i in range(1, ntap):
+            tbuf, tc, th_, tw_, tdt = taps[ntap - 1 - i]
+            cy = FPN_DIM
+            cat = ("buf", self.buf(nh * B * th_ * tw_ * (cy + tc), A))
+            self.emit(OpMeta(f"heads.cat{i}", "upcat", 0.0,
+                             nh * (B * th_ * tw_ * ((cy + tc) * self.esize(A) + tc * self.esize(tdt)) + B * yh * yw * cy * self.esize(A))),
+                      kind=L.OP_UPCAT, flags=L.FLAG_GROUP_IN_SLICE if i == 1 else 0, in_dtype=A, out_dtype=A, res_dtype=tdt, B=B,
+                      H=yh, W=yw, Ho=th_, Wo=tw_, Cin=cy + tc, Cin_total=nh * FPN_DIM if i == 1 else FPN_DIM, cin_off=0, Cout=cy + tc,
+                      aux0=cy, aux1=tc, groups=nh, in_=y, in2=tbuf, out=cat, scale=self.wref(f"heads.in_bn.{ntap - 1 - i}.scale"),
+                      shift=self.wref(f"heads.in_bn.{ntap - 1 - i}.shift"))
+            y = ("buf", self.buf(nh * B * th_ * tw_ * FPN_DIM, A))
+            self.conv(f"heads.upsamplers.{i}", cat, A, th_, tw_, cy + tc, cy + tc, 0, f"heads.L{i}", FPN_DIM, 3, 1, L.ACT_GELU, y, A,
+                      groups=nh)
+            yh, yw = th_, tw_
+        gs = B * yh * yw * FPN_DIM * self.esize(A)            # bytes between the heads' last-level tensors
         for hi, (name, out_dim, ch0) in enumerate(HEADS):
-            y, yh, yw, ystride, yoff = y0, h4, w4, nh * FPN_DIM, hi * FPN_DIM
-            for i in range(1, ntap):
-                tbuf, tc, th_, tw_, tdt = taps[ntap - 1 - i]
-                cy = FPN_DIM
-                cat = ("buf", self.buf(B * th_ * tw_ * (cy + tc), A))
-                q = f"{name}.in_bn.{ntap - 1 - i}"
-                self.emit(OpMeta(f"{name}.cat{i}", "upcat", 0.0,
-                                 B * th_ * tw_ * ((cy + tc) * self.esize(A) + tc * self.esize(tdt)) + B * yh * yw * cy * self.esize(A)),
-                          kind=L.OP_UPCAT, in_dtype=A, out_dtype=A, res_dtype=tdt, B=B, H=yh, W=yw, Ho=th_, Wo=tw_, Cin=cy + tc,
-                          Cin_total=ystride, cin_off=yoff, Cout=cy + tc, aux0=cy, aux1=tc,
-                          in_=y, in2=tbuf, out=cat, scale=self.wref(q + ".scale"), shift=self.wref(q + ".shift"))
-                y = ("buf", self.buf(B * th_ * tw_ * FPN_DIM, A))
-                self.conv(f"{name}.upsamplers.{i}", cat, A, th_, tw_, cy + tc, cy + tc, 0, f"{name}.upsamplers.{i}", FPN_DIM, 3, 1,
-                          L.ACT_GELU, y, A)
-                yh, yw, ystride, yoff = th_, tw_, FPN_DIM, 0
-            if ch0 >= 0:       # map heads write straight into their channel slice; channel 1 is the NMS slot
+            yi = ("buf", y[1], hi * gs)
+            if name in TOP6:
+                if name != TOP6[0]:
+                    continue                                   # covered by the grouped launch below
+                self.conv("heads.top6", yi, A, yh, yw, FPN_DIM, FPN_DIM, 0, "heads.top6", 1, 3, 1, L.ACT_NONE, ("heatmap", 0), L.F32,
+                          cout_total=10, cout_off=ch0 + 1, groups=len(TOP6), extra_flags=L.FLAG_GROUP_OUT_SLICE)
+            elif ch0 >= 0:     # map heads write straight into their channel slice; channel 1 is the NMS slot
                 off = 0 if ch0 == 0 else ch0 + 1
-                self.conv(f"{name}.top_conv", y, A, yh, yw, FPN_DIM, FPN_DIM, 0, f"{name}.top_conv", out_dim, 3, 1, L.ACT_NONE,
+                self.conv(f"{name}.top_conv", yi, A, yh, yw, FPN_DIM, FPN_DIM, 0, f"{name}.top_conv", out_dim, 3, 1, L.ACT_NONE,
                           ("heatmap", 0), L.F32, cout_total=10, cout_off=off)
             else:
-                self.conv(f"{name}.top_conv", y, A, yh, yw, FPN_DIM, FPN_DIM, 0, f"{name}.top_conv", out_dim, 3, 1, L.ACT_NONE,
+                self.conv(f"{name}.top_conv", yi, A, yh, yw, FPN_DIM, FPN_DIM, 0, f"{name}.top_conv", out_dim, 3, 1, L.ACT_NONE,
                           ("features", 0), L.F32, cout_total=feature_dim, cout_off=0)
         self.emit(OpMeta("nms", "nms", 0.0, B * mh * mw * 8.0), kind=L.OP_NMS, B=B, H=mh, W=mw, Ho=mh, Wo=mw, Cout_total=10,
                   out=("heatmap", 0))
@@ -399,7 +428,7 @@ class _Builder:
                         continue
                     r = getattr(o, k)
                     r.base = base_of[v[0]]
-                    r.offset = self.bufs[v[1]].offset if v[0] == "buf" else v[1]
+                    r.offset = self.bufs[v[1]].offset + (v[2] if len(v) > 2 else 0) if v[0] == "buf" else v[1]
                 else:
                     setattr(o, k, int(v))
         from . import tuning

@@ -27,7 +27,7 @@ _table: Optional[Dict[str, int]] = None
 
 def signature(o) -> str:
     return (f"w{o.w_dtype}i{o.in_dtype}o{o.out_dtype}_B{o.B}_{o.H}x{o.W}_c{o.Cin}of{o.Cin_total}_n{o.Cout}of{o.Cout_total}"
-            f"_k{o.ksize}s{o.stride}_f{o.flags}_a{o.act}")
+            f"_k{o.ksize}s{o.stride}_f{o.flags}_a{o.act}" + (f"_g{o.groups}" if o.groups > 1 else ""))
 
 
 def encode(cfg: int, stage: int, bk: int, halo: bool = False, splitk: int = 1) -> int:

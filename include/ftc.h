@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FTC_ABI_VERSION 1
+#define FTC_ABI_VERSION 2
 
 typedef enum ftc_status {
     FTC_OK = 0,
@@ -94,6 +94,10 @@ enum {
     FTC_FLAG_W_PER_IMAGE = 16, /* CONV: `w` holds B weight sets [B][Cout][k*k][Cin], image b uses set b (the SE
                                   excitation folded into the project weights, see FTC_FLAG_SE_FOLD).  The pixel
                                   tile of a workgroup must not straddle images: Ho*Wo % tile rows == 0 */
+    FTC_FLAG_GROUP_IN_SLICE = 64,  /* UPCAT with groups > 1: the upsampled inputs of the groups are channel slices of ONE
+                                  tensor (group g reads channels cin_off + g*aux0 ..) instead of stacked tensors */
+    FTC_FLAG_GROUP_OUT_SLICE = 128, /* CONV with groups > 1: the groups write channel slices of ONE tensor (group g writes
+                                  channels cout_off + g*Cout ..) instead of stacked tensors */
     FTC_FLAG_SE_FOLD = 32      /* SE: besides scale[b,c], write out2[b][n][c] = bf16(in[n][c] * scale[b,c]) for the
                                   bf16 matrix `in` [Cout_total][C] -- the following 1x1 convolution then runs with
                                   FTC_FLAG_W_PER_IMAGE on unscaled activations (both operands by DMA) */
@@ -122,6 +126,12 @@ typedef struct ftc_op {
                                   UPCAT: channels of the upsampled part (0 = none) */
     int32_t aux1;              /* SE: number of partial sums P;  UPCAT: tap channels */
     int32_t res_dtype;         /* ftc_dtype of in2 (CONV residual / UPCAT tap) */
+    int32_t groups;            /* CONV / UPCAT: G > 1 runs G independent instances of the op in ONE launch (the nine FPN
+                                  heads share every shape).  Operands of instance g are stacked, g-major: CONV in
+                                  [G][B,H,W,Cin_total], w [G][Cout][k*k][Cin], bias [G][rows][Cout], out [G][B,Ho,Wo,Cout_total];
+                                  UPCAT in [G][B,H,W,Cin_total], scale/shift [G][aux1], out [G][B,Ho,Wo,C], in2 (the backbone
+                                  tap) shared.  See FTC_FLAG_GROUP_IN_SLICE / _OUT_SLICE.  0 or 1 = a single instance */
+    int32_t reserved0;         /* must be 0 */
     ftc_ref in;                /* main input */
     ftc_ref in2;               /* CONV: residual [B,Ho,Wo,Cout];  UPCAT: backbone tap [B,Ho,Wo,aux1];
                                   SE: hidden-unit scratch fp32 [B,aux0] */

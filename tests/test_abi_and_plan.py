@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert getattr(lib, name) is not None
     assert lib.ftc_abi_version() == L.FTC_ABI_VERSION
-    assert C.sizeof(L.Op) == 22 * 4 + 11 * 16 and C.sizeof(L.Ref) == 16 and C.sizeof(L.Tile) == 32
+    assert C.sizeof(L.Op) == 24 * 4 + 11 * 16 and C.sizeof(L.Ref) == 16 and C.sizeof(L.Tile) == 32
 
 
 def test_device_info_fails_loudly_without_gpu():
@@ -84,7 +84,10 @@ def test_plan_structure_flops_and_arena(sd, mode):
     assert abs(sum(m.flops for m in pl.meta) / 2 / 1e9 - 865.0006) < 0.01
     kinds = [m.kind for m in pl.meta]
     assert kinds.count("dwconv3x3") == 80 and kinds.count("se") == 80 and kinds.count("stem") == 1 and kinds[-1] == "nms"
-    assert kinds.count("upcat") == 27 and sum(k.startswith("conv") for k in kinds) == 20 + 16 + 160 + 1 + 1 + 27 + 9
+    # nine heads x three levels of upsample+concat and conv, nine top convs: grouped launches count once per instance
+    inst = [max(1, pl.ops[i].groups) for i in range(len(kinds))]
+    assert sum(n for k, n in zip(kinds, inst) if k == "upcat") == 27 and kinds.count("upcat") == 3
+    assert sum(n for k, n in zip(kinds, inst) if k.startswith("conv")) == 20 + 16 + 160 + 1 + 1 + 27 + 9
     # arena: no two simultaneously-live buffers overlap
     live = {}
     ops = pl.ops

@@ -200,6 +200,73 @@ def test_se_fold_then_per_image_weight_conv(odt, aux0):
     assert err < 1.5e-2
 
 
+@pytest.mark.parametrize("aux0", [0, 4 + 32 + 512, 2 + 16 + 512, 65, 68], ids=["default", "64x128_dma2", "128x128_reg", "halo192", "halo64"])
+@pytest.mark.parametrize("mode", [CONV_MODES[0], CONV_MODES[1]], ids=["f32", "bf16"])
+@pytest.mark.parametrize("out_slice", [False, True], ids=["stacked", "out_slice"])
+def test_grouped_conv_runs_independent_instances(out_slice, mode, aux0):
+    """ftc_op.groups: G convolutions with their own inputs / weights / biases in one launch (the nine FPN heads)."""
+    _, wdt, idt, odt = mode
+    if out_slice:
+        odt = L.F32
+    g = torch.Generator().manual_seed(41)
+    G, B, H, W, Cin = 3, 2, 20, 12, 64
+    Cout = 2 if out_slice else 192
+    CoutT, coff = (10, 3) if out_slice else (Cout, 0)
+    x = torch.randn(G, B, H, W, Cin, generator=g)
+    w = torch.randn(G, Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bias = torch.randn(G, Cout, generator=g) * 0.3
+    if idt == L.BF16:
+        x = bf16_round(x)
+    wq = bf16_round(w) if wdt == L.BF16 else w
+    ref = torch.stack([F.gelu(F.conv2d(x[i].permute(0, 3, 1, 2), wq[i], bias[i], 1, 1)).permute(0, 2, 3, 1) for i in range(G)])
+    ar = Arena()
+    o_in = ar.put(to_dev_bytes(x, idt))
+    o_w = ar.put(to_dev_bytes(w.permute(0, 1, 3, 4, 2).reshape(G, Cout, 9, Cin), wdt))
+    o_b = ar.put(bias)
+    esz = 4 if odt == L.F32 else 2
+    o_out = ar.reserve((1 if out_slice else G) * B * H * W * CoutT * esz)
+    ar.materialize()
+    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_GROUP_OUT_SLICE if out_slice else 0, act=L.ACT_GELU, in_dtype=idt, out_dtype=odt, w_dtype=wdt,
+                B=B, H=H, W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cin, Cout=Cout, Cout_total=CoutT, cout_off=coff, ksize=3, stride=1,
+                aux0=aux0, groups=G, in_=o_in, out=o_out, w=o_w, bias=o_b), ar)
+    if out_slice:
+        full = ar.read(o_out, (B, H, W, CoutT), tdtype(odt)).float()
+        out = torch.stack([full[..., coff + i * Cout:coff + (i + 1) * Cout] for i in range(G)])
+    else:
+        out = ar.read(o_out, (G, B, H, W, Cout), tdtype(odt)).float()
+    err = _rel(out, ref)
+    _log(f"grouped conv out_slice={out_slice} {mode[0]} aux0={aux0} rel_err {err:.3e}")
+    assert err < (2e-4 if wdt == L.F32 else 1.5e-2)
+
+
+@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+@pytest.mark.parametrize("in_slice", [True, False], ids=["in_slice", "stacked"])
+def test_grouped_upcat(in_slice, dt):
+    g = torch.Generator().manual_seed(43)
+    G, B, Hi, Wi, Cy, Ct = 3, 2, 6, 5, 64, 32
+    y = torch.randn(G, B, Hi, Wi, Cy, generator=g)
+    tap = torch.randn(B, 2 * Hi, 2 * Wi, Ct, generator=g)
+    if dt == L.BF16:
+        y = bf16_round(y)
+    sc, sh = torch.rand(G, Ct, generator=g) + 0.5, torch.randn(G, Ct, generator=g)
+    ref = torch.stack([torch.cat([F.interpolate(y[i].permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True).permute(0, 2, 3, 1),
+                                  tap * sc[i] + sh[i]], -1) for i in range(G)])
+    ar = Arena()
+    y_dev = y.permute(1, 2, 3, 0, 4).reshape(B, Hi, Wi, G * Cy) if in_slice else y      # one tensor with G channel slices | stacked
+    o_y = ar.put(to_dev_bytes(y_dev.contiguous(), dt))
+    o_tap, o_sc, o_sh = ar.put(tap), ar.put(sc), ar.put(sh)
+    esz = 4 if dt == L.F32 else 2
+    o_out = ar.reserve(G * B * 4 * Hi * Wi * (Cy + Ct) * esz)
+    ar.materialize()
+    run_op(dict(kind=L.OP_UPCAT, flags=L.FLAG_GROUP_IN_SLICE if in_slice else 0, in_dtype=dt, out_dtype=dt, res_dtype=L.F32, B=B, H=Hi, W=Wi,
+                Ho=2 * Hi, Wo=2 * Wi, Cin=Cy + Ct, Cin_total=G * Cy if in_slice else Cy, Cout=Cy + Ct, aux0=Cy, aux1=Ct, groups=G,
+                in_=o_y, in2=o_tap, out=o_out, scale=o_sc, shift=o_sh), ar)
+    out = ar.read(o_out, (G, B, 2 * Hi, 2 * Wi, Cy + Ct), tdtype(dt)).float()
+    err = _rel(out, ref)
+    _log(f"grouped upcat in_slice={in_slice} dt={dt} rel_err {err:.3e}")
+    assert err < (1e-5 if dt == L.F32 else 6e-3)
+
+
 @pytest.mark.parametrize("dt", [L.F32, L.BF16])
 def test_conv_border_bias_folds_preceding_batchnorm(dt):
     """conv3x3(zero_pad(x*s + t)) == conv3x3_{W*s}(zero_pad(x)) + bias_table[border case]: how the

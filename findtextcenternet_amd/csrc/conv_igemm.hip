@@ -15,7 +15,7 @@ hipError_t launch_conv_bf16_ff(const ConvP& p, const ftc_op& o, hipStream_t s);
 void conv_kernel_label(const ftc_op& op, char* buf, int len) {
     const char* dt[] = {"f32", "bf16"};
     if (uses_halo(op)) {
-        snprintf(buf, len, "conv3x3_halo<%s,out=%s,tile=%dx16x16,bk=%d>", dt[op.w_dtype & 1], dt[op.out_dtype & 1], halo_sn(op) * 64,
+        snprintf(buf, len, (op.flags & FTC_FLAG_TOP_FUSE) ? "conv3x3_halo+top<%s,out=%s,tile=%dx16x16,bk=%d>" : "conv3x3_halo<%s,out=%s,tile=%dx16x16,bk=%d>", dt[op.w_dtype & 1], dt[op.out_dtype & 1], halo_sn(op) * 64,
                  halo_cpr(op) * (op.w_dtype == FTC_BF16 ? 8 : 4));
         if (op.groups > 1) snprintf(buf + strlen(buf) - 1, len - strlen(buf) + 1, ",groups=%d>", op.groups);
         return;
@@ -50,6 +50,13 @@ const char* conv_validate(const ftc_op& op) {
     if (in_bytes >= 0x7ff00000L || w_bytes >= 0x7ff00000L) return "conv: operand larger than 2 GiB (split the batch)";
     if ((op.flags & FTC_FLAG_W_PER_IMAGE) && (op.flags & (FTC_FLAG_SE_SCALE | FTC_FLAG_BORDER_BIAS))) return "conv: per-image weight sets exclude SE_SCALE / BORDER_BIAS";
     if (!wset_legal(op)) return "conv: per-image weight sets need a pixel tile that divides Ho*Wo";
+    if (op.flags & FTC_FLAG_TOP_FUSE) {
+        if (!uses_halo(op) || halo_sn(op) != 3 || halo_cpr(op) != 8 || op.Cout != 192 || op.Cout_total != 192 || op.cout_off != 0 ||
+            op.w_dtype != FTC_BF16 || op.in_dtype != FTC_BF16 || op.out_dtype != FTC_BF16)
+            return "conv: TOP_FUSE needs the bf16 LDS-halo kernel with one 192-channel tile (aux0 = 65, Cin % 64 == 0, Cout = 192)";
+        if (op.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_BORDER_BIAS | FTC_FLAG_GROUP_OUT_SLICE)) return "conv: TOP_FUSE excludes RESIDUAL / BORDER_BIAS / GROUP_OUT_SLICE";
+        if (op.aux1 < 4 || op.aux1 > 32 || op.aux1 % 4) return "conv: TOP_FUSE output row width (aux1) must be a multiple of 4 in 4..32";
+    }
     if (op.groups < 0 || op.groups > 64 || op.reserved0 != 0) return "conv: groups must be in 0..64 and reserved0 zero";
     if (op.groups > 1 && (op.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_SE_SCALE | FTC_FLAG_W_PER_IMAGE))) return "conv: grouped launches exclude RESIDUAL / SE_SCALE / W_PER_IMAGE";
     if ((op.flags & FTC_FLAG_GROUP_OUT_SLICE) && (op.groups <= 1 || op.cout_off + op.groups * op.Cout > op.Cout_total)) return "conv: GROUP_OUT_SLICE channel slices out of range";
@@ -91,6 +98,12 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
     p.out_gs = oslice ? 0 : (long)o.B * o.Ho * o.Wo * o.Cout_total * osz;
     p.out2_gs = oslice ? 0 : (long)o.B * o.Ho * o.Wo * o.Cout_total * 2;
     p.cout_gs = oslice ? o.Cout : 0;
+    p.w2 = nullptr; p.w2_gs = 0; p.Tw = 0;
+    if (o.flags & FTC_FLAG_TOP_FUSE) {
+        p.w2 = a.w2; p.w2_gs = (long)32 * o.Cout * 2; p.Tw = o.aux1;
+        p.out_gs = (long)o.B * o.Ho * o.Wo * o.aux1 * 4;       // `out` holds T [G][B,Ho,Wo][aux1] fp32
+        p.out2 = nullptr;
+    }
     if (o.w_dtype == FTC_F32) return launch_conv_f32(p, o, s);
     if (o.in_dtype == FTC_BF16 && o.out_dtype == FTC_BF16) return launch_conv_bf16_bb(p, o, s);
     if (o.in_dtype == FTC_F32 && o.out_dtype == FTC_BF16) return launch_conv_bf16_fb(p, o, s);

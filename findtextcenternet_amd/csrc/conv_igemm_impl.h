@@ -58,6 +58,10 @@ struct ConvP {
     int groups, nblk_g;
     long in_gs, w_gs, out_gs, out2_gs;   // bytes between the instances' operands
     int bias_gs, cout_gs;                // floats between bias tables; channel-slice step of the output (OUT_SLICE)
+    // FTC_FLAG_TOP_FUSE: the 32 x Cout tap matrix of the following top convolution and the width of its output rows
+    const void* w2;
+    long w2_gs;
+    int Tw;
 };
 
 // Turns the launch-wide parameter block into the one of the group that owns workgroup `bid`; returns the
@@ -71,6 +75,7 @@ __device__ __forceinline__ int enter_group(ConvP& p, int bid) {
     p.out = static_cast<char*>(p.out) + g * p.out_gs;
     if (p.out2) p.out2 = static_cast<char*>(p.out2) + g * p.out2_gs;
     p.cout_off += g * p.cout_gs;
+    if (p.w2) p.w2 = static_cast<const char*>(p.w2) + g * p.w2_gs;
     return bid - g * p.nblk_g;
 }
 
@@ -297,6 +302,78 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvP& p, f32x16 (&acc)[
                 store16<__bf16>(reinterpret_cast<__bf16*>(outp) + (size_t)m * p.CoutT + p.cout_off + n, f);
             } else {
                 *reinterpret_cast<u32x4*>(outp + (size_t)m * p.CoutT + p.cout_off + n) = raw;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FTC_FLAG_TOP_FUSE epilogue (bf16, the tile holds ALL Cout = TN channels of its pixels): the last FPN level of
+// a map head is consumed only by that head's `top_conv` (3x3, 1-2 output channels).  A 3x3 convolution with tiny
+// Cout is a per-pixel linear map followed by a 9-point sum:  T[p][tap*Co+o] = sum_c y[p][c] * Wtop[o][tap][c],
+// out[p][o] = bias[o] + sum_tap T[p + d(tap)][tap*Co+o].  The first half is one more MFMA GEMM on the output tile
+// while it sits in LDS (K = TN, 32 rows = 9*Co padded), so the 192-channel tensor (384 B/pixel) is never written:
+// only T (aux1 floats per pixel) leaves the CU, and FTC_OP_TAPSUM does the 9-point sum.
+// ------------------------------------------------------------------------------------------------
+template <int SN, int SM, int NTHREADS, int TN, int TM, typename RowFn>
+__device__ __forceinline__ void conv_epilogue_topfuse(const ConvP& p, f32x16 (&acc)[SN][SM], unsigned char* smem, int nw0, int pw0,
+                                                      int half, int l31, int wave, RowFn row_to_m) {
+    constexpr int PITCH = TN * 2;                           // bf16 image of the tile, [pixel][channel]
+    constexpr int CH = TN / 8;                              // 16-byte chunks per row
+    static_assert(PITCH % 128 == 0 && TM == 32 * (NTHREADS / 64), "one 32-pixel MFMA column block per wave");
+    __syncthreads();
+    float* lbias = reinterpret_cast<float*>(smem + TM * PITCH);
+    unsigned char* lwt = smem + TM * PITCH + TN * 4;        // tap matrix [32][TN] bf16, same swizzle as the image
+    for (int c = threadIdx.x; c < TN / 4; c += NTHREADS)
+        *reinterpret_cast<f32x4*>(lbias + 4 * c) = *reinterpret_cast<const f32x4*>(p.bias + 4 * c);
+    for (int c = threadIdx.x; c < 32 * CH; c += NTHREADS) {
+        const int r = c / CH, cc = c - r * CH;
+        *reinterpret_cast<u32x4*>(lwt + r * PITCH + ((cc ^ (r & 7)) * 16)) =
+            *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.w2) + ((size_t)r * TN + cc * 8) * 2);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SM; ++j) {
+        const int prow = pw0 + j * 32 + l31;
+        unsigned char* lrow = smem + prow * PITCH;
+#pragma unroll
+        for (int i = 0; i < SN; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = nw0 + i * 32 + 8 * q + 4 * half;
+                f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                v += *reinterpret_cast<const f32x4*>(lbias + nl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = apply_act_sel<true>(v[e], p.act);
+                const int chunk = (nl / 8) ^ (prow & 7);
+                store4<__bf16>(reinterpret_cast<__bf16*>(lrow + chunk * 16) + (nl % 8), v);
+            }
+        }
+    }
+    __syncthreads();
+    // wave w: pixels 32w .. 32w+31 of the tile;  A = tap matrix rows, B = image rows, K = TN in steps of 16
+    const int prow = wave * 32 + l31;
+    f32x16 t;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) t[e] = 0.0f;
+    const unsigned char* arow = lwt + l31 * PITCH;
+    const unsigned char* brow = smem + prow * PITCH;
+#pragma unroll
+    for (int g = 0; g < TN / 16; ++g) {
+        const int c = g * 2 + half;
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + ((c ^ (l31 & 7)) * 16));
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + ((c ^ (prow & 7)) * 16));
+        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, t, 0, 0, 0);
+    }
+    const int m = row_to_m(prow);
+    if (m >= 0) {
+        float* dst = reinterpret_cast<float*>(p.out) + (size_t)m * p.Tw;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int nq = 8 * q + 4 * half;                // rows (r&3) + 8*(r>>2) + 4*half of the C layout
+            if (nq < p.Tw) {
+                const f32x4 v = {t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+                *reinterpret_cast<f32x4*>(dst + nq) = v;
             }
         }
     }
@@ -789,7 +866,7 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
     }
 }
 
-template <typename WT, typename OutT, int CPR, int SN>
+template <typename WT, typename OutT, int CPR, int SN, bool TOPF = false>
 __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p_launch) {
     ConvP p = p_launch;
     constexpr int E = 16 / (int)sizeof(WT);
@@ -971,7 +1048,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p_launch)
         const int oy = ty0 + wm * 4 + j * 2 + (l31 >> 4), ox = tx0 + (l31 & 15);
         mrow[j] = (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
     }
-    if (epi_lds_ok<OutT>(p) && (size_t)TY * TX * epi_pitch<OutT>(TN) + (size_t)16 * TN * 4 <= (size_t)3 * WSLOT + 2 * HBUF) {
+    if constexpr (TOPF) {
+        static_assert(sizeof(WT) == 2 && sizeof(OutT) == 2, "");
+        conv_epilogue_topfuse<SN, SM, 512, TN, TY * TX>(p, acc, smem_raw, wn * SN * 32, wm * SM * 32, half, l31, wave, [&](int row) {
+            const int oy = ty0 + (row >> 4), ox = tx0 + (row & 15);
+            return (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
+        });
+    } else if (epi_lds_ok<OutT>(p) && (size_t)TY * TX * epi_pitch<OutT>(TN) + (size_t)16 * TN * 4 <= (size_t)3 * WSLOT + 2 * HBUF) {
         conv_epilogue_lds<WT, OutT, SN, SM, 512, TN, TY * TX>(p, acc, smem_raw, n0, wn * SN * 32, wm * SM * 32, half, l31, [&](int row) {
             const int oy = ty0 + (row >> 4), ox = tx0 + (row & 15);
             return (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
@@ -982,12 +1065,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p_launch)
     if (tl_on) tl[43] = __builtin_amdgcn_s_memtime();
 }
 
-template <typename WT, typename OutT, int CPR, int SN>
+template <typename WT, typename OutT, int CPR, int SN, bool TOPF = false>
 hipError_t launch_halo(ConvP p, hipStream_t s) {
     constexpr int E = 16 / (int)sizeof(WT);
     constexpr int TN = 2 * SN * 32;
     constexpr size_t lds_bytes = (size_t)3 * TN * CPR * 16 + (size_t)2 * 324 * CPR * 16;
-    auto kern = conv3x3_halo_kernel<WT, OutT, CPR, SN>;
+    static_assert(!TOPF || (size_t)256 * TN * 2 + TN * 4 + 32 * TN * 2 <= lds_bytes, "image + bias + tap matrix must fit the operand buffers");
+    auto kern = conv3x3_halo_kernel<WT, OutT, CPR, SN, TOPF>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1187,6 +1271,12 @@ hipError_t launch_tiles(const ConvP& p, int cfg, hipStream_t s) {
 template <typename WT, typename OutT>
 hipError_t launch_halo_dispatch(const ConvP& p, const ftc_op& o, hipStream_t s) {
     const int sn = halo_sn(o), cpr = halo_cpr(o);
+    if (o.flags & FTC_FLAG_TOP_FUSE) {
+        if constexpr (sizeof(WT) == 2 && sizeof(OutT) == 2) {
+            if (cpr == 8 && sn == 3) return launch_halo<WT, OutT, 8, 3, true>(p, s);
+        }
+        return hipErrorInvalidValue;
+    }
     if (cpr == 8) {
         if (sn == 3) return launch_halo<WT, OutT, 8, 3>(p, s);
         if (sn == 2) return launch_halo<WT, OutT, 8, 2>(p, s);

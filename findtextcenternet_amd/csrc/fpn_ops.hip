@@ -91,7 +91,42 @@ __global__ __launch_bounds__(256) void nms_kernel(float* __restrict__ heat, int 
     }
 }
 
+// 9-point sum that finishes a top convolution whose per-pixel taps T were produced by the FTC_FLAG_TOP_FUSE epilogue.
+// One lane = one (pixel, output); the nine 4-byte reads of a lane hit the rows of the neighbouring pixels, which its
+// neighbours in the wave read too (L1/L2 absorb the 9x reuse; T is read from HBM once).
+__global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ T, const int* __restrict__ map, const float* __restrict__ bias,
+                                                     float* __restrict__ out, int B, int H, int W, int Tw, int nout, int CH, long gs) {
+    const long total = (long)B * H * W * nout;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % nout);
+        const long pix = idx / nout;
+        const int x = (int)(pix % W), y = (int)((pix / W) % H);
+        const int g = map[4 * j], o = map[4 * j + 1], co = map[4 * j + 2], ch = map[4 * j + 3];
+        const float* Tg = T + g * gs + o;
+        float acc = bias[j];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) {
+                const int yy = y + r - 1, xx = x + s2 - 1;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                    acc += Tg[(pix + (long)(r - 1) * W + (s2 - 1)) * Tw + (r * 3 + s2) * co];
+            }
+        out[pix * CH + ch] = acc;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_tapsum(const OpArgs& a, hipStream_t s) {
+    const ftc_op& o = *a.op;
+    const long total = (long)o.B * o.H * o.W * o.aux1;
+    long nb = (total + 255) / 256;
+    if (nb > 65536) nb = 65536;
+    hipLaunchKernelGGL(tapsum_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float*)a.in, (const int*)a.w, a.bias, (float*)a.out, o.B, o.H,
+                       o.W, o.aux0, o.aux1, o.Cout_total, (long)o.B * o.H * o.W * o.aux0);
+    return hipGetLastError();
+}
 
 hipError_t launch_upcat(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;

@@ -98,6 +98,10 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if ((o.flags & FTC_FLAG_GROUP_IN_SLICE) && (o.groups <= 1 || o.cin_off + o.groups * o.aux0 > o.Cin_total)) return "upcat: GROUP_IN_SLICE channel slices out of range";
         if (o.groups > 1 && o.aux0 <= 0) return "upcat: grouped launches need an upsampled part";
         return nullptr;
+    case FTC_OP_TAPSUM:
+        if (!need(o.in, true, "in") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.bias, true, "bias")) return why->c_str();
+        if (o.aux0 < 4 || o.aux0 % 4 || o.aux1 < 1 || o.aux1 > 64 || o.Cout_total < 1 || o.groups < 1) return "tapsum: bad aux0 / aux1 / Cout_total / groups";
+        return nullptr;
     case FTC_OP_NMS:
         if (!need(o.out, true, "out")) return why->c_str();
         if (o.Cout_total < 2) return "nms: heat-map needs >= 2 channels";
@@ -133,6 +137,7 @@ hipError_t run_one(const ftc_op& o, void* const bases[FTC_NUM_BASES], hipStream_
     case FTC_OP_SE: return launch_se(a, s);
     case FTC_OP_UPCAT: return launch_upcat(a, s);
     case FTC_OP_NMS: return launch_nms(a, s);
+    case FTC_OP_TAPSUM: return launch_tapsum(a, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -226,6 +231,7 @@ int ftc_op_kernel_label(const ftc_op* op, char* buf, int len) {
     case FTC_OP_SE: std::snprintf(buf, len, "se_fc1+se_fc2"); break;
     case FTC_OP_UPCAT: std::snprintf(buf, len, "upcat_kernel<%s>", op->in_dtype == FTC_F32 ? "f32" : "bf16"); break;
     case FTC_OP_NMS: std::snprintf(buf, len, "nms_kernel"); break;
+    case FTC_OP_TAPSUM: std::snprintf(buf, len, "tapsum_kernel"); break;
     default: return fail(FTC_ERR_INVALID, "ftc_op_kernel_label: unknown op kind");
     }
     return FTC_OK;

@@ -136,5 +136,6 @@ hipError_t launch_dwconv(const OpArgs& a, hipStream_t s);
 hipError_t launch_se(const OpArgs& a, hipStream_t s);
 hipError_t launch_upcat(const OpArgs& a, hipStream_t s);
 hipError_t launch_nms(const OpArgs& a, hipStream_t s);
+hipError_t launch_tapsum(const OpArgs& a, hipStream_t s);
 const char* conv_validate(const ftc_op& op);   // NULL if supported, else reason
 void conv_kernel_label(const ftc_op& op, char* buf, int len);

@@ -19,6 +19,7 @@ Two steps:
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -186,6 +187,20 @@ def pack_weights(sd: Dict[str, torch.Tensor], mode: str = "fp32", model_size: st
     tops = [top(name) for name in TOP6]
     bl.add("heads.top6.w", _to_compute(np.stack([w for w, _ in tops]), mode))
     bl.add("heads.top6.b", np.stack([b for _, b in tops]).astype(np.float32))
+    if mode == "bf16":
+        # The eight map heads' top convolutions as per-pixel tap matrices for the fused last-level epilogue
+        # (FTC_FLAG_TOP_FUSE + FTC_OP_TAPSUM): row tap*Co + o of head g = top_conv weight [o, :, r, s], 32 rows zero padded.
+        wt = np.zeros((len(HEADS) - 1, 32, FPN_DIM))
+        bias, omap = [], []
+        for g, (name, co, ch0) in enumerate(HEADS[:-1]):
+            w, b = top(name)                                    # [co][9][192]
+            for o in range(co):
+                wt[g, np.arange(9) * co + o, :] = w[o]
+                bias.append(b[o])
+                omap.append((g, o, co, (0 if ch0 == 0 else ch0 + 1) + o))
+        bl.add("heads.top8.wt", _to_compute(wt, mode))
+        bl.add("heads.top8.b", np.asarray(bias, np.float32))
+        bl.add("heads.top8.map", np.asarray(omap, np.int32))
     return PackedWeights(bl.finish(), bl.table, mode, model_size)
 
 
@@ -248,7 +263,7 @@ class _Builder:
 
     def emit(self, meta: OpMeta, **f) -> None:
         idx = len(self.ops)
-        for k in ("in_", "in2", "out", "aux", "scale", "out2", "w"):
+        for k in ("in_", "in2", "out", "aux", "scale", "out2", "w", "w2"):
             r = f.get(k)
             if isinstance(r, tuple) and r[0] == "buf":
                 b = self.bufs[r[1]]
@@ -258,7 +273,7 @@ class _Builder:
 
     # --- op helpers ---------------------------------------------------------------------------
     def conv(self, name, x, xdt, H, W, cin, cin_total, cin_off, wname, cout, k, stride, act, out, odt, cout_total=None,
-             cout_off=0, residual=None, res_dt=0, se=None, out2=None, extra_flags=0, wsets=None, groups=1):
+             cout_off=0, residual=None, res_dt=0, se=None, out2=None, extra_flags=0, wsets=None, groups=1, w_off=0, b_off=0):
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         flags = (L.FLAG_RESIDUAL if residual is not None else 0) | (L.FLAG_SE_SCALE if se is not None else 0) | extra_flags
         macs = groups * self.B * Ho * Wo * cout * cin * k * k
@@ -274,8 +289,9 @@ class _Builder:
         self.emit(OpMeta(name, f"conv{k}x{k}", 2.0 * macs, byt), kind=L.OP_CONV, flags=flags, act=act, in_dtype=xdt,
                   out_dtype=odt, w_dtype=self.cdt, B=self.B, H=H, W=W, Ho=Ho, Wo=Wo, Cin=cin, Cin_total=cin_total,
                   cin_off=cin_off, Cout=cout, Cout_total=cout_total or cout, cout_off=cout_off, ksize=k, stride=stride,
-                  res_dtype=res_dt, in_=x, in2=residual, out=out, w=wsets if wsets is not None else self.wref(wname + ".w"),
-                  bias=self.wref(wname + ".b"), scale=se, out2=out2, groups=groups if groups > 1 else 0)
+                  res_dtype=res_dt, in_=x, in2=residual, out=out,
+                  w=wsets if wsets is not None else ("w", self.pw.table[wname + ".w"] + w_off),
+                  bias=("w", self.pw.table[wname + ".b"] + b_off), scale=se, out2=out2, groups=groups if groups > 1 else 0)
         return Ho, Wo
 
     def build(self) -> Plan:
@@ -363,6 +379,9 @@ class _Builder:
         # 3x3 convolution) over head-major stacked tensors [9][B,h,w,C] -- 2592 instead of 288 workgroups for the 96x96
         # level, no 1.1-round tails on 256 CUs.
         y, yh, yw = y0, h4, w4
+        nmap = nh - 1                                          # the map heads (all but `feature`)
+        fuse_top = dual and taps[0][1] + FPN_DIM == 256 and not os.environ.get("FTC_NO_TOPFUSE")
+        TW = 20                                                # floats per pixel of the tap tensor T (9 * 2 outputs, padded)
         for i in range(1, ntap):
             tbuf, tc, th_, tw_, tdt = taps[ntap - 1 - i]
             cy = FPN_DIM
@@ -373,12 +392,39 @@ class _Builder:
                       H=yh, W=yw, Ho=th_, Wo=tw_, Cin=cy + tc, Cin_total=nh * FPN_DIM if i == 1 else FPN_DIM, cin_off=0, Cout=cy + tc,
                       aux0=cy, aux1=tc, groups=nh, in_=y, in2=tbuf, out=cat, scale=self.wref(f"heads.in_bn.{ntap - 1 - i}.scale"),
                       shift=self.wref(f"heads.in_bn.{ntap - 1 - i}.shift"))
+            if i == ntap - 1 and fuse_top:
+                # Last level, bf16: the eight map heads never store their 192-channel output -- the epilogue multiplies the
+                # tile by the head's top-convolution taps and stores 20 floats per pixel; TAPSUM does the 9-point sum into
+                # the heat-map channels.  The feature head (100 output channels) keeps the two-kernel form.
+                M = B * th_ * tw_
+                T = ("buf", self.buf(nmap * M * TW, L.F32))
+                cin = cy + tc
+                nout = sum(co for _, co, _ in HEADS[:-1])
+                self.emit(OpMeta(f"heads.upsamplers.{i}+top", "conv3x3", 2.0 * nmap * M * FPN_DIM * cin * 9 + 2.0 * M * FPN_DIM * 9 * nout,
+                                 nmap * (M * cin * 2 + M * TW * 4 + FPN_DIM * cin * 9 * 2)),
+                          kind=L.OP_CONV, flags=L.FLAG_TOP_FUSE, act=L.ACT_GELU, in_dtype=A, out_dtype=A, w_dtype=self.cdt, B=B, H=th_, W=tw_,
+                          Ho=th_, Wo=tw_, Cin=cin, Cin_total=cin, Cout=FPN_DIM, Cout_total=FPN_DIM, ksize=3, stride=1, aux0=65, aux1=TW,
+                          groups=nmap, in_=cat, out=T, w=self.wref(f"heads.L{i}.w"), bias=self.wref(f"heads.L{i}.b"),
+                          w2=self.wref("heads.top8.wt"))
+                self.emit(OpMeta("heads.top8.tapsum", "tapsum", 0.0, nmap * M * TW * 4 + M * nout * 4),
+                          kind=L.OP_TAPSUM, B=B, H=th_, W=tw_, Ho=th_, Wo=tw_, Cout_total=10, aux0=TW, aux1=nout, groups=nmap,
+                          in_=T, out=("heatmap", 0), w=self.wref("heads.top8.map"), bias=self.wref("heads.top8.b"))
+                # feature head: its own last level + top convolution
+                fi = nh - 1
+                yf = ("buf", self.buf(M * FPN_DIM, A))
+                wsz = FPN_DIM * cin * 9 * self.esize(self.cdt)
+                self.conv(f"feature.upsamplers.{i}", ("buf", cat[1], fi * M * cin * self.esize(A)), A, th_, tw_, cin, cin, 0,
+                          f"heads.L{i}", FPN_DIM, 3, 1, L.ACT_GELU, yf, A, w_off=fi * wsz, b_off=fi * FPN_DIM * 4)
+                self.conv("feature.top_conv", yf, A, th_, tw_, FPN_DIM, FPN_DIM, 0, "feature.top_conv", feature_dim, 3, 1, L.ACT_NONE,
+                          ("features", 0), L.F32, cout_total=feature_dim, cout_off=0)
+                y = None
+                break
             y = ("buf", self.buf(nh * B * th_ * tw_ * FPN_DIM, A))
             self.conv(f"heads.upsamplers.{i}", cat, A, th_, tw_, cy + tc, cy + tc, 0, f"heads.L{i}", FPN_DIM, 3, 1, L.ACT_GELU, y, A,
                       groups=nh)
             yh, yw = th_, tw_
         gs = B * yh * yw * FPN_DIM * self.esize(A)            # bytes between the heads' last-level tensors
-        for hi, (name, out_dim, ch0) in enumerate(HEADS):
+        for hi, (name, out_dim, ch0) in enumerate(HEADS if y is not None else []):
             yi = ("buf", y[1], hi * gs)
             if name in TOP6:
                 if name != TOP6[0]:

@@ -77,7 +77,11 @@ typedef enum ftc_op_kind {
     FTC_OP_UPCAT = 5,
     /* 3x3 max-pool NMS on heatmap channel 0 -> channel 1 (CenterNetDetector.forward,
        detector.py:291-296) */
-    FTC_OP_NMS = 6
+    FTC_OP_NMS = 6,
+    FTC_OP_TAPSUM = 7          /* second half of a 3x3 convolution split as per-pixel taps + 9-point sum (FTC_FLAG_TOP_FUSE):
+                                  out[b,y,x,ch_j] = bias[j] + sum_{r,s} in[g_j][b,y+r-1,x+s-1][(3r+s)*co_j + o_j] (zero outside),
+                                  for the aux1 outputs j listed in `w` as int32 quadruples (g_j, o_j, co_j, ch_j);
+                                  in = T [groups][B,H,W][aux0] fp32, out = [B,H,W,Cout_total] fp32 */
 } ftc_op_kind;
 
 enum {
@@ -98,6 +102,10 @@ enum {
                                   tensor (group g reads channels cin_off + g*aux0 ..) instead of stacked tensors */
     FTC_FLAG_GROUP_OUT_SLICE = 128, /* CONV with groups > 1: the groups write channel slices of ONE tensor (group g writes
                                   channels cout_off + g*Cout ..) instead of stacked tensors */
+    FTC_FLAG_TOP_FUSE = 0x10000, /* CONV 3x3 (bf16 LDS-halo kernel, one 192-channel tile): the activated output tile is not
+                                  stored; instead T[p][0..32) = tile[p][:] . w2[0..32)[:] is computed on it and its first
+                                  aux1 values per pixel go to `out` = T [groups][B,Ho,Wo][aux1] fp32 (w2 = bf16 [groups][32][Cout]);
+                                  FTC_OP_TAPSUM finishes the following top convolution */
     FTC_FLAG_SE_FOLD = 32      /* SE: besides scale[b,c], write out2[b][n][c] = bf16(in[n][c] * scale[b,c]) for the
                                   bf16 matrix `in` [Cout_total][C] -- the following 1x1 convolution then runs with
                                   FTC_FLAG_W_PER_IMAGE on unscaled activations (both operands by DMA) */
@@ -124,7 +132,8 @@ typedef struct ftc_op {
     int32_t stride;            /* 1 or 2 */
     int32_t aux0;              /* DWCONV: number of row-strips P;  SE: squeeze channels;
                                   UPCAT: channels of the upsampled part (0 = none) */
-    int32_t aux1;              /* SE: number of partial sums P;  UPCAT: tap channels */
+    int32_t aux1;              /* SE: number of partial sums P;  UPCAT: tap channels;  CONV+TOP_FUSE: floats per pixel of T;
+                                  TAPSUM: number of outputs (aux0 = floats per pixel of T) */
     int32_t res_dtype;         /* ftc_dtype of in2 (CONV residual / UPCAT tap) */
     int32_t groups;            /* CONV / UPCAT: G > 1 runs G independent instances of the op in ONE launch (the nine FPN
                                   heads share every shape).  Operands of instance g are stacked, g-major: CONV in

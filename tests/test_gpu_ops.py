@@ -267,6 +267,61 @@ def test_grouped_upcat(in_slice, dt):
     assert err < (1e-5 if dt == L.F32 else 6e-3)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 48), (1, 21, 19)], ids=["32x48", "21x19_ragged"])
+def test_top_fuse_epilogue_plus_tapsum_equals_two_convolutions(shape):
+    """FTC_FLAG_TOP_FUSE + FTC_OP_TAPSUM: conv3x3+GELU (192 ch, never stored) followed by a 3x3 top convolution with bias,
+    for G heads with 1 / 2 / 1 output channels, against the two convolutions in fp32 (intermediate rounded to bf16 as the
+    kernel's LDS image is)."""
+    B, H, W = shape
+    G, Cin, Cm, TW = 3, 64, 192, 20
+    cos = [1, 2, 1]
+    chs = [[0], [2, 3], [5]]
+    g = torch.Generator().manual_seed(47)
+    x = bf16_round(torch.randn(G, B, H, W, Cin, generator=g))
+    w = bf16_round(torch.randn(G, Cm, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    bias = torch.randn(G, Cm, generator=g) * 0.3
+    wt = [bf16_round(torch.randn(co, Cm, 3, 3, generator=g) / (Cm * 9) ** 0.5) for co in cos]
+    bt = [torch.randn(co, generator=g) * 0.2 for co in cos]
+    ref = torch.full((B, H, W, 10), float("nan"))
+    for i in range(G):
+        y = bf16_round(F.gelu(F.conv2d(x[i].permute(0, 3, 1, 2), w[i], bias[i], 1, 1)))
+        o = F.conv2d(y, wt[i], bt[i], 1, 1).permute(0, 2, 3, 1)
+        for k, ch in enumerate(chs[i]):
+            ref[..., ch] = o[..., k]
+    wt_mat = torch.zeros(G, 32, Cm)
+    omap, ob = [], []
+    for i in range(G):
+        for o in range(cos[i]):
+            for tap in range(9):
+                wt_mat[i, tap * cos[i] + o] = wt[i][o, :, tap // 3, tap % 3]
+            omap.append((i, o, cos[i], chs[i][o]))
+            ob.append(float(bt[i][o]))
+    ar = Arena()
+    o_in = ar.put(to_dev_bytes(x, L.BF16))
+    o_w = ar.put(to_dev_bytes(w.permute(0, 1, 3, 4, 2).reshape(G, Cm, 9, Cin), L.BF16))
+    o_b = ar.put(bias)
+    o_wt = ar.put(to_dev_bytes(wt_mat, L.BF16))
+    o_map = ar.put(torch.tensor(omap, dtype=torch.int32))
+    o_ob = ar.put(torch.tensor(ob))
+    o_T = ar.reserve(G * B * H * W * TW * 4)
+    o_out = ar.reserve(B * H * W * 10 * 4)
+    ar.materialize()
+    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_TOP_FUSE, act=L.ACT_GELU, in_dtype=L.BF16, out_dtype=L.BF16, w_dtype=L.BF16, B=B, H=H, W=W, Ho=H,
+                Wo=W, Cin=Cin, Cin_total=Cin, Cout=Cm, Cout_total=Cm, ksize=3, stride=1, aux0=65, aux1=TW, groups=G, in_=o_in, out=o_T, w=o_w,
+                bias=o_b, w2=o_wt), ar)
+    run_op(dict(kind=L.OP_TAPSUM, B=B, H=H, W=W, Ho=H, Wo=W, Cout_total=10, aux0=TW, aux1=len(omap), groups=G, in_=o_T, out=o_out, w=o_map,
+                bias=o_ob), ar)
+    out = ar.read(o_out, (B, H, W, 10), torch.float32)
+    used = [c for cc in chs for c in cc]
+    err = _rel(out[..., used], ref[..., used])
+    _log(f"top_fuse+tapsum {shape} rel_err {err:.3e}")
+    assert err < 1.5e-2
+    raw = ar.buf[o_out:o_out + B * H * W * 40].cpu().view(B * H * W, 40)
+    untouched = [c for c in range(10) if c not in used]
+    for c in untouched:                                  # channels not listed in the map keep the 0xCD fill
+        assert (raw[:, 4 * c:4 * c + 4] == 0xCD).all()
+
+
 @pytest.mark.parametrize("dt", [L.F32, L.BF16])
 def test_conv_border_bias_folds_preceding_batchnorm(dt):
     """conv3x3(zero_pad(x*s + t)) == conv3x3_{W*s}(zero_pad(x)) + bias_table[border case]: how the

@@ -87,7 +87,10 @@ def test_plan_structure_flops_and_arena(sd, mode):
     # nine heads x three levels of upsample+concat and conv, nine top convs: grouped launches count once per instance
     inst = [max(1, pl.ops[i].groups) for i in range(len(kinds))]
     assert sum(n for k, n in zip(kinds, inst) if k == "upcat") == 27 and kinds.count("upcat") == 3
-    assert sum(n for k, n in zip(kinds, inst) if k.startswith("conv")) == 20 + 16 + 160 + 1 + 1 + 27 + 9
+    # bf16 mode: the eight map heads' top convolutions live in the epilogue of the last FPN level (+ one TAPSUM)
+    fused_top = 8 if mode == "bf16" else 0
+    assert sum(n for k, n in zip(kinds, inst) if k.startswith("conv")) == 20 + 16 + 160 + 1 + 1 + 27 + 9 - fused_top
+    assert kinds.count("tapsum") == (1 if fused_top else 0)
     # arena: no two simultaneously-live buffers overlap
     live = {}
     ops = pl.ops

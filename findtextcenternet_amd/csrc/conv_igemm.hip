@@ -36,7 +36,7 @@ const char* conv_validate(const ftc_op& op) {
     if (op.w_dtype == FTC_F32 && (op.out_dtype != FTC_F32)) return "conv: fp32 compute needs fp32 output";
     if (op.Cin % E) return "conv: Cin must be a multiple of the 16-byte chunk";
     if (op.Cin_total % Ein || op.cin_off % E) return "conv: input channel stride/offset not 16-byte aligned";
-    if (op.cin_off + op.Cin > op.Cin_total) return "conv: input channel slice out of range";
+    if (!(op.flags & FTC_FLAG_UPCAT_IN) && op.cin_off + op.Cin > op.Cin_total) return "conv: input channel slice out of range";
     if (op.cout_off + op.Cout > op.Cout_total) return "conv: output channel slice out of range";
     const int pad = (op.ksize - 1) / 2;
     if (op.Ho != (op.H + 2 * pad - op.ksize) / op.stride + 1 || op.Wo != (op.W + 2 * pad - op.ksize) / op.stride + 1)
@@ -50,6 +50,14 @@ const char* conv_validate(const ftc_op& op) {
     if (in_bytes >= 0x7ff00000L || w_bytes >= 0x7ff00000L) return "conv: operand larger than 2 GiB (split the batch)";
     if ((op.flags & FTC_FLAG_W_PER_IMAGE) && (op.flags & (FTC_FLAG_SE_SCALE | FTC_FLAG_BORDER_BIAS))) return "conv: per-image weight sets exclude SE_SCALE / BORDER_BIAS";
     if (!wset_legal(op)) return "conv: per-image weight sets need a pixel tile that divides Ho*Wo";
+    if (op.flags & FTC_FLAG_UPCAT_IN) {
+        const int bk = halo_cpr(op) * 8;
+        if (!uses_halo(op) || halo_sn(op) != 3 || op.w_dtype != FTC_BF16 || op.in_dtype != FTC_BF16 || op.out_dtype != FTC_BF16)
+            return "conv: UPCAT_IN needs the bf16 LDS-halo kernel with 192-channel tiles (aux0 = 65)";
+        if ((op.H | op.W) & 1 || op.cin_off != 0 || op.Cin_total <= 0 || op.Cin_total >= op.Cin || op.Cin_total % bk || (op.Cin - op.Cin_total) % bk)
+            return "conv: UPCAT_IN needs even H, W and both channel parts multiples of the K block";
+        if (op.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_SE_SCALE | FTC_FLAG_W_PER_IMAGE)) return "conv: UPCAT_IN excludes RESIDUAL / SE_SCALE / W_PER_IMAGE";
+    }
     if (op.flags & FTC_FLAG_TOP_FUSE) {
         if (!uses_halo(op) || halo_sn(op) != 3 || halo_cpr(op) != 8 || op.Cout != 192 || op.Cout_total != 192 || op.cout_off != 0 ||
             op.w_dtype != FTC_BF16 || op.in_dtype != FTC_BF16 || op.out_dtype != FTC_BF16)
@@ -99,6 +107,18 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
     p.out2_gs = oslice ? 0 : (long)o.B * o.Ho * o.Wo * o.Cout_total * 2;
     p.cout_gs = oslice ? o.Cout : 0;
     p.w2 = nullptr; p.w2_gs = 0; p.Tw = 0;
+    p.in2u = nullptr; p.in2u_bytes = 0; p.in2u_gs = 0; p.Cy = 0; p.Hi = p.Wi = 0; p.ry = p.rx = 0.f;
+    if (o.flags & FTC_FLAG_UPCAT_IN) {
+        p.Cy = o.Cin_total; p.Hi = o.H / 2; p.Wi = o.W / 2;
+        p.ry = o.H > 1 ? (float)(p.Hi - 1) / (float)(o.H - 1) : 0.f;
+        p.rx = o.W > 1 ? (float)(p.Wi - 1) / (float)(o.W - 1) : 0.f;
+        p.in_bytes = (unsigned)((long)o.B * p.Hi * p.Wi * p.Cy * 2);
+        p.in_gs = (long)p.in_bytes;
+        p.in2u = a.in2;
+        p.in2u_bytes = (unsigned)((long)o.B * o.H * o.W * (o.Cin - p.Cy) * 2);
+        p.in2u_gs = (long)p.in2u_bytes;
+        p.res = nullptr;
+    }
     if (o.flags & FTC_FLAG_TOP_FUSE) {
         p.w2 = a.w2; p.w2_gs = (long)32 * o.Cout * 2; p.Tw = o.aux1;
         p.out_gs = (long)o.B * o.Ho * o.Wo * o.aux1 * 4;       // `out` holds T [G][B,Ho,Wo][aux1] fp32

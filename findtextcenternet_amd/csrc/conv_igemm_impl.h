@@ -62,6 +62,13 @@ struct ConvP {
     const void* w2;
     long w2_gs;
     int Tw;
+    // FTC_FLAG_UPCAT_IN: channels [0, Cy) of the input are the x2 bilinear upsample (align_corners) of `in`
+    // [B,Hi,Wi,Cy], computed while the halo is staged; channels [Cy, Cin) come from in2u [B,H,W,Cin-Cy]
+    const void* in2u;
+    unsigned in2u_bytes;
+    long in2u_gs;
+    int Cy, Hi, Wi;
+    float ry, rx;
 };
 
 // Turns the launch-wide parameter block into the one of the group that owns workgroup `bid`; returns the
@@ -76,6 +83,7 @@ __device__ __forceinline__ int enter_group(ConvP& p, int bid) {
     if (p.out2) p.out2 = static_cast<char*>(p.out2) + g * p.out2_gs;
     p.cout_off += g * p.cout_gs;
     if (p.w2) p.w2 = static_cast<const char*>(p.w2) + g * p.w2_gs;
+    if (p.in2u) p.in2u = static_cast<const char*>(p.in2u) + g * p.in2u_gs;
     return bid - g * p.nblk_g;
 }
 
@@ -866,8 +874,9 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
     }
 }
 
-template <typename WT, typename OutT, int CPR, int SN, bool TOPF = false>
-__global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p_launch) {
+// (second launch bound = waves per SIMD: with 64-byte rows two workgroups fit the LDS of a CU, which needs <= 128 VGPRs)
+template <typename WT, typename OutT, int CPR, int SN, bool TOPF = false, bool UPIN = false>
+__global__ __launch_bounds__(512, (CPR == 4 && !UPIN && !TOPF) ? 4 : 2) void conv3x3_halo_kernel(const ConvP p_launch) {
     ConvP p = p_launch;
     constexpr int E = 16 / (int)sizeof(WT);
     constexpr int BK = CPR * E;
@@ -879,7 +888,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p_launch)
     constexpr int NLW = (WCH + 511) / 512, NLH = (HCH + 511) / 512;          // DMA passes of the 512 threads
     constexpr int WSLOT = TN * ROWB, HBUF = NH * ROWB;
     static_assert(CPR == 8 || CPR == 4, "");
-    static_assert(NLW + NLH <= 9, "");
+    static_assert(NLW + NLH <= 9 && NLH <= 8, "");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* const wbase = smem_raw;                   // 3 weight slots
@@ -923,8 +932,15 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p_launch)
         const int hr = q / CPR, kc = (q % CPR) ^ (CPR == 8 ? (hr >> 1) & 7 : (hr >> 2) & 3);
         const int iy = ty0 - 1 + hr / HW, ix = tx0 - 1 + hr % HW;
         const bool ok = q < HCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        h_off[i] = ok ? (((img * p.H + iy) * p.W + ix) * p.CinT + p.cin_off + kc * E) * (int)sizeof(WT) : OOB;
+        if constexpr (UPIN) h_off[i] = ok ? (((img * p.H + iy) * p.W + ix) * (p.Cin - p.Cy) + kc * E) * (int)sizeof(WT) : OOB;
+        else h_off[i] = ok ? (((img * p.H + iy) * p.W + ix) * p.CinT + p.cin_off + kc * E) * (int)sizeof(WT) : OOB;
     }
+    // UPIN: the channel blocks are walked tap-source first (plain DMA, so the prologue needs no arithmetic), then the
+    // upsampled ones, each produced by the VALU during the nine taps of the block before it.
+    const int ncb_up = UPIN ? p.Cy / BK : 0;
+    const int nb_dma = p.ncb - ncb_up;
+    const __amdgpu_buffer_rsrc_t rin2 = UPIN ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in2u), 0, p.in2u_bytes, 0x00020000) : rin;
+    auto phys_cb = [&](int j) { return UPIN ? (j < nb_dma ? ncb_up + j : j - nb_dma) : j; };
     // DMA instructions THIS wave issues per weight step / halo block (the last pass may cover fewer waves)
     int nlw = 0, nlh = 0;
 #pragma unroll
@@ -934,7 +950,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p_launch)
 
     auto issue_w = [&](int k) {                              // weights of K step k -> ring slot k % 3
         const int cb = k / 9, tap = k - cb * 9;
-        const int soff = (tap * p.Cin + cb * BK) * (int)sizeof(WT);
+        const int soff = (tap * p.Cin + phys_cb(cb) * BK) * (int)sizeof(WT);
         unsigned char* slot = wbase + (k % 3) * WSLOT;
 #pragma unroll
         for (int i = 0; i < NLW; ++i) {
@@ -951,7 +967,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p_launch)
         for (int i = 0; i < NLH; ++i) {
             if (i * 512 + wave * 64 < HCH) {
                 lds_void_t* dst = (lds_void_t*)(buf + (i * 512 + wave * 64) * 16);
-                if (i * 512 + t < HCH) glds16(rin, dst, h_off[i], soff);
+                if (i * 512 + t < HCH) glds16(UPIN ? rin2 : rin, dst, h_off[i], soff);
             }
         }
     };
@@ -1017,6 +1033,68 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p_launch)
         }
     };
 
+    // ---- UPIN: one pass = one 16-byte chunk (E channels of one halo pixel) per thread: four buffer loads at the bilinear
+    // corners (issued in one K step), interpolated and written to the halo image in the next (ATen upsample_bilinear2d,
+    // align_corners=True, same expression as upcat_kernel; halo pixels outside the image are the conv's zero padding).
+    // The corner offsets and weights of a pass do not depend on the channel block: computed once per tile
+    // (halo pixels outside the image get out-of-range offsets -> zeros -> the conv's zero padding).
+    constexpr int NUP = UPIN ? NLH : 1;
+    int up_off[NUP][4];
+    float up_ly[NUP], up_lx[NUP];
+    if constexpr (UPIN) {
+#pragma unroll
+        for (int i = 0; i < NLH; ++i) {
+            const int q = i * 512 + t;
+            const int hr = q / CPR, kc = (q % CPR) ^ (CPR == 8 ? (hr >> 1) & 7 : (hr >> 2) & 3);
+            const int iy = ty0 - 1 + hr / HW, ix = tx0 - 1 + hr % HW;
+            const bool ok = q < HCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const float sy = p.ry * (float)iy, sx = p.rx * (float)ix;
+            const int y0 = ok ? (int)sy : 0, x0 = ok ? (int)sx : 0;
+            const int y1 = y0 + (y0 < p.Hi - 1 ? 1 : 0), x1 = x0 + (x0 < p.Wi - 1 ? 1 : 0);
+            up_ly[i] = sy - (float)y0;
+            up_lx[i] = sx - (float)x0;
+            const int r0 = (img * p.Hi + y0) * p.Wi, r1 = (img * p.Hi + y1) * p.Wi;
+            const int pb = p.Cy * (int)sizeof(WT), cbase = kc * E * (int)sizeof(WT);
+            up_off[i][0] = ok ? (r0 + x0) * pb + cbase : OOB;
+            up_off[i][1] = ok ? (r0 + x1) * pb + cbase : OOB;
+            up_off[i][2] = ok ? (r1 + x0) * pb + cbase : OOB;
+            up_off[i][3] = ok ? (r1 + x1) * pb + cbase : OOB;
+        }
+    }
+    u32x4 st[4] = {};
+    auto up_load = [&](int pass, int ub) {
+        const int soff = ub * BK * (int)sizeof(WT);
+#pragma unroll
+        for (int i = 0; i < NUP; ++i)
+            if (i == pass) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) st[c] = bload(rin, up_off[i][c], soff);
+            }
+    };
+    auto up_store = [&](int pass, int bufidx) {
+        static_assert(!UPIN || sizeof(WT) == 2, "in-loader upsample: bf16 only");
+        const int q = pass * 512 + t;
+        if (q >= HCH) return;
+        float ly1 = 0.f, lx1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NUP; ++i)
+            if (i == pass) { ly1 = up_ly[i]; lx1 = up_lx[i]; }
+        const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+        float v[8];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                        // bf16 pair of dword w: low half = even channel
+                const float a = __builtin_bit_cast(float, h ? (st[0][w] & 0xffff0000u) : (st[0][w] << 16));
+                const float b = __builtin_bit_cast(float, h ? (st[1][w] & 0xffff0000u) : (st[1][w] << 16));
+                const float c = __builtin_bit_cast(float, h ? (st[2][w] & 0xffff0000u) : (st[2][w] << 16));
+                const float d = __builtin_bit_cast(float, h ? (st[3][w] & 0xffff0000u) : (st[3][w] << 16));
+                v[2 * w + h] = ly0 * (lx0 * a + lx1 * b) + ly1 * (lx0 * c + lx1 * d);
+            }
+        }
+        store16<__bf16>(reinterpret_cast<__bf16*>(hbase + bufidx * HBUF + q * 16), v);
+    };
+
     const int nk = 9 * p.ncb;
     // 0x1000: timeline of wave 0 of the first 512 workgroups into p.res (tools/conv_bench.py --timeline)
     const bool tl_on = (p.flags & 0x1000) && blockIdx.x < 512 && t == 0;
@@ -1031,11 +1109,19 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p_launch)
         // weights(k) (and, at tap 0, halo(cb)) have landed once only the later-issued DMAs remain outstanding:
         // weights(k+1), and the halo prefetch issued in step k-1 when that step was a tap 0
         const int kp = k - 1;
-        const bool halo_prev = kp >= 0 && (kp % 9) == 0 && (kp / 9 + 1) < p.ncb;
+        // a halo DMA was issued in step k-1 (tap 0 of a block whose successor is DMA-sourced)
+        const bool halo_prev = kp >= 0 && (kp % 9) == 0 && (kp / 9 + 1) < (UPIN ? nb_dma : p.ncb);
         if (p.flags & 0x100) wait_vmcnt<0>(); else wait_vmcnt_n((k + 1 < nk ? nlw : 0) + (halo_prev ? nlh : 0));
         if (!(p.flags & 0x800)) wg_barrier();                        // 0x800: ablation, no barrier
         if (!(p.flags & 0x100)) {                                    // 0x100/0x200: ablation switches of tools/conv_bench.py
-            if ((k % 9) == 0 && k / 9 + 1 < p.ncb) issue_h(k / 9 + 1);   // other halo buffer: last read 9 steps ago
+            const int cbj = k / 9, tapj = k - cbj * 9, nxt = cbj + 1;
+            if (tapj == 0 && nxt < (UPIN ? nb_dma : p.ncb)) issue_h(nxt);   // other halo buffer: last read 9 steps ago
+            if constexpr (UPIN) {
+                if (nxt < p.ncb && nxt >= nb_dma) {                  // next block is upsampled: produce its halo pass by pass
+                    if (tapj >= 1 && tapj - 1 < NLH) up_store(tapj - 1, nxt & 1);    // loads of step k-1 are complete (in-order, older than weights(k+1))
+                    if (tapj < NLH) up_load(tapj, nxt - nb_dma);                     // issued BEFORE weights(k+2): the next wait covers them
+                }
+            }
             if (k + 2 < nk) issue_w(k + 2);                              // slot (k+2)%3 was read in step k-1
         }
         if (!(p.flags & 0x200)) compute(k);
@@ -1065,13 +1151,13 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(const ConvP p_launch)
     if (tl_on) tl[43] = __builtin_amdgcn_s_memtime();
 }
 
-template <typename WT, typename OutT, int CPR, int SN, bool TOPF = false>
+template <typename WT, typename OutT, int CPR, int SN, bool TOPF = false, bool UPIN = false>
 hipError_t launch_halo(ConvP p, hipStream_t s) {
     constexpr int E = 16 / (int)sizeof(WT);
     constexpr int TN = 2 * SN * 32;
     constexpr size_t lds_bytes = (size_t)3 * TN * CPR * 16 + (size_t)2 * 324 * CPR * 16;
     static_assert(!TOPF || (size_t)256 * TN * 2 + TN * 4 + 32 * TN * 2 <= lds_bytes, "image + bias + tap matrix must fit the operand buffers");
-    auto kern = conv3x3_halo_kernel<WT, OutT, CPR, SN, TOPF>;
+    auto kern = conv3x3_halo_kernel<WT, OutT, CPR, SN, TOPF, UPIN>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1273,7 +1359,13 @@ hipError_t launch_halo_dispatch(const ConvP& p, const ftc_op& o, hipStream_t s) 
     const int sn = halo_sn(o), cpr = halo_cpr(o);
     if (o.flags & FTC_FLAG_TOP_FUSE) {
         if constexpr (sizeof(WT) == 2 && sizeof(OutT) == 2) {
-            if (cpr == 8 && sn == 3) return launch_halo<WT, OutT, 8, 3, true>(p, s);
+            if (cpr == 8 && sn == 3) return (o.flags & FTC_FLAG_UPCAT_IN) ? launch_halo<WT, OutT, 8, 3, true, true>(p, s) : launch_halo<WT, OutT, 8, 3, true>(p, s);
+        }
+        return hipErrorInvalidValue;
+    }
+    if (o.flags & FTC_FLAG_UPCAT_IN) {
+        if constexpr (sizeof(WT) == 2 && sizeof(OutT) == 2) {
+            if (sn == 3) return cpr == 8 ? launch_halo<WT, OutT, 8, 3, false, true>(p, s) : launch_halo<WT, OutT, 4, 3, false, true>(p, s);
         }
         return hipErrorInvalidValue;
     }

@@ -65,7 +65,7 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         return nullptr;
     case FTC_OP_CONV: {
         if (!need(o.in, true, "in") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.bias, true, "bias")) return why->c_str();
-        if (!need(o.in2, (o.flags & FTC_FLAG_RESIDUAL) != 0, "in2") || !need(o.scale, (o.flags & FTC_FLAG_SE_SCALE) != 0, "scale")) return why->c_str();
+        if (!need(o.in2, (o.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_UPCAT_IN)) != 0, "in2") || !need(o.scale, (o.flags & FTC_FLAG_SE_SCALE) != 0, "scale")) return why->c_str();
         if (!need(o.out2, false, "out2")) return why->c_str();
         if (o.out2.base != FTC_BASE_NULL && (o.out_dtype != FTC_F32 || o.Cout % 4)) return "conv: out2 (bf16 copy) needs an fp32 primary output and Cout % 4 == 0";
         return conv_validate(o);
@@ -96,7 +96,6 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if (o.in_dtype != o.out_dtype) return "upcat: in/out dtype must match";
         if (o.groups < 0 || o.groups > 64 || o.reserved0 != 0) return "upcat: groups must be in 0..64 and reserved0 zero";
         if ((o.flags & FTC_FLAG_GROUP_IN_SLICE) && (o.groups <= 1 || o.cin_off + o.groups * o.aux0 > o.Cin_total)) return "upcat: GROUP_IN_SLICE channel slices out of range";
-        if (o.groups > 1 && o.aux0 <= 0) return "upcat: grouped launches need an upsampled part";
         return nullptr;
     case FTC_OP_TAPSUM:
         if (!need(o.in, true, "in") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.bias, true, "bias")) return why->c_str();

@@ -382,46 +382,78 @@ class _Builder:
         nmap = nh - 1                                          # the map heads (all but `feature`)
         fuse_top = dual and taps[0][1] + FPN_DIM == 256 and not os.environ.get("FTC_NO_TOPFUSE")
         TW = 20                                                # floats per pixel of the tap tensor T (9 * 2 outputs, padded)
+        fuse_up = dual and not os.environ.get("FTC_NO_UPFUSE")
         for i in range(1, ntap):
             tbuf, tc, th_, tw_, tdt = taps[ntap - 1 - i]
             cy = FPN_DIM
-            cat = ("buf", self.buf(nh * B * th_ * tw_ * (cy + tc), A))
-            self.emit(OpMeta(f"heads.cat{i}", "upcat", 0.0,
-                             nh * (B * th_ * tw_ * ((cy + tc) * self.esize(A) + tc * self.esize(tdt)) + B * yh * yw * cy * self.esize(A))),
-                      kind=L.OP_UPCAT, flags=L.FLAG_GROUP_IN_SLICE if i == 1 else 0, in_dtype=A, out_dtype=A, res_dtype=tdt, B=B,
-                      H=yh, W=yw, Ho=th_, Wo=tw_, Cin=cy + tc, Cin_total=nh * FPN_DIM if i == 1 else FPN_DIM, cin_off=0, Cout=cy + tc,
-                      aux0=cy, aux1=tc, groups=nh, in_=y, in2=tbuf, out=cat, scale=self.wref(f"heads.in_bn.{ntap - 1 - i}.scale"),
-                      shift=self.wref(f"heads.in_bn.{ntap - 1 - i}.shift"))
-            if i == ntap - 1 and fuse_top:
+            cin = cy + tc
+            M = B * th_ * tw_
+            last = i == ntap - 1
+            bn_s, bn_t = self.wref(f"heads.in_bn.{ntap - 1 - i}.scale"), self.wref(f"heads.in_bn.{ntap - 1 - i}.shift")
+            wsz = FPN_DIM * cin * 9 * self.esize(self.cdt)
+            # bf16 mode, levels whose upsampled source is a stacked tensor (2..): the concatenated input is never
+            # materialised -- the convolution upsamples while it stages its halo (FTC_FLAG_UPCAT_IN) and reads the
+            # batch-normed backbone tap (one small grouped elementwise launch) as its second channel source.
+            # (measured: with 32-channel K blocks the per-block upsampling work outweighs the saved pass -- level 2, Cin 288,
+            # keeps the two-kernel form: 1032 us fused vs 643 + 194 us)
+            up_in = fuse_up and i >= 2 and th_ == 2 * yh and tw_ == 2 * yw and cy % 64 == 0 and tc % 64 == 0
+            if up_in:
+                tapbn = ("buf", self.buf(nh * M * tc, A))
+                self.emit(OpMeta(f"heads.tapbn{i}", "upcat", 0.0, nh * M * tc * self.esize(A) + M * tc * self.esize(tdt)),
+                          kind=L.OP_UPCAT, in_dtype=A, out_dtype=A, res_dtype=tdt, B=B, H=th_, W=tw_, Ho=th_, Wo=tw_, Cin=tc, Cout=tc,
+                          aux0=0, aux1=tc, groups=nh, in2=tbuf, out=tapbn, scale=bn_s, shift=bn_t)
+                src_bytes = B * yh * yw * cy * 2 + M * tc * 2
+            else:
+                cat = ("buf", self.buf(nh * M * cin, A))
+                self.emit(OpMeta(f"heads.cat{i}", "upcat", 0.0,
+                                 nh * (M * (cin * self.esize(A) + tc * self.esize(tdt)) + B * yh * yw * cy * self.esize(A))),
+                          kind=L.OP_UPCAT, flags=L.FLAG_GROUP_IN_SLICE if i == 1 else 0, in_dtype=A, out_dtype=A, res_dtype=tdt, B=B,
+                          H=yh, W=yw, Ho=th_, Wo=tw_, Cin=cin, Cin_total=nh * FPN_DIM if i == 1 else FPN_DIM, cin_off=0, Cout=cin,
+                          aux0=cy, aux1=tc, groups=nh, in_=y, in2=tbuf, out=cat, scale=bn_s, shift=bn_t)
+                src_bytes = M * cin * 2
+
+            def level_conv(name, g0, ng, out, top):
+                """groups [g0, g0+ng) of level i; `top`: fused top convolution (out = T) instead of the 192-channel output."""
+                f = dict(kind=L.OP_CONV, act=L.ACT_GELU, in_dtype=A, out_dtype=A, w_dtype=self.cdt, B=B, H=th_, W=tw_, Ho=th_, Wo=tw_,
+                         Cin=cin, Cout=FPN_DIM, Cout_total=FPN_DIM, ksize=3, stride=1, groups=ng if ng > 1 else 0, out=out,
+                         w=("w", self.pw.table[f"heads.L{i}.w"] + g0 * wsz), bias=("w", self.pw.table[f"heads.L{i}.b"] + g0 * FPN_DIM * 4))
+                flags = 0
+                if up_in:
+                    flags |= L.FLAG_UPCAT_IN
+                    f.update(Cin_total=cy, aux0=65, in_=("buf", y[1], g0 * B * yh * yw * cy * 2), in2=("buf", tapbn[1], g0 * M * tc * 2))
+                else:
+                    f.update(Cin_total=cin, in_=("buf", cat[1], g0 * M * cin * self.esize(A)))
+                flops = 2.0 * ng * M * FPN_DIM * cin * 9
+                byt = ng * (src_bytes + FPN_DIM * cin * 9 * self.esize(self.cdt))
+                if top:
+                    flags |= L.FLAG_TOP_FUSE
+                    nout = sum(co for _, co, _ in HEADS[:-1])
+                    f.update(aux0=65, aux1=TW, w2=self.wref("heads.top8.wt"))
+                    flops += 2.0 * M * FPN_DIM * 9 * nout
+                    byt += ng * M * TW * 4
+                else:
+                    byt += ng * M * FPN_DIM * self.esize(A)
+                self.emit(OpMeta(name, "conv3x3", flops, byt), flags=flags, **f)
+
+            if last and fuse_top:
                 # Last level, bf16: the eight map heads never store their 192-channel output -- the epilogue multiplies the
                 # tile by the head's top-convolution taps and stores 20 floats per pixel; TAPSUM does the 9-point sum into
                 # the heat-map channels.  The feature head (100 output channels) keeps the two-kernel form.
-                M = B * th_ * tw_
                 T = ("buf", self.buf(nmap * M * TW, L.F32))
-                cin = cy + tc
                 nout = sum(co for _, co, _ in HEADS[:-1])
-                self.emit(OpMeta(f"heads.upsamplers.{i}+top", "conv3x3", 2.0 * nmap * M * FPN_DIM * cin * 9 + 2.0 * M * FPN_DIM * 9 * nout,
-                                 nmap * (M * cin * 2 + M * TW * 4 + FPN_DIM * cin * 9 * 2)),
-                          kind=L.OP_CONV, flags=L.FLAG_TOP_FUSE, act=L.ACT_GELU, in_dtype=A, out_dtype=A, w_dtype=self.cdt, B=B, H=th_, W=tw_,
-                          Ho=th_, Wo=tw_, Cin=cin, Cin_total=cin, Cout=FPN_DIM, Cout_total=FPN_DIM, ksize=3, stride=1, aux0=65, aux1=TW,
-                          groups=nmap, in_=cat, out=T, w=self.wref(f"heads.L{i}.w"), bias=self.wref(f"heads.L{i}.b"),
-                          w2=self.wref("heads.top8.wt"))
+                level_conv(f"heads.upsamplers.{i}+top", 0, nmap, T, True)
                 self.emit(OpMeta("heads.top8.tapsum", "tapsum", 0.0, nmap * M * TW * 4 + M * nout * 4),
                           kind=L.OP_TAPSUM, B=B, H=th_, W=tw_, Ho=th_, Wo=tw_, Cout_total=10, aux0=TW, aux1=nout, groups=nmap,
                           in_=T, out=("heatmap", 0), w=self.wref("heads.top8.map"), bias=self.wref("heads.top8.b"))
-                # feature head: its own last level + top convolution
-                fi = nh - 1
                 yf = ("buf", self.buf(M * FPN_DIM, A))
-                wsz = FPN_DIM * cin * 9 * self.esize(self.cdt)
-                self.conv(f"feature.upsamplers.{i}", ("buf", cat[1], fi * M * cin * self.esize(A)), A, th_, tw_, cin, cin, 0,
-                          f"heads.L{i}", FPN_DIM, 3, 1, L.ACT_GELU, yf, A, w_off=fi * wsz, b_off=fi * FPN_DIM * 4)
+                level_conv(f"feature.upsamplers.{i}", nh - 1, 1, yf, False)
                 self.conv("feature.top_conv", yf, A, th_, tw_, FPN_DIM, FPN_DIM, 0, "feature.top_conv", feature_dim, 3, 1, L.ACT_NONE,
                           ("features", 0), L.F32, cout_total=feature_dim, cout_off=0)
                 y = None
                 break
-            y = ("buf", self.buf(nh * B * th_ * tw_ * FPN_DIM, A))
-            self.conv(f"heads.upsamplers.{i}", cat, A, th_, tw_, cy + tc, cy + tc, 0, f"heads.L{i}", FPN_DIM, 3, 1, L.ACT_GELU, y, A,
-                      groups=nh)
+            ynew = ("buf", self.buf(nh * M * FPN_DIM, A))
+            level_conv(f"heads.upsamplers.{i}", 0, nh, ynew, False)
+            y = ynew
             yh, yw = th_, tw_
         gs = B * yh * yw * FPN_DIM * self.esize(A)            # bytes between the heads' last-level tensors
         for hi, (name, out_dim, ch0) in enumerate(HEADS if y is not None else []):

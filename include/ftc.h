@@ -106,6 +106,11 @@ enum {
                                   stored; instead T[p][0..32) = tile[p][:] . w2[0..32)[:] is computed on it and its first
                                   aux1 values per pixel go to `out` = T [groups][B,Ho,Wo][aux1] fp32 (w2 = bf16 [groups][32][Cout]);
                                   FTC_OP_TAPSUM finishes the following top convolution */
+    FTC_FLAG_UPCAT_IN = 0x20000, /* CONV 3x3 stride 1 (bf16 LDS-halo kernel, 192-channel tiles): the input is the concatenation the
+                                  reference builds with UpsamplingBilinear2d + cat (models/detector.py:192-201), formed while the
+                                  halo is staged: channels [0, Cin_total) = x2 bilinear upsample (align_corners) of `in`
+                                  [groups][B,H/2,W/2,Cin_total], channels [Cin_total, Cin) = in2 [groups][B,H,W,Cin-Cin_total];
+                                  both channel counts multiples of the kernel's K block (64, or 32 when Cin % 64 != 0) */
     FTC_FLAG_SE_FOLD = 32      /* SE: besides scale[b,c], write out2[b][n][c] = bf16(in[n][c] * scale[b,c]) for the
                                   bf16 matrix `in` [Cout_total][C] -- the following 1x1 convolution then runs with
                                   FTC_FLAG_W_PER_IMAGE on unscaled activations (both operands by DMA) */

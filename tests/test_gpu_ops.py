@@ -322,6 +322,40 @@ def test_top_fuse_epilogue_plus_tapsum_equals_two_convolutions(shape):
         assert (raw[:, 4 * c:4 * c + 4] == 0xCD).all()
 
 
+@pytest.mark.parametrize("shape", [(2, 2, 16, 24, 192, 64), (3, 1, 22, 10, 64, 32), (1, 2, 40, 36, 192, 96), (2, 1, 8, 8, 128, 256)],
+                         ids=["k64_192+64", "k32_64+32", "k32_192+96_multi_tile", "k64_128+256"])
+def test_upcat_in_conv_equals_upsample_concat_conv(shape):
+    """FTC_FLAG_UPCAT_IN: conv3x3(cat[bilinear_x2(prev), tapbn]) with the concatenation formed in the halo loader, against
+    F.interpolate(align_corners=True) + cat + conv2d in fp32 (upsampled values rounded to bf16 as the kernel's LDS image is)."""
+    G, B, H, W, Cy, Ct = shape
+    g = torch.Generator().manual_seed(53)
+    prev = bf16_round(torch.randn(G, B, H // 2, W // 2, Cy, generator=g))
+    tap = bf16_round(torch.randn(G, B, H, W, Ct, generator=g))
+    Cin, Cout = Cy + Ct, 192
+    w = bf16_round(torch.randn(G, Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    bias = torch.randn(G, Cout, generator=g) * 0.3
+    ref = []
+    for i in range(G):
+        up = bf16_round(F.interpolate(prev[i].permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True))
+        xin = torch.cat([up, tap[i].permute(0, 3, 1, 2)], 1)
+        ref.append(F.gelu(F.conv2d(xin, w[i], bias[i], 1, 1)).permute(0, 2, 3, 1))
+    ref = torch.stack(ref)
+    ar = Arena()
+    o_prev = ar.put(to_dev_bytes(prev, L.BF16))
+    o_tap = ar.put(to_dev_bytes(tap, L.BF16))
+    o_w = ar.put(to_dev_bytes(w.permute(0, 1, 3, 4, 2).reshape(G, Cout, 9, Cin), L.BF16))
+    o_b = ar.put(bias)
+    o_out = ar.reserve(G * B * H * W * Cout * 2)
+    ar.materialize()
+    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_UPCAT_IN, act=L.ACT_GELU, in_dtype=L.BF16, out_dtype=L.BF16, w_dtype=L.BF16, B=B, H=H, W=W, Ho=H,
+                Wo=W, Cin=Cin, Cin_total=Cy, Cout=Cout, Cout_total=Cout, ksize=3, stride=1, aux0=65, groups=G if G > 1 else 0,
+                in_=o_prev, in2=o_tap, out=o_out, w=o_w, bias=o_b), ar)
+    out = ar.read(o_out, (G, B, H, W, Cout), torch.bfloat16).float()
+    err = _rel(out, ref)
+    _log(f"upcat_in conv {shape} rel_err {err:.3e}")
+    assert err < 1.5e-2
+
+
 @pytest.mark.parametrize("dt", [L.F32, L.BF16])
 def test_conv_border_bias_folds_preceding_batchnorm(dt):
     """conv3x3(zero_pad(x*s + t)) == conv3x3_{W*s}(zero_pad(x)) + bias_table[border case]: how the

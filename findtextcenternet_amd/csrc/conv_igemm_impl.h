@@ -1334,6 +1334,9 @@ inline bool splitk_legal(const ftc_op& o, int kg) {
 inline int halo_sn(const ftc_op& o) { const int c = select_cfg(o); return c == CFG_192x128 ? 3 : c == CFG_128x128 ? 2 : c == CFG_64x128 ? 1 : 0; }
 inline int halo_cpr(const ftc_op& o) {
     if (o.w_dtype == FTC_F32) return o.Cin % 32 == 0 ? 8 : 0;
+    // 128-byte rows (K step 64) unless the channel count or the tuning hint (bk = 32) asks for 64-byte rows: those halve
+    // the LDS footprint, so two workgroups share a CU and one's epilogue overlaps the other's K loop
+    if (hint_bk(o) == 32 && hint_halo(o) && !(o.flags & (FTC_FLAG_TOP_FUSE | FTC_FLAG_UPCAT_IN))) return o.Cin % 32 == 0 ? 4 : 0;
     return o.Cin % 64 == 0 ? 8 : (o.Cin % 32 == 0 ? 4 : 0);
 }
 inline bool halo_legal(const ftc_op& o) {

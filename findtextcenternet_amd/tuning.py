@@ -38,7 +38,7 @@ def describe(aux0: int) -> str:
     if aux0 == 0:
         return "default"
     if aux0 & 64:
-        return f"halo,channels={CFG_NAMES[(aux0 & 15) - 1].split('x')[0]}"
+        return f"halo,channels={CFG_NAMES[(aux0 & 15) - 1].split('x')[0]}" + (",bk=32" if (aux0 >> 8) & 3 == 1 else "")
     sk = [1, 2, 4, 1][(aux0 >> 10) & 3]
     return (f"tile={CFG_NAMES[(aux0 & 15) - 1]},stage={['auto', 'reg', 'dma2', 'dma3'][(aux0 >> 4) & 3]},bk={[0, 32, 64, 128][(aux0 >> 8) & 3]}"
             + (f",splitk={sk}" if sk > 1 else ""))
@@ -87,6 +87,8 @@ def candidates(o) -> List[int]:
     if o.ksize == 3 and o.stride == 1:
         for cfg in (0, 1, 3):                             # LDS-halo kernel with 192 / 128 / 64 channel tiles
             out.append(encode(cfg, 0, 0, halo=True))
+            if o.w_dtype == L.BF16 and o.Cin % 64 == 0:   # ... and with 64-byte rows (two workgroups per CU)
+                out.append(encode(cfg, 0, 32, halo=True))
     return out
 
 
@@ -137,7 +139,8 @@ def tune_plan(engine, plan, reps: int = 5, verbose: bool = False) -> Dict[str, i
                 best, best_t = aux, t
         choices[key] = best
         if verbose:
-            print(f"{key:70s} default {base_t * 1e3:8.1f} us -> {best_t * 1e3:8.1f} us  {describe(best)}", flush=True)
+            base = f"{base_t * 1e3:8.1f}" if base_t is not None else " illegal"
+            print(f"{key:70s} default {base} us -> {best_t * 1e3:8.1f} us  {describe(best)}", flush=True)
     return choices
 
 

@@ -578,6 +578,15 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(const ConvP p_laun
         for (int j = 0; j < SM; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    // One 32x32 tile per wave means every MFMA of a K step depends on the previous one (the s_memtime timeline of the
+    // 64x64 tile showed ~775 cycles of "compute" per step for 4 MFMAs); odd K groups go to a second accumulator that is
+    // added back once, after the K loop -- two independent chains (bf16 only; changes fp32 association, not determinism).
+    constexpr bool DUAL = sizeof(WT) == 2 && SN * SM == 1;
+    f32x16 accB[DUAL ? SN : 1][DUAL ? SM : 1];
+    if constexpr (DUAL) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accB[0][0][e] = 0.0f;
+    }
 
     using FragT = typename Frag<WT>::type;
     const WT* const fA = lds + (wn * SN * 32 + l31) * ROW + half * E;
@@ -614,8 +623,10 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(const ConvP p_laun
 #pragma unroll
                 for (int i = 0; i < SN; ++i)
 #pragma unroll
-                    for (int j = 0; j < SM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < SM; ++j) {
+                        if (DUAL && (g & 1)) accB[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], accB[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    }
             }
         }
     };
@@ -643,6 +654,10 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(const ConvP p_laun
             compute(0);
             __syncthreads();
         }
+    }
+    if constexpr (DUAL) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][0][e] += accB[0][0][e];
     }
     if constexpr (KG > 1) {
         conv_epilogue_splitk<WT, OutT, SN, SM, KG, TN, TM>(p, acc, smem_raw, kg, n0, wn * SN * 32, wm * SM * 32, half, l31,
@@ -781,6 +796,15 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p_laun
         for (int j = 0; j < SM; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    // One 32x32 tile per wave means every MFMA of a K step depends on the previous one (the s_memtime timeline of the
+    // 64x64 tile showed ~775 cycles of "compute" per step for 4 MFMAs); odd K groups go to a second accumulator that is
+    // added back once, after the K loop -- two independent chains (bf16 only; changes fp32 association, not determinism).
+    constexpr bool DUAL = sizeof(WT) == 2 && SN * SM == 1;
+    f32x16 accB[DUAL ? SN : 1][DUAL ? SM : 1];
+    if constexpr (DUAL) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accB[0][0][e] = 0.0f;
+    }
 
     using FragT = typename Frag<WT>::type;
     constexpr int G = CPR / 2;                   // MFMA K groups per tile (two chunks each: lower / upper half-wave)
@@ -813,8 +837,10 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p_laun
 #pragma unroll
                 for (int i = 0; i < SN; ++i)
 #pragma unroll
-                    for (int j = 0; j < SM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < SM; ++j) {
+                        if (DUAL && (g & 1)) accB[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], accB[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    }
             }
         }
     };
@@ -834,6 +860,10 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p_laun
         iss_off = iss_off + BUFB == NBUF * BUFB ? 0 : iss_off + BUFB;
         compute(cur_off);
         cur_off = cur_off + BUFB == NBUF * BUFB ? 0 : cur_off + BUFB;
+    }
+    if constexpr (DUAL) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][0][e] += accB[0][0][e];
     }
     if (epi_lds_ok<OutT>(p)) {
         conv_epilogue_lds<WT, OutT, SN, SM, 256, TN, TM>(p, acc, smem_raw, n0, wn * SN * 32, wm * SM * 32, half, l31,

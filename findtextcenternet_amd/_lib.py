@@ -19,7 +19,8 @@ FLAG_GROUP_IN_SLICE, FLAG_GROUP_OUT_SLICE = 64, 128
 FLAG_TOP_FUSE, FLAG_UPCAT_IN = 0x10000, 0x20000
 
 EXPORTS = ["ftc_abi_version", "ftc_last_error", "ftc_device_info", "ftc_plan_create", "ftc_plan_destroy",
-           "ftc_plan_num_ops", "ftc_plan_run", "ftc_plan_profile", "ftc_op_kernel_label", "ftc_decode_scratch_bytes", "ftc_decode", "ftc_tile_gather", "ftc_paste_maps"]
+           "ftc_plan_num_ops", "ftc_plan_run", "ftc_plan_profile", "ftc_op_kernel_label", "ftc_decode_scratch_bytes", "ftc_decode", "ftc_tile_gather", "ftc_paste_maps",
+           "ftc_page_merge_scratch_bytes", "ftc_box_hists", "ftc_page_merge"]
 
 
 class FtcLibraryError(RuntimeError):
@@ -77,6 +78,10 @@ def load():
     lib.ftc_decode.argtypes = [vp, vp, i32, i32, i32, i32, vp, C.c_float, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.ftc_tile_gather.argtypes = [vp, i32, i32, vp, i32, i32, i32, vp, vp]
     lib.ftc_paste_maps.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]
+    lib.ftc_page_merge_scratch_bytes.argtypes = [i32, i32, i32]
+    lib.ftc_page_merge_scratch_bytes.restype = i64
+    lib.ftc_box_hists.argtypes = [vp, i32, vp, i32, i32, C.c_float, vp, vp]
+    lib.ftc_page_merge.argtypes = [vp, vp, i32, vp, vp, C.c_float, vp, vp, i32, i32, i32, vp, vp, vp, vp, i64, vp]
     if lib.ftc_abi_version() != FTC_ABI_VERSION:
         raise FtcLibraryError(f"ABI mismatch: library {lib.ftc_abi_version()} vs binding {FTC_ABI_VERSION}")
     _lib = lib

@@ -13,6 +13,10 @@ hipError_t launch_decode(const float* heat, const float* feat, int B, int h, int
 
 hipError_t launch_tile_gather(const unsigned char* page, int PH, int PW, const int* origins, int B, int th, int tw, float* out,
                               hipStream_t s);
+hipError_t launch_box_hists(const float* loc, int N, const float* page, int PH, int PW, float cut_off, double* out, hipStream_t s);
+hipError_t launch_greedy(const float* loc, const int* order, int N, const double* hist1, const double* th, float cut_off, double* kept,
+                         int* keep_idx, int* n_keep, unsigned int* fill_big, long fill_big_words, const float* seps, const float* codes, int mh,
+                         int mw, int scale, float* out_loc, int* out_idx, int* out_n, hipStream_t s);
 hipError_t launch_paste_maps(const float* heat, const ftc_tile* tiles, int B, int h, int w, int scale, float* canv, int ph, int pw,
                              hipStream_t s);
 
@@ -289,6 +293,43 @@ int ftc_paste_maps(const float* heatmap, const ftc_tile* tiles_dev, int B, int h
     if (B <= 0 || h <= 0 || w <= 0 || scale <= 0 || page_mh <= 0 || page_mw <= 0) return fail(FTC_ERR_INVALID, "ftc_paste_maps: bad sizes");
     hipError_t e = launch_paste_maps(heatmap, tiles_dev, B, h, w, scale, canvases, page_mh, page_mw, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(e, "ftc_paste_maps");
+    return FTC_OK;
+}
+
+int64_t ftc_page_merge_scratch_bytes(int n_boxes, int page_h, int page_w) {
+    if (n_boxes <= 0 || page_h <= 0 || page_w <= 0) return 0;
+    // kept boxes (4 float64 each) + their source rows + the kept count + a coverage bit image as large as the page
+    return (int64_t)n_boxes * 32 + (int64_t)n_boxes * 4 + 256 + ((int64_t)page_h * page_w / 32 + 64) * 4;
+}
+
+int ftc_box_hists(const float* locations, int n_boxes, const float* page, int page_h, int page_w, float cut_off, double* hist_out,
+                  void* stream) {
+    if (!locations || !page || !hist_out) return fail(FTC_ERR_INVALID, "ftc_box_hists: null pointer argument");
+    if (n_boxes <= 0 || page_h <= 0 || page_w <= 0) return fail(FTC_ERR_INVALID, "ftc_box_hists: bad sizes");
+    hipError_t e = launch_box_hists(locations, n_boxes, page, page_h, page_w, cut_off, hist_out, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "ftc_box_hists");
+    return FTC_OK;
+}
+
+int ftc_page_merge(const float* locations, const int32_t* order, int n_boxes, const double* hist1, const double* threshold_dev,
+                   float cut_off, const float* seps, const float* codes, int mh, int mw, int scale, float* out_locations,
+                   int32_t* out_index, int32_t* out_count, void* scratch, int64_t scratch_bytes, void* stream) {
+    if (!locations || !order || !hist1 || !threshold_dev || !seps || !codes || !out_locations || !out_index || !out_count || !scratch)
+        return fail(FTC_ERR_INVALID, "ftc_page_merge: null pointer argument");
+    if (n_boxes <= 0 || mh <= 0 || mw <= 0 || scale <= 0) return fail(FTC_ERR_INVALID, "ftc_page_merge: bad sizes");
+    const int64_t fixed = (int64_t)n_boxes * 32 + (int64_t)n_boxes * 4 + 256;
+    if (scratch_bytes < fixed + 256) return fail(FTC_ERR_INVALID, "ftc_page_merge: scratch smaller than ftc_page_merge_scratch_bytes");
+    char* sp = static_cast<char*>(scratch);
+    double* kept = reinterpret_cast<double*>(sp);
+    int* keep_idx = reinterpret_cast<int*>(sp + (int64_t)n_boxes * 32);
+    int* n_keep = reinterpret_cast<int*>(sp + (int64_t)n_boxes * 36);
+    const int64_t fill_off = ((int64_t)n_boxes * 36 + 256 + 255) / 256 * 256;
+    unsigned int* fill_big = reinterpret_cast<unsigned int*>(sp + fill_off);
+    const long fill_words = (long)((scratch_bytes - fill_off) / 4);
+    hipError_t e = launch_greedy(locations, order, n_boxes, hist1, threshold_dev, cut_off, kept, keep_idx, n_keep, fill_big,
+                                 fill_words > 0 ? fill_words : 0, seps, codes, mh, mw, scale, out_locations, out_index, out_count,
+                                 static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "ftc_page_merge");
     return FTC_OK;
 }
 

@@ -10,10 +10,12 @@ What runs where
   tiles (the reference runs them one by one), peak decode + feature gather (``ftc_decode``), the
   ``np.maximum`` paste of the masked sigmoid maps (``ftc_paste_maps``).  Only the decoded peaks and the
   page-sized canvases come back over PCIe -- not 16 MB of maps per tile.
-* Host (numpy, as in the reference): the page-level selection -- 2-means contrast filter, greedy
-  overlap suppression with the coverage rule, separator filter, 3x3 code maximum
-  (``process_ocr_base.py:540-648``).  It is a sequential greedy over ~10^3 boxes; SURVEY.md 8(a) row 11
-  keeps it on the host ("next" row 8f-1 is its GPU version).
+  The page-level selection -- 2-means contrast filter, greedy overlap suppression with the coverage rule,
+  separator filter, 3x3 code maximum (``process_ocr_base.py:540-648``) -- runs on the GPU
+  too (``ftc_box_hists`` + ``ftc_page_merge``: float64, sequential semantics kept, bit-identical results);
+  only the selected boxes, their feature rows and the two page canvases come back over PCIe.
+* ``page_merge`` below is the same selection on host arrays (NumPy, as the reference runs it) for callers
+  that already hold host data; ``PageDetector`` does not use it.
 """
 from __future__ import annotations
 
@@ -148,6 +150,44 @@ def page_merge(locations: np.ndarray, glyphfeatures: np.ndarray, org_img: np.nda
     return locations.astype(np.float32), glyphfeatures
 
 
+def page_merge_gpu(boxes: torch.Tensor, feats: torch.Tensor, page: torch.Tensor, canv: torch.Tensor, cut_off: float):
+    """GPU page-level selection.  boxes [N,9] fp32 (rows with p < cut_off are inert, e.g. the zero padding of
+    ``decode_peaks``), feats [N,C] fp32, page [H,W,3] fp32 0..255, canv [7,mh,mw] fp32 (``ftc_paste_maps``), all on the GPU.
+    Returns device tensors (locations [M,9] fp32, glyphfeatures [M,C] fp32); one host sync (the kept count)."""
+    lib = L.load()
+    dev = boxes.device
+    boxes = boxes.contiguous()
+    N = boxes.shape[0]
+    ph, pw = page.shape[:2]
+    mh, mw = canv.shape[1:]
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        hist = torch.empty((2, N), dtype=torch.float64, device=dev)
+        L.check(lib.ftc_box_hists(boxes.data_ptr(), N, page.data_ptr(), ph, pw, C.c_float(cut_off), hist.data_ptr(), stream), "ftc_box_hists")
+        p = boxes[:, 0]
+        mask = p >= cut_off                                   # fp32 compare == the reference's float64 compare of fp32 values
+        M = mask.sum()
+        srt = torch.sort(torch.where(mask, hist[0], torch.full_like(hist[0], float("inf")))).values
+        lo = srt[torch.clamp((M - 1) // 2, min=0)]
+        hi = srt[torch.clamp(M // 2, max=N - 1)]
+        th = torch.where(M > 0, (lo + hi) / 2 / 5, torch.full_like(lo, float("nan"))).reshape(1).contiguous()   # np.median(hists) / 5
+        order = torch.sort(p, descending=True, stable=True).indices.to(torch.int32).contiguous()   # == np.argsort(-p, kind="stable")
+        out_loc = torch.empty((N, 9), dtype=torch.float32, device=dev)
+        out_idx = torch.empty((N,), dtype=torch.int32, device=dev)
+        out_n = torch.zeros((1,), dtype=torch.int32, device=dev)
+        nbytes = int(lib.ftc_page_merge_scratch_bytes(N, ph, pw))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        codes = canv[3:7].contiguous()
+        L.check(lib.ftc_page_merge(boxes.data_ptr(), order.data_ptr(), N, hist[1].data_ptr(), th.data_ptr(), C.c_float(cut_off),
+                                   canv[2].data_ptr(), codes.data_ptr(), mh, mw, scale, out_loc.data_ptr(), out_idx.data_ptr(),
+                                   out_n.data_ptr(), scratch.data_ptr(), nbytes, stream), "ftc_page_merge")
+        n = int(out_n.item())
+        if n < 0:
+            raise RuntimeError("ftc_page_merge: a box is larger than the page-sized coverage bitmap")
+        sel = out_idx[:n].long()
+        return out_loc[:n], feats.index_select(0, sel)
+
+
 # ------------------------------------------------------------------------------------------------
 # the pipeline
 # ------------------------------------------------------------------------------------------------
@@ -209,17 +249,17 @@ class PageDetector:
                 L.check(lib.ftc_paste_maps(heat.data_ptr(), tl.data_ptr(), hi - lo, heat.shape[1], heat.shape[2], scale, canv.data_ptr(),
                                            mh, mw, C.c_void_p(stream)), "ftc_paste_maps")
                 dec = decode_peaks(heat, feat, tl, cut_off=self.cut_off, max_boxes=self.max_boxes)
-                parts.append((dec.counts.cpu().numpy(), dec.boxes, dec.feats))
-        locs, feats = [np.zeros([1, 9])], [np.zeros([1, feature_dim], np.float32)]      # the reference's dummy first row (:478-479)
-        for counts, boxes, fts in parts:
-            if (counts > self.max_boxes).any():
-                raise RuntimeError(f"a tile produced {int(counts.max())} peaks > max_boxes={self.max_boxes}; raise max_boxes")
-            for b, n in enumerate(counts):
-                locs.append(boxes[b, :n].cpu().numpy().astype(np.float64))
-                feats.append(fts[b, :n].cpu().numpy())
-        canv_h = canv.cpu().numpy()
-        locations, glyph = page_merge(np.concatenate(locs), np.concatenate(feats), org_img, canv_h[2], list(canv_h[3:7]), self.cut_off)
-        return locations, glyph, canv_h[1], canv_h[2]
+                parts.append((dec.counts, dec.boxes, dec.feats))
+            # every tile's rows in tile order; rows past a tile's count are zeros (p = 0 < cut_off): inert padding
+            counts = torch.cat([c for c, _, _ in parts])
+            boxes = torch.cat([b.reshape(-1, 9) for _, b, _ in parts])
+            fts = torch.cat([f.reshape(-1, f.shape[-1]) for _, _, f in parts])
+            page_dev = torch.from_numpy(np.ascontiguousarray(org_img, dtype=np.float32)).to(self.device)
+            loc_d, glyph_d = page_merge_gpu(boxes, fts, page_dev, canv, self.cut_off)
+            if int(counts.max().item()) > self.max_boxes:
+                raise RuntimeError(f"a tile produced {int(counts.max().item())} peaks > max_boxes={self.max_boxes}; raise max_boxes")
+            canv_h = canv[1:3].cpu().numpy()
+            return loc_d.cpu().numpy(), glyph_d.cpu().numpy(), canv_h[0], canv_h[1]
 
 
 def linedetect_request(locations: np.ndarray, lines: np.ndarray, seps: np.ndarray) -> bytes:

@@ -237,6 +237,27 @@ int ftc_tile_gather(const unsigned char* page_u8, int page_h, int page_w, const 
 int ftc_paste_maps(const float* heatmap, const ftc_tile* tiles_dev, int B, int h, int w, int scale, float* canvases, int page_mh,
                    int page_mw, void* stream);
 
+/* Page-level box selection ----------------------------------------------------
+ * Replaces the host loop of OCR_Processer.run_detector, /root/reference/process_ocr_base.py:559-650: contrast filter
+ * (imageHist :652-693), greedy suppression in score order (IoU > 0.5, intersection > 0.75 of the box, > 50 % of the box
+ * covered by kept boxes), separator filter, 3x3 maximum of the code maps.  Float64 arithmetic, bit-identical results.
+ *
+ * locations  [N,9] fp32 rows (p, cx, cy, w, h, c1, c2, c4, c8) in the reference's concatenation order (its leading all-zero row
+ *            included or not: a row with p < cut_off is inert);  page [page_h,page_w,3] fp32 0..255;
+ * ftc_box_hists   -> hist_out [2][N] float64: row 0 = the contrast of the threshold sample (:563-571), row 1 = of the crop
+ *                    tested in the loop (:579-582).  The caller takes threshold = median(row 0 over p >= cut_off) / 5.
+ * ftc_page_merge  <- order [N] int32 = stable argsort of -p;  hist1 = row 1 above;  threshold_dev = 1 float64 on the device
+ *                    (NaN = no sample: nothing is dropped, as NumPy's comparison with NaN);  seps [mh,mw], codes [4][mh,mw]
+ *                    fp32 page canvases (ftc_paste_maps rows 2 and 3..6)
+ *                 -> out_locations [<=N,9] fp32 (codes updated), out_index [<=N] int32 source rows, out_count [1] int32
+ *                    (-1: scratch too small for a box's coverage bitmap), all on the device; kept order = score order. */
+int64_t ftc_page_merge_scratch_bytes(int n_boxes, int page_h, int page_w);
+int ftc_box_hists(const float* locations, int n_boxes, const float* page, int page_h, int page_w, float cut_off, double* hist_out,
+                  void* stream);
+int ftc_page_merge(const float* locations, const int32_t* order, int n_boxes, const double* hist1, const double* threshold_dev,
+                   float cut_off, const float* seps, const float* codes, int mh, int mw, int scale, float* out_locations,
+                   int32_t* out_index, int32_t* out_count, void* scratch, int64_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,51 @@ def test_paste_maps_matches_oracle():
         assert np.abs(got[k] - canv_ref[k]).max() < 3e-7               # GPU tanhf vs numpy tanh, values in [0,1]
 
 
+@pytest.mark.parametrize("seed,n_boxes,ph,pw", [(1, 1500, 900, 1100), (2, 4000, 1228, 1228), (3, 40, 768, 768), (4, 600, 768, 1228)])
+def test_page_merge_gpu_is_bit_identical_to_the_oracle(seed, n_boxes, ph, pw):
+    """ftc_box_hists + ftc_page_merge against oracle.page_merge (itself pinned bit-exactly by the reference's run_detector) on the
+    same boxes / page / canvases: contrast filter, IoU > 0.5, intersection > 0.75, coverage > 50 %, separator filter, code maximum."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    img = synth.page_uint8(70 + seed, ph, pw).astype(np.float32)
+    mh, mw = ph // 4, pw // 4
+    # clustered boxes: glyph-like sizes, many near-duplicates and partial overlaps, some hanging over the page border
+    centres = rng.uniform([0, 0], [pw, ph], size=(max(8, n_boxes // 6), 2))
+    cx = (centres[rng.integers(0, len(centres), n_boxes), 0] + rng.normal(0, 14, n_boxes)).astype(np.float32)
+    cy = (centres[rng.integers(0, len(centres), n_boxes), 1] + rng.normal(0, 14, n_boxes)).astype(np.float32)
+    w = np.exp(rng.uniform(np.log(6), np.log(90), n_boxes)).astype(np.float32)
+    h = np.exp(rng.uniform(np.log(6), np.log(90), n_boxes)).astype(np.float32)
+    pr = rng.uniform(0.2, 1.0, n_boxes).astype(np.float32)
+    pr[rng.integers(0, n_boxes, n_boxes // 10)] = np.float32(0.75)            # score ties: stable order must decide
+    codes = rng.uniform(0, 1, (n_boxes, 4)).astype(np.float32)
+    loc32 = np.concatenate([np.zeros((1, 9), np.float32), np.stack([pr, cx, cy, w, h, *codes.T], 1)])   # the reference's leading zero row
+    feats = rng.standard_normal((n_boxes + 1, 100)).astype(np.float32)
+    seps = (rng.uniform(0, 1, (mh, mw)) ** 4).astype(np.float32)              # ~16 % of the pixels above 0.5
+    code_all = [rng.uniform(0, 1, (mh, mw)).astype(np.float32) for _ in range(4)]
+    ref_loc, ref_gf = decode_oracle.page_merge(loc32.astype(np.float64), feats.copy(), img, seps, code_all, 0.4)
+    dev = torch.device("cuda")
+    canv = torch.zeros((7, mh, mw), dtype=torch.float32, device=dev)
+    canv[2] = torch.from_numpy(seps).to(dev)
+    for k in range(4):
+        canv[3 + k] = torch.from_numpy(code_all[k]).to(dev)
+    got_loc, got_gf = page.page_merge_gpu(torch.from_numpy(loc32).to(dev), torch.from_numpy(feats).to(dev), torch.from_numpy(img).to(dev),
+                                          canv, 0.4)
+    got_loc, got_gf = got_loc.cpu().numpy(), got_gf.cpu().numpy()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/test_detector.log", "a") as f:
+        f.write(f"page_merge_gpu seed {seed}: {n_boxes} boxes -> kept gpu {len(got_loc)} oracle {len(ref_loc)}\n")
+    assert len(ref_loc) > 5 and len(ref_loc) < (loc32[:, 0] >= 0.4).sum()      # the rules both keep and drop boxes
+    assert got_loc.shape == ref_loc.shape and np.array_equal(got_loc, ref_loc)
+    assert np.array_equal(got_gf, ref_gf)
+
+
+def test_page_merge_gpu_no_boxes_and_nan_threshold():
+    dev = torch.device("cuda")
+    img = torch.full((768, 768, 3), 255.0, device=dev)
+    canv = torch.zeros((7, 192, 192), device=dev)
+    loc, gf = page.page_merge_gpu(torch.zeros((5, 9), device=dev), torch.zeros((5, 100), device=dev), img, canv, 0.4)
+    assert loc.shape == (0, 9) and gf.shape == (0, 100)
+
+
 @pytest.fixture(scope="module")
 def detector():
     m = TextDetectorModel(pre_weights=False, precision="fp32")

@@ -20,7 +20,7 @@ FLAG_TOP_FUSE, FLAG_UPCAT_IN = 0x10000, 0x20000
 
 EXPORTS = ["ftc_abi_version", "ftc_last_error", "ftc_device_info", "ftc_plan_create", "ftc_plan_destroy",
            "ftc_plan_num_ops", "ftc_plan_run", "ftc_plan_profile", "ftc_op_kernel_label", "ftc_decode_scratch_bytes", "ftc_decode", "ftc_tile_gather", "ftc_paste_maps",
-           "ftc_page_merge_scratch_bytes", "ftc_box_hists", "ftc_page_merge"]
+           "ftc_page_merge_scratch_bytes", "ftc_box_hists", "ftc_page_merge", "ftc_adamw_schedulefree_step"]
 
 
 class FtcLibraryError(RuntimeError):
@@ -40,6 +40,10 @@ class Op(C.Structure):
         "kind", "flags", "act", "in_dtype", "out_dtype", "w_dtype", "B", "H", "W", "Ho", "Wo", "Cin", "Cin_total",
         "cin_off", "Cout", "Cout_total", "cout_off", "ksize", "stride", "aux0", "aux1", "res_dtype", "groups", "reserved0")] + [
         (n, Ref) for n in ("in_", "in2", "out", "w", "w2", "bias", "bias2", "scale", "shift", "aux", "out2")]
+
+
+class MtChunk(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("g", C.c_void_p), ("v", C.c_void_p), ("z", C.c_void_p), ("n", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Tile(C.Structure):
@@ -81,6 +85,7 @@ def load():
     lib.ftc_page_merge_scratch_bytes.argtypes = [i32, i32, i32]
     lib.ftc_page_merge_scratch_bytes.restype = i64
     lib.ftc_box_hists.argtypes = [vp, i32, vp, i32, i32, C.c_float, vp, vp]
+    lib.ftc_adamw_schedulefree_step.argtypes = [vp, i32] + [C.c_float] * 8 + [i32, vp]
     lib.ftc_page_merge.argtypes = [vp, vp, i32, vp, vp, C.c_float, vp, vp, i32, i32, i32, vp, vp, vp, vp, i64, vp]
     if lib.ftc_abi_version() != FTC_ABI_VERSION:
         raise FtcLibraryError(f"ABI mismatch: library {lib.ftc_abi_version()} vs binding {FTC_ABI_VERSION}")

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libftc_hip.so")
 SOURCES = ["conv_igemm_bf16_bb.hip", "conv_igemm_bf16_fb.hip", "conv_igemm_bf16_bf.hip", "conv_igemm_bf16_ff.hip",
-           "conv_igemm_f32.hip", "conv_igemm.hip", "backbone_ops.hip", "fpn_ops.hip", "decode.hip", "page_ops.hip", "page_merge.hip", "ftc_api.hip"]
+           "conv_igemm_f32.hip", "conv_igemm.hip", "backbone_ops.hip", "fpn_ops.hip", "decode.hip", "page_ops.hip", "page_merge.hip", "optim.hip", "ftc_api.hip"]
 HEADERS = [os.path.join(CSRC, "ftc_common.h"), os.path.join(CSRC, "conv_igemm_impl.h"), os.path.join(os.path.dirname(HERE), "include", "ftc.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function"]
 

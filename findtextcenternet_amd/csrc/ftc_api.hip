@@ -13,6 +13,8 @@ hipError_t launch_decode(const float* heat, const float* feat, int B, int h, int
 
 hipError_t launch_tile_gather(const unsigned char* page, int PH, int PW, const int* origins, int B, int th, int tw, float* out,
                               hipStream_t s);
+hipError_t launch_adamw_sf(const ftc_mt_chunk* chunks, int n_chunks, float beta2, float one_minus_beta2, float bias_correction2, float eps,
+                           float decay, float ckp1, float y_alpha, float lr, int write_grad, hipStream_t s);
 hipError_t launch_box_hists(const float* loc, int N, const float* page, int PH, int PW, float cut_off, double* out, hipStream_t s);
 hipError_t launch_greedy(const float* loc, const int* order, int N, const double* hist1, const double* th, float cut_off, double* kept,
                          int* keep_idx, int* n_keep, unsigned int* fill_big, long fill_big_words, const float* seps, const float* codes, int mh,
@@ -330,6 +332,16 @@ int ftc_page_merge(const float* locations, const int32_t* order, int n_boxes, co
                                  fill_words > 0 ? fill_words : 0, seps, codes, mh, mw, scale, out_locations, out_index, out_count,
                                  static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(e, "ftc_page_merge");
+    return FTC_OK;
+}
+
+int ftc_adamw_schedulefree_step(const ftc_mt_chunk* chunks_dev, int n_chunks, float beta2, float one_minus_beta2, float bias_correction2,
+                                float eps, float weight_decay, float ckp1, float y_alpha, float lr, int write_grad, void* stream) {
+    if (!chunks_dev || n_chunks <= 0) return fail(FTC_ERR_INVALID, "ftc_adamw_schedulefree_step: empty chunk table");
+    if (!(bias_correction2 > 0.0f)) return fail(FTC_ERR_INVALID, "ftc_adamw_schedulefree_step: bias_correction2 must be positive");
+    hipError_t e = launch_adamw_sf(chunks_dev, n_chunks, beta2, one_minus_beta2, bias_correction2, eps, weight_decay, ckp1, y_alpha, lr,
+                                   write_grad, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "ftc_adamw_schedulefree_step");
     return FTC_OK;
 }
 

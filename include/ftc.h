@@ -258,6 +258,24 @@ int ftc_page_merge(const float* locations, const int32_t* order, int n_boxes, co
                    float cut_off, const float* seps, const float* codes, int mh, int mw, int scale, float* out_locations,
                    int32_t* out_index, int32_t* out_count, void* scratch, int64_t scratch_bytes, void* stream);
 
+/* Schedule-Free AdamW step as one multi-tensor kernel ------------------------------
+ * Replaces the ten torch._foreach_* passes of AdamWScheduleFree.step, /root/reference/models/adamw_schedulefree.py:157-184.
+ * chunks_dev: device array; every entry is a run of <= 4096 fp32 elements of one parameter (16-byte aligned) with its
+ * gradient, exp_avg_sq and z.  The scalars are the fp32 values the reference passes to ATen for this step
+ * (findtextcenternet_amd/optim.py computes them in float64 as the reference does):
+ *   one_minus_beta2 = 1-beta2, bias_correction2 = 1-beta2^(k+1), ckp1 = weight/weight_sum, y_alpha = lr*(beta1*(1-ckp1)-1).
+ * write_grad != 0 also stores the normalised gradient back, as the reference does in place. */
+typedef struct ftc_mt_chunk {
+    void* y;                   /* parameter (the optimizer's y iterate while training) */
+    void* g;                   /* gradient */
+    void* v;                   /* exp_avg_sq */
+    void* z;                   /* z iterate */
+    int32_t n;                 /* elements in this chunk */
+    int32_t reserved;
+} ftc_mt_chunk;
+int ftc_adamw_schedulefree_step(const ftc_mt_chunk* chunks_dev, int n_chunks, float beta2, float one_minus_beta2, float bias_correction2,
+                                float eps, float weight_decay, float ckp1, float y_alpha, float lr, int write_grad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -213,7 +213,41 @@ def gen_tf_import(model):
     print("wrote g5_tf_import_digest.json.gz", len(digest), "tensors")
 
 
+def gen_adamw():
+    """g6: the reference's own AdamWScheduleFree (models/adamw_schedulefree.py, foreach branch) on CPU: parameters after every
+    step, the final state and the eval-mode parameters, for seeded parameters / gradients (inputs regenerated from the seed by
+    the test: tests/synth.py adamw_case)."""
+    from models.adamw_schedulefree import AdamWScheduleFree as RefOpt
+    import synth
+    out = {}
+    for ci, cfg in enumerate(synth.ADAMW_CASES):
+        params0, grads = synth.adamw_case(ci)
+        ps = [torch.nn.Parameter(torch.from_numpy(a.copy())) for a in params0]
+        opt = RefOpt(ps, **cfg["kwargs"])
+        opt.train()
+        sched = []
+        for step, gs in enumerate(grads):
+            for p, g in zip(ps, gs):
+                p.grad = torch.from_numpy(g.copy())
+            opt.step()
+            grp = opt.param_groups[0]
+            sched.append([grp["scheduled_lr"], grp["lr_max"], grp["weight_sum"]])
+            for pi, p in enumerate(ps):
+                out[f"c{ci}_step{step}_p{pi}"] = p.detach().numpy().copy()
+        for pi, p in enumerate(ps):
+            out[f"c{ci}_z{pi}"] = opt.state[p]["z"].numpy().copy()
+            out[f"c{ci}_v{pi}"] = opt.state[p]["exp_avg_sq"].numpy().copy()
+        opt.eval()
+        for pi, p in enumerate(ps):
+            out[f"c{ci}_eval_p{pi}"] = p.detach().numpy().copy()
+        out[f"c{ci}_sched"] = np.asarray(sched, np.float64)
+    save("g6_adamw_schedulefree.npz", **out)
+
+
 def main():
+    if "--adamw-only" in sys.argv:
+        gen_adamw()
+        return
     torch.manual_seed(0)
     model = ref_detector.TextDetectorModel(pre_weights=False)
     gen_schema(model)
@@ -224,6 +258,7 @@ def main():
     gen_forward(det)
     gen_nms()
     gen_decode()
+    gen_adamw()
 
 
 if __name__ == "__main__":

@@ -64,3 +64,20 @@ def detector_maps(seed: int, b: int = 1, h: int = 192, w: int = 192, density: fl
             hm[bi, 6 + k] = rng.standard_normal((h, w)).astype(np.float32) * 2.0
     feat = rng.standard_normal((b, 100, h, w)).astype(np.float32) * 4.0
     return hm, feat
+
+
+# ---- Schedule-Free AdamW cases (g6): seeded parameters and per-step gradients ---------------------------------------------
+ADAMW_CASES = [
+    {"kwargs": dict(lr=0.0025, weight_decay=0.01, warmup_steps=3), "shapes": [(5000,), (37, 5), (3, 3, 3, 3), (1,)], "steps": 6},
+    {"kwargs": dict(lr=0.01, betas=(0.95, 0.99), eps=1e-6, weight_decay=0, warmup_steps=0, r=1.0, weight_lr_power=1.0),
+     "shapes": [(4097,), (8, 8)], "steps": 4},
+]
+
+
+def adamw_case(ci: int):
+    """(params0: list of fp32 arrays, grads: per step a list of fp32 arrays) of ADAMW_CASES[ci]."""
+    cfg = ADAMW_CASES[ci]
+    rng = np.random.Generator(np.random.PCG64(4000 + ci))
+    params0 = [rng.standard_normal(s).astype(np.float32) for s in cfg["shapes"]]
+    grads = [[(rng.standard_normal(s) * 10.0 ** rng.uniform(-3, 1)).astype(np.float32) for s in cfg["shapes"]] for _ in range(cfg["steps"])]
+    return params0, grads

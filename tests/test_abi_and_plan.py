@@ -197,3 +197,21 @@ def test_tf_npz_importer_matches_reference_load_weight(tmp_path):
         assert hashlib.sha1(after[key].contiguous().numpy().tobytes()).hexdigest()[:16] == d, key
     assert torch.equal(after["backbone.features.4.0.block.2.fc1.bias"], bias_before)     # SE biases are not imported (reference quirk)
     assert load_tf_efficientnetv2_npz(det, str(tmp_path / "missing.npz")) is False
+
+
+def test_adamw_schedulefree_host_schedule_matches_reference_fixture():
+    """The float64 per-step scalars of findtextcenternet_amd.optim.step_scalars against what the reference's own optimizer
+    recorded in its param_group (scheduled_lr, lr_max, weight_sum) -- tests/golden/g6_adamw_schedulefree.npz."""
+    import synth
+    from findtextcenternet_amd.optim import step_scalars
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "g6_adamw_schedulefree.npz"))
+    for ci, cfg in enumerate(synth.ADAMW_CASES):
+        kw = dict(lr=0.0025, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, warmup_steps=0, r=0.0, weight_lr_power=2.0)
+        kw.update(cfg["kwargs"])
+        group = dict(kw, k=0, weight_sum=0.0, lr_max=-1.0, scheduled_lr=0.0)
+        for step in range(cfg["steps"]):
+            sc = step_scalars(group)
+            group["k"] += 1
+            want = gold[f"c{ci}_sched"][step]
+            assert [group["scheduled_lr"], group["lr_max"], group["weight_sum"]] == list(want)
+            assert 0 < sc["bias_correction2"] <= 1 and sc["lr"] == group["scheduled_lr"]

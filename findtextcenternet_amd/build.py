@@ -13,6 +13,9 @@ SOURCES = ["conv_igemm_bf16_bb.hip", "conv_igemm_bf16_fb.hip", "conv_igemm_bf16_
            "conv_igemm_f32.hip", "conv_igemm.hip", "backbone_ops.hip", "fpn_ops.hip", "decode.hip", "page_ops.hip", "page_merge.hip", "optim.hip", "ftc_api.hip"]
 HEADERS = [os.path.join(CSRC, "ftc_common.h"), os.path.join(CSRC, "conv_igemm_impl.h"), os.path.join(os.path.dirname(HERE), "include", "ftc.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function"]
+# conv_igemm_part.hip is compiled once per (combination, part): (object name, -D flags)
+PARTS = [(f"conv_igemm_bf16_{name}_p{part}.o", [f"-DFTC_PART_FN=launch_conv_bf16_{name}_p{part}", f"-DFTC_PART_OUT={outt}", f"-DFTC_PART={part}"])
+         for name, outt in (("bb", "__bf16"), ("bf", "float")) for part in range(4)]
 
 
 def _hipcc() -> str:
@@ -38,11 +41,17 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + HEADERS):
-            jobs.append((s, o))
+            jobs.append((s, o, []))
+    part_src = os.path.join(CSRC, "conv_igemm_part.hip")
+    for obj, defs in PARTS:
+        o = os.path.join(objdir, obj)
+        if force or _stale(o, [part_src] + HEADERS):
+            jobs.append((part_src, o, defs))
+    jobs.sort(key=lambda j: 0 if "conv_igemm" in j[1] else 1)          # the long compiles first
 
     def cc(job):
-        s, o = job
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        s, o, defs = job
+        cmd = [hipcc] + FLAGS + defs + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
@@ -53,9 +62,9 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     if jobs:
         if verbose:
             print(f"[ftc build] compiling {len(jobs)} HIP source(s) for gfx950 ...", flush=True)
-        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, len(jobs))) as ex:
             list(ex.map(cc, jobs))
-    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES] + [os.path.join(objdir, obj) for obj, _ in PARTS]
     if force or jobs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -1,7 +1,17 @@
-// One (compute, input, output) type combination of the implicit-GEMM conv kernel (see conv_igemm_impl.h);
-// split per combination so the ~20 tile/BK/buffering instantiations of each compile in parallel.
+// Dispatcher of the (bf16 compute, bf16 input, float output) combination: its four parts are separate translation units
+// (conv_igemm_part.hip compiled with different -D flags, see build.py).
 #include "conv_igemm_impl.h"
 
+hipError_t launch_conv_bf16_bf_p0(const convimpl::ConvP& p, const ftc_op& o, hipStream_t s);
+hipError_t launch_conv_bf16_bf_p1(const convimpl::ConvP& p, const ftc_op& o, hipStream_t s);
+hipError_t launch_conv_bf16_bf_p2(const convimpl::ConvP& p, const ftc_op& o, hipStream_t s);
+hipError_t launch_conv_bf16_bf_p3(const convimpl::ConvP& p, const ftc_op& o, hipStream_t s);
+
 hipError_t launch_conv_bf16_bf(const convimpl::ConvP& p, const ftc_op& o, hipStream_t s) {
-    return convimpl::launch_types<__bf16, __bf16, float>(p, o, s);
+    switch (convimpl::conv_part<__bf16, __bf16>(o)) {
+    case convimpl::PART_HALO: return launch_conv_bf16_bf_p0(p, o, s);
+    case convimpl::PART_BK32: return launch_conv_bf16_bf_p1(p, o, s);
+    case convimpl::PART_BK64: return launch_conv_bf16_bf_p2(p, o, s);
+    default: return launch_conv_bf16_bf_p3(p, o, s);
+    }
 }

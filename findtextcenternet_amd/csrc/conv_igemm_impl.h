@@ -1415,20 +1415,49 @@ hipError_t launch_halo_dispatch(const ConvP& p, const ftc_op& o, hipStream_t s) 
     return hipErrorInvalidValue;
 }
 
-template <typename WT, typename InT, typename OutT>
-hipError_t launch_types(const ConvP& p, const ftc_op& o, hipStream_t s) {
+// The instantiations of one type combination fall into four independent parts (halo kernels; tiles with K step 32 / 64 / 128),
+// so that the two heavy combinations can be compiled as four translation units each (conv_igemm_part.hip).
+enum { PART_HALO = 0, PART_BK32 = 1, PART_BK64 = 2, PART_BK128 = 3 };
+
+template <typename WT, typename InT>
+int conv_part(const ftc_op& o) {
     if constexpr (sizeof(WT) == sizeof(InT)) {
-        if (uses_halo(o)) return launch_halo_dispatch<WT, OutT>(p, o, s);
+        if (uses_halo(o)) return PART_HALO;
     }
-    const int cfg = select_cfg(o);
     if constexpr (sizeof(WT) == 2) {
         const int bk = select_bk(o);
         if constexpr (sizeof(InT) == 2) {
-            if (bk == 128) return launch_tiles<WT, InT, OutT, 128>(p, cfg, s);
+            if (bk == 128) return PART_BK128;
         }
-        if (bk >= 64) return launch_tiles<WT, InT, OutT, 64>(p, cfg, s);
+        if (bk >= 64) return PART_BK64;
     }
-    return launch_tiles<WT, InT, OutT, 32>(p, cfg, s);
+    return PART_BK32;
+}
+
+template <typename WT, typename InT, typename OutT, int PART>
+hipError_t launch_part(const ConvP& p, const ftc_op& o, hipStream_t s) {
+    if constexpr (PART == PART_HALO) {
+        if constexpr (sizeof(WT) == sizeof(InT)) return launch_halo_dispatch<WT, OutT>(p, o, s);
+        else return hipErrorInvalidValue;
+    } else if constexpr (PART == PART_BK128) {
+        if constexpr (sizeof(WT) == 2 && sizeof(InT) == 2) return launch_tiles<WT, InT, OutT, 128>(p, select_cfg(o), s);
+        else return hipErrorInvalidValue;
+    } else if constexpr (PART == PART_BK64) {
+        if constexpr (sizeof(WT) == 2) return launch_tiles<WT, InT, OutT, 64>(p, select_cfg(o), s);
+        else return hipErrorInvalidValue;
+    } else {
+        return launch_tiles<WT, InT, OutT, 32>(p, select_cfg(o), s);
+    }
+}
+
+template <typename WT, typename InT, typename OutT>
+hipError_t launch_types(const ConvP& p, const ftc_op& o, hipStream_t s) {
+    switch (conv_part<WT, InT>(o)) {
+    case PART_HALO: return launch_part<WT, InT, OutT, PART_HALO>(p, o, s);
+    case PART_BK128: return launch_part<WT, InT, OutT, PART_BK128>(p, o, s);
+    case PART_BK64: return launch_part<WT, InT, OutT, PART_BK64>(p, o, s);
+    default: return launch_part<WT, InT, OutT, PART_BK32>(p, o, s);
+    }
 }
 
 }  // namespace convimpl

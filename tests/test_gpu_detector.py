@@ -213,3 +213,25 @@ def test_forward_768_bf16_speed_mode(det_bf16, golden_dir):
     _log(f"bf16 768 page: heatmap Linf {e:.3e} ({100 * e / rng:.2f}% of range {rng:.1f})  features Linf {e_ft:.3e} "
          f"({100 * e_ft / frng:.2f}% of range)  peaks ref {len(idx_ref)} bf16 {len(idx_bf)} common {inter} jaccard {jac:.3f}")
     assert e / rng < 0.05 and e_ft / frng < 0.05 and jac > 0.85
+
+
+@pytest.mark.parametrize("shape", [(3, 256, 192), (1, 320, 544), (5, 128, 128), (2, 448, 768)], ids=lambda s: "x".join(map(str, s)))
+def test_bf16_mode_tracks_fp32_mode_on_other_geometries(det_fp32, det_bf16, shape):
+    """The bf16 plan differs structurally from the fp32 one (fused top convolutions, in-loader upsample, per-image project weights,
+    grouped heads): on map sizes that are not multiples of the 16x16 pixel tiles and on odd batch sizes both must describe the same
+    network -- bf16 within its rounding noise of the fp32 (parity-mode) result, -inf NMS slots in the same places up to near-ties."""
+    B, H, W = shape
+    x = torch.from_numpy(synth.page_images(777 + H, B, H, W)).permute(0, 3, 1, 2).to("cuda")
+    with torch.no_grad():
+        h32, f32_ = det_fp32(x)
+        h16, f16 = det_bf16(x)
+    h32, f32_, h16, f16 = h32.cpu().numpy(), f32_.cpu().numpy(), h16.cpu().numpy(), f16.cpu().numpy()
+    fin = np.isfinite(h32) & np.isfinite(h16)
+    rng = float(h32[np.isfinite(h32)].max() - h32[np.isfinite(h32)].min())
+    e = float(np.abs(h32[fin] - h16[fin]).max())
+    frng = float(f32_.max() - f32_.min())
+    ef = float(np.abs(f32_ - f16).max())
+    flips = int((np.isfinite(h32[:, 1]) != np.isfinite(h16[:, 1])).sum())
+    _log(f"bf16 vs fp32 {shape}: heatmap Linf {100 * e / rng:.2f}% of range, features {100 * ef / frng:.2f}%, NMS flips {flips} of {h32[:, 1].size}")
+    assert e / rng < 0.03 and ef / frng < 0.03
+    assert flips < 0.02 * h32[:, 1].size

@@ -322,8 +322,20 @@ def test_top_fuse_epilogue_plus_tapsum_equals_two_convolutions(shape):
         assert (raw[:, 4 * c:4 * c + 4] == 0xCD).all()
 
 
-@pytest.mark.parametrize("shape", [(2, 2, 16, 24, 192, 64), (3, 1, 22, 10, 64, 32), (1, 2, 40, 36, 192, 96), (2, 1, 8, 8, 128, 256)],
-                         ids=["k64_192+64", "k32_64+32", "k32_192+96_multi_tile", "k64_128+256"])
+def _upcat_in_fuzz_shapes(n):
+    out = []
+    for seed in range(n):
+        rng = np.random.Generator(np.random.PCG64(700 + seed))
+        if rng.integers(0, 2):
+            cy, ct = int(rng.choice([64, 128, 192])), int(rng.choice([64, 128]))          # 64-channel K blocks
+        else:
+            cy, ct = int(rng.choice([64, 192])), int(rng.choice([32, 96]))                 # 32-channel K blocks
+        out.append((int(rng.integers(1, 4)), int(rng.integers(1, 3)), 2 * int(rng.integers(3, 26)), 2 * int(rng.integers(3, 26)), cy, ct))
+    return out
+
+
+@pytest.mark.parametrize("shape", [(2, 2, 16, 24, 192, 64), (3, 1, 22, 10, 64, 32), (1, 2, 40, 36, 192, 96), (2, 1, 8, 8, 128, 256)] + _upcat_in_fuzz_shapes(12),
+                         ids=lambda s: "x".join(map(str, s)))
 def test_upcat_in_conv_equals_upsample_concat_conv(shape):
     """FTC_FLAG_UPCAT_IN: conv3x3(cat[bilinear_x2(prev), tapbn]) with the concatenation formed in the halo loader, against
     F.interpolate(align_corners=True) + cat + conv2d in fp32 (upsampled values rounded to bf16 as the kernel's LDS image is)."""

@@ -62,7 +62,7 @@ const char* conv_validate(const ftc_op& op) {
         if (!uses_halo(op) || halo_sn(op) != 3 || halo_cpr(op) != 8 || op.Cout != 192 || op.Cout_total != 192 || op.cout_off != 0 ||
             op.w_dtype != FTC_BF16 || op.in_dtype != FTC_BF16 || op.out_dtype != FTC_BF16)
             return "conv: TOP_FUSE needs the bf16 LDS-halo kernel with one 192-channel tile (aux0 = 65, Cin % 64 == 0, Cout = 192)";
-        if (op.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_BORDER_BIAS | FTC_FLAG_GROUP_OUT_SLICE)) return "conv: TOP_FUSE excludes RESIDUAL / BORDER_BIAS / GROUP_OUT_SLICE";
+        if (op.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_GROUP_OUT_SLICE)) return "conv: TOP_FUSE excludes RESIDUAL / GROUP_OUT_SLICE";
         if (op.aux1 < 4 || op.aux1 > 32 || op.aux1 % 4) return "conv: TOP_FUSE output row width (aux1) must be a multiple of 4 in 4..32";
     }
     if (op.groups < 0 || op.groups > 64 || op.reserved0 != 0) return "conv: groups must be in 0..64 and reserved0 zero";
@@ -116,7 +116,7 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
         p.in_gs = (long)p.in_bytes;
         p.in2u = a.in2;
         p.in2u_bytes = (unsigned)((long)o.B * o.H * o.W * (o.Cin - p.Cy) * 2);
-        p.in2u_gs = (long)p.in2u_bytes;
+        p.in2u_gs = (o.flags & FTC_FLAG_GROUP_IN2_SHARED) ? 0 : (long)p.in2u_bytes;
         p.res = nullptr;
     }
     if (o.flags & FTC_FLAG_TOP_FUSE) {

@@ -83,7 +83,7 @@ __device__ __forceinline__ int enter_group(ConvP& p, int bid) {
     if (p.out2) p.out2 = static_cast<char*>(p.out2) + g * p.out2_gs;
     p.cout_off += g * p.cout_gs;
     if (p.w2) p.w2 = static_cast<const char*>(p.w2) + g * p.w2_gs;
-    if (p.in2u) p.in2u = static_cast<const char*>(p.in2u) + g * p.in2u_gs;
+    if (p.in2u) p.in2u = static_cast<const char*>(p.in2u) + g * p.in2u_gs;      // (stride 0: one tensor shared by the groups)
     return bid - g * p.nblk_g;
 }
 
@@ -330,9 +330,10 @@ __device__ __forceinline__ void conv_epilogue_topfuse(const ConvP& p, f32x16 (&a
     constexpr int CH = TN / 8;                              // 16-byte chunks per row
     static_assert(PITCH % 128 == 0 && TM == 32 * (NTHREADS / 64), "one 32-pixel MFMA column block per wave");
     __syncthreads();
+    const int nrows = (p.flags & FTC_FLAG_BORDER_BIAS) ? 16 : 1;   // 16 border cases when a BatchNorm of the input is folded in
     float* lbias = reinterpret_cast<float*>(smem + TM * PITCH);
-    unsigned char* lwt = smem + TM * PITCH + TN * 4;        // tap matrix [32][TN] bf16, same swizzle as the image
-    for (int c = threadIdx.x; c < TN / 4; c += NTHREADS)
+    unsigned char* lwt = smem + TM * PITCH + 16 * TN * 4;   // tap matrix [32][TN] bf16, same swizzle as the image
+    for (int c = threadIdx.x; c < nrows * (TN / 4); c += NTHREADS)
         *reinterpret_cast<f32x4*>(lbias + 4 * c) = *reinterpret_cast<const f32x4*>(p.bias + 4 * c);
     for (int c = threadIdx.x; c < 32 * CH; c += NTHREADS) {
         const int r = c / CH, cc = c - r * CH;
@@ -344,13 +345,22 @@ __device__ __forceinline__ void conv_epilogue_topfuse(const ConvP& p, f32x16 (&a
     for (int j = 0; j < SM; ++j) {
         const int prow = pw0 + j * 32 + l31;
         unsigned char* lrow = smem + prow * PITCH;
+        const float* brow = lbias;
+        if (p.flags & FTC_FLAG_BORDER_BIAS) {
+            const int m = row_to_m(prow);
+            if (m >= 0) {
+                const int rem = m % (p.Ho * p.Wo);
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                brow += ((oy == 0 ? 1 : 0) | (oy == p.Ho - 1 ? 2 : 0) | (ox == 0 ? 4 : 0) | (ox == p.Wo - 1 ? 8 : 0)) * TN;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < SN; ++i) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int nl = nw0 + i * 32 + 8 * q + 4 * half;
                 f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                v += *reinterpret_cast<const f32x4*>(lbias + nl);
+                v += *reinterpret_cast<const f32x4*>(brow + nl);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = apply_act_sel<true>(v[e], p.act);
                 const int chunk = (nl / 8) ^ (prow & 7);
@@ -1186,7 +1196,7 @@ hipError_t launch_halo(ConvP p, hipStream_t s) {
     constexpr int E = 16 / (int)sizeof(WT);
     constexpr int TN = 2 * SN * 32;
     constexpr size_t lds_bytes = (size_t)3 * TN * CPR * 16 + (size_t)2 * 324 * CPR * 16;
-    static_assert(!TOPF || (size_t)256 * TN * 2 + TN * 4 + 32 * TN * 2 <= lds_bytes, "image + bias + tap matrix must fit the operand buffers");
+    static_assert(!TOPF || (size_t)256 * TN * 2 + 16 * TN * 4 + 32 * TN * 2 <= lds_bytes, "image + bias rows + tap matrix must fit the operand buffers");
     auto kern = conv3x3_halo_kernel<WT, OutT, CPR, SN, TOPF, UPIN>;
     static bool attr_set = false;
     if (!attr_set) {

@@ -176,6 +176,31 @@ def pack_weights(sd: Dict[str, torch.Tensor], mode: str = "fp32", model_size: st
         bl.add(f"heads.L{i}.w", _to_compute(np.stack([_kmajor(w) for w, _ in wb]), mode))
         bl.add(f"heads.L{i}.b", np.stack([b for _, b in wb]).astype(np.float32))
 
+    if mode == "bf16" and ntap >= 2:
+        # Last level with the input BatchNorm of the backbone tap folded in exactly (as level 0 above): scale into the tap
+        # columns of the weights, shift into a 16-case border bias table -- so the convolution reads the shared bf16 trunk
+        # copy of the tap instead of nine batch-normed copies (FTC_FLAG_GROUP_IN2_SHARED + FTC_FLAG_BORDER_BIAS).
+        i = ntap - 1
+        ws, bs = [], []
+        for name, _, _ in HEADS:
+            q = f"{name}.in_bn.0"
+            g = sd[q + ".weight"].detach().cpu().double().numpy()
+            si = g / np.sqrt(sd[q + ".running_var"].detach().cpu().double().numpy() + HEAD_BN_EPS)
+            ti = sd[q + ".bias"].detach().cpu().double().numpy() - sd[q + ".running_mean"].detach().cpu().double().numpy() * si
+            wf, bo = _fold(sd, f"{name}.upsamplers.{i}.0.weight", f"{name}.upsamplers.{i}.1", HEAD_BN_EPS)      # [192, 192+tc, 3, 3]
+            wm = wf.copy()
+            wm[:, FPN_DIM:] *= si[None, :, None, None]
+            tmap = np.einsum("ncrs,c->nrs", wf[:, FPN_DIM:], ti)
+            b16 = np.zeros((16, wf.shape[0]))
+            for idx in range(16):
+                rows = [r for r in range(3) if not (r == 0 and idx & 1) and not (r == 2 and idx & 2)]
+                cols = [c for c in range(3) if not (c == 0 and idx & 4) and not (c == 2 and idx & 8)]
+                b16[idx] = bo + tmap[np.ix_(range(wf.shape[0]), rows, cols)].sum(axis=(1, 2))
+            ws.append(_kmajor(wm))
+            bs.append(b16)
+        bl.add(f"heads.L{i}f.w", _to_compute(np.stack(ws), mode))
+        bl.add(f"heads.L{i}f.b", np.stack(bs).astype(np.float32))                               # [9][16][192]
+
     def top(name):
         w = sd[f"{name}.top_conv.0.weight"].detach().cpu().double().numpy()
         return _kmajor(w), sd[f"{name}.top_conv.0.bias"].detach().cpu().float().numpy()
@@ -317,6 +342,7 @@ class _Builder:
                   B=B, H=H, W=W, Ho=h, Wo=w, Cin=3, Cout=c0, ksize=3, stride=2, in_=("input", 0), out=x, out2=xb,
                   w=self.wref("stem.w"), bias=self.wref("stem.b"))
         taps = []
+        tap_copies = []                           # bf16 trunk copies of the backbone taps (bf16 mode), same order
         for si, stage in enumerate(stages):
             for blk in stage:
                 p = blk.prefix + ".block"
@@ -362,6 +388,7 @@ class _Builder:
                 x, xb, h, w = y, yb, ho, wo
             if (si + 1) in (2, 3, 5):
                 taps.append((x, stage[-1].cout, h, w, T))
+                tap_copies.append(xb)
         nfeat = len(stages) + 1
         hp = f"backbone.features.{nfeat}"
         x4 = ("buf", self.buf(B * h * w * LAST_CHANNEL, A))
@@ -397,7 +424,14 @@ class _Builder:
             # (measured: with 32-channel K blocks the per-block upsampling work outweighs the saved pass -- level 2, Cin 288,
             # keeps the two-kernel form: 1032 us fused vs 643 + 194 us)
             up_in = fuse_up and i >= 2 and th_ == 2 * yh and tw_ == 2 * yw and cy % 64 == 0 and tc % 64 == 0
-            if up_in:
+            # ... and on the last level the tap's BatchNorm is folded into the weights + a border bias table, so that all heads read
+            # the ONE bf16 trunk copy of the tap (no batch-normed copies at all)
+            tap_copy = tap_copies[ntap - 1 - i] if ntap - 1 - i < len(tap_copies) else None
+            bn_fold = up_in and last and tap_copy is not None and f"heads.L{i}f.w" in self.pw.table and not os.environ.get("FTC_NO_BNFOLD")
+            if bn_fold:
+                tapbn = tap_copy
+                src_bytes = B * yh * yw * cy * 2 + M * tc * 2 // nh
+            elif up_in:
                 tapbn = ("buf", self.buf(nh * M * tc, A))
                 self.emit(OpMeta(f"heads.tapbn{i}", "upcat", 0.0, nh * M * tc * self.esize(A) + M * tc * self.esize(tdt)),
                           kind=L.OP_UPCAT, in_dtype=A, out_dtype=A, res_dtype=tdt, B=B, H=th_, W=tw_, Ho=th_, Wo=tw_, Cin=tc, Cout=tc,
@@ -414,11 +448,16 @@ class _Builder:
 
             def level_conv(name, g0, ng, out, top):
                 """groups [g0, g0+ng) of level i; `top`: fused top convolution (out = T) instead of the 192-channel output."""
+                wname = f"heads.L{i}f" if bn_fold else f"heads.L{i}"
+                brows = 16 if bn_fold else 1
                 f = dict(kind=L.OP_CONV, act=L.ACT_GELU, in_dtype=A, out_dtype=A, w_dtype=self.cdt, B=B, H=th_, W=tw_, Ho=th_, Wo=tw_,
                          Cin=cin, Cout=FPN_DIM, Cout_total=FPN_DIM, ksize=3, stride=1, groups=ng if ng > 1 else 0, out=out,
-                         w=("w", self.pw.table[f"heads.L{i}.w"] + g0 * wsz), bias=("w", self.pw.table[f"heads.L{i}.b"] + g0 * FPN_DIM * 4))
+                         w=("w", self.pw.table[wname + ".w"] + g0 * wsz), bias=("w", self.pw.table[wname + ".b"] + g0 * brows * FPN_DIM * 4))
                 flags = 0
-                if up_in:
+                if bn_fold:
+                    flags |= L.FLAG_UPCAT_IN | L.FLAG_BORDER_BIAS | L.FLAG_GROUP_IN2_SHARED
+                    f.update(Cin_total=cy, aux0=65, in_=("buf", y[1], g0 * B * yh * yw * cy * 2), in2=tapbn)
+                elif up_in:
                     flags |= L.FLAG_UPCAT_IN
                     f.update(Cin_total=cy, aux0=65, in_=("buf", y[1], g0 * B * yh * yw * cy * 2), in2=("buf", tapbn[1], g0 * M * tc * 2))
                 else:

@@ -111,6 +111,8 @@ enum {
                                   halo is staged: channels [0, Cin_total) = x2 bilinear upsample (align_corners) of `in`
                                   [groups][B,H/2,W/2,Cin_total], channels [Cin_total, Cin) = in2 [groups][B,H,W,Cin-Cin_total];
                                   both channel counts multiples of the kernel's K block (64, or 32 when Cin % 64 != 0) */
+    FTC_FLAG_GROUP_IN2_SHARED = 0x200000, /* CONV + UPCAT_IN with groups > 1: in2 is ONE tensor [B,H,W,Cin-Cin_total] read by every group
+                                  (the backbone tap; its per-head BatchNorm folded into the weights and a BORDER_BIAS table) */
     FTC_FLAG_SE_FOLD = 32      /* SE: besides scale[b,c], write out2[b][n][c] = bf16(in[n][c] * scale[b,c]) for the
                                   bf16 matrix `in` [Cout_total][C] -- the following 1x1 convolution then runs with
                                   FTC_FLAG_W_PER_IMAGE on unscaled activations (both operands by DMA) */

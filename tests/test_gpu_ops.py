@@ -368,6 +368,81 @@ def test_upcat_in_conv_equals_upsample_concat_conv(shape):
     assert err < 1.5e-2
 
 
+@pytest.mark.parametrize("top", [False, True], ids=["plain", "top_fuse"])
+def test_upcat_in_with_tap_batchnorm_folded_and_shared_tap(top):
+    """Last FPN level as the bf16 plan runs it: the nine heads read ONE backbone tap (FTC_FLAG_GROUP_IN2_SHARED); each head's input
+    BatchNorm of the tap is folded into its weights and a 16-case border bias table (FTC_FLAG_BORDER_BIAS) -- against
+    conv3x3(cat[upsample(prev_g), BN_g(tap)]) + GELU (then the 3x3 top convolution for the TOP_FUSE variant) in fp32."""
+    G, B, H, W, Cy, Ct, Cm = 3, 2, 22, 36, 192, 64, 192
+    g = torch.Generator().manual_seed(67)
+    prev = bf16_round(torch.randn(G, B, H // 2, W // 2, Cy, generator=g))
+    tap = bf16_round(torch.randn(B, H, W, Ct, generator=g))
+    si, ti = torch.rand(G, Ct, generator=g) + 0.5, torch.randn(G, Ct, generator=g) * 0.5
+    Cin = Cy + Ct
+    w = torch.randn(G, Cm, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bo = torch.randn(G, Cm, generator=g) * 0.3
+    wt = bf16_round(torch.randn(G, 1, Cm, 3, 3, generator=g) / (Cm * 9) ** 0.5)
+    bt = torch.randn(G, 1, generator=g) * 0.2
+    wm = w.clone()
+    wm[:, :, Cy:] *= si[:, None, :, None, None]
+    wm = bf16_round(wm)
+    b16 = torch.zeros(G, 16, Cm, dtype=torch.float64)
+    for i in range(G):
+        tmap = torch.einsum("ncrs,c->nrs", w[i, :, Cy:].double(), ti[i].double())
+        for idx in range(16):
+            rows = [r for r in range(3) if not (r == 0 and idx & 1) and not (r == 2 and idx & 2)]
+            cols = [c for c in range(3) if not (c == 0 and idx & 4) and not (c == 2 and idx & 8)]
+            b16[i, idx] = bo[i].double() + tmap[:, rows][:, :, cols].sum((1, 2))
+    # reference: the folded bf16 weights applied to (upsample, tap) plus what the shift contributes through the in-image taps
+    ys = []
+    for i in range(G):
+        up = bf16_round(F.interpolate(prev[i].permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True))
+        xin = torch.cat([up, tap.permute(0, 3, 1, 2)], 1)
+        shift = F.conv2d(torch.ones(B, Ct, H, W) * ti[i][None, :, None, None], w[i, :, Cy:], None, 1, 1)      # zero padded: border aware
+        ys.append(F.gelu(F.conv2d(xin, wm[i], None, 1, 1) + shift + bo[i][None, :, None, None]))
+    ar = Arena()
+    o_prev = ar.put(to_dev_bytes(prev, L.BF16))
+    o_tap = ar.put(to_dev_bytes(tap, L.BF16))
+    o_w = ar.put(to_dev_bytes(wm.permute(0, 1, 3, 4, 2).reshape(G, Cm, 9, Cin), L.BF16))
+    o_b = ar.put(b16.float())
+    flags = L.FLAG_UPCAT_IN | L.FLAG_BORDER_BIAS | L.FLAG_GROUP_IN2_SHARED
+    if not top:
+        o_out = ar.reserve(G * B * H * W * Cm * 2)
+        ar.materialize()
+        run_op(dict(kind=L.OP_CONV, flags=flags, act=L.ACT_GELU, in_dtype=L.BF16, out_dtype=L.BF16, w_dtype=L.BF16, B=B, H=H, W=W, Ho=H, Wo=W,
+                    Cin=Cin, Cin_total=Cy, Cout=Cm, Cout_total=Cm, ksize=3, stride=1, aux0=65, groups=G, in_=o_prev, in2=o_tap, out=o_out,
+                    w=o_w, bias=o_b), ar)
+        out = ar.read(o_out, (G, B, H, W, Cm), torch.bfloat16).float()
+        ref = torch.stack([y.permute(0, 2, 3, 1) for y in ys])
+    else:
+        TW = 12
+        wt_mat = torch.zeros(G, 32, Cm)
+        for i in range(G):
+            for tp in range(9):
+                wt_mat[i, tp] = wt[i, 0, :, tp // 3, tp % 3]
+        o_wt = ar.put(to_dev_bytes(wt_mat, L.BF16))
+        o_map = ar.put(torch.tensor([(i, 0, 1, i) for i in range(G)], dtype=torch.int32))
+        o_ob = ar.put(bt[:, 0].contiguous())
+        o_T = ar.reserve(G * B * H * W * TW * 4)
+        o_out = ar.reserve(B * H * W * G * 4)
+        ar.materialize()
+        run_op(dict(kind=L.OP_CONV, flags=flags | L.FLAG_TOP_FUSE, act=L.ACT_GELU, in_dtype=L.BF16, out_dtype=L.BF16, w_dtype=L.BF16, B=B, H=H,
+                    W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cy, Cout=Cm, Cout_total=Cm, ksize=3, stride=1, aux0=65, aux1=TW, groups=G,
+                    in_=o_prev, in2=o_tap, out=o_T, w=o_w, bias=o_b, w2=o_wt), ar)
+        run_op(dict(kind=L.OP_TAPSUM, B=B, H=H, W=W, Ho=H, Wo=W, Cout_total=G, aux0=TW, aux1=G, groups=G, in_=o_T, out=o_out, w=o_map,
+                    bias=o_ob), ar)
+        out = ar.read(o_out, (B, H, W, G), torch.float32)
+        ref = torch.stack([F.conv2d(bf16_round(ys[i]), wt[i], bt[i], 1, 1)[:, 0] for i in range(G)], -1)
+    err = _rel(out, ref)
+    _log(f"upcat_in + folded tap BN (top={top}) rel_err {err:.3e}")
+    assert err < 1.5e-2
+    # the image border is where a wrong border-bias case would show: same bound on the outermost ring alone
+    ring = torch.ones(H, W, dtype=torch.bool)
+    ring[1:-1, 1:-1] = False
+    sel = (lambda a: a[:, :, ring]) if not top else (lambda a: a[:, ring])
+    assert float((sel(out) - sel(ref)).abs().max()) < 1.5e-2 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("dt", [L.F32, L.BF16])
 def test_conv_border_bias_folds_preceding_batchnorm(dt):
     """conv3x3(zero_pad(x*s + t)) == conv3x3_{W*s}(zero_pad(x)) + bias_table[border case]: how the

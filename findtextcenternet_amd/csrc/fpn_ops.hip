@@ -92,27 +92,44 @@ __global__ __launch_bounds__(256) void nms_kernel(float* __restrict__ heat, int 
 }
 
 // 9-point sum that finishes a top convolution whose per-pixel taps T were produced by the FTC_FLAG_TOP_FUSE epilogue.
-// One lane = one (pixel, output); the nine 4-byte reads of a lane hit the rows of the neighbouring pixels, which its
-// neighbours in the wave read too (L1/L2 absorb the 9x reuse; T is read from HBM once).
+// Workgroup = a 16x16 pixel tile of one image; for each head in turn the 18x18 halo of its tap rows is staged in LDS with
+// coalesced 16-byte loads (T is read once, sequentially), then lane = pixel adds the nine taps of the head's outputs.
 __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ T, const int* __restrict__ map, const float* __restrict__ bias,
-                                                     float* __restrict__ out, int B, int H, int W, int Tw, int nout, int CH, long gs) {
-    const long total = (long)B * H * W * nout;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int j = (int)(idx % nout);
-        const long pix = idx / nout;
-        const int x = (int)(pix % W), y = (int)((pix / W) % H);
-        const int g = map[4 * j], o = map[4 * j + 1], co = map[4 * j + 2], ch = map[4 * j + 3];
-        const float* Tg = T + g * gs + o;
-        float acc = bias[j];
+                                                     float* __restrict__ out, int H, int W, int Tw, int nout, int CH, long gs, int G) {
+    extern __shared__ __attribute__((aligned(16))) float rows[];          // [18*18][Tw]
+    const int t = threadIdx.x;
+    const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
+    int bid = blockIdx.x;
+    const int b = bid / (tilesX * tilesY);
+    bid -= b * tilesX * tilesY;
+    const int y0 = (bid / tilesX) * 16, x0 = (bid % tilesX) * 16;
+    const int ly = t >> 4, lx = t & 15;
+    const int y = y0 + ly, x = x0 + lx;
+    const bool inside = y < H && x < W;
+    const long pix = ((long)b * H + y) * W + x;
+    const int Q = Tw >> 2;                                                // float4 per pixel row
+    for (int g = 0; g < G; ++g) {
+        __syncthreads();                                                  // previous head's rows are consumed
+        const f32x4* Tg = reinterpret_cast<const f32x4*>(T + g * gs + (long)b * H * W * Tw);
+        for (int c = t; c < 324 * Q; c += 256) {
+            const int hp = c / Q, q = c - hp * Q;
+            const int yy = y0 - 1 + hp / 18, xx = x0 - 1 + hp % 18;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};                               // zero padding of the top convolution
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = Tg[((long)yy * W + xx) * Q + q];
+            reinterpret_cast<f32x4*>(rows)[c] = v;
+        }
+        __syncthreads();
+        if (!inside) continue;
+        for (int j = 0; j < nout; ++j) {
+            if (map[4 * j] != g) continue;
+            const int o = map[4 * j + 1], co = map[4 * j + 2], ch = map[4 * j + 3];
+            float acc = bias[j];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int s2 = 0; s2 < 3; ++s2) {
-                const int yy = y + r - 1, xx = x + s2 - 1;
-                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-                    acc += Tg[(pix + (long)(r - 1) * W + (s2 - 1)) * Tw + (r * 3 + s2) * co];
-            }
-        out[pix * CH + ch] = acc;
+                for (int s2 = 0; s2 < 3; ++s2) acc += rows[((ly + r) * 18 + lx + s2) * Tw + (r * 3 + s2) * co + o];
+            out[pix * CH + ch] = acc;
+        }
     }
 }
 
@@ -120,11 +137,9 @@ __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ T
 
 hipError_t launch_tapsum(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
-    const long total = (long)o.B * o.H * o.W * o.aux1;
-    long nb = (total + 255) / 256;
-    if (nb > 65536) nb = 65536;
-    hipLaunchKernelGGL(tapsum_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float*)a.in, (const int*)a.w, a.bias, (float*)a.out, o.B, o.H,
-                       o.W, o.aux0, o.aux1, o.Cout_total, (long)o.B * o.H * o.W * o.aux0);
+    const int nb = o.B * ((o.H + 15) / 16) * ((o.W + 15) / 16);
+    hipLaunchKernelGGL(tapsum_kernel, dim3(nb), dim3(256), (size_t)324 * o.aux0 * sizeof(float), s, (const float*)a.in, (const int*)a.w, a.bias,
+                       (float*)a.out, o.H, o.W, o.aux0, o.aux1, o.Cout_total, (long)o.B * o.H * o.W * o.aux0, o.groups > 1 ? o.groups : 1);
     return hipGetLastError();
 }
 

@@ -105,7 +105,7 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         return nullptr;
     case FTC_OP_TAPSUM:
         if (!need(o.in, true, "in") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.bias, true, "bias")) return why->c_str();
-        if (o.aux0 < 4 || o.aux0 % 4 || o.aux1 < 1 || o.aux1 > 64 || o.Cout_total < 1 || o.groups < 1) return "tapsum: bad aux0 / aux1 / Cout_total / groups";
+        if (o.aux0 < 4 || o.aux0 > 32 || o.aux0 % 4 || o.aux1 < 1 || o.aux1 > 64 || o.Cout_total < 1 || o.groups < 1) return "tapsum: bad aux0 / aux1 / Cout_total / groups";
         return nullptr;
     case FTC_OP_NMS:
         if (!need(o.out, true, "out")) return why->c_str();

@@ -100,6 +100,7 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if (o.aux0 % (o.in_dtype == FTC_F32 ? 4 : 8) || o.aux1 % (o.in_dtype == FTC_F32 ? 4 : 8) || o.aux1 <= 0) return "upcat: channel counts must be multiples of one 16-byte access (4 fp32 / 8 bf16)";
         if (o.aux0 > 0 && o.Cin_total > 0 && (o.Cin_total % 4 || o.cin_off % 4 || o.cin_off + o.aux0 > o.Cin_total)) return "upcat: bad channel slice of the upsampled tensor";
         if (o.in_dtype != o.out_dtype) return "upcat: in/out dtype must match";
+        if ((long)o.B * o.Ho * o.Wo * (o.aux0 + o.aux1) / 4 >= 0x7fffffffL) return "upcat: more than 2^31 output chunks per group";
         if (o.groups < 0 || o.groups > 64 || o.reserved0 != 0) return "upcat: groups must be in 0..64 and reserved0 zero";
         if ((o.flags & FTC_FLAG_GROUP_IN_SLICE) && (o.groups <= 1 || o.cin_off + o.groups * o.aux0 > o.Cin_total)) return "upcat: GROUP_IN_SLICE channel slices out of range";
         return nullptr;

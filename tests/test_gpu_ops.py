@@ -499,11 +499,12 @@ def test_conv_dual_output_bf16_copy():
     assert torch.equal(out2, out.to(torch.bfloat16))            # the copy is the RNE rounding of the fp32 value
 
 
+@pytest.mark.parametrize("C0", [32, 24, 12])
 @pytest.mark.parametrize("odt", [L.F32, L.BF16])
 @pytest.mark.parametrize("nchw", [False, True])
-def test_stem(nchw, odt):
+def test_stem(nchw, odt, C0):
     g = torch.Generator().manual_seed(3)
-    B, H, W, C0 = 2, 64, 96, 32
+    B, H, W = 2, 64, 94
     x = torch.rand(B, H, W, 3, generator=g)
     w = torch.randn(C0, 3, 3, 3, generator=g) * 0.3
     bias = torch.randn(C0, generator=g) * 0.2

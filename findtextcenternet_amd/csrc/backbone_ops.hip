@@ -20,13 +20,14 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
     for (int i = threadIdx.x; i < 27 * C0; i += blockDim.x) sw[i] = w[i];
     __syncthreads();
     const int CQ = C0 >> 2;
-    const long total = (long)B * Ho * Wo * CQ;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int cq = (int)(idx % CQ);
-        const long pix = idx / CQ;
-        const int ox = (int)(pix % Wo);
-        const int oy = (int)((pix / Wo) % Ho);
-        const int b = (int)(pix / ((long)Wo * Ho));
+    const unsigned total = (unsigned)B * Ho * Wo * CQ;          // 32-bit index arithmetic (validated)
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const unsigned pix = idx / (unsigned)CQ;
+        const int cq = (int)(idx - pix * CQ);
+        const unsigned row = pix / (unsigned)Wo;
+        const int ox = (int)(pix - row * Wo);
+        const int b = (int)(row / (unsigned)Ho);
+        const int oy = (int)(row - (unsigned)b * Ho);
         f32x4 acc = *reinterpret_cast<const f32x4*>(bias + cq * 4);
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -48,8 +49,8 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = act_silu_precise(acc[e]);
-        store4<OutT>(out + pix * C0 + cq * 4, acc);
-        if (out2) store4<__bf16>(out2 + pix * C0 + cq * 4, acc);
+        store4<OutT>(out + (long)pix * C0 + cq * 4, acc);
+        if (out2) store4<__bf16>(out2 + (long)pix * C0 + cq * 4, acc);
     }
 }
 

@@ -65,6 +65,7 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
     case FTC_OP_STEM:
         if (!need(o.in, true, "in") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.bias, true, "bias")) return why->c_str();
         if (o.Cout % 4 || o.Cout > 256) return "stem: Cout must be a multiple of 4 (<= 256)";
+        if ((long)o.B * o.Ho * o.Wo * (o.Cout / 4) >= 0x7fffffffL) return "stem: more than 2^31 output quads";
         if (!need(o.out2, false, "out2")) return why->c_str();
         if (o.out2.base != FTC_BASE_NULL && o.out_dtype != FTC_F32) return "stem: out2 (bf16 copy) needs an fp32 primary output";
         if (o.Ho != (o.H - 1) / 2 + 1 || o.Wo != (o.W - 1) / 2 + 1) return "stem: Ho/Wo inconsistent";

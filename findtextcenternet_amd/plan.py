@@ -101,6 +101,9 @@ TOP6 = ("textline", "sepatator", "code1", "code2", "code4", "code8")      # head
 def pack_weights(sd: Dict[str, torch.Tensor], mode: str = "fp32", model_size: str = "xl") -> PackedWeights:
     """sd: ``CenterNetDetection`` state_dict (keys without the ``detector.`` prefix)."""
     assert mode in ("fp32", "bf16")
+    bmode = os.environ.get("FTC_EXP_BACKBONE", mode)      # experiment switches: numeric mode of the backbone / of the heads
+    hmode = os.environ.get("FTC_EXP_HEADS", mode)
+    mode = bmode
     if any(k.startswith("detector.") for k in sd):
         sd = {k[len("detector."):]: v for k, v in sd.items() if k.startswith("detector.")}
     bl = _Blob()
@@ -136,6 +139,7 @@ def pack_weights(sd: Dict[str, torch.Tensor], mode: str = "fp32", model_size: st
     nfeat = len(STAGES[model_size]) + 1
     hp = f"backbone.features.{nfeat}"
     conv_bn(hp, hp + ".0.weight", hp + ".1", BACKBONE_BN_EPS)
+    mode = hmode
     ntap = len(TAP_DIMS[model_size])
     # FPN level 0 of all nine heads as ONE convolution over the shared 1/32 tap: each head's input
     # BatchNorm is folded in exactly -- scale into the weights, shift into a 16-entry border-case bias
@@ -226,7 +230,9 @@ def pack_weights(sd: Dict[str, torch.Tensor], mode: str = "fp32", model_size: st
         bl.add("heads.top8.wt", _to_compute(wt, mode))
         bl.add("heads.top8.b", np.asarray(bias, np.float32))
         bl.add("heads.top8.map", np.asarray(omap, np.int32))
-    return PackedWeights(bl.finish(), bl.table, mode, model_size)
+    pw = PackedWeights(bl.finish(), bl.table, bmode, model_size)
+    pw.hmode = hmode
+    return pw
 
 
 # ------------------------------------------------------------------------------------------------
@@ -391,9 +397,20 @@ class _Builder:
                 tap_copies.append(xb)
         nfeat = len(stages) + 1
         hp = f"backbone.features.{nfeat}"
-        x4 = ("buf", self.buf(B * h * w * LAST_CHANNEL, A))
-        self.conv(hp, xb if dual else x, G, h, w, stages[-1][-1].cout, stages[-1][-1].cout, 0, hp, LAST_CHANNEL, 1, 1, L.ACT_SILU, x4, A)
-        taps.append((x4, LAST_CHANNEL, h, w, A))
+        hmode = getattr(self.pw, "hmode", self.mode)
+        if hmode != self.mode:                    # experiment: heads in the other numeric mode
+            x4dt = L.F32
+        else:
+            x4dt = A
+        x4 = ("buf", self.buf(B * h * w * LAST_CHANNEL, x4dt))
+        self.conv(hp, xb if dual else x, G, h, w, stages[-1][-1].cout, stages[-1][-1].cout, 0, hp, LAST_CHANNEL, 1, 1, L.ACT_SILU, x4, x4dt)
+        taps.append((x4, LAST_CHANNEL, h, w, x4dt))
+        if hmode != self.mode:
+            self.mode = hmode
+            A = self.act = L.F32 if hmode == "fp32" else L.BF16
+            self.cdt = A
+            dual = False
+            tap_copies = []
         mh, mw = taps[0][2], taps[0][3]
         # heads.  Level 0 of all nine heads is one convolution (see pack_weights); levels 1.. per head.
         ntap = len(taps)

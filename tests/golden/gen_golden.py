@@ -92,6 +92,76 @@ def gen_forward(det):
     save("g2_fwd768_page.npz", heatmap=hm, feat_pos=pos, feat_at=ft[0].reshape(100, -1)[:, pos], seed=np.array(4242))
 
 
+def _nms_keep(k):
+    """keep mask of CenterNetDetector.forward (models/detector.py:291-296) for key maps k[..., h, w] (numpy, any float dtype)."""
+    h, w = k.shape[-2:]
+    pad = np.pad(k, [(0, 0)] * (k.ndim - 2) + [(1, 1), (1, 1)], constant_values=-np.inf)
+    win = np.stack([pad[..., dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)]).max(0)
+    return ~(k < win)
+
+
+def gen_instability(det, tag, xt):
+    """Which keep/suppress and above/below-cut decisions of the REFERENCE are decided by its own fp32 rounding?
+
+    Runs the reference's detector on the fixture input (a) in fp32 with 1, 2, 4 and 8 CPU threads (oneDNN picks other
+    blockings and reduction orders) and (b) in float64 (`det.double()`: same code, rounding error ~1e-13).  Writes
+      nms_unstable  [B,h,w] bool: the NMS decision differs among those five runs, or the float64 key logit is within `noise`
+                    of the float64 maximum of its 8 neighbours (noise = 2 x the largest |fp32 - float64| difference measured on
+                    the key map over all fp32 runs -- the reference's own rounding envelope);
+      cut_unstable  [B,h,w] bool: the float64 key logit is within `noise` of a cut-off logit(0.4) or logit(0.35)
+                    (test_image1_torch.py:124-126, process_ocr_base.py:41), or the >= decision differs among the runs.
+    A GPU fp32 result may differ from the fp32 golden only inside these masks (tests/test_gpu_detector.py).
+    """
+    keys = []
+    nthr0 = torch.get_num_threads()
+    for n in (1, 2, 4, 8):
+        torch.set_num_threads(n)
+        with torch.no_grad():
+            hm, _ = det(xt.float())
+        keys.append(hm[:, 0].numpy().copy())
+    torch.set_num_threads(nthr0)
+    det64 = ref_detector.CenterNetDetector(det.detector).double()
+    det64.eval()
+    with torch.no_grad():
+        hm64, _ = det64(xt.double())
+    det.float()                                   # .double() converted the shared parameters in place
+    k64 = hm64[:, 0].numpy()
+    noise = 2.0 * max(float(np.abs(k.astype(np.float64) - k64).max()) for k in keys)
+    h, w = k64.shape[-2:]
+    pad = np.pad(k64, [(0, 0), (1, 1), (1, 1)], constant_values=-np.inf)
+    nb = np.stack([pad[:, dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3) if (dy, dx) != (1, 1)]).max(0)
+    keeps = [_nms_keep(k) for k in keys] + [_nms_keep(k64)]
+    nms_unstable = np.abs(k64 - nb) <= noise
+    for kp in keeps[1:]:
+        nms_unstable |= kp != keeps[0]
+    cuts = [float(np.log(0.4 / 0.6)), float(np.log(0.35 / 0.65))]
+    cut_unstable = np.zeros_like(nms_unstable)
+    for c in cuts:
+        cut_unstable |= np.abs(k64 - c) <= noise
+        for k in keys[1:]:
+            cut_unstable |= (k >= np.float32(c)) != (keys[0] >= np.float32(c))
+    flips = int(sum((kp != keeps[0]).sum() for kp in keeps[1:]))
+    print(f"{tag}: fp32-vs-float64 noise {noise / 2:.2e}, NMS-unstable px {int(nms_unstable.sum())} of {nms_unstable.size} "
+          f"(decision flips among the reference's own runs: {flips}), cut-unstable px {int(cut_unstable.sum())}")
+    save(f"g2_{tag}_unstable.npz", nms_unstable=np.packbits(nms_unstable), cut_unstable=np.packbits(cut_unstable),
+         shape=np.array(nms_unstable.shape), noise=np.array(noise), threads=np.array([1, 2, 4, 8]),
+         key_float64_minus_fp32_max=np.array(noise / 2),
+         # float64 run, stored as fp32: the key logits and their distance to the best of the 8 neighbours, so that a
+         # test can widen the envelope by the error IT measures (an implementation that is e away from the golden can
+         # only flip decisions whose float64 margin is below noise + 2e)
+         key64=k64.astype(np.float32), margin64=np.abs(k64 - nb).astype(np.float32))
+
+
+def gen_instability_all(det):
+    """Reference-side decision-stability masks for the three forward fixtures (see gen_instability)."""
+    x = np.concatenate([synth.noise_images(1234, 1, 128, 128), synth.page_images(77, 1, 128, 128)])
+    gen_instability(det, "fwd128", torch.from_numpy(x).permute(0, 3, 1, 2))
+    from PIL import Image
+    im0 = np.asarray(Image.open(os.path.join(HERE, "test1_padded.png")).convert("RGB")).astype(np.float32)
+    gen_instability(det, "fwd768_test1", torch.from_numpy(im0[None] / 255.).permute(0, 3, 1, 2))
+    gen_instability(det, "fwd768_page", torch.from_numpy(synth.page_images(4242, 1, 768, 768)).permute(0, 3, 1, 2))
+
+
 def gen_nms():
     # G4: NMS on a hand-made map with ties, plateaus, -inf and borders, through the reference's
     # CenterNetDetector.forward (models/detector.py:289-296) with a stub detector.
@@ -250,12 +320,17 @@ def main():
         return
     torch.manual_seed(0)
     model = ref_detector.TextDetectorModel(pre_weights=False)
-    gen_schema(model)
-    gen_tf_import(model)
+    if "--instability-only" not in sys.argv:
+        gen_schema(model)
+        gen_tf_import(model)
     model.load_state_dict(deterministic_state_dict(SEED_W))
     det = ref_detector.CenterNetDetector(model.detector)
     det.eval()
+    if "--instability-only" in sys.argv:
+        gen_instability_all(det)
+        return
     gen_forward(det)
+    gen_instability_all(det)
     gen_nms()
     gen_decode()
     gen_adamw()

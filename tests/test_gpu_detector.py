@@ -53,36 +53,56 @@ def det_bf16(sd):
     return d
 
 
-def _nms_margin(hm_ref, b, y, x):
-    """|key - best other neighbour| in the reference map: how close the keep/suppress call was."""
-    k = hm_ref[b, 0]
-    h, w = k.shape
-    win = [k[yy, xx] for yy in range(max(0, y - 1), min(h, y + 2)) for xx in range(max(0, x - 1), min(w, x + 2)) if (yy, xx) != (y, x)]
-    return abs(float(k[y, x]) - max(win))
+def _load_unstable(golden_dir, tag):
+    """Reference-side decision-stability data written by tests/golden/gen_golden.py::gen_instability: which keep/suppress and
+    above/below-cut decisions the REFERENCE itself takes differently between its fp32 runs at 1/2/4/8 threads and its float64
+    run, plus the float64 key map and 3x3 margins."""
+    u = np.load(os.path.join(golden_dir, f"g2_{tag}_unstable.npz"))
+    shape = tuple(int(v) for v in u["shape"])
+    n = int(np.prod(shape))
+    return {"nms": np.unpackbits(u["nms_unstable"])[:n].reshape(shape).astype(bool),
+            "cut": np.unpackbits(u["cut_unstable"])[:n].reshape(shape).astype(bool),
+            "noise": float(u["noise"]), "key64": u["key64"], "margin64": u["margin64"]}
 
 
-def _compare_maps(tag, hm, ft, g_hm, g_ft=None, tol=TOL):
-    """L-inf on finite entries < tol; the -inf (suppressed) pattern of the NMS channel must be
-    identical wherever the reference's own keep/suppress call had a margin above MARGIN = 1e-4
-    (20x the fp32 summation-order noise we measure, 10x below tol): in flat background regions
-    (white page padding) neighbouring key logits differ by ~1e-6, so which of them "wins" the 3x3
-    window is decided by the last fp32 bit in the reference itself (3e-5
-    between 4 and 8 CPU threads)."""
-    MARGIN = 1e-4
+def _oracle_unstable(o_hm):
+    """Same envelope for inputs that have no reference-written fixture: margins from the CPU oracle's map, noise = the bound to
+    which tests/test_oracle.py pins the oracle against the reference's goldens (1e-4)."""
+    k = o_hm[:, 0].astype(np.float64)
+    h, w = k.shape[-2:]
+    pad = np.pad(k, [(0, 0), (1, 1), (1, 1)], constant_values=-np.inf)
+    nb = np.stack([pad[:, dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3) if (dy, dx) != (1, 1)]).max(0)
+    z = np.zeros(k.shape, bool)
+    return {"nms": z, "cut": z, "noise": 1e-4, "key64": k.astype(np.float32), "margin64": np.abs(k - nb).astype(np.float32)}
+
+
+def _compare_maps(tag, hm, ft, g_hm, g_ft=None, tol=TOL, unstable=None):
+    """L-inf on finite entries < tol.  The -inf (suppressed) pattern of the NMS channel must be IDENTICAL to the reference's
+    outside the reference-derived instability mask: pixels whose keep/suppress decision the reference itself takes differently
+    among its own fp32 (1/2/4/8 threads) and float64 runs, or whose float64 margin to the best neighbour is within the
+    reference's fp32 rounding envelope widened by twice the key-map error measured HERE (a result that is e away from the
+    golden can only flip decisions whose exact margin is below noise + 2e).  Without a mask (oracle-generated cases) no flip
+    is allowed at all."""
     fin_ref, fin = np.isfinite(g_hm), np.isfinite(hm)
     both = fin & fin_ref
     e_hm = float(np.abs(hm[both] - g_hm[both]).max())
-    mism = np.argwhere(fin != fin_ref)
-    assert (mism[:, 1] == 1).all() if len(mism) else True          # only the NMS channel can hold -inf
-    margins = np.array([_nms_margin(g_hm, b, y, x) for b, c, y, x in mism])
-    above = sum(1 for b, c, y, x in mism if g_hm[b, 0, y, x] > np.log(0.4 / 0.6))
+    e_key = float(np.abs(hm[:, 0] - g_hm[:, 0]).max())
+    mism = fin != fin_ref
+    assert not mism[:, [0] + list(range(2, 10))].any()              # only the NMS channel can hold -inf
+    flips = mism[:, 1]
     e_ft = float(np.abs(ft - g_ft).max()) if g_ft is not None else None
-    _log(f"{tag}: heatmap Linf {e_hm:.3e}  features Linf {e_ft}  NMS-mask flips {len(mism)} of {int(fin_ref[:, 1].size)} px "
-         f"(max ref margin {margins.max() if len(mism) else 0:.1e}, {above} of them above the 0.4 cut-off)  "
+    if unstable is not None:
+        allowed = unstable["nms"] | (unstable["margin64"] <= unstable["noise"] + 2 * e_key)
+        n_allowed = int(allowed.sum())
+    else:
+        allowed, n_allowed = np.zeros_like(flips), 0
+    outside = int((flips & ~allowed).sum())
+    _log(f"{tag}: heatmap Linf {e_hm:.3e} (key {e_key:.2e})  features Linf {e_ft}  NMS-mask flips {int(flips.sum())} of "
+         f"{flips.size} px, {outside} outside the reference-derived instability mask ({n_allowed} px)  "
          f"hm range [{g_hm[fin_ref].min():.2f},{g_hm[fin_ref].max():.2f}]")
     assert e_hm < tol
-    assert len(mism) == 0 or margins.max() < MARGIN
-    return e_hm
+    assert outside == 0
+    return e_hm, e_key
 
 
 def test_forward_128_fp32_golden(det_fp32, golden_dir):
@@ -93,7 +113,7 @@ def test_forward_128_fp32_golden(det_fp32, golden_dir):
         hm, ft = det_fp32(xt)
     assert hm.shape == (2, 10, 32, 32) and ft.shape == (2, 100, 32, 32) and hm.dtype == torch.float32
     hm, ft = hm.cpu().numpy(), ft.cpu().numpy()
-    _compare_maps("g1 128x128 fp32", hm, ft, g["heatmap"], g["features"])
+    _compare_maps("g1 128x128 fp32", hm, ft, g["heatmap"], g["features"], unstable=_load_unstable(golden_dir, "fwd128"))
     assert float(np.abs(ft - g["features"]).max()) < TOL
 
 
@@ -114,7 +134,8 @@ def test_forward_768_fp32_golden_and_decode(det_fp32, golden_dir, name):
             h_, f_ = det_fp32(torch.from_numpy(synth.page_images(4242, 1, 768, 768)).permute(0, 3, 1, 2).to("cuda"))
         hm, ft = h_.cpu().numpy(), f_.cpu().numpy()
     assert hm.shape == (1, 10, 192, 192) and ft.shape == (1, 100, 192, 192)
-    _compare_maps(f"g2 768 {name} fp32", hm, None, g["heatmap"])
+    un = _load_unstable(golden_dir, f"fwd768_{name}")
+    _, e_key = _compare_maps(f"g2 768 {name} fp32", hm, None, g["heatmap"], unstable=un)
     e_ft = float(np.abs(ft[0].reshape(100, -1)[:, g["feat_pos"]] - g["feat_at"]).max())
     _log(f"g2 768 {name}: features@1024 Linf {e_ft:.3e}")
     assert e_ft < TOL
@@ -128,19 +149,18 @@ def test_forward_768_fp32_golden_and_decode(det_fp32, golden_dir, name):
     # oracle on the golden heat-map (features are not needed for the index set)
     loc, _, idx_ref = decode_oracle.decode_tile(g["heatmap"], np.zeros((1, 100, 192, 192), np.float32), 0, 0, 768, 768, 0.4, rect)
     only_gpu, only_ref = set(idx_gpu) - set(idx_ref), set(idx_ref) - set(idx_gpu)
-    _log(f"g2 768 {name}: peaks gpu {n} ref {len(idx_ref)} only_gpu {len(only_gpu)} only_ref {len(only_ref)}")
-    # a difference is tolerated only where the reference's own decision was an fp32 tie: score within
-    # 2*TOL of the cut-off, or 3x3 keep/suppress margin below 1e-4 (test1.png is mostly white padding:
-    # its flat background sits above the cut-off with random weights and neighbouring logits differ
-    # by ~1e-6, so the reference's own peak list there depends on its thread count)
-    hard = []
-    for i in only_gpu | only_ref:
-        y, x = divmod(int(i), 192)
-        near_cut = abs(float(g["heatmap"][0, 0, y, x]) - np.log(0.4 / 0.6)) < 2 * TOL
-        if not (near_cut or _nms_margin(g["heatmap"], 0, y, x) < 1e-4):
-            hard.append((y, x))
-    _log(f"g2 768 {name}: differing peaks that are NOT reference-side ties: {len(hard)}")
+    # A peak may differ from the reference's list only where the reference's OWN decision is unstable (see _load_unstable):
+    # its NMS call (plateaus along the white padding of test1.png: the reference flips 1136 of those decisions between its own
+    # thread counts) or its comparison with the cut-off, each envelope widened by twice the error measured in this run.
+    allowed = (un["nms"] | (un["margin64"] <= un["noise"] + 2 * e_key) | un["cut"]
+               | (np.abs(un["key64"] - np.float32(np.log(0.4 / 0.6))) <= un["noise"] + 2 * e_key))[0].reshape(-1)
+    hard = sorted(int(i) for i in only_gpu | only_ref if not allowed[int(i)])
+    n_ref_stable = sum(1 for i in idx_ref if not allowed[int(i)])
+    _log(f"g2 768 {name}: peaks gpu {n} ref {len(idx_ref)} only_gpu {len(only_gpu)} only_ref {len(only_ref)}; outside the "
+         f"reference-derived instability mask: {len(hard)} differ, {n_ref_stable} reference peaks are stable and all found")
     assert not hard and n > 20
+    # bounded inside the mask as well: no more differing peaks than unstable pixels above the cut-off
+    assert len(only_gpu | only_ref) <= int((allowed & (un["key64"][0].reshape(-1) > np.log(0.4 / 0.6) - 1e-3)).sum())
     if name == "page":
         assert not only_gpu and not only_ref                           # realistic page: index set bit-exact
 
@@ -153,7 +173,8 @@ def test_matches_oracle_on_fresh_input(det_fp32, sd):
     o_hm, o_ft = detector_oracle.detector_forward(sd, xt)
     with torch.no_grad():
         hm, ft = det_fp32(xt.to("cuda"))
-    _compare_maps("oracle 256x192 B3 fp32", hm.cpu().numpy(), ft.cpu().numpy(), o_hm.numpy(), o_ft.numpy())
+    _compare_maps("oracle 256x192 B3 fp32", hm.cpu().numpy(), ft.cpu().numpy(), o_hm.numpy(), o_ft.numpy(),
+                  unstable=_oracle_unstable(o_hm.numpy()))
     assert float((ft.cpu() - o_ft).abs().max()) < TOL
 
 

@@ -8,47 +8,171 @@
 
 A step = one pass over one batch of 8 synthetic 768x768x3 tiles per GPU (BASELINE.json configs[1],
 "batch=8 synthetic 768x768x3, full EffNetV2-XL detector fwd on 1xMI355X bf16"); inputs are resident
-in HBM before the timed region; weak scaling (per-GPU batch fixed).  Rank 0 prints ONE JSON line.
+in HBM before the timed region and every output buffer is allocated before it; weak scaling (per-GPU batch fixed).
+Rank 0 prints ONE JSON line.  `value` = images of all ranks / wall time of the K timed steps (barrier + synchronize on both
+sides, max over ranks); `ms_per_step_median` is the median of the per-step HIP-event times on the launch stream.
+
+Besides the headline (bf16 speed mode) the same line carries
+  parity      -- L-inf / peak-set agreement of image 0 of the timed batch against the CPU oracle, for the timed bf16 model AND
+                 for the fp32 parity mode (whose own images/s is reported there: the two are different programs);
+  roofline    -- the kernel with the largest share of the forward, HIP-event timed inside this run;
+  cpu_baseline-- the CPU oracle ("port") on this host: thread sweep, batch 1 and 8, forward+NMS and +decode.
+`--dry-run` exercises the whole N-rank control flow (sharding, decode records, gather, JSON) on CPU tensors under gloo
+without touching the HIP library: it is what tests/test_bench_dryrun.py runs with world size 2.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+GFLOP_PER_IMAGE = 865.0006                 # SURVEY.md 8(d); reproduced by the library's own op list (tests/test_abi_and_plan.py)
 
 
-def cpu_baseline(sd, seconds_budget: float = 25.0):
-    """The CPU oracle (restatement of the reference path, kind "port") timed on this host's cores:
-    forward + NMS + host decode of single 768x768 tiles, batch 1 as every reference caller does."""
-    import synth
+def source_hash() -> str:
+    """Hash of everything that decides which kernels run (kernel sources + tuning table): a PMC traffic profile is only
+    quoted when it was taken from the same sources."""
+    h = hashlib.sha1()
+    base = os.path.join(ROOT, "findtextcenternet_amd")
+    files = sorted(os.listdir(os.path.join(base, "csrc")))
+    for f in files:
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(base, "csrc", f), "rb").read())
+    h.update(open(os.path.join(base, "tuning_gfx950.json"), "rb").read())
+    return h.hexdigest()[:12]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1 only): the oracle = pure-torch/numpy restatement of the reference path, kind "port"
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(sd, budget_s: float):
+    """fp32, no_grad, thread count chosen by a sweep, batch 1 and batch 8, forward+NMS and
+    forward+NMS+host decode separately, same seeded inputs as the GPU run.  Returns (record, oracle maps of image 0)."""
+    from findtextcenternet_amd import synth
     from oracle import decode_oracle, detector_oracle
-    x = torch.from_numpy(synth.noise_images(1234, 1, 768, 768)).permute(0, 3, 1, 2)
+    ncpu = os.cpu_count() or 1
+    x8 = torch.from_numpy(synth.noise_images(1234, 8, 768, 768)).permute(0, 3, 1, 2)
+    x1 = x8[:1]
     rect = decode_oracle.tile_keep_rect(0, 0, 768, 768, 0.6)
-    detector_oracle.detector_forward(sd, x)                       # warm-up (thread pools, allocations)
-    n, t0 = 0, time.perf_counter()
-    while True:
+    nthr0 = torch.get_num_threads()
+    t_start = time.perf_counter()
+
+    def fwd(x):
+        t0 = time.perf_counter()
         hm, ft = detector_oracle.detector_forward(sd, x)
-        decode_oracle.decode_tile(hm.numpy(), ft.numpy(), 0, 0, 768, 768, 0.4, rect)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 12:
+        return time.perf_counter() - t0, hm, ft
+
+    def dec(hm, ft):
+        t0 = time.perf_counter()
+        for b in range(hm.shape[0]):
+            decode_oracle.decode_tile(hm[b:b + 1].numpy(), ft[b:b + 1].numpy(), 0, 0, 768, 768, 0.4, rect)
+        return time.perf_counter() - t0
+
+    fwd(x1)                                                    # warm-up (thread pools, allocations, oneDNN primitives)
+    sweep = {}
+    for n in [t for t in (8, 16, 32, 64, 128, 256) if t <= ncpu] or [ncpu]:
+        torch.set_num_threads(n)
+        fwd(x1)
+        sweep[n] = min(fwd(x1)[0] for _ in range(2))
+        if time.perf_counter() - t_start > 0.5 * budget_s:
             break
-    return {"value": round(n / el, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} x (1 tile 768x768, fp32 torch-CPU oracle forward+NMS + numpy decode), {el:.1f} s"}
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    t1, d1 = [], []
+    hm0 = ft0 = None
+    for _ in range(5):
+        t, hm, ft = fwd(x1)
+        t1.append(t)
+        d1.append(dec(hm, ft))
+        hm0, ft0 = hm, ft
+        if time.perf_counter() - t_start > 0.8 * budget_s and len(t1) >= 3:
+            break
+    t8, hm8, ft8 = fwd(x8)
+    d8 = dec(hm8, ft8)
+    torch.set_num_threads(nthr0)
+    m1, md1 = statistics.median(t1), statistics.median(d1)
+    rec = {"value": round(1.0 / (m1 + md1), 4), "unit": "images/s", "cores": best, "kind": "port",
+           "sample": (f"CPU oracle (torch fp32 forward+NMS, numpy decode), 768x768 noise tiles, {best} of {ncpu} host threads chosen by "
+                      f"sweep; batch 1: median of {len(t1)} after warm-up; batch 8: 1 pass; {time.perf_counter() - t_start:.0f} s total"),
+           "threads_sweep_images_per_s_b1_fwd_nms": {str(k): round(1.0 / v, 4) for k, v in sweep.items()},
+           "b1_fwd_nms_images_per_s": round(1.0 / m1, 4), "b1_fwd_nms_decode_images_per_s": round(1.0 / (m1 + md1), 4),
+           "b8_fwd_nms_images_per_s": round(8.0 / t8, 4), "b8_fwd_nms_decode_images_per_s": round(8.0 / (t8 + d8), 4)}
+    return rec, hm0.numpy(), ft0.numpy()
+
+
+def parity_record(heat_nhwc, feat_nhwc, o_hm, o_ft):
+    """Image 0 of the GPU batch against the oracle's maps of the same image."""
+    from oracle import decode_oracle
+    hm = heat_nhwc[:1].permute(0, 3, 1, 2).cpu().numpy()
+    ft = feat_nhwc[:1].permute(0, 3, 1, 2).cpu().numpy()
+    fin = np.isfinite(o_hm)
+    both = fin & np.isfinite(hm)
+    rect = decode_oracle.tile_keep_rect(0, 0, 768, 768, 0.6)
+    z = np.zeros((1, 100, hm.shape[2], hm.shape[3]), np.float32)
+    _, _, ir = decode_oracle.decode_tile(o_hm, z, 0, 0, 768, 768, 0.4, rect)
+    _, _, ig = decode_oracle.decode_tile(hm, z, 0, 0, 768, 768, 0.4, rect)
+    sr, sg = set(int(i) for i in ir), set(int(i) for i in ig)
+    return {"heatmap_linf": float(f"{np.abs(hm[both] - o_hm[both]).max():.3e}"), "features_linf": float(f"{np.abs(ft - o_ft).max():.3e}"),
+            "heatmap_range": round(float(o_hm[fin].max() - o_hm[fin].min()), 2),
+            "nms_mask_flips": int((np.isfinite(hm[:, 1]) != fin[:, 1]).sum()), "peaks_ref": len(sr), "peaks_gpu": len(sg),
+            "peaks_common": len(sr & sg), "peak_jaccard": round(len(sr & sg) / max(1, len(sr | sg)), 4), "peak_set_identical": sr == sg}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def dry_run(args, rank, world):
+    """The N-rank control flow on CPU tensors (gloo): shard, build decode-shaped records, gather, reduce the time, print the
+    JSON line.  No HIP library, no model: this only proves that the first real multi-GPU launch is not the first execution
+    of this code path."""
+    from findtextcenternet_amd.decode import REC_W
+    from findtextcenternet_amd.dist import all_gather_boxes, shard_range
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = args.batch
+    lo, hi = shard_range(world * B, rank, world)
+    g = torch.Generator().manual_seed(77 + rank)
+    counts = torch.randint(50, 400, (hi - lo,), generator=g, dtype=torch.int32)
+    rec = torch.randn(hi - lo, args.max_boxes, REC_W, generator=g)
+    out = None
+    for _ in range(args.warmup):
+        out = all_gather_boxes(counts, rec)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = all_gather_boxes(counts, rec)
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ok = out.counts.shape[0] == world * B and torch.equal(out.counts[lo:hi], counts)
+    if rank == 0:
+        print(json.dumps({"metric": "768x768 images/s (detector fwd+NMS)", "value": round(world * B * args.steps / el, 2), "unit": "images/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * el / args.steps, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
+                          "dry_run": True, "gather_ok": bool(ok), "gather_message_bytes_per_rank": out.message_bytes_per_rank,
+                          "config": {"workload": "DRY RUN (CPU tensors, gloo): control flow of the N-rank bench only, no detector work",
+                                     "global_batch": world * B, "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -59,65 +183,81 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="tiles per GPU per step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--max-boxes", type=int, default=2048)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and with it the parity records)")
+    ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of CPU-oracle time to aim for")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode record")
     ap.add_argument("--dump-ops", default="", help="write per-op timings (JSON) to this path")
+    ap.add_argument("--dry-run", action="store_true", help="CPU/gloo walk through the N-rank control flow (no GPU work)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    import synth
     from findtextcenternet_amd import (CenterNetDetector, TextDetectorModel, TileGeom, decode_peaks, deterministic_state_dict,
-                                       exact_logit_cut, tile_keep_rect, tiles_to_device)
+                                       exact_logit_cut, synth, tile_keep_rect, tiles_to_device)
     from findtextcenternet_amd import _lib as L
+    from findtextcenternet_amd.decode import DecodeWorkspace
     from findtextcenternet_amd.dist import all_gather_boxes
 
     sd = deterministic_state_dict(0)
-    model = TextDetectorModel(pre_weights=False, precision=args.precision)
-    model.load_state_dict(sd)
-    det = CenterNetDetector(model.detector)
-    det.to(device=dev)
-    det.eval()
 
+    def make(precision):
+        model = TextDetectorModel(pre_weights=False, precision=precision)
+        model.load_state_dict(sd)
+        d = CenterNetDetector(model.detector)
+        d.to(device=dev)
+        d.eval()
+        return model, d
+
+    model, det = make(args.precision)
     B = args.batch
     x = torch.from_numpy(synth.noise_images(1234 + rank, B, 768, 768)).to(dev).permute(0, 3, 1, 2)   # resident in HBM
     rect = tile_keep_rect(0, 0, 768, 768, 0.6)
     tiles = tiles_to_device([TileGeom(0, 0, 768, 768, rect) for _ in range(B)], dev, 192, 192)
     lcut = exact_logit_cut(0.4)
+    # every output of a step is allocated once, before the timed region
+    heat = torch.empty((B, 192, 192, 10), dtype=torch.float32, device=dev)
+    feat = torch.empty((B, 192, 192, 100), dtype=torch.float32, device=dev)
+    dws = DecodeWorkspace(B, 192, 192, 100, args.max_boxes, dev)
 
     def step():
         with torch.no_grad():
-            heat, feat = det.forward_nhwc(x)
-        dec = decode_peaks(heat, feat, tiles, cut_off=0.4, max_boxes=args.max_boxes, logit_cut=lcut)
+            det.forward_nhwc(x, out=(heat, feat))
+        dec = decode_peaks(heat, feat, tiles, cut_off=0.4, max_boxes=args.max_boxes, logit_cut=lcut, workspace=dws)
         if world > 1:
-            return all_gather_boxes(dec.counts, dec.boxes, dec.feats)
+            return all_gather_boxes(dec.counts, dec.records)
         return dec
 
     for _ in range(args.warmup):
         out = step()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # the kernels run on torch's current stream
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev[0].record()
     el_enqueue = 0.0
     for i in range(args.steps):
         out = step()
+        ev[i + 1].record()
         if i == 0:
             el_enqueue = time.perf_counter() - t0  # host side of ONE step (later steps can block on a full hardware queue)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -136,29 +276,33 @@ def main():
                                    + (" + RCCL all-gather of boxes" if world > 1 else ""),
                        "global_batch": world * B, "tile": "768x768x3", "weights": "deterministic seed 0 (random-init)",
                        "parallelism": f"dp{world}", "mean_peaks_per_tile": round(peaks, 1)},
+            "ms_per_step_median": round(statistics.median(step_ms), 3),
+            "ms_per_step_min_max": [round(min(step_ms), 3), round(max(step_ms), 3)],
+            "timing": "value from wall time around the K steps (barrier + synchronize both sides, max over ranks); "
+                      "ms_per_step_median from per-step HIP events on the launch stream (rank 0)",
+            "source_hash": source_hash(),
         }
+        if world > 1:
+            result["gather_message_bytes_per_rank"] = out.message_bytes_per_rank
         result["host_enqueue_ms_first_step"] = round(1000 * el_enqueue, 3)
-        gflop = 865.0006
-        result["path_tflops_per_gpu"] = round(value / world * gflop / 1000, 2)
-        result["path_frac_of_mfma_peak"] = round(value / world * gflop / 1000 / PEAK[args.precision], 4)
+        result["path_tflops_per_gpu"] = round(value / world * GFLOP_PER_IMAGE / 1000, 2)
+        result["path_frac_of_mfma_peak"] = round(value / world * GFLOP_PER_IMAGE / 1000 / PEAK[args.precision], 4)
 
     # ---- per-kernel attribution with HIP events on the launch stream (rank 0) -------------------
     if rank == 0 and not args.no_profile:
         lib = L.load()
         eng = model.detector._engine
-        pl = eng.get_plan(B, 768, 768, False)
-        heat = torch.empty((B, pl.h, pl.w, 10), dtype=torch.float32, device=dev)
-        feat = torch.empty((B, pl.h, pl.w, 100), dtype=torch.float32, device=dev)
+        pl = eng.plan(B, 768, 768, False)
         bases = (C.c_void_p * L.NUM_BASES)(None, eng.workspace.data_ptr(), eng.wdev.data_ptr(), x.data_ptr(), heat.data_ptr(), feat.data_ptr())
         n_ops = len(pl.ops)
         ms = (C.c_float * n_ops)()
-        acc = np.zeros(n_ops)
         reps = max(3, min(args.steps, 10))
+        acc = np.zeros((reps, n_ops))
         stream = torch.cuda.current_stream(dev).cuda_stream
-        for _ in range(reps):
+        for r in range(reps):
             L.check(lib.ftc_plan_profile(pl.handle, bases, C.c_void_p(stream), ms), "ftc_plan_profile")
-            acc += np.frombuffer(ms, dtype=np.float32)
-        acc /= reps
+            acc[r] = np.frombuffer(ms, dtype=np.float32)
+        acc = np.median(acc, axis=0)
         by = {}
         buf = C.create_string_buffer(128)
         for i in range(n_ops):
@@ -167,10 +311,8 @@ def main():
             d = by.setdefault(k, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
             d["ms"] += float(acc[i]); d["flops"] += pl.meta[i].flops; d["bytes"] += pl.meta[i].bytes; d["launches"] += 1
         total_ms = float(acc.sum())
-        dom = max(by.items(), key=lambda kv: kv[1]["ms"])
-        name, d = dom
-        is_conv = name.startswith("conv")
-        if is_conv:
+        name, d = max(by.items(), key=lambda kv: kv[1]["ms"])
+        if name.startswith("conv"):
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK["bf16" if "<bf16" in name else "fp32"], "unit": "TFLOP/s"}
         else:
@@ -178,22 +320,26 @@ def main():
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s"}
         roof["frac"] = round(roof["achieved"] / roof["peak"], 4)
         roof["traffic"] = None
-        # HBM-side traffic of this kernel from the committed PMC passes (profiles/*_pmc_traffic.json: rocprofv3
-        # FETCH_SIZE / WRITE_SIZE collected separately, gfx950 correction applied); null if not profiled.
+        # HBM-side traffic of this kernel from the committed PMC passes (profiles/*_pmc_traffic.json: rocprofv3 FETCH_SIZE /
+        # WRITE_SIZE collected in separate passes, gfx950 correction applied) -- quoted only when that profile was taken from
+        # the same kernel sources + tuning table as this run (source_hash), else null.
         try:
             import glob
             for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
-                tab = json.load(open(pth)).get("by_label", {})
-                for lab, rec in tab.items():
-                    if lab.split("|")[0] == name and args.precision == "bf16" and B == 8:
+                prof = json.load(open(pth))
+                if prof.get("source_hash") != result["source_hash"] or prof.get("batch") != B or prof.get("precision") != args.precision:
+                    continue
+                for lab, rec in prof.get("by_label", {}).items():
+                    if lab.split("|")[0] == name:
                         roof["traffic"] = rec["traffic_bytes"]
-                        roof["traffic_note"] = f"bytes/launch, {os.path.basename(pth)}"
+                        roof["traffic_note"] = f"bytes/launch, {os.path.basename(pth)} (source_hash {prof['source_hash']})"
         except Exception:
             pass
         roof["kernel"] = name
         roof["launches_per_step"] = d["launches"]
         roof["avg_launch_ms"] = round(d["ms"] / d["launches"], 4)
         roof["algorithmic_gflop_per_launch"] = round(d["flops"] / d["launches"] / 1e9, 3)
+        roof["algorithmic_mbytes_per_launch"] = round(d["bytes"] / d["launches"] / 1e6, 2)
         roof["share_of_forward_time"] = round(d["ms"] / total_ms, 3)
         result["roofline"] = roof
         conv_ms = sum(v["ms"] for k, v in by.items() if k.startswith("conv"))
@@ -207,8 +353,42 @@ def main():
             with open(args.dump_ops, "w") as f:
                 json.dump({"by_kernel": by, "ops": ops}, f, indent=1)
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline({k: v for k, v in sd.items()})
+    # ---- the other numeric mode, parity of both against the CPU oracle, CPU baseline (rank 0, N = 1) -------------
+    if rank == 0 and world == 1:
+        other = "fp32" if args.precision == "bf16" else "bf16"
+        rec_other = None
+        heat2 = feat2 = None
+        if not args.no_fp32:
+            model2, det2 = make(other)
+            heat2, feat2 = torch.empty_like(heat), torch.empty_like(feat)
+            dws2 = DecodeWorkspace(B, 192, 192, 100, args.max_boxes, dev)
+
+            def step2():
+                with torch.no_grad():
+                    det2.forward_nhwc(x, out=(heat2, feat2))
+                return decode_peaks(heat2, feat2, tiles, cut_off=0.4, max_boxes=args.max_boxes, logit_cut=lcut, workspace=dws2)
+            k2 = max(3, args.steps // 4)
+            step2()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k2):
+                step2()
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t0
+            rec_other = {"dtype": other, "images_per_s": round(B * k2 / e2, 2), "ms_per_step": round(1000 * e2 / k2, 3), "steps": k2,
+                         "path_frac_of_mfma_peak": round(B * k2 / e2 * GFLOP_PER_IMAGE / 1000 / PEAK[other], 4)}
+        if not args.no_cpu_baseline:
+            cpu, o_hm, o_ft = cpu_baseline({k: v for k, v in sd.items()}, args.cpu_budget)
+            result["cpu_baseline"] = cpu
+            result["parity"] = {"reference": "CPU oracle (restatement of the reference path pinned by tests/golden), image 0 of the timed batch",
+                                args.precision: parity_record(heat, feat, o_hm, o_ft)}
+            if rec_other is not None:
+                result["parity"][other] = parity_record(heat2, feat2, o_hm, o_ft)
+        if rec_other is not None:
+            key = "fp32_parity_mode" if other == "fp32" else "bf16_speed_mode"
+            result[key] = rec_other
+            if "parity" in result and other in result["parity"]:
+                result[key].update({k: result["parity"][other][k] for k in ("heatmap_linf", "features_linf", "peak_set_identical", "peak_jaccard")})
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

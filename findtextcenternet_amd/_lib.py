@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libftc_hip.so")
 
-FTC_ABI_VERSION = 2
+FTC_ABI_VERSION = 3
 F32, BF16 = 0, 1
 (BASE_NULL, BASE_WORKSPACE, BASE_WEIGHTS, BASE_INPUT, BASE_HEATMAP, BASE_FEATURES, NUM_BASES) = range(7)
 OP_STEM, OP_CONV, OP_DWCONV, OP_SE, OP_UPCAT, OP_NMS, OP_TAPSUM = 1, 2, 3, 4, 5, 6, 7
@@ -20,7 +20,9 @@ FLAG_TOP_FUSE, FLAG_UPCAT_IN, FLAG_GROUP_IN2_SHARED = 0x10000, 0x20000, 0x200000
 
 EXPORTS = ["ftc_abi_version", "ftc_last_error", "ftc_device_info", "ftc_plan_create", "ftc_plan_destroy",
            "ftc_plan_num_ops", "ftc_plan_run", "ftc_plan_profile", "ftc_op_kernel_label", "ftc_decode_scratch_bytes", "ftc_decode", "ftc_tile_gather", "ftc_paste_maps",
-           "ftc_page_merge_scratch_bytes", "ftc_box_hists", "ftc_page_merge", "ftc_adamw_schedulefree_step"]
+           "ftc_page_merge_scratch_bytes", "ftc_box_hists", "ftc_page_merge", "ftc_adamw_schedulefree_step",
+           "ftc_create", "ftc_destroy", "ftc_weights_bytes", "ftc_weights_host", "ftc_weights_offset", "ftc_workspace_bytes", "ftc_forward",
+           "ftc_model_plan", "ftc_model_op_info", "ftc_plan_op"]
 
 
 class FtcLibraryError(RuntimeError):
@@ -40,6 +42,19 @@ class Op(C.Structure):
         "kind", "flags", "act", "in_dtype", "out_dtype", "w_dtype", "B", "H", "W", "Ho", "Wo", "Cin", "Cin_total",
         "cin_off", "Cout", "Cout_total", "cout_off", "ksize", "stride", "aux0", "aux1", "res_dtype", "groups", "reserved0")] + [
         (n, Ref) for n in ("in_", "in2", "out", "w", "w2", "bias", "bias2", "scale", "shift", "aux", "out2")]
+
+
+class Tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("dtype", C.c_int32), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_ops", "map_h", "map_w", "reserved")] + [
+        (n, C.c_int64) for n in ("workspace_bytes", "weights_bytes", "peak_live_bytes", "total_buffer_bytes")]
+
+
+class OpInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("kind", C.c_char * 16), ("flops", C.c_double), ("bytes", C.c_double)]
 
 
 class MtChunk(C.Structure):
@@ -79,7 +94,7 @@ def load():
     lib.ftc_op_kernel_label.argtypes = [C.POINTER(Op), C.c_char_p, i32]
     lib.ftc_decode_scratch_bytes.argtypes = [i32, i32, i32]
     lib.ftc_decode_scratch_bytes.restype = i64
-    lib.ftc_decode.argtypes = [vp, vp, i32, i32, i32, i32, vp, C.c_float, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.ftc_decode.argtypes = [vp, vp, i32, i32, i32, i32, vp, C.c_float, i32, i32, vp, i32, vp, i32, vp, vp, vp, vp]
     lib.ftc_tile_gather.argtypes = [vp, i32, i32, vp, i32, i32, i32, vp, vp]
     lib.ftc_paste_maps.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32, i32, vp]
     lib.ftc_page_merge_scratch_bytes.argtypes = [i32, i32, i32]
@@ -87,6 +102,21 @@ def load():
     lib.ftc_box_hists.argtypes = [vp, i32, vp, i32, i32, C.c_float, vp, vp]
     lib.ftc_adamw_schedulefree_step.argtypes = [vp, i32] + [C.c_float] * 8 + [i32, vp]
     lib.ftc_page_merge.argtypes = [vp, vp, i32, vp, vp, C.c_float, vp, vp, i32, i32, i32, vp, vp, vp, vp, i64, vp]
+    lib.ftc_create.argtypes = [C.POINTER(Tensor), i32, C.c_char_p, i32, C.POINTER(vp)]
+    lib.ftc_destroy.argtypes = [vp]
+    lib.ftc_destroy.restype = None
+    lib.ftc_weights_bytes.argtypes = [vp]
+    lib.ftc_weights_bytes.restype = i64
+    lib.ftc_weights_host.argtypes = [vp]
+    lib.ftc_weights_host.restype = vp
+    lib.ftc_weights_offset.argtypes = [vp, C.c_char_p]
+    lib.ftc_weights_offset.restype = i64
+    lib.ftc_workspace_bytes.argtypes = [vp, i32, i32, i32]
+    lib.ftc_workspace_bytes.restype = i64
+    lib.ftc_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+    lib.ftc_model_plan.argtypes = [vp, i32, i32, i32, i32, C.POINTER(vp), C.POINTER(PlanInfo)]
+    lib.ftc_model_op_info.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(OpInfo)]
+    lib.ftc_plan_op.argtypes = [vp, i32, C.POINTER(Op)]
     if lib.ftc_abi_version() != FTC_ABI_VERSION:
         raise FtcLibraryError(f"ABI mismatch: library {lib.ftc_abi_version()} vs binding {FTC_ABI_VERSION}")
     _lib = lib

@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256) void decode_rank_gather_kernel(const float* __
                                                                  const ftc_tile* __restrict__ tiles, int h, int w, int C, int scale,
                                                                  const unsigned long long* __restrict__ cand,
                                                                  const int32_t* __restrict__ counts, int max_boxes,
-                                                                 float* __restrict__ boxes, float* __restrict__ feats,
-                                                                 int32_t* __restrict__ index) {
+                                                                 float* __restrict__ boxes, int box_stride, float* __restrict__ feats,
+                                                                 int feat_stride, int32_t* __restrict__ index) {
     __shared__ unsigned long long keys[256];
     __shared__ int s_rank[256];
     __shared__ int s_idx[256];
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void decode_rank_gather_kernel(const float* __
     if (s_rank[t] >= 0) {
         const float* px = hb + (long)idx * 10;
         const int y = idx / w, x = idx - y * w;
-        float* o = boxes + ((long)b * max_boxes + rank) * 9;
+        float* o = boxes + ((long)b * max_boxes + rank) * box_stride;
         o[0] = ref_sigmoid(px[1]);
         o[1] = (float)(x * scale + tl.offset_x);
         o[2] = (float)(y * scale + tl.offset_y);
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void decode_rank_gather_kernel(const float* __
         const int r = s_rank[k];
         if (r < 0) continue;
         const float* src = fb + (long)s_idx[k] * C;
-        float* dst = feats + ((long)b * max_boxes + r) * C;
+        float* dst = feats + ((long)b * max_boxes + r) * feat_stride;
         for (int q = lane; q < CQ; q += 64) reinterpret_cast<f32x4*>(dst)[q] = reinterpret_cast<const f32x4*>(src)[q];
     }
 }
@@ -110,8 +110,8 @@ __global__ __launch_bounds__(256) void decode_rank_gather_kernel(const float* __
 extern "C" int64_t ftc_decode_scratch_bytes(int B, int h, int w) { return (int64_t)B * h * w * 8; }
 
 hipError_t launch_decode(const float* heat, const float* feat, int B, int h, int w, int C, const ftc_tile* tiles,
-                         float logit_cut, int scale, int max_boxes, float* boxes, float* feats, int32_t* index,
-                         int32_t* counts, void* scratch, hipStream_t s) {
+                         float logit_cut, int scale, int max_boxes, float* boxes, int box_stride, float* feats, int feat_stride,
+                         int32_t* index, int32_t* counts, void* scratch, hipStream_t s) {
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * B, s);
     if (e != hipSuccess) return e;
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(scratch);
@@ -120,6 +120,6 @@ hipError_t launch_decode(const float* heat, const float* feat, int B, int h, int
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(decode_rank_gather_kernel, dim3(nb, B), dim3(256), 0, s, heat, feat, tiles, h, w, C, scale, cand, counts,
-                       max_boxes, boxes, feats, index);
+                       max_boxes, boxes, box_stride, feats, feat_stride, index);
     return hipGetLastError();
 }

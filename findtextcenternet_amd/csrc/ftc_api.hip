@@ -6,10 +6,11 @@
 #include <vector>
 
 #include "ftc_common.h"
+#include "ftc_host.h"
 
 hipError_t launch_decode(const float* heat, const float* feat, int B, int h, int w, int C, const ftc_tile* tiles,
-                         float logit_cut, int scale, int max_boxes, float* boxes, float* feats, int32_t* index,
-                         int32_t* counts, void* scratch, hipStream_t s);
+                         float logit_cut, int scale, int max_boxes, float* boxes, int box_stride, float* feats, int feat_stride,
+                         int32_t* index, int32_t* counts, void* scratch, hipStream_t s);
 
 hipError_t launch_tile_gather(const unsigned char* page, int PH, int PW, const int* origins, int B, int th, int tw, float* out,
                               hipStream_t s);
@@ -21,12 +22,6 @@ hipError_t launch_greedy(const float* loc, const int* order, int N, const double
                          int mw, int scale, float* out_loc, int* out_idx, int* out_n, hipStream_t s);
 hipError_t launch_paste_maps(const float* heat, const ftc_tile* tiles, int B, int h, int w, int scale, float* canv, int ph, int pw,
                              hipStream_t s);
-
-struct ftc_plan {
-    std::vector<ftc_op> ops;
-    int64_t workspace_bytes;
-    int64_t weights_bytes;
-};
 
 namespace {
 
@@ -162,6 +157,8 @@ int check_bases(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], int firs
 
 }  // namespace
 
+int ftc_set_error(int code, const std::string& msg) { return fail(code, msg); }
+
 extern "C" {
 
 int ftc_abi_version(void) { return FTC_ABI_VERSION; }
@@ -269,15 +266,17 @@ int ftc_plan_profile(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], voi
 }
 
 int ftc_decode(const float* heatmap, const float* features, int B, int h, int w, int C, const ftc_tile* tiles_dev,
-               float logit_cut, int scale, int max_boxes, float* boxes, float* feats, int32_t* index, int32_t* counts,
-               void* scratch_dev, void* stream) {
+               float logit_cut, int scale, int max_boxes, float* boxes, int box_stride, float* feats, int feat_stride,
+               int32_t* index, int32_t* counts, void* scratch_dev, void* stream) {
     if (!heatmap || !features || !tiles_dev || !boxes || !feats || !index || !counts || !scratch_dev)
         return fail(FTC_ERR_INVALID, "ftc_decode: null pointer argument");
     if (B <= 0 || h <= 0 || w <= 0 || C <= 0 || (C & 3) || max_boxes <= 0 || scale <= 0)
         return fail(FTC_ERR_INVALID, "ftc_decode: bad sizes (C must be a multiple of 4)");
     if ((long)h * w > 0x7fffffffL / 16) return fail(FTC_ERR_INVALID, "ftc_decode: map too large");
-    hipError_t e = launch_decode(heatmap, features, B, h, w, C, tiles_dev, logit_cut, scale, max_boxes, boxes, feats, index,
-                                 counts, scratch_dev, static_cast<hipStream_t>(stream));
+    if (box_stride < 9 || feat_stride < C || (feat_stride & 3) || (reinterpret_cast<uintptr_t>(feats) & 15) || (reinterpret_cast<uintptr_t>(features) & 15))
+        return fail(FTC_ERR_INVALID, "ftc_decode: box_stride >= 9, feat_stride >= C and a multiple of 4 floats, feature rows 16-byte aligned");
+    hipError_t e = launch_decode(heatmap, features, B, h, w, C, tiles_dev, logit_cut, scale, max_boxes, boxes, box_stride, feats,
+                                 feat_stride, index, counts, scratch_dev, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(e, "ftc_decode");
     return FTC_OK;
 }

@@ -75,12 +75,37 @@ class TileGeom:
     rect: Tuple[int, int, int, int]      # x_min, x_max, y_min, y_max
 
 
+REC_W = 112          # floats per record row: box (9) + 3 pad + feature row (100, 16-byte aligned)
+REC_FEAT0 = 12
+
+
 @dataclass
 class Decoded:
-    boxes: torch.Tensor      # [B, max_boxes, 9] f32: p, ix, iy, w, h, code1, code2, code4, code8
-    feats: torch.Tensor      # [B, max_boxes, C] f32
+    boxes: torch.Tensor      # [B, max_boxes, 9] f32 view: p, ix, iy, w, h, code1, code2, code4, code8
+    feats: torch.Tensor      # [B, max_boxes, C] f32 view
     index: torch.Tensor      # [B, max_boxes] int32 flat map index y*w+x
     counts: torch.Tensor     # [B] int32 number of peaks found (may exceed max_boxes)
+    records: Optional[torch.Tensor] = None   # [B, max_boxes, 112] f32: the block `boxes` / `feats` are views of
+
+
+class DecodeWorkspace:
+    """Output block + scratch of ``decode_peaks`` for a fixed (B, h, w, C, max_boxes), allocated once and reused:
+    nothing is allocated or cleared per call, so rows at and beyond ``counts[b]`` keep whatever an earlier call left there."""
+
+    def __init__(self, B: int, h: int, w: int, C_: int, max_boxes: int, device):
+        if C_ + REC_FEAT0 > REC_W and C_ != feature_dim:
+            raise ValueError("record layout is sized for the 100-d feature rows")
+        lib = L.load()
+        self.key = (B, h, w, C_, max_boxes)
+        self.rec_w = REC_W if C_ + REC_FEAT0 <= REC_W else (C_ + REC_FEAT0 + 3) // 4 * 4
+        self.records = torch.zeros((B, max_boxes, self.rec_w), dtype=torch.float32, device=device)
+        self.index = torch.full((B, max_boxes), -1, dtype=torch.int32, device=device)
+        self.counts = torch.zeros((B,), dtype=torch.int32, device=device)
+        self.scratch = torch.empty(int(lib.ftc_decode_scratch_bytes(B, h, w)), dtype=torch.uint8, device=device)
+
+    def decoded(self) -> Decoded:
+        C_ = self.key[3]
+        return Decoded(self.records[:, :, 0:9], self.records[:, :, REC_FEAT0:REC_FEAT0 + C_], self.index, self.counts, self.records)
 
 
 def tiles_to_device(tiles: Sequence[TileGeom], device, h: int, w: int) -> torch.Tensor:
@@ -93,9 +118,11 @@ def tiles_to_device(tiles: Sequence[TileGeom], device, h: int, w: int) -> torch.
 
 
 def decode_peaks(heat_nhwc: torch.Tensor, feat_nhwc: torch.Tensor, tiles, cut_off: float = 0.4,
-                 max_boxes: int = 4096, logit_cut: Optional[float] = None) -> Decoded:
+                 max_boxes: int = 4096, logit_cut: Optional[float] = None, workspace: Optional[DecodeWorkspace] = None) -> Decoded:
     """heat_nhwc [B,h,w,10] fp32, feat_nhwc [B,h,w,C] fp32 (NHWC memory, on the GPU); ``tiles`` is a
-    sequence of TileGeom or the [B,8] int32 device tensor from ``tiles_to_device``."""
+    sequence of TileGeom or the [B,8] int32 device tensor from ``tiles_to_device``.  The kernel writes box and feature row
+    of a peak into ONE record row (``Decoded.records`` [B,max_boxes,112]); ``boxes`` / ``feats`` are views of it.  Without a
+    ``workspace`` a fresh zero-filled block is allocated per call."""
     if not (heat_nhwc.is_cuda and feat_nhwc.is_cuda):
         raise RuntimeError("decode_peaks runs on the GPU only (no CPU fallback)")
     lib = L.load()
@@ -111,17 +138,17 @@ def decode_peaks(heat_nhwc: torch.Tensor, feat_nhwc: torch.Tensor, tiles, cut_of
             assert tl_dev.shape == (B, 8) and tl_dev.dtype == torch.int32 and tl_dev.device == dev and tl_dev.is_contiguous()
         else:
             tl_dev = tiles_to_device(tiles, dev, h, w)
-        boxes = torch.zeros((B, max_boxes, 9), dtype=torch.float32, device=dev)
-        feats = torch.zeros((B, max_boxes, Cf), dtype=torch.float32, device=dev)
-        index = torch.full((B, max_boxes), -1, dtype=torch.int32, device=dev)
-        counts = torch.empty((B,), dtype=torch.int32, device=dev)
-        scratch = torch.empty(int(lib.ftc_decode_scratch_bytes(B, h, w)), dtype=torch.uint8, device=dev)
+        ws = workspace
+        if ws is None:
+            ws = DecodeWorkspace(B, h, w, Cf, max_boxes, dev)
+        elif ws.key != (B, h, w, Cf, max_boxes) or ws.records.device != dev:
+            raise ValueError(f"DecodeWorkspace was built for {ws.key}, not {(B, h, w, Cf, max_boxes)}")
         lc = exact_logit_cut(cut_off) if logit_cut is None else logit_cut
         stream = torch.cuda.current_stream(dev).cuda_stream
         L.check(lib.ftc_decode(heat_nhwc.data_ptr(), feat_nhwc.data_ptr(), B, h, w, Cf, tl_dev.data_ptr(), C.c_float(lc),
-                               scale, max_boxes, boxes.data_ptr(), feats.data_ptr(), index.data_ptr(), counts.data_ptr(),
-                               scratch.data_ptr(), C.c_void_p(stream)), "ftc_decode")
-    return Decoded(boxes, feats, index, counts)
+                               scale, max_boxes, ws.records.data_ptr(), ws.rec_w, ws.records.data_ptr() + 4 * REC_FEAT0, ws.rec_w,
+                               ws.index.data_ptr(), ws.counts.data_ptr(), ws.scratch.data_ptr(), C.c_void_p(stream)), "ftc_decode")
+    return ws.decoded()
 
 
 class HipDetectorBackend:

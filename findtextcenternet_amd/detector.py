@@ -25,11 +25,12 @@ import math
 import os
 from typing import Dict, Optional, Tuple
 
+import numpy as np
 import torch
 from torch import nn
 
 from . import _lib as L
-from . import plan as P
+from .model import FtcModel
 from .schema import decoder_schema, detector_schema, feature_dim
 
 
@@ -71,52 +72,61 @@ def _populate(root: nn.Module, schema) -> None:
 
 
 class _HipEngine:
-    """Weights blob + per-shape plans + workspace for one CenterNetDetection instance."""
+    """The library-side model (``ftc_create``: folded + packed weights, per-shape plans) of one CenterNetDetection instance, its
+    weight blob in HBM and the activation workspace.  All network knowledge lives in the C library; this class only owns
+    device memory and notices when the module's parameters change."""
 
     def __init__(self, precision: str, model_size: str):
         self.precision = precision
         self.model_size = model_size
-        self.pw: Optional[P.PackedWeights] = None
+        self.model: Optional[FtcModel] = None
         self.wdev: Optional[torch.Tensor] = None
-        self.plans: Dict[Tuple, P.Plan] = {}
         self.workspace: Optional[torch.Tensor] = None
+        self.fingerprint = None
+        self._flat = None
 
     def invalidate(self) -> None:
-        self.pw, self.wdev = None, None
-        self.release_plans()
-
-    def release_plans(self) -> None:
-        if self.plans:
-            lib = L.load()
-            for pl in self.plans.values():
-                if pl.handle:
-                    lib.ftc_plan_destroy(pl.handle)
-                    pl.handle = None
-        self.plans = {}
+        if self.model is not None:
+            self.model.close()
+        self.model, self.wdev, self.fingerprint, self._flat = None, None, None, None
 
     def __del__(self):
         try:
-            self.release_plans()
+            self.invalidate()
         except Exception:
             pass
 
-    def ensure_weights(self, state_dict_fn, device) -> None:
-        if self.pw is None:                       # only then: enumerating the 2444-tensor state dict costs ~8 ms of host time
-            self.pw = P.pack_weights(state_dict_fn(), self.precision, self.model_size)
-            self.wdev = None
+    def _fingerprint(self, module: nn.Module):
+        # Parameters and buffers can change behind our back (optimizer.step(), p.data.copy_(), .half().float(), the
+        # schedule-free optimizer's train()/eval() swap ...): in-place writes bump Tensor._version, re-allocations move
+        # data_ptr.  ~1 ms of host time for the 2400 tensors, hidden behind the previous forward's GPU work.
+        if self._flat is None:
+            self._flat = list(module.parameters()) + list(module.buffers())
+        return (sum(t._version for t in self._flat), sum(t.data_ptr() for t in self._flat))
+
+    def ensure_model(self, module: nn.Module, device) -> None:
+        fp = self._fingerprint(module)
+        if self.model is None or fp != self.fingerprint:
+            self.invalidate()
+            self.model = FtcModel(module.state_dict(), self.precision, self.model_size)      # folds + packs in the library (seconds)
+            self.fingerprint = self._fingerprint(module)
         if self.wdev is None or self.wdev.device != device:
-            self.wdev = torch.from_numpy(self.pw.blob).to(device)
+            self.wdev = torch.from_numpy(self.model.weights_host()).to(device)              # one H2D copy of the packed blob
 
-    def get_plan(self, B, H, W, nchw) -> P.Plan:
-        key = (B, H, W, nchw)
-        pl = self.plans.get(key)
-        if pl is None:
-            pl = P.build_plan(self.pw, B, H, W, nchw)
-            P.create_handle(pl, self.pw.nbytes)
-            self.plans[key] = pl
-        return pl
+    @property
+    def handle(self):
+        return self.model.handle if self.model is not None else None
 
-    def run(self, x: torch.Tensor, state_dict_fn, with_nms: bool = True):
+    def plan(self, B, H, W, nchw=False):
+        return self.model.plan(B, H, W, nchw)
+
+    def ensure_workspace(self, B, H, W, device) -> None:
+        need = self.model.workspace_bytes(B, H, W)
+        if self.workspace is None or self.workspace.device != device or self.workspace.numel() < need:
+            self.workspace = None
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=device)
+
+    def run(self, x: torch.Tensor, module: nn.Module, with_nms: bool = True, out=None):
         if not x.is_cuda:
             raise RuntimeError("findtextcenternet_amd: the detector runs on MI355X (gfx950) only -- move the module and "
                                "the input to 'cuda' (there is no CPU fallback)")
@@ -132,21 +142,25 @@ class _HipEngine:
             nchw = True
         else:
             x, nchw = x.contiguous(memory_format=torch.channels_last), False
+        if H % 32 or W % 32:
+            raise ValueError("H and W must be multiples of 32 (the reference always uses 768)")
         dev = x.device
         with torch.cuda.device(dev):
-            self.ensure_weights(state_dict_fn, dev)
-            pl = self.get_plan(B, H, W, nchw)
-            if self.workspace is None or self.workspace.device != dev or self.workspace.numel() < pl.workspace_bytes:
-                self.workspace = None
-                self.workspace = torch.empty(pl.workspace_bytes, dtype=torch.uint8, device=dev)
-            heat = torch.empty((B, pl.h, pl.w, 10), dtype=torch.float32, device=dev)
-            feat = torch.empty((B, pl.h, pl.w, feature_dim), dtype=torch.float32, device=dev)
-            bases = (C.c_void_p * L.NUM_BASES)(None, self.workspace.data_ptr(), self.wdev.data_ptr(), x.data_ptr(),
-                                               heat.data_ptr(), feat.data_ptr())
+            self.ensure_model(module, dev)
+            self.ensure_workspace(B, H, W, dev)
+            h, w = H // 4, W // 4
+            if out is None:
+                heat = torch.empty((B, h, w, 10), dtype=torch.float32, device=dev)
+                feat = torch.empty((B, h, w, feature_dim), dtype=torch.float32, device=dev)
+            else:
+                heat, feat = out
+                if (tuple(heat.shape) != (B, h, w, 10) or tuple(feat.shape) != (B, h, w, feature_dim) or heat.dtype != torch.float32
+                        or feat.dtype != torch.float32 or not heat.is_contiguous() or not feat.is_contiguous() or heat.device != dev):
+                    raise ValueError("out=(heat [B,h,w,10], feat [B,h,w,100]) must be contiguous fp32 tensors on the input's device")
             stream = torch.cuda.current_stream(dev).cuda_stream
-            last = -1 if with_nms else len(pl.ops) - 2
-            L.check(lib.ftc_plan_run(pl.handle, bases, C.c_void_p(stream), 0, last), "ftc_plan_run")
-        # keep x alive until the work is enqueued on the same stream: it is (stream-ordered allocator)
+            L.check(lib.ftc_forward(self.handle, self.wdev.data_ptr(), x.data_ptr(), B, H, W, 1 if nchw else 0, 1 if with_nms else 0,
+                                    heat.data_ptr(), feat.data_ptr(), self.workspace.data_ptr(), C.c_void_p(stream)), "ftc_forward")
+        # x stays alive until the work is enqueued on the same stream (stream-ordered allocator)
         return heat, feat
 
 
@@ -160,8 +174,7 @@ class CenterNetDetection(nn.Module):
         prec = precision or os.environ.get("FTC_PRECISION", "fp32")
         if prec not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16'")
-        self._engine = _HipEngine(prec, model_size)
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._engine.invalidate())
+        object.__setattr__(self, "_engine", _HipEngine(prec, model_size))
         # pre_weights: the reference looks for efficientnetv2-xl-21k.npz next to detector.py and
         # silently continues when it is missing (models/detector.py:34-36, :129-130); use
         # findtextcenternet_amd.weights.load_tf_efficientnetv2_npz() to import one explicitly.
@@ -177,14 +190,33 @@ class CenterNetDetection(nn.Module):
             self._engine.invalidate()
             self._engine.precision = precision
 
-    def _sd(self):
-        return {k: v for k, v in self.state_dict().items()}
+    # the engine holds C handles and device memory: a copy / pickle of the module gets a fresh one
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_engine"] = self._engine.precision           # only the numeric mode survives a pickle
+        return st
 
-    def forward_nhwc(self, x, with_nms: bool):
-        """(heat[B,h,w,10] fp32, feat[B,h,w,100] fp32) in NHWC memory; channel 1 is the NMS slot."""
+    def __setstate__(self, st):
+        prec = st.pop("_engine", None) or os.environ.get("FTC_PRECISION", "fp32")
+        super().__setstate__(st)
+        object.__setattr__(self, "_engine", _HipEngine(prec, self.model_size))
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != "_engine":
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        object.__setattr__(new, "_engine", _HipEngine(self._engine.precision, self.model_size))
+        return new
+
+    def forward_nhwc(self, x, with_nms: bool, out=None):
+        """(heat[B,h,w,10] fp32, feat[B,h,w,100] fp32) in NHWC memory; channel 1 is the NMS slot.  ``out=(heat, feat)``
+        writes into caller-owned tensors instead of allocating."""
         if self.training:
             raise NotImplementedError("findtextcenternet_amd implements the inference path (eval mode) only; call .eval()")
-        return self._engine.run(x, self._sd, with_nms)
+        return self._engine.run(x, self, with_nms, out)
 
     def forward(self, x):
         heat, feat = self.forward_nhwc(x, with_nms=False)
@@ -226,8 +258,8 @@ class CenterNetDetector(nn.Module):
         self.detector = detector
         self.minval = torch.tensor(float("-inf"))
 
-    def forward_nhwc(self, x):
-        return self.detector.forward_nhwc(x, with_nms=True)
+    def forward_nhwc(self, x, out=None):
+        return self.detector.forward_nhwc(x, with_nms=True, out=out)
 
     def forward(self, x):
         heat, feat = self.detector.forward_nhwc(x, with_nms=True)

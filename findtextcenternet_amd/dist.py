@@ -2,15 +2,21 @@
 
 The reference has no distributed code; tiles are independent units in eval
 mode, so the batch is split into contiguous blocks, one process per GPU, weights replicated, and the
-only exchange is the gather of the decoded peaks (never the 1 GB of heat-maps): counts first, then
-one fixed-capacity ``[B_local, cap, 9+C]`` fp32 record block per rank.  ``backend='nccl'`` is RCCL
-on ROCm; over xGMI the message (a few MB) is latency-bound, so a single all_gather_into_tensor per
-array is used.  The same code runs under ``gloo`` on CPU tensors for the world_size-2 tests.
+only exchange is the gather of the decoded peaks (never the 1 GB of heat-maps):
+
+1. ``counts`` (one int32 per local tile, padded to the largest local batch) -- a few bytes per rank;
+2. the record block ``[B_pad, n_max, 112]`` fp32 cut to ``n_max`` = the largest count on any rank (capped at the
+   decode capacity): box (9 floats), 3 pad, the 100-d feature row -- exactly the rows ``ftc_decode`` wrote, no
+   repacking (counts first, then pad to the global maximum).
+
+``backend='nccl'`` is RCCL on ROCm; over xGMI a message of this size (about 0.7 MB per tile at 1600 peaks) is
+latency-bound, so one ``all_gather_into_tensor`` per array is used.  The same code runs under ``gloo`` on CPU
+tensors for the world_size-2 tests.
 """
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Optional, Tuple
+from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -25,28 +31,51 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 @dataclass
 class GatheredBoxes:
-    counts: torch.Tensor      # [world * B_local] int32 peaks found per tile (global tile order)
-    records: torch.Tensor     # [world * B_local, cap, 9 + C] fp32: box (9) ++ feature row (C)
+    counts: torch.Tensor      # [n_tiles] int32 peaks found per tile, global tile order
+    records: torch.Tensor     # [n_tiles, n_max, W] fp32 record rows (W = 112: box 0..8, feature row 12..111)
+    feat0: int = 12
+    message_bytes_per_rank: int = 0
 
     def tile(self, i: int):
         n = min(int(self.counts[i]), self.records.shape[1])
         r = self.records[i, :n]
-        return r[:, :9], r[:, 9:]
+        return r[:, :9], r[:, self.feat0:]
 
 
-def pack_records(boxes: torch.Tensor, feats: torch.Tensor) -> torch.Tensor:
-    return torch.cat([boxes, feats], dim=2).contiguous()
-
-
-def all_gather_boxes(counts: torch.Tensor, boxes: torch.Tensor, feats: torch.Tensor,
-                     group: Optional[dist.ProcessGroup] = None) -> GatheredBoxes:
-    """counts [B] int32, boxes [B,cap,9], feats [B,cap,C] (same B and cap on every rank)."""
-    rec = pack_records(boxes, feats)
+def all_gather_boxes(counts: torch.Tensor, records: torch.Tensor, group: Optional[dist.ProcessGroup] = None,
+                     feat0: int = 12) -> GatheredBoxes:
+    """counts [B_local] int32, records [B_local, cap, W] fp32 (``Decoded.records``).  ``B_local`` may differ between
+    ranks (``shard_range`` hands out uneven blocks when the tile count is not a multiple of the world size): every rank
+    pads to the largest local batch with count-0 tiles and the padding is dropped again after the gather, so the result
+    is in global tile order on every rank."""
+    cap = records.shape[1]
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return GatheredBoxes(counts.clone(), rec)
+        n_max = min(cap, int(counts.max().item())) if counts.numel() else 0
+        return GatheredBoxes(counts.clone(), records[:, :n_max].contiguous(), feat0, 0)
     world = dist.get_world_size(group)
-    out_c = torch.empty((world * counts.shape[0],), dtype=counts.dtype, device=counts.device)
-    out_r = torch.empty((world * rec.shape[0],) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
-    dist.all_gather_into_tensor(out_c, counts.contiguous(), group=group)
-    dist.all_gather_into_tensor(out_r, rec, group=group)
-    return GatheredBoxes(out_c, out_r)
+    dev = counts.device
+    B = counts.shape[0]
+    # step 1: [B_local, max count] of every rank
+    meta = torch.tensor([B, int(counts.max().item()) if B else 0], dtype=torch.int32, device=dev)
+    metas = torch.empty((world * 2,), dtype=torch.int32, device=dev)          # flat output: what gloo and RCCL both accept
+    dist.all_gather_into_tensor(metas, meta, group=group)
+    metas_h = metas.cpu().view(world, 2)
+    b_pad = int(metas_h[:, 0].max())
+    n_max = min(cap, int(metas_h[:, 1].max()))
+    cnt = counts
+    if B < b_pad:
+        cnt = torch.cat([counts, torch.zeros(b_pad - B, dtype=counts.dtype, device=dev)])
+    out_c = torch.empty((world * b_pad,), dtype=counts.dtype, device=dev)
+    dist.all_gather_into_tensor(out_c, cnt.contiguous(), group=group)
+    # step 2: only the rows any rank filled
+    rec = records[:, :n_max]
+    if B < b_pad:
+        rec = torch.cat([rec, torch.zeros((b_pad - B,) + tuple(rec.shape[1:]), dtype=rec.dtype, device=dev)])
+    rec = rec.contiguous()                                   # a strided slice of the decode block: one copy of the live rows
+    out_r = torch.empty((world * b_pad,) + tuple(rec.shape[1:]), dtype=rec.dtype, device=dev)
+    if rec.numel():
+        dist.all_gather_into_tensor(out_r.view(-1), rec.view(-1), group=group)
+    if (metas_h[:, 0] != b_pad).any():                       # drop the padding tiles of the short ranks
+        keep = torch.cat([torch.arange(r * b_pad, r * b_pad + int(metas_h[r, 0])) for r in range(world)]).to(dev)
+        out_c, out_r = out_c.index_select(0, keep), out_r.index_select(0, keep)
+    return GatheredBoxes(out_c, out_r, feat0, rec.numel() * rec.element_size() + cnt.numel() * 4 + 8)

@@ -40,7 +40,6 @@ class AdamWScheduleFree(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, r=r, k=0, warmup_steps=warmup_steps, train_mode=False, weight_sum=0.0,
                         lr_max=-1.0, scheduled_lr=0.0, weight_lr_power=weight_lr_power, weight_decay=weight_decay, foreach=foreach)
         super().__init__(params, defaults)
-        self._tables: Dict[int, Tuple[tuple, torch.Tensor, int]] = {}
 
     # x = the averaged iterate (evaluation / checkpoints), y = where gradients are taken (training): p holds one or the other
     @torch.no_grad()
@@ -63,14 +62,24 @@ class AdamWScheduleFree(torch.optim.Optimizer):
         self._swap(True)
 
     def _chunk_table(self, gi: int, active: List[torch.Tensor]) -> Tuple[torch.Tensor, int]:
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in active)
-        hit = self._tables.get(gi)
+        # The table holds raw device pointers of the parameter, its gradient AND its two state tensors, so all four are in the
+        # cache key: load_state_dict(), state.clear() or a moved state tensor would otherwise leave the kernel writing through
+        # stale pointers.  `_tables` is created lazily: Optimizer.__setstate__ (unpickle, deepcopy) does not restore it.
+        tables = self.__dict__.setdefault("_tables", {})
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["z"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(), p.numel())
+                    for p in active)
+        hit = tables.get(gi)
         if hit is not None and hit[0] == key:
             return hit[1], hit[2]
         rows = []
         for p in active:
             st = self.state[p]
             n = p.numel()
+            for name, t in (("parameter", p), ("gradient", p.grad), ("z", st["z"]), ("exp_avg_sq", st["exp_avg_sq"])):
+                if t.data_ptr() % 16 or t.device != p.device or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n:
+                    raise RuntimeError(f"findtextcenternet_amd.AdamWScheduleFree: {name} of a parameter is not a 16-byte aligned, "
+                                       "contiguous fp32 tensor on the parameter's device (view parameters / bucket-view gradients "
+                                       "are not supported by the 16-byte-lane kernel)")
             for off in range(0, n, CHUNK):
                 rows.append((p.data_ptr() + 4 * off, p.grad.data_ptr() + 4 * off, st["exp_avg_sq"].data_ptr() + 4 * off,
                              st["z"].data_ptr() + 4 * off, min(CHUNK, n - off)))
@@ -79,7 +88,7 @@ class AdamWScheduleFree(torch.optim.Optimizer):
             arr[i].y, arr[i].g, arr[i].v, arr[i].z, arr[i].n = y, g, v, z, n
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         dev = host.to(active[0].device)
-        self._tables[gi] = (key, dev, len(rows))
+        tables[gi] = (key, dev, len(rows))
         return dev, len(rows)
 
     @torch.no_grad()

@@ -14,8 +14,8 @@ What runs where
   separator filter, 3x3 code maximum (``process_ocr_base.py:540-648``) -- runs on the GPU
   too (``ftc_box_hists`` + ``ftc_page_merge``: float64, sequential semantics kept, bit-identical results);
   only the selected boxes, their feature rows and the two page canvases come back over PCIe.
-* ``page_merge`` below is the same selection on host arrays (NumPy, as the reference runs it) for callers
-  that already hold host data; ``PageDetector`` does not use it.
+  (There is no host implementation of the selection in this package: the NumPy restatement the GPU kernels are checked
+  against is test infrastructure, ``oracle/decode_oracle.py``.)
 """
 from __future__ import annotations
 
@@ -44,112 +44,8 @@ def tile_origins(page_h: int, page_w: int, stepx: int, stepy: int) -> List[Tuple
 
 
 # ------------------------------------------------------------------------------------------------
-# host page merge (process_ocr_base.py:540-648)
+# page-level selection on the GPU (process_ocr_base.py:540-648)
 # ------------------------------------------------------------------------------------------------
-def _two_means_distance(hist: np.ndarray) -> float:
-    """Distance between the centres of a 1-D 2-means clustering of a 256-bin histogram
-    (``imageHist.cluster_dist``, process_ocr_base.py:654-684)."""
-    total = hist.sum()
-    if total == 0:
-        return 0
-    idx = np.arange(hist.shape[0])
-    weighted = hist * idx
-    cut = int(weighted.sum() / total + 0.5)
-    n_lo, n_hi = hist[:cut].sum(), hist[cut:].sum()
-    if n_lo == 0 or n_hi == 0:
-        return 0
-    c_lo, c_hi = weighted[:cut].sum() / n_lo, weighted[cut:].sum() / n_hi
-    last, dist = 256.0, abs(c_lo - c_hi)
-    while last != dist:
-        last = dist
-        lo = np.abs(idx - c_lo) < np.abs(idx - c_hi)
-        n_lo, n_hi = hist[lo].sum(), hist[~lo].sum()
-        if n_lo == 0 or n_hi == 0:
-            return 0
-        c_lo, c_hi = weighted[lo].sum() / n_lo, weighted[~lo].sum() / n_hi
-        dist = abs(c_lo - c_hi)
-    return last
-
-
-def image_contrast(patch: np.ndarray) -> float:
-    """``OCR_Processer.imageHist`` (process_ocr_base.py:652-693)."""
-    best = -1
-    for ch in range(3):
-        best = max(best, _two_means_distance(np.histogram(patch[:, :, ch], bins=256, range=(0, 256))[0]))
-    return best
-
-
-def page_merge(locations: np.ndarray, glyphfeatures: np.ndarray, org_img: np.ndarray, seps_all: np.ndarray,
-               code_all: Sequence[np.ndarray], cut_off: float):
-    """locations float64 [N,9] in page coordinates (any order), glyphfeatures [N,100]."""
-    page_h, page_w = org_img.shape[:2]
-    mh, mw = page_h // scale, page_w // scale
-    n = locations.shape[0]
-    above = locations[:, 0] >= cut_off
-    # contrast threshold: median of the per-box contrast / 5 (:543-557); crop bounds as in the reference,
-    # including its use of possibly negative slice starts
-    hists = []
-    for i in np.nonzero(above)[0]:
-        _, cx, cy, w, h = locations[i, :5]
-        hists.append(image_contrast(org_img[int(cy - h / 2) - 1:int(cy + h / 2) + 2, int(cx - w / 2) - 1:int(cx + w / 2) + 2, :]))
-    th_hist = np.median(hists) / 5 if hists else np.nan
-
-    kept_boxes = np.zeros([0, 4])
-    kept: List[int] = []
-    for i in np.argsort(-locations[:, 0], kind="stable"):
-        p, cx, cy, w, h = locations[i, :5]
-        if p < cut_off:
-            break
-        x0, x1 = max(0, int(cx - w / 2)), min(page_w - 1, int(cx + w / 2) + 1)
-        y0, y1 = max(0, int(cy - h / 2)), min(page_h - 1, int(cy + h / 2) + 1)
-        if image_contrast(org_img[y0:y1, x0:x1, :]) < th_hist:
-            continue
-        if kept_boxes.shape[0] > 0:
-            area = w * h
-            ix0 = np.maximum(cx - w / 2, kept_boxes[:, 0] - kept_boxes[:, 2] / 2)
-            iy0 = np.maximum(cy - h / 2, kept_boxes[:, 1] - kept_boxes[:, 3] / 2)
-            ix1 = np.minimum(cx + w / 2, kept_boxes[:, 0] + kept_boxes[:, 2] / 2)
-            iy1 = np.minimum(cy + h / 2, kept_boxes[:, 1] + kept_boxes[:, 3] / 2)
-            inter = np.maximum(ix1 - ix0, 0.) * np.maximum(iy1 - iy0, 0.)
-            union = area + kept_boxes[:, 2] * kept_boxes[:, 3] - inter
-            iou = np.where(union > 0., inter / union, 0.)
-            if iou.max() > 0.5 or inter.max() > area * 0.75:
-                continue
-            covered = np.zeros([int(w), int(h)], dtype=bool)
-            for j in np.nonzero(iou > 0)[0]:
-                kx, ky, kw, kh = kept_boxes[j]
-                a0 = int(max(kx - kw / 2, cx - w / 2) - (cx - w / 2))
-                a1 = int(min(kx + kw / 2, cx + w / 2) - (cx - w / 2)) + 1
-                b0 = int(max(ky - kh / 2, cy - h / 2) - (cy - h / 2))
-                b1 = int(min(ky + kh / 2, cy + h / 2) - (cy - h / 2)) + 1
-                covered[a0:a1, b0:b1] = True
-            if np.mean(covered) > 0.5:
-                continue
-        kept_boxes = np.vstack([kept_boxes, np.array([cx, cy, w, h])])
-        kept.append(i)
-
-    final = []
-    for i in kept:
-        x, y = int(locations[i, 1] / scale), int(locations[i, 2] / scale)
-        if 0 <= x < mw and 0 <= y < mh and seps_all[y, x] > 0.5:
-            continue
-        final.append(i)
-    if final:
-        sel = np.array(final)
-        locations, glyphfeatures = locations[sel, :].copy(), glyphfeatures[sel, :]
-    else:
-        locations, glyphfeatures = np.zeros([0, 9]), np.zeros([0, feature_dim], dtype=np.float32)
-    for i in range(locations.shape[0]):
-        cx, cy = locations[i, 1], locations[i, 2]
-        x, y = int(cx / scale), int(cy / scale)
-        if 0 <= x < mw and 0 <= y < mh:
-            xs = slice(max(0, int(cx / scale - 1)), min(mw, int(cx / scale + 1) + 1))
-            ys = slice(max(0, int(cy / scale - 1)), min(mh, int(cy / scale + 1) + 1))
-            for k in range(4):
-                locations[i, 5 + k] = max(np.max(code_all[k][ys, xs]), locations[i, 5 + k])
-    return locations.astype(np.float32), glyphfeatures
-
-
 def page_merge_gpu(boxes: torch.Tensor, feats: torch.Tensor, page: torch.Tensor, canv: torch.Tensor, cut_off: float):
     """GPU page-level selection.  boxes [N,9] fp32 (rows with p < cut_off are inert, e.g. the zero padding of
     ``decode_peaks``), feats [N,C] fp32, page [H,W,3] fp32 0..255, canv [7,mh,mw] fp32 (``ftc_paste_maps``), all on the GPU.

@@ -6,8 +6,9 @@ bit-identical results (same K summation order) but differ up to 2x in speed depe
 workgroups the layer yields and how long its K loop is.  ``tune_plan`` times every legal variant of
 every distinct conv shape of a plan on the GPU (single-op plans over the real operand buffers, HIP
 events through ``ftc_plan_profile``) and records the fastest in a table keyed by the layer signature;
-``apply`` writes the choice into ``ftc_op.aux0``.  The table measured on MI355X is committed as
-``tuning_gfx950.json``; shapes missing from it fall back to the heuristics in conv_igemm_impl.h.
+the library applies the choice (``ftc_op.aux0``) when it builds a plan (csrc/model.hip: the table is compiled in as
+csrc/tuning_table.inc, generated from ``tuning_gfx950.json`` by build.py -- rebuild after re-tuning).  Shapes missing from
+the table fall back to the heuristics in conv_igemm_impl.h.
 
     python -m findtextcenternet_amd.tuning --batch 8 --precision bf16 [--out path.json]
 """
@@ -93,7 +94,8 @@ def candidates(o) -> List[int]:
 
 
 def tune_plan(engine, plan, reps: int = 5, verbose: bool = False) -> Dict[str, int]:
-    """engine: detector._HipEngine with weights + workspace resident and one forward already run."""
+    """engine: detector._HipEngine with weights + workspace resident and one forward already run; plan: model.PlanView built with
+    FTC_NO_TUNING=1 (so that aux0 holds the untuned defaults)."""
     import numpy as np
     import torch
     lib = L.load()
@@ -120,7 +122,7 @@ def tune_plan(engine, plan, reps: int = 5, verbose: bool = False) -> Dict[str, i
             C.memmove(C.byref(one[0]), C.byref(o), C.sizeof(L.Op))
             one[0].aux0 = aux
             h = C.c_void_p()
-            if lib.ftc_plan_create(one, 1, plan.workspace_bytes, engine.pw.nbytes, C.byref(h)) != 0:
+            if lib.ftc_plan_create(one, 1, plan.workspace_bytes, engine.model.weights_bytes, C.byref(h)) != 0:
                 continue                                     # not legal for this op
             ts = []
             ok = lib.ftc_plan_run(h, bases, stream, 0, -1) == 0
@@ -171,7 +173,7 @@ def main():
             with torch.no_grad():
                 det(x)
             eng = model.detector._engine
-            plan = eng.get_plan(B, a.size, a.size, False)
+            plan = eng.plan(B, a.size, a.size, False)
             ch = tune_plan(eng, plan, verbose=True)
             allc.update(ch)
         del det, model
@@ -179,7 +181,7 @@ def main():
     with open(a.out, "w") as f:
         json.dump({"device": "MI355X gfx950", "note": "aux0 per conv signature, measured by findtextcenternet_amd.tuning",
                    "choices": dict(sorted(allc.items()))}, f, indent=0)
-    print("wrote", a.out, len(allc), "entries")
+    print("wrote", a.out, len(allc), "entries -- rebuild the library (python -m findtextcenternet_amd.build) to compile them in")
 
 
 if __name__ == "__main__":

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FTC_ABI_VERSION 2
+#define FTC_ABI_VERSION 3
 
 typedef enum ftc_status {
     FTC_OK = 0,
@@ -195,6 +195,63 @@ int ftc_plan_profile(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], voi
    "conv_igemm<bf16,in=bf16,out=bf16,tile=192x128>"; used to attribute rocprof / HIP-event time. */
 int ftc_op_kernel_label(const ftc_op* op, char* buf, int len);
 
+/* Model ------------------------------------------------------------------------------------ */
+/*
+ * The self-contained entry points a non-Python host binds: the network graph, BatchNorm folding, K-major weight packing,
+ * the activation arena and the measured kernel selection all live in the library.  They replace, for the detector path,
+ *   TextDetectorModel(...).load_state_dict(...) + CenterNetDetector(model.detector)   (/root/reference/process_ocr_torch.py:12-27)
+ *   heatmap, features = detector(images)                                              (/root/reference/process_ocr_torch.py:43-49,
+ *                                                                                       /root/reference/models/detector.py:289-296)
+ */
+typedef struct ftc_tensor {
+    const char* name;          /* state_dict key of the reference checkpoint, with or without the "detector." prefix
+                                  (e.g. "detector.backbone.features.4.0.block.2.fc1.weight"); "decoder.*" keys are ignored */
+    const void* data;          /* HOST pointer, contiguous, row-major in the PyTorch shape (conv weights OIHW) */
+    int32_t dtype;             /* FTC_F32; tensors of any other dtype (num_batches_tracked) are skipped */
+    int32_t ndim;              /* 0..4 */
+    int64_t shape[4];
+} ftc_tensor;
+
+typedef struct ftc_model ftc_model;
+
+/* Folds and packs the checkpoint (host only; a few seconds for the 242 M detector parameters).  model_size: "xl" (default when
+   NULL), "l", "m", "s" (models/detector.py:131-136); precision: FTC_F32 = parity mode (what the reference computes), FTC_BF16 =
+   speed mode (bf16 MFMA, fp32 accumulation / residual trunk / outputs).  Fails with FTC_ERR_INVALID naming the first missing
+   or mis-shaped tensor.  The tensors may be freed after the call. */
+int ftc_create(const ftc_tensor* tensors, int n_tensors, const char* model_size, int precision, ftc_model** out);
+void ftc_destroy(ftc_model* model);
+/* The packed weight blob: the caller copies ftc_weights_bytes() bytes from ftc_weights_host() into device memory
+   (256-byte aligned) once and passes that address to every ftc_forward. */
+int64_t ftc_weights_bytes(const ftc_model* model);
+const void* ftc_weights_host(const ftc_model* model);
+/* Byte offset of a packed tensor inside the blob ("<layer>.w" / "<layer>.b", e.g. "heads.L0.w"), -1 if absent (tests). */
+int64_t ftc_weights_offset(const ftc_model* model, const char* name);
+/* Activation arena the caller must provide for this input shape (builds and caches the plan); -1 on error. */
+int64_t ftc_workspace_bytes(ftc_model* model, int B, int H, int W);
+/*
+ * image: [B,H,W,3] fp32 in 0..1 (NHWC; nchw != 0: [B,3,H,W]) in device memory, H and W multiples of 32;
+ * heatmap [B,H/4,W/4,10] fp32, features [B,H/4,W/4,100] fp32 (device, caller-owned, NHWC);  with_nms = 0 leaves heat-map
+ * channel 1 untouched (CenterNetDetection.forward), != 0 fills it (CenterNetDetector.forward).  Enqueues on `stream`, never
+ * synchronises, allocates nothing.  One model may be used from several host threads with separate workspaces and streams.
+ */
+int ftc_forward(ftc_model* model, const void* weights_dev, const void* image, int B, int H, int W, int nchw, int with_nms,
+                void* heatmap, void* features, void* workspace, void* stream);
+
+/* Introspection (parity tests, profiling, the tuner): the plan ftc_forward runs for a shape -- borrowed, owned by the model. */
+typedef struct ftc_plan_info {
+    int32_t n_ops, map_h, map_w, reserved;
+    int64_t workspace_bytes, weights_bytes, peak_live_bytes, total_buffer_bytes;
+} ftc_plan_info;
+typedef struct ftc_op_info {
+    char name[64];             /* reference module path of the op, e.g. "backbone.features.4.0.block.3" */
+    char kind[16];             /* stem | conv1x1 | conv3x3 | dwconv3x3 | se | upcat | tapsum | nms */
+    double flops;              /* 2 * MACs of the convolution (bias / activation excluded) */
+    double bytes;              /* algorithmic bytes: inputs + outputs + weights, each once */
+} ftc_op_info;
+int ftc_model_plan(ftc_model* model, int B, int H, int W, int nchw, const ftc_plan** plan, ftc_plan_info* info);
+int ftc_model_op_info(ftc_model* model, int B, int H, int W, int nchw, int index, ftc_op_info* out);
+int ftc_plan_op(const ftc_plan* plan, int index, ftc_op* out);
+
 /* Peak decode ------------------------------------------------------------------------------ */
 /* Per-image geometry of the tile being decoded (process_ocr_base.py:487-503). */
 typedef struct ftc_tile {
@@ -208,9 +265,12 @@ typedef struct ftc_tile {
  * 123-143): keeps pixels of heatmap channel 1 (NMS'd key logit) inside the tile's trusted
  * rectangle whose logit >= logit_cut, drops boxes with w,h <= 0 or larger than the page, orders
  * them by (score desc, pixel index asc) and writes for the first `max_boxes` of them
- *   boxes[b, i, 0:9]  = p, ix, iy, w, h, code1, code2, code4, code8   (fp32)
- *   feats[b, i, 0:C]  = features[b, y, x, :]                           (fp32)
- *   index[b, i]       = y * w + x                                      (int32)
+ *   boxes[(b*max_boxes + i)*box_stride + 0..8]  = p, ix, iy, w, h, code1, code2, code4, code8   (fp32)
+ *   feats[(b*max_boxes + i)*feat_stride + 0..C) = features[b, y, x, :]                           (fp32)
+ *   index[b, i]                                 = y * w + x                                      (int32)
+ * Row strides are in floats: box_stride = 9, feat_stride = C give two dense arrays; box_stride = feat_stride = 112 with
+ * feats = boxes + 12 gives ONE record block [B, max_boxes, 112] (box, 3 pad, feature row 16-byte aligned) -- the message
+ * of the multi-GPU box gather, written without a concatenation pass.
  * counts[b] receives the TOTAL number of kept peaks (may exceed max_boxes: caller detects
  * truncation).  heatmap [B,h,w,10] fp32 NHWC, features [B,h,w,C] fp32 NHWC, tiles_dev = B
  * ftc_tile records in DEVICE memory, scratch_dev >= ftc_decode_scratch_bytes(B,h,w) bytes.
@@ -218,7 +278,7 @@ typedef struct ftc_tile {
 int64_t ftc_decode_scratch_bytes(int B, int h, int w);
 int ftc_decode(const float* heatmap, const float* features, int B, int h, int w, int C,
                const ftc_tile* tiles_dev, float logit_cut, int scale, int max_boxes,
-               float* boxes, float* feats, int32_t* index, int32_t* counts,
+               float* boxes, int box_stride, float* feats, int feat_stride, int32_t* index, int32_t* counts,
                void* scratch_dev, void* stream);
 
 /* Page front / back end ("next" rows of SURVEY.md 8f) ----------------------------------------- */

@@ -57,12 +57,11 @@ def main():
     a = ap.parse_args()
 
     from findtextcenternet_amd import _lib as L
-    from findtextcenternet_amd import plan as P
+    from findtextcenternet_amd.model import FtcModel
     from findtextcenternet_amd.weights import deterministic_state_dict
     lib = L.load()
     sd = deterministic_state_dict(0)
-    pw = P.pack_weights(sd, a.precision, "xl")
-    pl = P.build_plan(pw, a.batch, a.size, a.size, False)
+    pl = FtcModel(sd, a.precision, "xl").plan(a.batch, a.size, a.size, False)      # the plan ftc_forward runs (host-only call)
     n_ops = len(pl.meta)
     buf = C.create_string_buffer(128)
     labels = []

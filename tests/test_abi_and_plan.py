@@ -10,7 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from findtextcenternet_amd import _lib as L
-from findtextcenternet_amd import plan as P
+from findtextcenternet_amd.model import FtcModel
 from findtextcenternet_amd import tuning
 from findtextcenternet_amd.weights import deterministic_state_dict
 
@@ -26,6 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert getattr(lib, name) is not None
     assert lib.ftc_abi_version() == L.FTC_ABI_VERSION
     assert C.sizeof(L.Op) == 24 * 4 + 11 * 16 and C.sizeof(L.Ref) == 16 and C.sizeof(L.Tile) == 32
+    assert C.sizeof(L.Tensor) == 56 and C.sizeof(L.PlanInfo) == 48 and C.sizeof(L.OpInfo) == 96
 
 
 def test_device_info_fails_loudly_without_gpu():
@@ -74,12 +75,40 @@ def sd():
     return deterministic_state_dict(0, prefix_detector=False)
 
 
+@pytest.fixture(scope="module")
+def models(sd):
+    """Library-side models (ftc_create: host-only, works without a GPU) of the seeded checkpoint, one per numeric mode."""
+    return {mode: FtcModel(sd, mode) for mode in ("fp32", "bf16")}
+
+
+def _blob(model, name, dtype, shape):
+    off = model.offset(name)
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    return model.weights_host()[off:off + n].view(dtype).reshape(shape).copy()
+
+
+def test_create_rejects_bad_checkpoints(sd):
+    bad = dict(sd)
+    del bad["keyheatmap.top_conv.0.bias"]
+    with pytest.raises(L.FtcError, match="keyheatmap.top_conv.0.bias"):
+        FtcModel(bad, "fp32")
+    bad = dict(sd)
+    bad["backbone.features.4.0.block.2.fc1.weight"] = torch.zeros(24, 383, 1, 1)
+    with pytest.raises(L.FtcError, match="shape"):
+        FtcModel(bad, "bf16")
+    with pytest.raises(L.FtcError, match="model_size"):
+        FtcModel(sd, "fp32", "xxl")
+    m = FtcModel(sd, "bf16")
+    with pytest.raises(L.FtcError, match="multiples of 32"):
+        m.plan(1, 100, 768)
+    # TextDetectorModel keys (detector.* + decoder.*) are accepted as they come out of model.pt
+    full = deterministic_state_dict(0)
+    assert FtcModel(full, "bf16").weights_bytes == m.weights_bytes
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
-def test_plan_structure_flops_and_arena(sd, mode):
-    pw = P.pack_weights(sd, mode)
-    pl = P.build_plan(pw, 2, 768, 768)
-    P.create_handle(pl, pw.nbytes)                       # every op passes the C-side validation
-    L.load().ftc_plan_destroy(pl.handle)
+def test_plan_structure_flops_and_arena(models, mode):
+    pl = models[mode].plan(2, 768, 768)                  # built AND validated (ftc_plan_create rules) inside the library
     # forward work of the reference network (SURVEY.md 8d): 432.50 GMAC = 865.0 GFLOP per image
     assert abs(sum(m.flops for m in pl.meta) / 2 / 1e9 - 865.0006) < 0.01
     kinds = [m.kind for m in pl.meta]
@@ -103,19 +132,21 @@ def test_plan_structure_flops_and_arena(sd, mode):
             if r.base == L.BASE_WORKSPACE:
                 s = spans.setdefault(r.offset, [i, i])
                 s[1] = i
-    assert max(spans) < pl.workspace_bytes and pl.workspace_bytes < 0.5 * pl.total_buffer_bytes
-    assert pl.h == 192 and pl.w == 192
+    assert max(spans) < pl.workspace_bytes and pl.workspace_bytes < 0.5 * pl.info.total_buffer_bytes
+    assert pl.h == 192 and pl.w == 192 and pl.info.weights_bytes == models[mode].weights_bytes
+    # the same op list is accepted by the op-list entry point
+    h = C.c_void_p()
+    assert L.load().ftc_plan_create(pl.ops, len(pl.ops), pl.workspace_bytes, pl.info.weights_bytes, C.byref(h)) == 0
+    L.load().ftc_plan_destroy(h)
 
 
-def test_bn_fold_and_kmajor_layout_match_torch(sd):
-    """pack_weights: conv + eval BatchNorm == conv with folded weights + bias, in the K-major layout."""
-    pw = P.pack_weights(sd, "fp32")
+def test_bn_fold_and_kmajor_layout_match_torch(sd, models):
+    """ftc_create: conv + eval BatchNorm == conv with folded weights + bias, in the K-major layout."""
     name = "backbone.features.2.1.block.0"
     w = sd[name + ".0.weight"]
     cout, cin, k, _ = w.shape
-    off_w, off_b = pw.table[name + ".w"], pw.table[name + ".b"]
-    wk = torch.from_numpy(pw.blob[off_w:off_w + cout * cin * k * k * 4].view(np.float32).reshape(cout, k * k, cin).copy())
-    b = torch.from_numpy(pw.blob[off_b:off_b + cout * 4].view(np.float32).copy())
+    wk = torch.from_numpy(_blob(models["fp32"], name + ".w", np.float32, (cout, k * k, cin)))
+    b = torch.from_numpy(_blob(models["fp32"], name + ".b", np.float32, (cout,)))
     x = torch.randn(1, cin, 9, 9)
     ref = F.batch_norm(F.conv2d(x, w, None, 1, 1), sd[name + ".1.running_mean"], sd[name + ".1.running_var"], sd[name + ".1.weight"],
                        sd[name + ".1.bias"], False, 0.0, 1e-3)
@@ -123,14 +154,12 @@ def test_bn_fold_and_kmajor_layout_match_torch(sd):
     assert float((ref - mine).abs().max()) < 1e-5
 
 
-def test_merged_fpn_level0_border_bias_is_exact(sd):
+def test_merged_fpn_level0_border_bias_is_exact(sd, models):
     """The nine per-head (in_bn -> conv3x3 -> BN) at the 1/32 tap packed as ONE conv with a
     16-case border bias equals the reference composition (Leafmap.forward i=0, detector.py:194-197)."""
-    pw = P.pack_weights(sd, "fp32")
     C4, N = 1280, 9 * 192
-    ow, ob = pw.table["heads.L0.w"], pw.table["heads.L0.b"]
-    wk = torch.from_numpy(pw.blob[ow:ow + N * 9 * C4 * 4].view(np.float32).reshape(N, 3, 3, C4).copy()).permute(0, 3, 1, 2)
-    b16 = torch.from_numpy(pw.blob[ob:ob + 16 * N * 4].view(np.float32).reshape(16, N).copy())
+    wk = torch.from_numpy(_blob(models["fp32"], "heads.L0.w", np.float32, (N, 3, 3, C4))).permute(0, 3, 1, 2)
+    b16 = torch.from_numpy(_blob(models["fp32"], "heads.L0.b", np.float32, (16, N)))
     x = torch.randn(1, C4, 4, 5)
     y = F.conv2d(x, wk, None, 1, 1)
     H, W = 4, 5
@@ -148,12 +177,22 @@ def test_merged_fpn_level0_border_bias_is_exact(sd):
         assert float((ref - y[:, h * 192:(h + 1) * 192]).abs().max()) < 2e-4
 
 
-def test_tuning_table_entries_are_legal():
+def test_tuning_table_entries_are_legal(models):
     tab = tuning.load_table()
     assert isinstance(tab, dict)
     for k, v in tab.items():
         assert 0 <= v <= 0xfff and (v & 15) - 1 < len(tuning.CFG_NAMES), (k, v)
         assert tuning.describe(v)
+    # the table compiled into the library (csrc/tuning_table.inc) is the committed JSON: the bench plan carries its choices
+    pl = models["bf16"].plan(8, 768, 768)
+    hits = 0
+    for i in range(len(pl.ops)):
+        if pl.ops[i].kind == L.OP_CONV:
+            want = tab.get(tuning.signature(pl.ops[i]))
+            if want:
+                hits += 1
+                assert pl.ops[i].aux0 == want, (pl.meta[i].name, pl.ops[i].aux0, want)
+    assert hits > 100
 
 
 def test_drop_in_module_schema_and_loud_failures():

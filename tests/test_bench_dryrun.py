@@ -1,0 +1,36 @@
+"""CPU: bench.py's N>1 code path itself (launched exactly as the driver launches it, 2 ranks, gloo, --dry-run) so that the
+first real multi-GPU run is not the first execution of the sharding / gather / max-over-ranks / JSON code."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_dry_run():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "3",
+           "--max-boxes", "512", "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                         # rank 0 prints ONE JSON line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak" and j["dry_run"] is True
+    assert j["gather_ok"] is True and j["config"]["global_batch"] == 6 and j["value"] > 0
+    # counts first, then only the rows any rank filled: far below the 512-row capacity of the decode block
+    assert 0 < j["gather_message_bytes_per_rank"] <= 3 * 400 * 112 * 4 + 3 * 4 + 8
+
+
+def test_bench_single_rank_dry_run():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--max-boxes", "512"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 1 and j["gather_ok"] is True

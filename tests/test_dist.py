@@ -20,39 +20,52 @@ def test_shard_range_partitions_everything():
             assert got == list(range(n))
 
 
-def _worker(rank, world, port, q):
+W, F0 = 112, 12
+
+
+def _rank_data(r, B, cap):
+    g = torch.Generator().manual_seed(100 + r)
+    counts = torch.randint(0, cap, (B,), generator=g, dtype=torch.int32)
+    rec = torch.randn(B, cap, W, generator=g)
+    return counts, rec
+
+
+def _worker(rank, world, port, q, uneven):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    B, cap, Cf = 3, 16, 100
-    g = torch.Generator().manual_seed(100 + rank)
-    counts = torch.randint(0, cap, (B,), generator=g, dtype=torch.int32)
-    boxes = torch.randn(B, cap, 9, generator=g)
-    feats = torch.randn(B, cap, Cf, generator=g)
-    out = all_gather_boxes(counts, boxes, feats)
-    ok = out.counts.shape == (world * B,) and out.records.shape == (world * B, cap, 9 + Cf)
-    for r in range(world):                                   # every rank sees every rank's records, in rank order
-        gr = torch.Generator().manual_seed(100 + r)
-        c = torch.randint(0, cap, (B,), generator=gr, dtype=torch.int32)
-        bx = torch.randn(B, cap, 9, generator=gr)
-        ft = torch.randn(B, cap, Cf, generator=gr)
-        ok &= torch.equal(out.counts[r * B:(r + 1) * B], c)
-        ok &= torch.equal(out.records[r * B:(r + 1) * B, :, :9], bx) and torch.equal(out.records[r * B:(r + 1) * B, :, 9:], ft)
-    bt, ftile = out.tile(B)                                   # first tile of rank 1
-    ok &= bt.shape[0] == int(out.counts[B])
+    cap = 16
+    n_tiles = 5 if uneven else 6                              # 5 tiles over 2 ranks: shards of 3 and 2
+    shards = [shard_range(n_tiles, r, world) for r in range(world)]
+    Bs = [hi - lo for lo, hi in shards]
+    counts, rec = _rank_data(rank, Bs[rank], cap)
+    out = all_gather_boxes(counts, rec)
+    n_max = max(int(_rank_data(r, Bs[r], cap)[0].max()) for r in range(world))
+    ok = out.counts.shape == (n_tiles,) and out.records.shape == (n_tiles, n_max, W)
+    for r in range(world):                                    # every rank sees every rank's records, in global tile order
+        c, rc = _rank_data(r, Bs[r], cap)
+        lo, hi = shards[r]
+        ok &= torch.equal(out.counts[lo:hi], c)
+        ok &= torch.equal(out.records[lo:hi], rc[:, :n_max])
+    lo1 = shards[1][0]
+    bt, ftile = out.tile(lo1)                                  # first tile of rank 1
+    c1, rc1 = _rank_data(1, Bs[1], cap)
+    n1 = int(c1[0])
+    ok &= bt.shape == (n1, 9) and ftile.shape == (n1, W - F0) and torch.equal(ftile, rc1[0, :n1, F0:])
+    ok &= out.message_bytes_per_rank == max(Bs) * n_max * W * 4 + max(Bs) * 4 + 8
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_all_gather_boxes_world2_gloo():
+def _run_world2(uneven):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, uneven)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(2))
@@ -62,8 +75,16 @@ def test_all_gather_boxes_world2_gloo():
     assert res == [(0, True), (1, True)]
 
 
+def test_all_gather_boxes_world2_gloo():
+    _run_world2(False)
+
+
+def test_all_gather_boxes_uneven_shards_world2_gloo():
+    _run_world2(True)
+
+
 def test_single_process_passthrough():
     counts = torch.tensor([2, 0], dtype=torch.int32)
-    boxes, feats = torch.randn(2, 4, 9), torch.randn(2, 4, 100)
-    out = all_gather_boxes(counts, boxes, feats)
-    assert torch.equal(out.counts, counts) and torch.equal(out.records[..., :9], boxes)
+    rec = torch.randn(2, 4, W)
+    out = all_gather_boxes(counts, rec)
+    assert torch.equal(out.counts, counts) and torch.equal(out.records, rec[:, :2]) and out.message_bytes_per_rank == 0

@@ -96,7 +96,7 @@ def test_truncation_empty_and_ties():
     empty = hm.copy()
     empty[:, 1] = -np.inf
     d = decode_peaks(_nhwc(empty), _nhwc(ft), [g], cut_off=0.4)
-    assert int(d.counts[0]) == 0 and (d.index == -1).all() and (d.boxes == 0).all()
+    assert int(d.counts[0]) == 0 and (d.index == -1).all() and (d.boxes == 0).all() and (d.records == 0).all()
     tie = np.full((1, 10, 192, 192), -5.0, np.float32)
     tie[0, 1] = -np.inf
     for (y, x) in [(100, 7), (3, 150), (3, 20), (50, 50)]:
@@ -119,3 +119,26 @@ def test_cut_off_boundary_is_exact():
         ft = np.zeros((1, 100, 8, 8), np.float32)
         d = decode_peaks(_nhwc(hm), _nhwc(ft), [TileGeom(0, 0, 1000, 1000, (0, 8, 0, 8))], cut_off=cut)
         assert int(d.counts[0]) == 1 and int(d.index[0, 0]) == 2 * 8 + 2
+
+
+def test_record_block_and_workspace_reuse():
+    """boxes / feats are views of ONE [B, max, 112] record block (the multi-GPU gather message, written by the kernel itself),
+    and a preallocated DecodeWorkspace gives the same rows as a fresh zero-filled one up to counts[b]."""
+    from findtextcenternet_amd.decode import REC_FEAT0, REC_W, DecodeWorkspace
+    hm = np.concatenate([synth.detector_maps(31)[0], synth.detector_maps(32)[0]])
+    ft = np.concatenate([synth.detector_maps(31)[1], synth.detector_maps(32)[1]])
+    g = [TileGeom(0, 0, 768, 768, tile_keep_rect(0, 0, 768, 768, 0.6))] * 2
+    fresh = decode_peaks(_nhwc(hm), _nhwc(ft), g, cut_off=0.4, max_boxes=2048)
+    assert fresh.records.shape == (2, 2048, REC_W) and fresh.boxes.data_ptr() == fresh.records.data_ptr()
+    assert fresh.feats.data_ptr() == fresh.records.data_ptr() + 4 * REC_FEAT0 and (fresh.records[:, :, 9:REC_FEAT0] == 0).all()
+    ws = DecodeWorkspace(2, 192, 192, 100, 2048, "cuda")
+    ws.records.fill_(7.0)                                                # stale contents of an earlier call
+    for _ in range(2):
+        d = decode_peaks(_nhwc(hm), _nhwc(ft), g, cut_off=0.4, max_boxes=2048, workspace=ws)
+        assert torch.equal(d.counts, fresh.counts)
+        for b in range(2):
+            n = int(d.counts[b])
+            assert torch.equal(d.boxes[b, :n], fresh.boxes[b, :n]) and torch.equal(d.feats[b, :n], fresh.feats[b, :n])
+            assert torch.equal(d.index[b, :n], fresh.index[b, :n])
+    with pytest.raises(ValueError):
+        decode_peaks(_nhwc(hm[:1]), _nhwc(ft[:1]), g[:1], cut_off=0.4, max_boxes=2048, workspace=ws)

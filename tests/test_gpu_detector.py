@@ -19,6 +19,10 @@ from oracle import decode_oracle
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
+# peak-set agreement of the bf16 speed mode with the fp32 reference golden; the reference itself under CPU bf16 autocast reaches
+# 0.85 Jaccard / 0.93 recall against its own fp32 run (1590 common of 1702 vs 1765)
+BF16_JACCARD_GATE = 0.88
+BF16_RECALL_GATE = 0.93
 
 
 def _log(msg):
@@ -231,9 +235,11 @@ def test_forward_768_bf16_speed_mode(det_bf16, golden_dir):
     _, _, idx_bf = decode_oracle.decode_tile(hm, np.zeros((1, 100, 192, 192), np.float32), 0, 0, 768, 768, 0.4, rect)
     inter = len(set(idx_ref) & set(idx_bf))
     jac = inter / max(1, len(set(idx_ref) | set(idx_bf)))
+    recall = inter / max(1, len(set(idx_ref)))
     _log(f"bf16 768 page: heatmap Linf {e:.3e} ({100 * e / rng:.2f}% of range {rng:.1f})  features Linf {e_ft:.3e} "
-         f"({100 * e_ft / frng:.2f}% of range)  peaks ref {len(idx_ref)} bf16 {len(idx_bf)} common {inter} jaccard {jac:.3f}")
-    assert e / rng < 0.05 and e_ft / frng < 0.05 and jac > 0.85
+         f"({100 * e_ft / frng:.2f}% of range)  peaks ref {len(idx_ref)} bf16 {len(idx_bf)} common {inter} jaccard {jac:.3f} recall {recall:.3f} "
+         f"(the reference under its own CPU bf16 autocast: jaccard 0.847, recall 0.934 -- SURVEY.md Appendix C)")
+    assert e / rng < 0.05 and e_ft / frng < 0.05 and jac >= BF16_JACCARD_GATE and recall >= BF16_RECALL_GATE
 
 
 @pytest.mark.parametrize("shape", [(3, 256, 192), (1, 320, 544), (5, 128, 128), (2, 448, 768)], ids=lambda s: "x".join(map(str, s)))
@@ -256,3 +262,85 @@ def test_bf16_mode_tracks_fp32_mode_on_other_geometries(det_fp32, det_bf16, shap
     _log(f"bf16 vs fp32 {shape}: heatmap Linf {100 * e / rng:.2f}% of range, features {100 * ef / frng:.2f}%, NMS flips {flips} of {h32[:, 1].size}")
     assert e / rng < 0.03 and ef / frng < 0.03
     assert flips < 0.02 * h32[:, 1].size
+
+
+def _peak_sets(hm):
+    rect = tile_keep_rect(0, 0, 768, 768, 0.6)
+    z = np.zeros((1, 100, 192, 192), np.float32)
+    return [set(decode_oracle.decode_tile(hm[b:b + 1], z, 0, 0, 768, 768, 0.4, rect)[2].tolist()) for b in range(hm.shape[0])]
+
+
+@pytest.mark.parametrize("B", [8, 32])
+def test_bench_plans_b8_b32_bf16_match_their_b1_results_and_the_golden(det_bf16, golden_dir, B):
+    """BASELINE configs[1] (batch 8, what bench.py times) and configs[3] (batch 32, forward + NMS + decode + gather): the plan is
+    built per batch size and the measured kernel table is keyed by it, so the big-batch plans get their own check -- every image
+    against the SAME image run alone (tiles are independent units), image 0 against the reference golden, and the GPU decode of
+    the whole batch against the oracle decode of the same maps."""
+    g = np.load(os.path.join(golden_dir, "g2_fwd768_page.npz"))
+    imgs = np.concatenate([synth.page_images(4242, 1, 768, 768)] + [synth.noise_images(900 + i, 1, 768, 768) if i % 2 else
+                                                                     synth.page_images(900 + i, 1, 768, 768) for i in range(1, B)])
+    x = torch.from_numpy(imgs).permute(0, 3, 1, 2).to("cuda")
+    with torch.no_grad():
+        heat, feat = det_bf16.forward_nhwc(x)
+        rect = tile_keep_rect(0, 0, 768, 768, 0.6)
+        dec = decode_peaks(heat, feat, [TileGeom(0, 0, 768, 768, rect)] * B, cut_off=0.4, max_boxes=4096)
+        hm = heat.permute(0, 3, 1, 2).cpu().numpy()
+        ft = feat.permute(0, 3, 1, 2).cpu().numpy()
+        worst, worst_f, flips, npx, jmin = 0.0, 0.0, 0, 0, 1.0
+        sets_b = _peak_sets(hm)
+        for b in ([0, 1, 2, B // 2, B - 1] if B > 8 else range(B)):
+            h1, f1 = det_bf16.forward_nhwc(x[b:b + 1])
+            h1, f1 = h1.permute(0, 3, 1, 2).cpu().numpy(), f1.permute(0, 3, 1, 2).cpu().numpy()
+            fin = np.isfinite(h1) & np.isfinite(hm[b:b + 1])
+            rng_b = float(h1[np.isfinite(h1)].max() - h1[np.isfinite(h1)].min())
+            worst = max(worst, float(np.abs(h1[fin] - hm[b:b + 1][fin]).max()) / rng_b)
+            worst_f = max(worst_f, float(np.abs(f1 - ft[b:b + 1]).max()) / float(f1.max() - f1.min()))
+            flips += int((np.isfinite(h1[:, 1]) != np.isfinite(hm[b:b + 1, 1])).sum())
+            npx += h1[:, 1].size
+            s1 = _peak_sets(h1)[0]
+            jmin = min(jmin, len(s1 & sets_b[b]) / max(1, len(s1 | sets_b[b])))
+    # Same network and the same bf16 rounding POINTS in both plans, but the batch-N plan picks other tile shapes / split-K variants
+    # (measured per shape): their fp32 sums associate differently, which moves a fraction of the bf16 roundings of the activations
+    # by one ulp.  Two bf16 plans therefore agree to bf16 noise (as bf16 vs fp32 does), not to fp32 noise.
+    _log(f"bf16 B={B} vs B=1 plans: heatmap Linf {100 * worst:.2f}% of range, features {100 * worst_f:.2f}%, NMS flips {flips} of {npx}, "
+         f"min peak jaccard {jmin:.3f}")
+    assert worst < 0.02 and worst_f < 0.02 and flips < 0.02 * npx and jmin >= BF16_JACCARD_GATE
+    gh = g["heatmap"]
+    both = np.isfinite(hm[:1]) & np.isfinite(gh)
+    rng = float(gh[np.isfinite(gh)].max() - gh[np.isfinite(gh)].min())
+    e = float(np.abs(hm[:1][both] - gh[both]).max())
+    ref, got = _peak_sets(gh)[0], sets_b[0]
+    jac = len(ref & got) / max(1, len(ref | got))
+    recall = len(ref & got) / max(1, len(ref))
+    _log(f"bf16 B={B} image 0 vs reference golden: heatmap Linf {e:.3e} ({100 * e / rng:.2f}% of range), peak jaccard {jac:.3f} recall {recall:.3f}")
+    assert e / rng < 0.03 and jac >= BF16_JACCARD_GATE and recall >= BF16_RECALL_GATE
+    # GPU decode + gather of the whole batch == oracle decode of the same maps (bit-exact index sets, copied feature rows)
+    for b in range(B):
+        n = int(dec.counts[b])
+        assert n == len(sets_b[b]) and set(dec.index[b, :n].cpu().tolist()) == sets_b[b]
+        k = min(n, 16)
+        idx = dec.index[b, :k].cpu().numpy()
+        assert np.array_equal(dec.feats[b, :k].cpu().numpy(), ft[b].reshape(100, -1)[:, idx].T)
+
+
+def test_parameter_edits_are_noticed(sd):
+    """The packed weight blob must follow the module: in-place edits (optimizer.step(), p.data.copy_()), dtype round trips and
+    load_state_dict all change the next forward; a deep copy gets its own engine."""
+    import copy
+    m = TextDetectorModel(pre_weights=False, precision="bf16")
+    m.load_state_dict(sd)
+    d = CenterNetDetector(m.detector).to("cuda").eval()
+    x = torch.from_numpy(synth.page_images(3, 1, 128, 128)).permute(0, 3, 1, 2).to("cuda")
+    with torch.no_grad():
+        h0, _ = d(x)
+        p = m.detector.keyheatmap.top_conv._modules["0"].bias
+        p.add_(1.0)                                        # what an optimizer step does
+        h1, _ = d(x)
+        assert float((h1[:, 0] - h0[:, 0] - 1.0).abs().max()) < 1e-5
+        p.data = p.data - 1.0                              # re-allocation: same version, new address
+        h2, _ = d(x)
+        assert torch.equal(h2[:, 0], h0[:, 0])
+        d2 = copy.deepcopy(d)
+        assert d2.detector._engine is not d.detector._engine and d2.detector._engine.model is None
+        h3, _ = d2(x)
+        assert torch.equal(h3, h2)

@@ -76,3 +76,35 @@ def test_throughput_of_the_fused_step_is_hbm_bound():
     with open("gpurun_out/test_ops.log", "a") as f:
         f.write(f"adamw_schedulefree fused step: {n / 1e6:.0f} M params {ms:.3f} ms = {gbs:.0f} GB/s\n")
     assert gbs > 1500
+
+
+def test_state_reload_rebuilds_the_pointer_table():
+    """load_state_dict() replaces the state tensors while parameter and gradient keep their addresses: the cached chunk table
+    (raw device pointers) must be rebuilt, and a deep-copied optimizer must work (its table cache is not restored)."""
+    import copy
+    torch.manual_seed(0)
+    p = torch.nn.Parameter(torch.randn(5000, device="cuda"))
+    opt = AdamWScheduleFree([p], lr=0.01, warmup_steps=0)
+    opt.train()
+    g = torch.randn(5000, device="cuda")
+    p.grad = g.clone()
+    opt.step()
+    saved = copy.deepcopy(opt.state_dict())
+    snap = p.detach().clone()
+    p.grad = g.clone()
+    opt.step()                                   # step 2 from the live state
+    after_live = p.detach().clone()
+    with torch.no_grad():
+        p.copy_(snap)                            # back to the state after step 1
+    opt.load_state_dict(saved)                   # NEW z / exp_avg_sq tensors, same parameter and gradient addresses
+    p.grad.copy_(g)
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(p.detach(), after_live)   # the restored state was used (and nothing was written through stale pointers)
+    opt2 = copy.deepcopy(opt)
+    assert "_tables" not in opt2.__dict__
+    p2 = opt2.param_groups[0]["params"][0]
+    p2.grad = g.clone()
+    opt2.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(p2).all()

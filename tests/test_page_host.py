@@ -1,5 +1,6 @@
-"""CPU: the host-side page merge and the linedetect wire format of findtextcenternet_amd.page against
-the reference's own outputs (tests/golden/g3_decode_*.npz, written by OCR_Processer.run_detector)."""
+"""CPU: the oracle's page merge (oracle/decode_oracle.py, the checker of the GPU page kernels) and the tiling rule / linedetect
+wire format of findtextcenternet_amd.page against the reference's own outputs (tests/golden/g3_decode_*.npz, written by
+OCR_Processer.run_detector)."""
 import os
 
 import numpy as np
@@ -31,7 +32,7 @@ def test_page_merge_matches_reference_run_detector():
         l, f, _ = decode_oracle.decode_tile(hm, ft, x, y, pw, ph, 0.4, rect)
         locs.append(l)
         feats.append(f)
-    loc, gf = page.page_merge(np.concatenate(locs), np.concatenate(feats), img, canv[2], canv[3:], 0.4)
+    loc, gf = decode_oracle.page_merge(np.concatenate(locs), np.concatenate(feats), img, canv[2], canv[3:], 0.4)
     assert loc.shape == g["locations"].shape and loc.shape[0] > 100
     assert np.array_equal(loc, g["locations"]) and np.array_equal(gf, g["glyphfeatures"])
 
@@ -44,10 +45,10 @@ def test_page_merge_single_tile_and_empty():
     canv = [np.zeros([192, 192], np.float32) for _ in range(7)]
     decode_oracle.paste_maps(canv, hm, 0, 0, rect)
     l, f, _ = decode_oracle.decode_tile(hm, ft, 0, 0, 768, 768, 0.4, rect)
-    loc, gf = page.page_merge(np.concatenate([np.zeros([1, 9]), l]), np.concatenate([np.zeros([1, 100], np.float32), f]), img,
+    loc, gf = decode_oracle.page_merge(np.concatenate([np.zeros([1, 9]), l]), np.concatenate([np.zeros([1, 100], np.float32), f]), img,
                               canv[2], canv[3:], 0.4)
     assert np.array_equal(loc, g["locations"]) and np.array_equal(gf, g["glyphfeatures"])
-    loc, gf = page.page_merge(np.zeros([1, 9]), np.zeros([1, 100], np.float32), img, canv[2], canv[3:], 0.4)
+    loc, gf = decode_oracle.page_merge(np.zeros([1, 9]), np.zeros([1, 100], np.float32), img, canv[2], canv[3:], 0.4)
     assert loc.shape == (0, 9) and gf.shape == (0, 100)
 
 

@@ -22,7 +22,7 @@ with torch.no_grad():
 torch.cuda.synchronize()
 lib = L.load()
 eng = model.detector._engine
-pl = eng.get_plan(B, 768, 768, False)
+pl = eng.plan(B, 768, 768, False)
 heat = torch.empty((B, pl.h, pl.w, 10), dtype=torch.float32, device="cuda")
 feat = torch.empty((B, pl.h, pl.w, 100), dtype=torch.float32, device="cuda")
 bases = (C.c_void_p * L.NUM_BASES)(None, eng.workspace.data_ptr(), eng.wdev.data_ptr(), x.data_ptr(), heat.data_ptr(), feat.data_ptr())

@@ -22,7 +22,9 @@ EXPORTS = ["ftc_abi_version", "ftc_last_error", "ftc_device_info", "ftc_plan_cre
            "ftc_plan_num_ops", "ftc_plan_run", "ftc_plan_profile", "ftc_op_kernel_label", "ftc_decode_scratch_bytes", "ftc_decode", "ftc_tile_gather", "ftc_paste_maps",
            "ftc_page_merge_scratch_bytes", "ftc_box_hists", "ftc_page_merge", "ftc_adamw_schedulefree_step",
            "ftc_create", "ftc_destroy", "ftc_weights_bytes", "ftc_weights_host", "ftc_weights_offset", "ftc_workspace_bytes", "ftc_forward",
-           "ftc_model_plan", "ftc_model_op_info", "ftc_plan_op"]
+           "ftc_model_plan", "ftc_model_op_info", "ftc_plan_op",
+           "ftc_topk_mask", "ftc_mask_compact", "ftc_gather_rows", "ftc_decoder_workspace_bytes", "ftc_decoder_forward",
+           "ftc_losses_scratch_bytes", "ftc_losses", "ftc_cov_weighting_step"]
 
 
 class FtcLibraryError(RuntimeError):
@@ -117,6 +119,15 @@ def load():
     lib.ftc_model_plan.argtypes = [vp, i32, i32, i32, i32, C.POINTER(vp), C.POINTER(PlanInfo)]
     lib.ftc_model_op_info.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(OpInfo)]
     lib.ftc_plan_op.argtypes = [vp, i32, C.POINTER(Op)]
+    lib.ftc_topk_mask.argtypes = [vp, i64, i64, vp, vp, vp, vp]
+    lib.ftc_mask_compact.argtypes = [vp, i64, vp, i64, vp, vp]
+    lib.ftc_gather_rows.argtypes = [vp, vp, vp, i64, i32, i32, vp, i32, vp]
+    lib.ftc_decoder_workspace_bytes.argtypes = [vp, i32]
+    lib.ftc_decoder_workspace_bytes.restype = i64
+    lib.ftc_decoder_forward.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    lib.ftc_losses_scratch_bytes.restype = i64
+    lib.ftc_losses.argtypes = [vp, C.POINTER(i64), vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp]
+    lib.ftc_cov_weighting_step.argtypes = [vp, i32, i32, vp, vp, vp]
     if lib.ftc_abi_version() != FTC_ABI_VERSION:
         raise FtcLibraryError(f"ABI mismatch: library {lib.ftc_abi_version()} vs binding {FTC_ABI_VERSION}")
     _lib = lib

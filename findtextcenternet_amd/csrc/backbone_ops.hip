@@ -385,6 +385,60 @@ __global__ __launch_bounds__(256) void se_fc2_kernel(const float* __restrict__ h
     }
 }
 
+
+// FOLD, second version (bf16 speed mode).  The first version spent ~5 us of each launch in its prologue: every lane walked the S
+// rows of fc2 for ITS channel with only 8 loads in flight.  Here a workgroup owns 64 channels: the 256 lanes split S four ways
+// (all of a lane's S/4 loads independent and unrolled), the four partial dots meet in LDS in fixed order, and the 64 scale values
+// then stream the [N][64] column block of the project weights: 8 lanes x 16 B per row, 32 rows per pass, rows split over gridDim.z.
+// Same arithmetic per element as se_fc2_kernel<true> except for the association of the S-sum (4 partial sums of S/4 terms).
+__global__ __launch_bounds__(256) void se_fc2_fold64_kernel(const float* __restrict__ hidden, const float* __restrict__ w2t,
+                                                            const float* __restrict__ b2, float* __restrict__ scale, int C, int S,
+                                                            const __bf16* __restrict__ wp, __bf16* __restrict__ wb, int N) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];      // [S] hidden | [4][64] partial dots | [64] scale
+    float* hid = lds_f;
+    float* part = lds_f + ((S + 3) & ~3);
+    float* lsc = part + 256;
+    const int b = blockIdx.y, t = threadIdx.x;
+    for (int s = t; s < S; s += 256) hid[s] = hidden[(long)b * S + s];
+    __syncthreads();
+    const int cl = t & 63, sg = t >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int s_lo = sg * ((S + 3) / 4), s_hi = min(S, s_lo + (S + 3) / 4);
+    float acc = 0.f;
+    if (c < C) {
+#pragma unroll 8
+        for (int s = s_lo; s < s_hi; ++s) acc += hid[s] * w2t[(long)s * C + c];
+    }
+    part[sg * 64 + cl] = acc;
+    __syncthreads();
+    if (t < 64) {
+        float sc = 0.f;
+        if (c < C) {
+            sc = sigmoid_precise(b2[c] + ((part[cl] + part[64 + cl]) + (part[128 + cl] + part[192 + cl])));
+            if (blockIdx.z == 0) scale[(long)b * C + c] = sc;
+        }
+        lsc[cl] = sc;
+    }
+    __syncthreads();
+    const int chunk = t & 7, r0 = t >> 3;                         // 8 lanes x 8 channels = the 64-channel block, 32 rows per pass
+    const int cc = blockIdx.x * 64 + chunk * 8;
+    if (cc >= C) return;                                           // C % 8 == 0 (validated)
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = lsc[chunk * 8 + e];
+    const int rows = (N + gridDim.z - 1) / gridDim.z;
+    const int n_lo = blockIdx.z * rows, n_hi = min(N, n_lo + rows);
+    __bf16* dst = wb + (long)b * N * C;
+#pragma unroll 4
+    for (int n = n_lo + r0; n < n_hi; n += 32) {
+        float x[8];
+        load16<__bf16>(wp + (long)n * C + cc, x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] *= f[e];
+        store16<__bf16>(dst + (long)n * C + cc, x);
+    }
+}
+
 }  // namespace
 
 hipError_t launch_stem(const OpArgs& a, hipStream_t s) {
@@ -441,7 +495,14 @@ hipError_t launch_se(const OpArgs& a, hipStream_t s) {
                        (const float*)a.w, a.bias, hidden, C, S, P, 1.0f / (float)(o.H * o.W));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (o.flags & FTC_FLAG_SE_FOLD) {
+    if ((o.flags & FTC_FLAG_SE_FOLD) && !(o.flags & 0x100)) {
+        const int cb = (C + 63) / 64;
+        int nz = (768 + cb * o.B - 1) / (cb * o.B);                  // ~3 workgroups per CU
+        const int max_nz = (o.Cout_total + 31) / 32;
+        nz = nz < 1 ? 1 : nz > max_nz ? max_nz : nz;
+        hipLaunchKernelGGL(se_fc2_fold64_kernel, dim3(cb, o.B, nz), dim3(256), (size_t)(((S + 3) & ~3) + 256 + 64) * sizeof(float), s, hidden,
+                           (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)a.in, (__bf16*)a.out2, o.Cout_total);
+    } else if (o.flags & FTC_FLAG_SE_FOLD) {                         // 0x100: the first version (kept for A/B measurements)
         const int cb = (C + 255) / 256;
         int nz = 512 / (cb * o.B);
         nz = nz < 1 ? 1 : nz > 8 ? 8 : nz;

@@ -23,6 +23,14 @@ hipError_t launch_greedy(const float* loc, const int* order, int N, const double
 hipError_t launch_paste_maps(const float* heat, const ftc_tile* tiles, int B, int h, int w, int scale, float* canv, int ph, int pw,
                              hipStream_t s);
 
+hipError_t launch_topk_mask(const float* vals, long n, long k, unsigned char* mask, int32_t* sel_index, int32_t* count, hipStream_t s);
+hipError_t launch_mask_compact(const unsigned char* mask, long n, int32_t* sel_index, long cap, int32_t* count, hipStream_t s);
+hipError_t launch_gather_rows(const float* feat, const int32_t* sel_index, const int32_t* count, long cap, int C, int Cpad, void* rows, int out_dtype,
+                              hipStream_t s);
+hipError_t launch_losses(const float* heat, const long* hstrides, const float* label, const int32_t* idmap, int B, int h, int w, const float* const* dec,
+                         const int* mod, const int32_t* sel_index, const int32_t* count, long cap, float* out, void* scratch, hipStream_t s);
+hipError_t launch_cov_step(const float* L, int n, int iter, float* state, float* out_loss, hipStream_t s);
+
 namespace {
 
 thread_local std::string g_err;
@@ -343,6 +351,58 @@ int ftc_adamw_schedulefree_step(const ftc_mt_chunk* chunks_dev, int n_chunks, fl
     hipError_t e = launch_adamw_sf(chunks_dev, n_chunks, beta2, one_minus_beta2, bias_correction2, eps, weight_decay, ckp1, y_alpha, lr,
                                    write_grad, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(e, "ftc_adamw_schedulefree_step");
+    return FTC_OK;
+}
+
+int ftc_topk_mask(const float* values, int64_t n, int64_t k, unsigned char* mask, int32_t* sel_index, int32_t* count, void* stream) {
+    if (!values || !mask) return fail(FTC_ERR_INVALID, "ftc_topk_mask: null pointer argument");
+    if (n <= 0 || n >= 0x7fffffffL || k < 0) return fail(FTC_ERR_INVALID, "ftc_topk_mask: need 0 < n < 2^31 and k >= 0");
+    hipError_t e = launch_topk_mask(values, (long)n, (long)k, mask, sel_index, count, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "ftc_topk_mask");
+    return FTC_OK;
+}
+
+int ftc_mask_compact(const unsigned char* mask, int64_t n, int32_t* sel_index, int64_t cap, int32_t* count, void* stream) {
+    if (!mask || !sel_index || !count) return fail(FTC_ERR_INVALID, "ftc_mask_compact: null pointer argument");
+    if (n <= 0 || n >= 0x7fffffffL || cap < 0) return fail(FTC_ERR_INVALID, "ftc_mask_compact: need 0 < n < 2^31 and cap >= 0");
+    hipError_t e = launch_mask_compact(mask, (long)n, sel_index, (long)cap, count, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "ftc_mask_compact");
+    return FTC_OK;
+}
+
+int ftc_gather_rows(const float* features, const int32_t* sel_index, const int32_t* count, int64_t cap, int C, int c_pad, void* rows,
+                    int out_dtype, void* stream) {
+    if (!features || !sel_index || !rows) return fail(FTC_ERR_INVALID, "ftc_gather_rows: null pointer argument");
+    if (cap <= 0 || C <= 0 || (C & 3) || c_pad < C || (c_pad & 7) || (out_dtype != FTC_F32 && out_dtype != FTC_BF16))
+        return fail(FTC_ERR_INVALID, "ftc_gather_rows: need cap > 0, C % 4 == 0, c_pad >= C, c_pad % 8 == 0, out_dtype fp32 | bf16");
+    hipError_t e = launch_gather_rows(features, sel_index, count, (long)cap, C, c_pad, rows, out_dtype, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "ftc_gather_rows");
+    return FTC_OK;
+}
+
+int64_t ftc_losses_scratch_bytes(void) { return (int64_t)(512 * 9 + 512 * 4) * 8; }
+
+int ftc_losses(const float* heatmap, const int64_t heat_strides[4], const float* labelmap, const int32_t* idmap, int B, int h, int w,
+               const float* dec0, const float* dec1, const float* dec2, const int32_t* sel_index, const int32_t* count, int64_t cap,
+               float* out, void* scratch, void* stream) {
+    if (!heatmap || !heat_strides || !labelmap || !idmap || !out || !scratch) return fail(FTC_ERR_INVALID, "ftc_losses: null pointer argument");
+    if (B <= 0 || h <= 0 || w <= 0) return fail(FTC_ERR_INVALID, "ftc_losses: bad sizes");
+    const bool has_dec = dec0 || dec1 || dec2;
+    if (has_dec && (!dec0 || !dec1 || !dec2 || !sel_index || !count || cap <= 0)) return fail(FTC_ERR_INVALID, "ftc_losses: decoder outputs need all three heads, sel_index, count and cap > 0");
+    const long hs[4] = {(long)heat_strides[0], (long)heat_strides[1], (long)heat_strides[2], (long)heat_strides[3]};
+    const float* dec[3] = {dec0, dec1, dec2};
+    static const int mod[3] = {1091, 1093, 1097};                   // util_func.py:5 modulo_list
+    hipError_t e = launch_losses(heatmap, hs, labelmap, idmap, B, h, w, has_dec ? dec : nullptr, mod, sel_index, count, (long)cap, out, scratch,
+                                 static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "ftc_losses");
+    return FTC_OK;
+}
+
+int ftc_cov_weighting_step(const float* losses, int n, int iteration, float* state, float* out_loss, void* stream) {
+    if (!losses || !state || !out_loss) return fail(FTC_ERR_INVALID, "ftc_cov_weighting_step: null pointer argument");
+    if (n <= 0 || n > 16 || iteration < 0) return fail(FTC_ERR_INVALID, "ftc_cov_weighting_step: need 0 < n <= 16 and iteration >= 0");
+    hipError_t e = launch_cov_step(losses, n, iteration, state, out_loss, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "ftc_cov_weighting_step");
     return FTC_OK;
 }
 

@@ -69,6 +69,8 @@ constexpr double BACKBONE_BN_EPS = 1e-3, HEAD_BN_EPS = 1e-5;     // models/detec
 const HeadSpec HEADS[9] = {{"keyheatmap", 1, 0}, {"sizes", 2, 1}, {"textline", 1, 3}, {"sepatator", 1, 4}, {"code1", 1, 5},
                            {"code2", 1, 6}, {"code4", 1, 7}, {"code8", 1, 8}, {"feature", FEATURE_DIM, -1}};
 constexpr int NHEADS = 9;
+constexpr int DECODER_MID = 2048, DECODER_KPAD = 128;
+const int DECODER_MODULO[3] = {1091, 1093, 1097};          // util_func.py:5 modulo_list
 
 int make_divisible(double v, int d = 8) {        // torchvision _make_divisible
     int nv = std::max(d, (int)(v + d / 2.0) / d * d);
@@ -240,8 +242,10 @@ struct ftc_model {
     std::string size;
     int precision;                          // FTC_F32 | FTC_BF16
     Blob blob;
+    bool has_decoder = false;               // the checkpoint carried the "decoder.*" tensors (SimpleDecoder)
     std::mutex mu;
     std::map<std::tuple<int, int, int, int>, std::unique_ptr<ModelPlan>> plans;
+    std::map<int, std::unique_ptr<ModelPlan>> decoder_plans;     // by number of rows
 };
 
 namespace {
@@ -446,6 +450,33 @@ int pack_weights(ftc_model* m, Weights& w) {
         }
     }
     if (!ok) return ftc_set_error(FTC_ERR_INVALID, "ftc_create: " + (w.missing.empty() ? std::string("weight packing failed") : w.missing));
+    // SimpleDecoder (models/detector.py:232-254), optional: three MLPs Linear(100,2048,no bias) -> BatchNorm1d -> GELU -> Linear(2048,2048,
+    // no bias) -> BatchNorm1d -> GELU -> Linear(2048, modulo).  Eval-mode BatchNorm1d (eps 1e-5) folds into the Linear before it; a Linear
+    // weight [out][in] already is the K-major layout of a 1x1 convolution.  The first layer's K is zero-padded 100 -> 128.
+    if (w.t.count("decoder.blocks.0.0.weight")) {
+        for (int i = 0; i < 3 && ok; ++i) {
+            const std::string p = "decoder.blocks." + std::to_string(i), q = "decoder." + std::to_string(i);
+            const int mod = DECODER_MODULO[i];
+            const TensorView *w0 = w.get(p + ".0.weight", {DECODER_MID, FEATURE_DIM}), *w1 = w.get(p + ".3.weight", {DECODER_MID, DECODER_MID}),
+                             *w2 = w.get(p + ".6.weight", {mod, DECODER_MID}), *b2 = w.get(p + ".6.bias", {mod});
+            BnAffine a0, a1;
+            if (!w0 || !w1 || !w2 || !b2 || !bn_affine(w, p + ".1", DECODER_MID, HEAD_BN_EPS, &a0) || !bn_affine(w, p + ".4", DECODER_MID, HEAD_BN_EPS, &a1)) { ok = false; break; }
+            std::vector<double> l0((size_t)DECODER_MID * DECODER_KPAD, 0.0), l1((size_t)DECODER_MID * DECODER_MID), l2((size_t)mod * DECODER_MID);
+            for (int o = 0; o < DECODER_MID; ++o) {
+                for (int c = 0; c < FEATURE_DIM; ++c) l0[(size_t)o * DECODER_KPAD + c] = (double)w0->data[(size_t)o * FEATURE_DIM + c] * a0.s[o];
+                for (int c = 0; c < DECODER_MID; ++c) l1[(size_t)o * DECODER_MID + c] = (double)w1->data[(size_t)o * DECODER_MID + c] * a1.s[o];
+            }
+            for (size_t j = 0; j < l2.size(); ++j) l2[j] = (double)w2->data[j];
+            bl.add_compute(q + ".l0.w", l0.data(), (int64_t)l0.size(), bf);
+            bl.add_f32(q + ".l0.b", a0.t.data(), DECODER_MID);
+            bl.add_compute(q + ".l1.w", l1.data(), (int64_t)l1.size(), bf);
+            bl.add_f32(q + ".l1.b", a1.t.data(), DECODER_MID);
+            bl.add_compute(q + ".l2.w", l2.data(), (int64_t)l2.size(), bf);
+            bl.add_f32(q + ".l2.b", b2->data, mod);
+        }
+        if (!ok) return ftc_set_error(FTC_ERR_INVALID, "ftc_create: decoder: " + (w.missing.empty() ? std::string("weight packing failed") : w.missing));
+        m->has_decoder = true;
+    }
     return FTC_OK;
 }
 
@@ -502,6 +533,7 @@ public:
         cdt_ = act_;
     }
     int build(ModelPlan* out);
+    int build_decoder(ModelPlan* out);          // constructed with B = 1, H = rows, W = 1
 
 private:
     ftc_model* m_;
@@ -802,6 +834,21 @@ int Builder::build(ModelPlan* out) {
     return finish(out, mh, mw);
 }
 
+// SimpleDecoder.forward (models/detector.py:249-254) on `H` gathered feature rows: ops 3i .. 3i+2 = head i; the head's output is
+// addressed through FTC_BASE_HEATMAP so that ftc_decoder_forward runs each op range with that base pointing at its own buffer.
+int Builder::build_decoder(ModelPlan* out) {
+    const int A = act_;
+    for (int i = 0; i < 3; ++i) {
+        const std::string q = "decoder." + std::to_string(i), name = "decoder.blocks." + std::to_string(i);
+        const R a = buf((int64_t)H * DECODER_MID, A), b = buf((int64_t)H * DECODER_MID, A);
+        conv(name + ".0", {3, 0, 0}, A, H, 1, DECODER_KPAD, DECODER_KPAD, 0, q + ".l0", DECODER_MID, 1, 1, FTC_ACT_GELU, a, A);
+        conv(name + ".3", a, A, H, 1, DECODER_MID, DECODER_MID, 0, q + ".l1", DECODER_MID, 1, 1, FTC_ACT_GELU, b, A);
+        conv(name + ".6", b, A, H, 1, DECODER_MID, DECODER_MID, 0, q + ".l2", DECODER_MODULO[i], 1, 1, FTC_ACT_NONE, {4, 0, 0}, FTC_F32);
+    }
+    if (!err_.empty()) return ftc_set_error(FTC_ERR_INVALID, "ftc decoder plan: " + err_);
+    return finish(out, H, 1);
+}
+
 // liveness-based first-fit arena + resolution of the symbolic operands
 int Builder::finish(ModelPlan* out, int mh, int mw) {
     std::vector<int> order(bufs_.size());
@@ -897,8 +944,7 @@ int ftc_create(const ftc_tensor* tensors, int n_tensors, const char* model_size,
         if (t.dtype != FTC_F32) continue;                               // e.g. num_batches_tracked (int64): not used by the forward pass
         if (t.ndim < 0 || t.ndim > 4) return ftc_set_error(FTC_ERR_INVALID, std::string("ftc_create: tensor '") + t.name + "' has more than 4 dimensions");
         std::string name = t.name;
-        if (name.rfind("detector.", 0) == 0) name = name.substr(9);     // TextDetectorModel keys
-        else if (name.rfind("decoder.", 0) == 0) continue;
+        if (name.rfind("detector.", 0) == 0) name = name.substr(9);     // TextDetectorModel keys ("decoder.*" keep their prefix)
         TensorView v;
         v.data = static_cast<const float*>(t.data);
         v.shape.assign(t.shape, t.shape + t.ndim);
@@ -941,6 +987,49 @@ int ftc_forward(ftc_model* model, const void* weights_dev, const void* image, in
     void* bases[FTC_NUM_BASES] = {nullptr, workspace, const_cast<void*>(weights_dev), const_cast<void*>(image), heatmap, features};
     const int n = (int)mp->plan.ops.size();
     return ftc_plan_run(&mp->plan, bases, stream, 0, with_nms ? n - 1 : n - 2);
+}
+
+static int get_decoder_plan(ftc_model* m, int n_rows, ModelPlan** out) {
+    if (!m) return ftc_set_error(FTC_ERR_INVALID, "ftc decoder: null model");
+    if (!m->has_decoder) return ftc_set_error(FTC_ERR_INVALID, "ftc decoder: the model was created from a checkpoint without decoder.* tensors");
+    if (n_rows <= 0) return ftc_set_error(FTC_ERR_INVALID, "ftc decoder: n_rows must be positive");
+    std::lock_guard<std::mutex> lk(m->mu);
+    auto it = m->decoder_plans.find(n_rows);
+    if (it == m->decoder_plans.end()) {
+        std::unique_ptr<ModelPlan> mp(new (std::nothrow) ModelPlan());
+        if (!mp) return ftc_set_error(FTC_ERR_NOMEM, "ftc decoder: out of host memory");
+        Builder b(m, 1, n_rows, 1, false);
+        int rc = b.build_decoder(mp.get());
+        if (rc != FTC_OK) return rc;
+        ftc_plan* checked = nullptr;
+        rc = ftc_plan_create(mp->plan.ops.data(), (int)mp->plan.ops.size(), mp->plan.workspace_bytes, mp->plan.weights_bytes, &checked);
+        if (rc != FTC_OK) return rc;
+        ftc_plan_destroy(checked);
+        it = m->decoder_plans.emplace(n_rows, std::move(mp)).first;
+    }
+    *out = it->second.get();
+    return FTC_OK;
+}
+
+int64_t ftc_decoder_workspace_bytes(ftc_model* model, int n_rows) {
+    ModelPlan* mp = nullptr;
+    if (get_decoder_plan(model, n_rows, &mp) != FTC_OK) return -1;
+    return mp->plan.workspace_bytes;
+}
+
+int ftc_decoder_forward(ftc_model* model, const void* weights_dev, const void* rows, int n_rows, float* out0, float* out1, float* out2,
+                        void* workspace, void* stream) {
+    if (!weights_dev || !rows || !out0 || !out1 || !out2 || !workspace) return ftc_set_error(FTC_ERR_INVALID, "ftc_decoder_forward: null pointer argument");
+    ModelPlan* mp = nullptr;
+    int rc = get_decoder_plan(model, n_rows, &mp);
+    if (rc != FTC_OK) return rc;
+    float* outs[3] = {out0, out1, out2};
+    for (int i = 0; i < 3; ++i) {
+        void* bases[FTC_NUM_BASES] = {nullptr, workspace, const_cast<void*>(weights_dev), const_cast<void*>(rows), outs[i], nullptr};
+        rc = ftc_plan_run(&mp->plan, bases, stream, 3 * i, 3 * i + 2);
+        if (rc != FTC_OK) return rc;
+    }
+    return FTC_OK;
 }
 
 int ftc_model_plan(ftc_model* model, int B, int H, int W, int nchw, const ftc_plan** plan, ftc_plan_info* info) {

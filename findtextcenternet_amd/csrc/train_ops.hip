@@ -1,0 +1,346 @@
+// Validation / training-step adjuncts of the detector (BASELINE config 5), forward only:
+//
+//   ftc_topk_mask      TextDetectorModel.get_fmask      /root/reference/models/detector.py:270-281
+//   ftc_mask_compact   `features[fmask]` index list      /root/reference/models/detector.py:265-266
+//   ftc_gather_rows    the boolean-mask gather itself    (rows of the NHWC feature map -> decoder input rows)
+//   ftc_detector_losses / ftc_id_losses   loss_function /root/reference/loss_func.py:94-177 (heatmap_loss :74-92)
+//   ftc_cov_weighting_step                CoVWeightingLoss.forward /root/reference/loss_func.py:24-72
+//
+// Everything here is bandwidth-trivial (a few MB per step); the kernels are written for determinism: integer histograms,
+// fixed-order two-stage reductions (per-workgroup partials summed in index order in float64), no floating-point atomics.
+#include "ftc_common.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t orderable(float v) {          // larger float <=> larger unsigned key
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Top-k selection mask: mask[i] = 1 for the k largest values (ties at the k-th value: lowest index first, which is what the
+// reference's stable CPU sort yields), plus the selected indices in ascending order (the row order of `x[mask]`).
+// ONE 1024-thread workgroup (n <= a few 10^5): 4 radix passes of 8 bits over LDS histograms find the k-th key exactly, then
+// every thread walks ITS contiguous chunk of indices, so a block-wide exclusive scan of the per-thread counts gives both the
+// tie cut and the compaction offsets.
+// ------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int* lds /* [1024 + 1] */) {
+    const int t = threadIdx.x;
+    lds[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int add = t >= off ? lds[t - off] : 0;
+        __syncthreads();
+        lds[t] += add;
+        __syncthreads();
+    }
+    const int incl = lds[t];
+    if (t == 1023) lds[1024] = incl;
+    __syncthreads();
+    return incl - v;
+}
+
+__global__ __launch_bounds__(1024) void topk_mask_kernel(const float* __restrict__ vals, long n, long k, unsigned char* __restrict__ mask,
+                                                         int32_t* __restrict__ sel_index, int32_t* __restrict__ count_out) {
+    __shared__ int hist[256];
+    __shared__ int scan[1025];
+    __shared__ uint32_t s_prefix;
+    __shared__ long s_need;
+    const int t = threadIdx.x;
+    if (k > n) k = n;
+    if (t == 0) { s_prefix = 0u; s_need = k; }
+    __syncthreads();
+    for (int pass = 0; pass < 4 && k > 0; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (t < 256) hist[t] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        const uint32_t pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+        for (long i = t; i < n; i += 1024) {
+            const uint32_t key = orderable(vals[i]);
+            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+        }
+        __syncthreads();
+        if (t == 0) {
+            long need = s_need;
+            int b = 255;
+            for (; b > 0; --b) {                 // buckets in DEscending key order
+                if (hist[b] >= need) break;
+                need -= hist[b];
+            }
+            s_prefix = prefix | ((uint32_t)b << shift);
+            s_need = need;                       // how many of the elements that match the new prefix are still needed
+        }
+        __syncthreads();
+    }
+    const uint32_t T = s_prefix;                 // the k-th largest key
+    const long need_eq = s_need;                 // how many elements equal to it belong to the top k
+    const long chunk = (n + 1023) / 1024;
+    const long lo = (long)t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    int n_eq = 0;
+    for (long i = lo; i < hi; ++i) n_eq += (k > 0 && orderable(vals[i]) == T) ? 1 : 0;
+    const int eq_before = block_exclusive_scan_1024(n_eq, scan);
+    __syncthreads();
+    int n_sel = 0, e = eq_before;
+    for (long i = lo; i < hi; ++i) {
+        const uint32_t key = orderable(vals[i]);
+        bool s = k > 0 && key > T;
+        if (k > 0 && key == T) { s = e < need_eq; ++e; }
+        mask[i] = s ? 1 : 0;
+        n_sel += s ? 1 : 0;
+    }
+    const int sel_before = block_exclusive_scan_1024(n_sel, scan);
+    if (sel_index) {
+        int o = sel_before;
+        for (long i = lo; i < hi; ++i)
+            if (mask[i]) sel_index[o++] = (int32_t)i;
+    }
+    if (t == 1023 && count_out) *count_out = sel_before + n_sel;
+}
+
+__global__ __launch_bounds__(1024) void mask_compact_kernel(const unsigned char* __restrict__ mask, long n, int32_t* __restrict__ sel_index,
+                                                            long cap, int32_t* __restrict__ count_out) {
+    __shared__ int scan[1025];
+    const int t = threadIdx.x;
+    const long chunk = (n + 1023) / 1024;
+    const long lo = (long)t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    int c = 0;
+    for (long i = lo; i < hi; ++i) c += mask[i] ? 1 : 0;
+    int o = block_exclusive_scan_1024(c, scan);
+    for (long i = lo; i < hi; ++i)
+        if (mask[i]) { if (o < cap) sel_index[o] = (int32_t)i; ++o; }
+    if (t == 1023) *count_out = o;
+}
+
+// rows[i][0..C) = feat[sel_index[i]][0..C), rows[i][C..Cpad) = 0; 16-byte lanes (C % 4 == 0).
+template <typename OutT>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ feat, const int32_t* __restrict__ sel_index,
+                                                          const int32_t* __restrict__ count, long cap, int C, int Cpad, OutT* __restrict__ rows) {
+    const long n = count ? (*count < cap ? *count : cap) : cap;
+    const int Q = Cpad / 4;
+    const long total = cap * Q;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / Q;
+        const int c = (int)(idx - r * Q) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < n && c < C) v = *reinterpret_cast<const f32x4*>(feat + (long)sel_index[r] * C + c);
+        store4<OutT>(rows + r * Cpad + c, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// loss_function, map part (loss_func.py:94-133): one pass over the B*h*w pixels, 12 partial sums per workgroup.
+//   0 keymap focal sum        heatmap_loss :74-92 (alpha 2, beta 4, pos_th 1)       -> mean * 10
+//   1 size numerator          sum over keylabel > 0.85 of (huber(x) + huber(y)) * weight1      2 weight1 sum
+//   3 textline BCE sum   4 separator BCE sum   5..8 weighted code BCE sums (weight = 1 + bit*w2 + w2)
+// Strided views: heat (b, c, y, x) strides in elements for the NINE reference channels, so both the NHWC block the detector
+// writes and a plain NCHW tensor are accepted.
+// ------------------------------------------------------------------------------------------------------------------------
+struct MapLossP {
+    const float* heat; long hs_b, hs_c, hs_y, hs_x;
+    const float* label;       // [B,5,h,w] contiguous
+    const int32_t* idmap;     // [B,2,h,w] contiguous
+    int B, h, w;
+};
+constexpr int NMAP = 9;
+
+__device__ __forceinline__ float bce_logits(float x, float y) {          // max(x,0) - x*y + log1p(exp(-|x|))
+    return fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float huber1(float a, float b) {
+    const float d = fabsf(a - b);
+    return d < 1.0f ? 0.5f * d * d : d - 0.5f;
+}
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log1pf(expf(x)); }      // torch threshold = 20
+
+__global__ __launch_bounds__(256) void map_loss_kernel(MapLossP p, double* __restrict__ partial /* [gridDim.x][NMAP] */) {
+    __shared__ float red[NMAP][256];
+    const long hw = (long)p.h * p.w, n = (long)p.B * hw;
+    float acc[NMAP];
+#pragma unroll
+    for (int j = 0; j < NMAP; ++j) acc[j] = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long b = i / hw, r = i - b * hw;
+        const int y = (int)(r / p.w), x = (int)(r - (long)y * p.w);
+        const float* hp = p.heat + b * p.hs_b + y * p.hs_y + x * p.hs_x;
+        const float* lp = p.label + b * 5 * hw + r;
+        const float key = lp[0];
+        // heatmap_loss
+        const float lg = hp[0];
+        const float pr = 1.0f / (1.0f + expf(-lg));
+        if (key >= 1.0f) {
+            const float logsig = fminf(lg, 0.f) - log1pf(expf(-fabsf(lg)));
+            acc[0] += -logsig * (1.f - pr) * (1.f - pr);
+        } else {
+            const float om = 1.f - key;
+            acc[0] += (lg + softplusf_(-lg)) * pr * pr * (om * om * om * om);
+        }
+        const float w2 = fmaxf(key - 0.85f, 0.f) / (1.f - 0.85f);
+        if (key > 0.85f) {
+            acc[1] += (huber1(hp[1 * p.hs_c], lp[1 * hw]) + huber1(hp[2 * p.hs_c], lp[2 * hw])) * w2;
+            acc[2] += w2;
+        }
+        acc[3] += bce_logits(hp[3 * p.hs_c], lp[3 * hw]);
+        acc[4] += bce_logits(hp[4 * p.hs_c], lp[4 * hw]);
+        const int code = p.idmap[(b * 2 + 1) * hw + r];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float bit = (code & (1 << k)) ? 1.f : 0.f;
+            acc[5 + k] += (1.f + bit * w2 + w2) * bce_logits(hp[(5 + k) * p.hs_c], bit);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NMAP; ++j) red[j][threadIdx.x] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < NMAP) {
+        double s = 0.0;
+        for (int k = 0; k < 256; ++k) s += (double)red[threadIdx.x][k];
+        partial[(long)blockIdx.x * NMAP + threadIdx.x] = s;
+    }
+}
+
+// id part (loss_func.py:135-163): one wave per selected pixel; three decoder heads.
+//   partial[.][0] = sum of weight3 * (CE0 + CE1 + CE2) over mask3, [1] = weight3 sum, [2] = rows with all three arg-maxes right
+//   (over mask4), [3] = rows in mask4
+struct IdLossP {
+    const float* dec[3]; int mod[3];
+    const int32_t* sel_index; const int32_t* count; long cap;
+    const float* label; const int32_t* idmap; long hw;
+};
+
+__global__ __launch_bounds__(256) void id_loss_kernel(IdLossP p, double* __restrict__ partial /* [gridDim.x][4] */) {
+    __shared__ double red[4][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long n = *p.count < p.cap ? *p.count : p.cap;
+    double a_ce = 0.0, a_w = 0.0, a_ok = 0.0, a_tot = 0.0;
+    for (long r = (long)blockIdx.x * 4 + wave; r < n; r += (long)gridDim.x * 4) {
+        const long px = p.sel_index[r];
+        const long b = px / p.hw, q = px - b * p.hw;
+        const float key = p.label[b * 5 * p.hw + q];
+        const int id = p.idmap[b * 2 * p.hw + q];
+        const bool m3 = key > 0.99f && id > 0, m4 = key == 1.0f && id > 0;
+        if (!m3 && !m4) continue;                                   // wave-uniform
+        float ce_sum = 0.f;
+        int right = 0;
+        for (int hd = 0; hd < 3; ++hd) {
+            const int m = p.mod[hd];
+            const float* row = p.dec[hd] + r * m;
+            float mx = -INFINITY;
+            int am = 0x7fffffff;
+            for (int c = lane; c < m; c += 64) {
+                const float v = row[c];
+                if (v > mx) { mx = v; am = c; }                      // first maximum within the lane's strided walk
+            }
+            for (int o = 32; o > 0; o >>= 1) {                       // (max, lowest index) over the wave: torch.argmax returns the first
+                const float omx = __shfl_xor(mx, o, 64);
+                const int oam = __shfl_xor(am, o, 64);
+                if (omx > mx || (omx == mx && oam < am)) { mx = omx; am = oam; }
+            }
+            float se = 0.f;
+            for (int c = lane; c < m; c += 64) se += expf(row[c] - mx);
+            se = wave_sum(se);
+            const int tgt = id % m;
+            ce_sum += (mx + logf(se)) - row[tgt];                    // -log_softmax[target]
+            right += (am == tgt) ? 1 : 0;
+        }
+        if (lane == 0) {
+            if (m3) { const float w3 = fmaxf(key - 0.99f, 0.f) / (1.f - 0.99f); a_ce += (double)(ce_sum * w3); a_w += (double)w3; }
+            if (m4) { a_tot += 1.0; a_ok += right == 3 ? 1.0 : 0.0; }
+        }
+    }
+    if (lane == 0) { red[0][wave] = a_ce; red[1][wave] = a_w; red[2][wave] = a_ok; red[3][wave] = a_tot; }
+    __syncthreads();
+    if (threadIdx.x < 4) partial[(long)blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+// out[0..13) = loss, keymap, size, textline, separator, id, code1, code2, code4, code8, correct, total, reserved
+__global__ void finish_losses_kernel(const double* __restrict__ map_partial, int n_map, const double* __restrict__ id_partial, int n_id,
+                                     double n_pixels, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s[NMAP] = {0}, d[4] = {0};
+    for (int i = 0; i < n_map; ++i)
+        for (int j = 0; j < NMAP; ++j) s[j] += map_partial[(long)i * NMAP + j];
+    for (int i = 0; i < n_id; ++i)
+        for (int j = 0; j < 4; ++j) d[j] += id_partial[(long)i * 4 + j];
+    const float keymap = (float)(s[0] / n_pixels) * 10.f;
+    const float size = (float)(s[1] / fmax(1.0, s[2]));
+    const float textline = (float)(s[3] / n_pixels), sep = (float)(s[4] / n_pixels);
+    const float idl = n_id > 0 ? (float)(d[0] / fmax(1.0, d[1])) : 0.f;
+    float total = keymap + size + textline + sep + idl;
+    for (int k = 0; k < 4; ++k) { out[6 + k] = (float)(s[5 + k] / n_pixels); total += out[6 + k]; }
+    out[0] = total; out[1] = keymap; out[2] = size; out[3] = textline; out[4] = sep; out[5] = idl;
+    out[10] = (float)d[2]; out[11] = (float)d[3]; out[12] = 0.f;
+}
+
+// CoVWeightingLoss.forward (loss_func.py:24-72) for n <= 16 losses; state = [mean_L, mean_l, S_l, std_l][16] floats + alphas[16].
+// (The reference's `if not self.train:` tests a bound method and is never true: the weighted form is used in validation too.)
+__global__ void cov_step_kernel(const float* __restrict__ L, int n, int iter, float* __restrict__ state, float* __restrict__ out_loss) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float* mean_L = state; float* mean_l = state + 16; float* S_l = state + 32; float* std_l = state + 48; float* alphas = state + 64;
+    float l[16];
+    for (int i = 0; i < n; ++i) l[i] = L[i] / (iter == 0 ? L[i] : mean_L[i]);
+    if (iter <= 1) {
+        for (int i = 0; i < n; ++i) alphas[i] = 1.0f / (float)n;
+    } else {
+        float ls[16], tot = 0.f;
+        for (int i = 0; i < n; ++i) { ls[i] = std_l[i] / mean_l[i]; tot += ls[i]; }
+        for (int i = 0; i < n; ++i) alphas[i] = ls[i] / tot;
+    }
+    // Python computes mean_param and (1 - mean_param) in float64 and hands each to a float32 tensor op
+    const double mpd = iter == 0 ? 0.0 : (1.0 - 1.0 / (double)(iter + 1));
+    const float mp = (float)mpd, omp = (float)(1.0 - mpd);
+    float loss = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float new_mean = mp * mean_l[i] + omp * l[i];
+        S_l[i] += (l[i] - mean_l[i]) * (l[i] - new_mean);
+        mean_l[i] = new_mean;
+        std_l[i] = sqrtf(fmaxf(S_l[i] / (float)(iter + 1), 1e-16f));
+        mean_L[i] = mp * mean_L[i] + omp * L[i];
+    }
+    for (int i = 0; i < n; ++i) loss += alphas[i] * L[i];          // sum(weighted_losses) in key order, as the reference's Python sum
+    *out_loss = loss;
+}
+
+}  // namespace
+
+hipError_t launch_topk_mask(const float* vals, long n, long k, unsigned char* mask, int32_t* sel_index, int32_t* count, hipStream_t s) {
+    hipLaunchKernelGGL(topk_mask_kernel, dim3(1), dim3(1024), 0, s, vals, n, k, mask, sel_index, count);
+    return hipGetLastError();
+}
+hipError_t launch_mask_compact(const unsigned char* mask, long n, int32_t* sel_index, long cap, int32_t* count, hipStream_t s) {
+    hipLaunchKernelGGL(mask_compact_kernel, dim3(1), dim3(1024), 0, s, mask, n, sel_index, cap, count);
+    return hipGetLastError();
+}
+hipError_t launch_gather_rows(const float* feat, const int32_t* sel_index, const int32_t* count, long cap, int C, int Cpad, void* rows, int out_dtype,
+                              hipStream_t s) {
+    const long total = cap * (Cpad / 4);
+    const int nb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (out_dtype == FTC_F32) hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(nb), dim3(256), 0, s, feat, sel_index, count, cap, C, Cpad, (float*)rows);
+    else hipLaunchKernelGGL(gather_rows_kernel<__bf16>, dim3(nb), dim3(256), 0, s, feat, sel_index, count, cap, C, Cpad, (__bf16*)rows);
+    return hipGetLastError();
+}
+hipError_t launch_losses(const float* heat, const long* hstrides, const float* label, const int32_t* idmap, int B, int h, int w, const float* const* dec,
+                         const int* mod, const int32_t* sel_index, const int32_t* count, long cap, float* out, void* scratch, hipStream_t s) {
+    MapLossP mp{heat, hstrides[0], hstrides[1], hstrides[2], hstrides[3], label, idmap, B, h, w};
+    const long n = (long)B * h * w;
+    const int nb_map = (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
+    double* map_partial = static_cast<double*>(scratch);
+    double* id_partial = map_partial + (long)512 * NMAP;
+    hipLaunchKernelGGL(map_loss_kernel, dim3(nb_map), dim3(256), 0, s, mp, map_partial);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int nb_id = 0;
+    if (dec && sel_index && count && cap > 0) {
+        IdLossP ip{{dec[0], dec[1], dec[2]}, {mod[0], mod[1], mod[2]}, sel_index, count, cap, label, idmap, (long)h * w};
+        nb_id = (int)((cap + 3) / 4 < 512 ? (cap + 3) / 4 : 512);
+        hipLaunchKernelGGL(id_loss_kernel, dim3(nb_id), dim3(256), 0, s, ip, id_partial);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(finish_losses_kernel, dim3(1), dim3(64), 0, s, map_partial, nb_map, id_partial, nb_id, (double)n, out);
+    return hipGetLastError();
+}
+hipError_t launch_cov_step(const float* L, int n, int iter, float* state, float* out_loss, hipStream_t s) {
+    hipLaunchKernelGGL(cov_step_kernel, dim3(1), dim3(64), 0, s, L, n, iter, state, out_loss);
+    return hipGetLastError();
+}

@@ -76,9 +76,10 @@ class _HipEngine:
     weight blob in HBM and the activation workspace.  All network knowledge lives in the C library; this class only owns
     device memory and notices when the module's parameters change."""
 
-    def __init__(self, precision: str, model_size: str):
+    def __init__(self, precision: str, model_size: str, module: nn.Module):
         self.precision = precision
         self.model_size = model_size
+        self.module = module                     # whose state_dict is packed: a CenterNetDetection, or the TextDetectorModel that owns it
         self.model: Optional[FtcModel] = None
         self.wdev: Optional[torch.Tensor] = None
         self.workspace: Optional[torch.Tensor] = None
@@ -96,7 +97,8 @@ class _HipEngine:
         except Exception:
             pass
 
-    def _fingerprint(self, module: nn.Module):
+    def _fingerprint(self):
+        module = self.module
         # Parameters and buffers can change behind our back (optimizer.step(), p.data.copy_(), .half().float(), the
         # schedule-free optimizer's train()/eval() swap ...): in-place writes bump Tensor._version, re-allocations move
         # data_ptr.  ~1 ms of host time for the 2400 tensors, hidden behind the previous forward's GPU work.
@@ -104,12 +106,12 @@ class _HipEngine:
             self._flat = list(module.parameters()) + list(module.buffers())
         return (sum(t._version for t in self._flat), sum(t.data_ptr() for t in self._flat))
 
-    def ensure_model(self, module: nn.Module, device) -> None:
-        fp = self._fingerprint(module)
+    def ensure_model(self, device) -> None:
+        fp = self._fingerprint()
         if self.model is None or fp != self.fingerprint:
             self.invalidate()
-            self.model = FtcModel(module.state_dict(), self.precision, self.model_size)      # folds + packs in the library (seconds)
-            self.fingerprint = self._fingerprint(module)
+            self.model = FtcModel(self.module.state_dict(), self.precision, self.model_size)      # folds + packs in the library (seconds)
+            self.fingerprint = self._fingerprint()
         if self.wdev is None or self.wdev.device != device:
             self.wdev = torch.from_numpy(self.model.weights_host()).to(device)              # one H2D copy of the packed blob
 
@@ -126,7 +128,7 @@ class _HipEngine:
             self.workspace = None
             self.workspace = torch.empty(need, dtype=torch.uint8, device=device)
 
-    def run(self, x: torch.Tensor, module: nn.Module, with_nms: bool = True, out=None):
+    def run(self, x: torch.Tensor, with_nms: bool = True, out=None):
         if not x.is_cuda:
             raise RuntimeError("findtextcenternet_amd: the detector runs on MI355X (gfx950) only -- move the module and "
                                "the input to 'cuda' (there is no CPU fallback)")
@@ -146,7 +148,7 @@ class _HipEngine:
             raise ValueError("H and W must be multiples of 32 (the reference always uses 768)")
         dev = x.device
         with torch.cuda.device(dev):
-            self.ensure_model(module, dev)
+            self.ensure_model(dev)
             self.ensure_workspace(B, H, W, dev)
             h, w = H // 4, W // 4
             if out is None:
@@ -174,7 +176,7 @@ class CenterNetDetection(nn.Module):
         prec = precision or os.environ.get("FTC_PRECISION", "fp32")
         if prec not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16'")
-        object.__setattr__(self, "_engine", _HipEngine(prec, model_size))
+        object.__setattr__(self, "_engine", _HipEngine(prec, model_size, self))
         # pre_weights: the reference looks for efficientnetv2-xl-21k.npz next to detector.py and
         # silently continues when it is missing (models/detector.py:34-36, :129-130); use
         # findtextcenternet_amd.weights.load_tf_efficientnetv2_npz() to import one explicitly.
@@ -199,7 +201,7 @@ class CenterNetDetection(nn.Module):
     def __setstate__(self, st):
         prec = st.pop("_engine", None) or os.environ.get("FTC_PRECISION", "fp32")
         super().__setstate__(st)
-        object.__setattr__(self, "_engine", _HipEngine(prec, self.model_size))
+        object.__setattr__(self, "_engine", _HipEngine(prec, self.model_size, self))
 
     def __deepcopy__(self, memo):
         import copy
@@ -208,7 +210,7 @@ class CenterNetDetection(nn.Module):
         for k, v in self.__dict__.items():
             if k != "_engine":
                 new.__dict__[k] = copy.deepcopy(v, memo)
-        object.__setattr__(new, "_engine", _HipEngine(self._engine.precision, self.model_size))
+        object.__setattr__(new, "_engine", _HipEngine(self._engine.precision, self.model_size, new))
         return new
 
     def forward_nhwc(self, x, with_nms: bool, out=None):
@@ -216,7 +218,7 @@ class CenterNetDetection(nn.Module):
         writes into caller-owned tensors instead of allocating."""
         if self.training:
             raise NotImplementedError("findtextcenternet_amd implements the inference path (eval mode) only; call .eval()")
-        return self._engine.run(x, self, with_nms, out)
+        return self._engine.run(x, with_nms, out)
 
     def forward(self, x):
         heat, feat = self.forward_nhwc(x, with_nms=False)
@@ -225,27 +227,133 @@ class CenterNetDetection(nn.Module):
 
 
 class SimpleDecoder(nn.Module):
-    """Parameter container for models/detector.py:232-254 (checkpoint compatibility; the decoder
-    belongs to the training / glyph-classification steps, outside this hot path)."""
+    """models/detector.py:232-254: three MLPs 100 -> 2048 -> 2048 -> {1091, 1093, 1097} (BatchNorm1d + GELU between the Linear
+    layers) that classify a glyph's 100-d feature into the CRT residues of its code point.  Parameter container with the
+    reference's keys (``blocks.<i>.{0,3,6}.weight`` ...); ``forward`` (eval mode) runs inside the library: BatchNorm1d folded into the
+    Linear before it, the Linear layers as 1x1 implicit GEMMs on the MFMA conv kernel with fused bias + exact GELU
+    (``ftc_decoder_forward``).  Called through ``TextDetectorModel`` (which owns the packed weights)."""
 
     def __init__(self, *args, **kwargs) -> None:
         super().__init__(*args, **kwargs)
         _populate(self, decoder_schema())
+        object.__setattr__(self, "_owner", None)
 
     def forward(self, x):
-        raise NotImplementedError("SimpleDecoder is outside the MI355X detector hot path")
+        owner = self.__dict__.get("_owner")
+        if owner is None:
+            raise NotImplementedError("SimpleDecoder runs as part of a TextDetectorModel (it shares the model's packed weight blob)")
+        return owner._decode_rows(x)
 
 
 class TextDetectorModel(nn.Module):
-    """models/detector.py:256-281."""
+    """models/detector.py:256-281.  ``forward(x, fmask)`` and ``get_fmask`` implement the reference's eval-mode (validation) step
+    on the GPU; training-mode forward (batch-statistics BatchNorm, stochastic depth) and backward are not implemented."""
 
     def __init__(self, pre_weights=True, model_size="xl", precision: Optional[str] = None, **kwargs) -> None:
         super().__init__(**kwargs)
         self.detector = CenterNetDetection(pre_weights=pre_weights, model_size=model_size, precision=precision)
         self.decoder = SimpleDecoder()
+        self._bind()
+
+    def _bind(self) -> None:
+        # ONE engine for the whole model: detector and decoder weights live in one packed blob (ftc_create accepts the
+        # "detector." / "decoder." prefixed keys of model.pt as they are); the detector module shares it.
+        eng = _HipEngine(self.detector.precision, self.detector.model_size, self)
+        old = self.detector.__dict__.get("_engine")
+        if old is not None:
+            old.invalidate()
+        object.__setattr__(self.detector, "_engine", eng)
+        object.__setattr__(self, "_engine", eng)
+        object.__setattr__(self.decoder, "_owner", self)
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_engine"] = None
+        return st
+
+    def __setstate__(self, st):
+        st.pop("_engine", None)
+        super().__setstate__(st)
+        self._bind()
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != "_engine":
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        new._bind()
+        return new
+
+    def _decode_rows(self, feats: torch.Tensor, rows_ready: bool = False):
+        """feats [N,100] fp32 (or, rows_ready, [N,128] already in the compute dtype) -> three [N, modulo] fp32 tensors."""
+        if self.training:
+            raise NotImplementedError("findtextcenternet_amd implements the eval-mode forward only; call .eval()")
+        if not feats.is_cuda:
+            raise RuntimeError("findtextcenternet_amd: the decoder runs on MI355X (gfx950) only (there is no CPU fallback)")
+        lib = L.load()
+        dev = feats.device
+        eng = self._engine
+        with torch.cuda.device(dev):
+            eng.ensure_model(dev)
+            n = feats.shape[0]
+            cdt = torch.float32 if eng.precision == "fp32" else torch.bfloat16
+            if rows_ready:
+                rows = feats
+            else:
+                rows = torch.zeros((n, 128), dtype=cdt, device=dev)
+                rows[:, :feature_dim] = feats.to(cdt)
+            need = int(lib.ftc_decoder_workspace_bytes(eng.handle, n))
+            if need < 0:
+                L.check(-1, "ftc_decoder_workspace_bytes")
+            if eng.workspace is None or eng.workspace.device != dev or eng.workspace.numel() < need:
+                eng.workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            outs = [torch.empty((n, m), dtype=torch.float32, device=dev) for m in (1091, 1093, 1097)]
+            L.check(lib.ftc_decoder_forward(eng.handle, eng.wdev.data_ptr(), rows.data_ptr(), n, outs[0].data_ptr(), outs[1].data_ptr(),
+                                            outs[2].data_ptr(), eng.workspace.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                    "ftc_decoder_forward")
+        return outs
 
     def forward(self, x, fmask):
-        raise NotImplementedError("training forward (train1.py) is outside the MI355X detector hot path")
+        """(heatmap [B,9,h,w], [dec0, dec1, dec2]) -- detector forward, boolean-mask gather of the flattened NHWC feature map
+        (``features.permute(0,2,3,1).flatten(0,-2)[fmask]``, models/detector.py:265-266) on the GPU, decoder on the gathered rows."""
+        if self.training:
+            raise NotImplementedError("findtextcenternet_amd implements the eval-mode forward only; call .eval()")
+        from .loss_func import mask_to_index
+        lib = L.load()
+        heat, feat = self.detector.forward_nhwc(x, with_nms=False)
+        dev = heat.device
+        sel, cnt = mask_to_index(fmask)
+        n = int(cnt.item())                                           # the reference's boolean indexing synchronises here as well
+        cdt = torch.float32 if self.detector.precision == "fp32" else torch.bfloat16
+        rows = torch.empty((max(n, 1), 128), dtype=cdt, device=dev)
+        with torch.cuda.device(dev):
+            L.check(lib.ftc_gather_rows(feat.data_ptr(), sel.data_ptr(), cnt.data_ptr(), max(n, 1), feature_dim, 128, rows.data_ptr(),
+                                        L.F32 if cdt == torch.float32 else L.BF16, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                    "ftc_gather_rows")
+        idx = torch.tensor([0, 2, 3, 4, 5, 6, 7, 8, 9], device=dev)
+        heatmap = heat.index_select(3, idx).permute(0, 3, 1, 2)
+        if n == 0:
+            return heatmap, [torch.empty((0, m), dtype=torch.float32, device=dev) for m in (1091, 1093, 1097)]
+        return heatmap, self._decode_rows(rows[:n], rows_ready=True)
+
+    def get_fmask(self, heatmap, mask):
+        """models/detector.py:270-281: boolean mask over the flattened [B,h,w] key-label map marking its 1024*B largest entries
+        (ties at the boundary: lowest index first, what the reference's stable CPU sort gives).  ``heatmap`` is the LABEL map
+        in the reference's training loop (train1.py:174)."""
+        if not heatmap.is_cuda:
+            raise RuntimeError("findtextcenternet_amd: get_fmask runs on the GPU only (there is no CPU fallback)")
+        lib = L.load()
+        B = heatmap.shape[0]
+        vals = heatmap[:, 0, :, :].to(torch.float32).contiguous().reshape(-1)
+        n = vals.numel()
+        if mask is None or mask.shape != vals.shape or mask.dtype != torch.bool or mask.device != vals.device:
+            mask = torch.zeros(n, dtype=torch.bool, device=vals.device)
+        with torch.cuda.device(vals.device):
+            L.check(lib.ftc_topk_mask(vals.data_ptr(), n, 1024 * B, mask.data_ptr(), None, None,
+                                      C.c_void_p(torch.cuda.current_stream(vals.device).cuda_stream)), "ftc_topk_mask")
+        return mask
 
 
 class CenterNetDetector(nn.Module):

@@ -81,3 +81,63 @@ def adamw_case(ci: int):
     params0 = [rng.standard_normal(s).astype(np.float32) for s in cfg["shapes"]]
     grads = [[(rng.standard_normal(s) * 10.0 ** rng.uniform(-3, 1)).astype(np.float32) for s in cfg["shapes"]] for _ in range(cfg["steps"])]
     return params0, grads
+
+
+# ---- training / validation labels (config 5: train1.py data layout) --------------------------------------------------------
+def train_labels(seed: int, b: int, h: int, w: int, n_glyphs: int = 0):
+    """Synthetic label maps with the semantics of the reference's sample synthesiser (dataset/processer.pyx:133-202):
+
+    labelmap [B,5,h,w] f32 -- 0: Gaussian centre map (max of per-glyph kernels, exactly 1.0 at a glyph centre),
+                              1-2: log-size maps ``log(px/1024)+3`` inside the glyph ellipse, 3: text-line map, 4: separator map (0..1);
+    idmap    [B,2,h,w] int32 -- 0: glyph id (unicode-like code point) inside the ellipse, 1: 4-bit code flags.
+    All values come from the seed; there are NO ties among the centre-map values other than the exact 0 background and the exact
+    1.0 centres (so that the top-k of get_fmask is well defined away from those two plateaus)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    label = np.zeros((b, 5, h, w), np.float32)
+    idmap = np.zeros((b, 2, h, w), np.int32)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    n_glyphs = n_glyphs or max(4, h * w // 96)
+    for bi in range(b):
+        label[bi, 1:3] = 0.0
+        for _ in range(n_glyphs):
+            cy, cx = float(rng.uniform(1, h - 2)), float(rng.uniform(1, w - 2))
+            gw, gh = float(rng.uniform(6, 40)), float(rng.uniform(6, 40))          # glyph size in input pixels
+            fw, fh = max(gw / 4 / 2, 1.0), max(gh / 4 / 2, 1.0)                    # center_map: half sizes in map pixels
+            yi, xi = int(round(cy)), int(round(cx))
+            g = np.exp(-(((xx - xi) / (fw / 4)) ** 2 + ((yy - yi) / (fh / 4)) ** 2) / 2).astype(np.float32)
+            g *= (np.abs(xx - xi) <= max(fw, fh) * 1.5) & (np.abs(yy - yi) <= max(fw, fh) * 1.5)
+            g[yi, xi] = 1.0
+            label[bi, 0] = np.maximum(label[bi, 0], g)
+            ex, ey = max(gw / 10, 4.0), max(gh / 10, 4.0)                          # box_map / id_map ellipse, input pixels
+            inside = ((xx * 4 - cx * 4) / ex) ** 2 + ((yy * 4 - cy * 4) / ey) ** 2 < 1
+            label[bi, 1][inside] = np.log(gw / 1024) + 3
+            label[bi, 2][inside] = np.log(gh / 1024) + 3
+            idmap[bi, 0][inside] = int(rng.integers(0x20, 0x2FFFF))
+            idmap[bi, 1][inside] = int(rng.integers(0, 16))
+        # tiny seeded jitter on the non-plateau values: no accidental ties for the top-k selection
+        jit = rng.random((h, w), dtype=np.float32) * np.float32(1e-4)
+        k = label[bi, 0]
+        label[bi, 0] = np.where((k > 0) & (k < 1), np.clip(k + jit, 1e-6, 1 - 1e-6), k)
+        label[bi, 3] = np.clip(_smooth(rng, h, w, 2) * 2 + 0.3, 0, 1)
+        label[bi, 4] = np.clip(_smooth(rng, h, w, 2) * 2 - 0.2, 0, 1)
+    return label, idmap
+
+
+def cov_loss_sequence(seed: int, steps: int = 6):
+    """Per-step raw loss values fed to CoVWeightingLoss (train1.py:106-113 key order)."""
+    keys = ["keymap_loss", "size_loss", "textline_loss", "separator_loss", "id_loss", "code1_loss", "code2_loss", "code4_loss", "code8_loss"]
+    rng = np.random.Generator(np.random.PCG64(seed))
+    base = rng.uniform(0.2, 3.0, len(keys))
+    return keys, [(base * (0.9 ** s) * rng.uniform(0.8, 1.2, len(keys))).astype(np.float32) for s in range(steps)]
+
+
+def loss_case(seed: int, b: int, h: int, w: int, target_ids: np.ndarray, modulo=(1091, 1093, 1097)):
+    """Synthetic network outputs for the loss kernels: heatmap [B,9,h,w] f32 and three decoder-logit arrays [N, modulo] whose rows
+    predict their target id about half of the time (so `correct` is neither 0 nor `total`)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    hm = (rng.standard_normal((b, 9, h, w)) * 2).astype(np.float32)
+    dec = [(rng.standard_normal((len(target_ids), m)) * 3).astype(np.float32) for m in modulo]
+    for j, m in enumerate(modulo):
+        rows = np.nonzero(rng.random(len(target_ids)) < 0.5)[0]
+        dec[j][rows, target_ids[rows] % m] += 25.0
+    return hm, dec

@@ -320,6 +320,40 @@ int ftc_page_merge(const float* locations, const int32_t* order, int n_boxes, co
                    float cut_off, const float* seps, const float* codes, int mh, int mw, int scale, float* out_locations,
                    int32_t* out_index, int32_t* out_count, void* scratch, int64_t scratch_bytes, void* stream);
 
+/* Validation / training-step adjuncts (forward only) --------------------------------------------
+ * The reference's validation step (train1.py:133-139 test_step, eval mode): fmask = model.get_fmask(labelmap) ->
+ * heatmap, decoder_outputs = model(image, fmask) -> loss_function(...) -> CoVWeightingLoss(...).  All pointers are device memory. */
+
+/* TextDetectorModel.get_fmask (models/detector.py:270-281): mask[i] = 1 for the k largest of values[0..n) (ties at the k-th value:
+   lowest index first, as the reference's stable sort), sel_index[0..k) = the selected indices ascending (= row order of `x[mask]`),
+   count[0] = number selected (min(k, n)).  sel_index / count may be NULL. */
+int ftc_topk_mask(const float* values, int64_t n, int64_t k, unsigned char* mask, int32_t* sel_index, int32_t* count, void* stream);
+/* Index list of an arbitrary boolean mask (`features[fmask]`, models/detector.py:265-266): sel_index[0..min(count, cap)) ascending. */
+int ftc_mask_compact(const unsigned char* mask, int64_t n, int32_t* sel_index, int64_t cap, int32_t* count, void* stream);
+/* rows[i][0..C) = features[sel_index[i]][0..C), zero-padded to c_pad columns (c_pad % 8 == 0), for i < min(count, cap); rows at and
+   beyond count are zero.  features = the NHWC block [P, C] fp32 the detector wrote; rows in `out_dtype` (FTC_F32 | FTC_BF16). */
+int ftc_gather_rows(const float* features, const int32_t* sel_index, const int32_t* count, int64_t cap, int C, int c_pad, void* rows,
+                    int out_dtype, void* stream);
+/* SimpleDecoder.forward in eval mode (models/detector.py:232-254): three MLPs 100 -> 2048 -> 2048 -> {1091, 1093, 1097} with
+   BatchNorm1d folded into the Linear layers and exact GELU, as 1x1 implicit GEMMs on the conv kernel.  The model must have been
+   created from a checkpoint that contains the "decoder.*" tensors.  rows [n_rows, 128] in the model's compute dtype
+   (ftc_gather_rows with c_pad = 128), out[j] [n_rows, modulo_j] fp32. */
+int64_t ftc_decoder_workspace_bytes(ftc_model* model, int n_rows);
+int ftc_decoder_forward(ftc_model* model, const void* weights_dev, const void* rows, int n_rows, float* out0, float* out1, float* out2,
+                        void* workspace, void* stream);
+/* loss_function (loss_func.py:94-177, heatmap_loss :74-92).  heatmap = the NINE reference channels addressed through element strides
+   (batch, channel, y, x) so that NHWC and NCHW memory are both accepted; labelmap [B,5,h,w] fp32 and idmap [B,2,h,w] int32 contiguous;
+   dec0..2 [cap, 1091 | 1093 | 1097] fp32 decoder outputs of the pixels sel_index[0..count) (may all be NULL: id_loss = 0).
+   out[0..12) = loss, keymap, size, textline, separator, id, code1, code2, code4, code8, correct, total (fp32).
+   scratch >= ftc_losses_scratch_bytes() bytes. */
+int64_t ftc_losses_scratch_bytes(void);
+int ftc_losses(const float* heatmap, const int64_t heat_strides[4], const float* labelmap, const int32_t* idmap, int B, int h, int w,
+               const float* dec0, const float* dec1, const float* dec2, const int32_t* sel_index, const int32_t* count, int64_t cap,
+               float* out, void* scratch, void* stream);
+/* CoVWeightingLoss.forward (loss_func.py:24-72): one step for n <= 16 losses.  state = 80 floats (zero-initialised before iteration
+   0): running mean of L, mean of l, S_l, std_l, alphas (16 each).  out_loss[0] = sum(alphas * losses). */
+int ftc_cov_weighting_step(const float* losses, int n, int iteration, float* state, float* out_loss, void* stream);
+
 /* Schedule-Free AdamW step as one multi-tensor kernel ------------------------------
  * Replaces the ten torch._foreach_* passes of AdamWScheduleFree.step, /root/reference/models/adamw_schedulefree.py:157-184.
  * chunks_dev: device array; every entry is a run of <= 4096 fp32 elements of one parameter (16-byte aligned) with its

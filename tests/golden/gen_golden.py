@@ -314,9 +314,59 @@ def gen_adamw():
     save("g6_adamw_schedulefree.npz", **out)
 
 
+def gen_validation_step(model):
+    """g7: the reference's validation step (train1.py:133-139 test_step in eval mode, :218-231) on CPU fp32:
+    model.get_fmask(labelmap) -> TextDetectorModel.forward(image, fmask) (models/detector.py:262-281, SimpleDecoder :232-254) ->
+    loss_function (loss_func.py:94-177) -> CoVWeightingLoss (loss_func.py:8-72) over a sequence of steps.  Inputs are regenerated
+    from seeds by the tests (findtextcenternet_amd/synth.py: page_images, train_labels, cov_loss_sequence)."""
+    import loss_func as ref_loss  # noqa: E402  (reference code)
+    B, H, W = 2, 256, 256
+    x = synth.page_images(515, B, H, W)
+    label, idmap = synth.train_labels(616, B, H // 4, W // 4)
+    model.eval()
+    lab_t, id_t = torch.from_numpy(label), torch.from_numpy(idmap).to(torch.long)
+    with torch.no_grad():
+        fmask = model.get_fmask(lab_t, None)
+        heatmap, dec = model(torch.from_numpy(x).permute(0, 3, 1, 2), fmask)
+        raw = ref_loss.loss_function(fmask, lab_t, id_t, heatmap, dec)
+    rows = np.random.Generator(np.random.PCG64(5)).choice(int(fmask.sum()), 96, replace=False)
+    out = {"fmask": np.packbits(fmask.numpy()), "n_mask": np.array(int(fmask.sum())), "heatmap": heatmap.numpy(), "dec_rows": rows}
+    for j in range(3):                      # decoder logits: 96 full rows + arg-max / max / log-sum-exp of every row (27 MB otherwise)
+        d = dec[j].numpy()
+        out[f"dec{j}_at"] = d[rows]
+        out[f"dec{j}_argmax"] = d.argmax(1).astype(np.int32)
+        out[f"dec{j}_max"] = d.max(1)
+        out[f"dec{j}_lse"] = torch.logsumexp(dec[j], 1).numpy()
+    for k, v in raw.items():
+        out["loss_" + k] = np.asarray(v.item() if torch.is_tensor(v) else v, dtype=np.float64)
+    # loss_function alone on synthetic maps / decoder outputs (independent of the network): the fixture of the loss kernels
+    tgt = id_t[:, 0].flatten()[fmask].numpy()
+    hm2, dec2 = synth.loss_case(717, B, H // 4, W // 4, tgt, ref_util.modulo_list)
+    with torch.no_grad():
+        raw2 = ref_loss.loss_function(fmask, lab_t, id_t, torch.from_numpy(hm2), [torch.from_numpy(d) for d in dec2])
+    for k, v in raw2.items():
+        out["loss2_" + k] = np.asarray(v.item() if torch.is_tensor(v) else v, dtype=np.float64)
+    # CoVWeightingLoss over a sequence of steps (its `if not self.train:` tests a bound method, loss_func.py:29: always weighted)
+    keys, seq = synth.cov_loss_sequence(818)
+    cov = ref_loss.CoVWeightingLoss(losses=keys)
+    cov_out, alphas = [], []
+    for vals in seq:
+        cov_out.append(float(cov({k: torch.tensor(float(v), dtype=torch.float32) for k, v in zip(keys, vals)})))
+        alphas.append(cov.alphas.numpy().copy())
+    out["cov_loss"] = np.asarray(cov_out, np.float64)
+    out["cov_alphas"] = np.stack(alphas)
+    save("g7_validation_step.npz", **out)
+
+
 def main():
     if "--adamw-only" in sys.argv:
         gen_adamw()
+        return
+    if "--validation-only" in sys.argv:
+        torch.manual_seed(0)
+        model = ref_detector.TextDetectorModel(pre_weights=False)
+        model.load_state_dict(deterministic_state_dict(SEED_W))
+        gen_validation_step(model)
         return
     torch.manual_seed(0)
     model = ref_detector.TextDetectorModel(pre_weights=False)
@@ -334,6 +384,7 @@ def main():
     gen_nms()
     gen_decode()
     gen_adamw()
+    gen_validation_step(model)
 
 
 if __name__ == "__main__":

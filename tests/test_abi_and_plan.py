@@ -103,7 +103,12 @@ def test_create_rejects_bad_checkpoints(sd):
         m.plan(1, 100, 768)
     # TextDetectorModel keys (detector.* + decoder.*) are accepted as they come out of model.pt
     full = deterministic_state_dict(0)
-    assert FtcModel(full, "bf16").weights_bytes == m.weights_bytes
+    mf = FtcModel(full, "bf16")
+    lib = L.load()
+    # ... and then the SimpleDecoder is packed too (3 x (2048x128 + 2048x2048 + modulo x 2048) bf16 + fp32 biases)
+    assert 38_000_000 < mf.weights_bytes - m.weights_bytes < 42_000_000 and mf.offset("decoder.0.l1.w") > 0
+    assert lib.ftc_decoder_workspace_bytes(mf.handle, 2048) > 0
+    assert lib.ftc_decoder_workspace_bytes(m.handle, 2048) == -1 and b"decoder" in lib.ftc_last_error()
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])

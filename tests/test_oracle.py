@@ -129,3 +129,42 @@ def test_decode_sparse_equals_per_tile_decode():
     ys, xs = idx // 192, idx % 192
     assert (6, 6) in set(zip(ys.tolist(), xs.tolist())) and (6, 18) not in set(zip(ys.tolist(), xs.tolist()))
     assert (30, 30) not in set(zip(ys.tolist(), xs.tolist())) and (42, 42) not in set(zip(ys.tolist(), xs.tolist()))
+
+
+def test_validation_step_oracle_matches_reference():
+    """oracle/loss_oracle.py against what the reference's own models/detector.py + loss_func.py produced on CPU (g7)."""
+    from oracle import loss_oracle
+    g = np.load(os.path.join(G, "g7_validation_step.npz"))
+    B, H, W = 2, 256, 256
+    label, idmap = synth.train_labels(616, B, H // 4, W // 4)
+    lab_t, id_t = torch.from_numpy(label), torch.from_numpy(idmap).to(torch.long)
+    fmask = loss_oracle.get_fmask(lab_t)
+    assert int(fmask.sum()) == int(g["n_mask"]) == 1024 * B
+    assert np.array_equal(np.packbits(fmask.numpy()), g["fmask"])
+    # forward: detector oracle (9 reference channels) + decoder on the gathered rows
+    sd_full = deterministic_state_dict(0)
+    sd_det = {k[len("detector."):]: v for k, v in sd_full.items() if k.startswith("detector.")}
+    x = torch.from_numpy(synth.page_images(515, B, H, W)).permute(0, 3, 1, 2)
+    hm10, ft = detector_oracle.detector_forward(sd_det, x)
+    hm9 = hm10[:, [0, 2, 3, 4, 5, 6, 7, 8, 9]]
+    assert float((hm9 - torch.from_numpy(g["heatmap"])).abs().max()) < 1e-4
+    rows = ft.permute(0, 2, 3, 1).flatten(0, -2)[fmask]
+    dec = loss_oracle.simple_decoder(sd_full, rows)
+    for j in range(3):
+        assert float((dec[j][torch.from_numpy(g["dec_rows"])] - torch.from_numpy(g[f"dec{j}_at"])).abs().max()) < 2e-3
+        assert float((torch.logsumexp(dec[j], 1) - torch.from_numpy(g[f"dec{j}_lse"])).abs().max()) < 2e-3
+    # losses on the network's outputs and on the synthetic case
+    tgt = id_t[:, 0].flatten()[fmask].numpy()
+    hm2, dec2 = synth.loss_case(717, B, H // 4, W // 4, tgt)
+    for tag, hm_in, dec_in, tol in (("loss_", torch.from_numpy(g["heatmap"]), dec, 2e-4), ("loss2_", torch.from_numpy(hm2), [torch.from_numpy(d) for d in dec2], 2e-6)):
+        out = loss_oracle.loss_function(fmask, lab_t, id_t, hm_in, dec_in)
+        for k, v in out.items():
+            want = float(g[tag + k])
+            assert abs(float(v) - want) <= tol * max(1.0, abs(want)), (tag, k, float(v), want)
+    assert float(g["loss2_correct"]) > 0 and float(g["loss2_total"]) > float(g["loss2_correct"])
+    keys, seq = synth.cov_loss_sequence(818)
+    cov = loss_oracle.CoVWeighting(len(keys))
+    for step, vals in enumerate(seq):
+        got = cov(vals)
+        assert abs(got - float(g["cov_loss"][step])) < 2e-6 * max(1.0, abs(got)), (step, got, g["cov_loss"][step])
+        assert np.abs(cov.alphas - g["cov_alphas"][step]).max() < 2e-6

@@ -1,0 +1,19 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root):  tools/profile_round.sh <tag>     e.g. r02a
+# One kernel-trace pass (durations, --stats) and five PMC passes (counters only with --kernel-trace, as gpurun requires) over the
+# SAME command: the timed bf16 batch-8 bench without its CPU / fp32 legs.  Raw output under gpurun_out/prof_<tag>/; the summaries
+# that get committed are made afterwards by profiles/pmc_kernels.py and profiles/summarize_rocpd.py.
+set -u
+TAG="${1:-r02}"
+ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
+OUT="$ROOT/gpurun_out/prof_$TAG"
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
+CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-fp32 --no-profile"
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32 --dump-ops "$OUT/ops.json" > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
+rocprofv3 --kernel-trace --stats -d "$OUT" -o trace -- $CMD > "$OUT/trace.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT" -o write -- $CMD > "$OUT/write.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d "$OUT" -o sq1 -- $CMD > "$OUT/sq1.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "$OUT" -o sq2 -- $CMD > "$OUT/sq2.log" 2>&1
+ls -la "$OUT" | head -40

@@ -13,8 +13,8 @@ Rank 0 prints ONE JSON line.  `value` = images of all ranks / wall time of the K
 sides, max over ranks); `ms_per_step_median` is the median of the per-step HIP-event times on the launch stream.
 
 Besides the headline (bf16 speed mode) the same line carries
-  parity      -- L-inf / peak-set agreement of image 0 of the timed batch against the CPU oracle, for the timed bf16 model AND
-                 for the fp32 parity mode (whose own images/s is reported there: the two are different programs);
+  parity      -- L-inf / peak-set agreement of image 0 of the timed batch against the CPU oracle, for the timed bf16 model AND for
+                 the fp32 parity mode and the fp16 mode (whose own images/s are reported there: they are different programs);
   roofline    -- the kernel with the largest share of the forward, HIP-event timed inside this run;
   cpu_baseline-- the CPU oracle ("port") on this host: thread sweep, batch 1 and 8, forward+NMS and +decode.
 `--dry-run` exercises the whole N-rank control flow (sharding, decode records, gather, JSON) on CPU tensors under gloo
@@ -39,7 +39,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
 GFLOP_PER_IMAGE = 865.0006                 # SURVEY.md 8(d); reproduced by the library's own op list (tests/test_abi_and_plan.py)
 
 
@@ -181,7 +181,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="tiles per GPU per step")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp16"])
     ap.add_argument("--max-boxes", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and with it the parity records)")
     ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of CPU-oracle time to aim for")
@@ -314,7 +314,7 @@ def main():
         name, d = max(by.items(), key=lambda kv: kv[1]["ms"])
         if name.startswith("conv"):
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK["bf16" if "<bf16" in name else "fp32"], "unit": "TFLOP/s"}
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK["fp32" if "<f32" in name else "bf16"], "unit": "TFLOP/s"}
         else:
             ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s"}
@@ -355,10 +355,9 @@ def main():
 
     # ---- the other numeric mode, parity of both against the CPU oracle, CPU baseline (rank 0, N = 1) -------------
     if rank == 0 and world == 1:
-        other = "fp32" if args.precision == "bf16" else "bf16"
-        rec_other = None
-        heat2 = feat2 = None
-        if not args.no_fp32:
+        others = [] if args.no_fp32 else [p_ for p_ in ("fp32", "fp16", "bf16") if p_ != args.precision]
+        recs, maps = {}, {}
+        for other in others:
             model2, det2 = make(other)
             heat2, feat2 = torch.empty_like(heat), torch.empty_like(feat)
             dws2 = DecodeWorkspace(B, 192, 192, 100, args.max_boxes, dev)
@@ -367,7 +366,8 @@ def main():
                 with torch.no_grad():
                     det2.forward_nhwc(x, out=(heat2, feat2))
                 return decode_peaks(heat2, feat2, tiles, cut_off=0.4, max_boxes=args.max_boxes, logit_cut=lcut, workspace=dws2)
-            k2 = max(3, args.steps // 4)
+            k2 = max(3, args.steps // 4) if other == "fp32" else args.steps
+            step2()
             step2()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -375,20 +375,23 @@ def main():
                 step2()
             torch.cuda.synchronize()
             e2 = time.perf_counter() - t0
-            rec_other = {"dtype": other, "images_per_s": round(B * k2 / e2, 2), "ms_per_step": round(1000 * e2 / k2, 3), "steps": k2,
-                         "path_frac_of_mfma_peak": round(B * k2 / e2 * GFLOP_PER_IMAGE / 1000 / PEAK[other], 4)}
+            recs[other] = {"dtype": other, "images_per_s": round(B * k2 / e2, 2), "ms_per_step": round(1000 * e2 / k2, 3), "steps": k2,
+                           "path_frac_of_mfma_peak": round(B * k2 / e2 * GFLOP_PER_IMAGE / 1000 / PEAK[other], 4)}
+            maps[other] = (heat2[:1].clone(), feat2[:1].clone())
+            del model2, det2, heat2, feat2, dws2
+            torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             cpu, o_hm, o_ft = cpu_baseline({k: v for k, v in sd.items()}, args.cpu_budget)
             result["cpu_baseline"] = cpu
             result["parity"] = {"reference": "CPU oracle (restatement of the reference path pinned by tests/golden), image 0 of the timed batch",
                                 args.precision: parity_record(heat, feat, o_hm, o_ft)}
-            if rec_other is not None:
-                result["parity"][other] = parity_record(heat2, feat2, o_hm, o_ft)
-        if rec_other is not None:
-            key = "fp32_parity_mode" if other == "fp32" else "bf16_speed_mode"
-            result[key] = rec_other
-            if "parity" in result and other in result["parity"]:
-                result[key].update({k: result["parity"][other][k] for k in ("heatmap_linf", "features_linf", "peak_set_identical", "peak_jaccard")})
+            for other in others:
+                result["parity"][other] = parity_record(maps[other][0], maps[other][1], o_hm, o_ft)
+        names = {"fp32": "fp32_parity_mode", "fp16": "fp16_mode", "bf16": "bf16_speed_mode"}
+        for other in others:
+            result[names[other]] = recs[other]
+            if "parity" in result:
+                result[names[other]].update({k: result["parity"][other][k] for k in ("heatmap_linf", "features_linf", "peak_set_identical", "peak_jaccard")})
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

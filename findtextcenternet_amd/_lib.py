@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libftc_hip.so")
 
 FTC_ABI_VERSION = 3
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 (BASE_NULL, BASE_WORKSPACE, BASE_WEIGHTS, BASE_INPUT, BASE_HEATMAP, BASE_FEATURES, NUM_BASES) = range(7)
 OP_STEM, OP_CONV, OP_DWCONV, OP_SE, OP_UPCAT, OP_NMS, OP_TAPSUM = 1, 2, 3, 4, 5, 6, 7
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2

@@ -12,9 +12,9 @@ namespace {
 // Stem: y = SiLU(conv3x3_s2(x*2-1, W') + b'), W'/b' = BN-folded.  Cin = 3, so K = 27: direct
 // convolution on the VALU; lanes = (pixel, channel quad) so a wave writes 1 KiB contiguous.
 // ------------------------------------------------------------------------------------------
-template <typename OutT>
+template <typename OutT, typename CopyT>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, const float* __restrict__ w,
-                                                   const float* __restrict__ bias, OutT* __restrict__ out, __bf16* __restrict__ out2,
+                                                   const float* __restrict__ bias, OutT* __restrict__ out, CopyT* __restrict__ out2,
                                                    int B, int H, int W, int Ho, int Wo, int C0, int nchw) {
     extern __shared__ __attribute__((aligned(16))) float sw[];   // [27][C0]
     for (int i = threadIdx.x; i < 27 * C0; i += blockDim.x) sw[i] = w[i];
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = act_silu_precise(acc[e]);
         store4<OutT>(out + (long)pix * C0 + cq * 4, acc);
-        if (out2) store4<__bf16>(out2 + (long)pix * C0 + cq * 4, acc);
+        if (out2) store4<CopyT>(out2 + (long)pix * C0 + cq * 4, acc);
     }
 }
 
@@ -204,21 +204,22 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, lds_ptr_t* dst, 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, 0, 0, 0);     // LDS[dst + lane*16] = 16 bytes at r[voff]; zeros when voff is out of range
 }
 
-__global__ __launch_bounds__(256) void dwconv_strip_kernel(const __bf16* __restrict__ in, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, __bf16* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__ in, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, T* __restrict__ out,
                                                            float* __restrict__ partial, int H, int W, int C, int tilesX,
                                                            int P, int tiles_per_wg) {
     constexpr int TH = 8, TW = 8, IW = 10, NPX = 100;
     constexpr int NLD = 4;                                               // DMA passes: 4 waves x 8 pixels x (8 lanes x 16 B) each
     constexpr int OOB = 0x7ffffff0;
-    __shared__ __attribute__((aligned(16))) __bf16 tile[2][NLD * 32 * 64];
+    __shared__ __attribute__((aligned(16))) T tile[2][NLD * 32 * 64];
     __shared__ __attribute__((aligned(16))) float red[16 * 64];
 
     const int t = threadIdx.x;
     const int b = blockIdx.z;
     const int c0 = blockIdx.x * 64;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(in + (long)b * H * W * C), 0,
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in + (long)b * H * W * C), 0,
                                                                          H * W * C * 2, 0x00020000);
     // staging role: pixel wave*8 + lane/8 of each 32-pixel pass, 8 channels (16 B)
     const int s_px = wave * 8 + (lane >> 3);
@@ -265,12 +266,12 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const __bf16* __restr
         const int ty = tileId / tilesX, tx = tileId - ty * tilesX;
         const int oy0 = ty * TH + rh * 4, ox = tx * TW + col;
         f32x4 acc[4] = {bv, bv, bv, bv};
-        const __bf16* tp = &tile[buf][((rh * 4) * IW + col) * 64 + cq * 4];
+        const T* tp = &tile[buf][((rh * 4) * IW + col) * 64 + cq * 4];
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             f32x4 x[3];
 #pragma unroll
-            for (int s2 = 0; s2 < 3; ++s2) x[s2] = load4<__bf16>(tp + (r * IW + s2) * 64);
+            for (int s2 = 0; s2 < 3; ++s2) x[s2] = load4<T>(tp + (r * IW + s2) * 64);
 #pragma unroll
             for (int oo = 0; oo < 4; ++oo) {
                 const int kr = r - oo;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const __bf16* __restr
             if (cok && oy < H && ox < W) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[oo][e] = act_silu_fast(acc[oo][e]);
-                store4<__bf16>(out + (((long)b * H + oy) * W + ox) * C + c, acc[oo]);
+                store4<T>(out + (((long)b * H + oy) * W + ox) * C + c, acc[oo]);
                 sum += acc[oo];
             }
         }
@@ -322,6 +323,19 @@ __global__ __launch_bounds__(512) void se_fc1_kernel(const float* __restrict__ p
     const int b = blockIdx.y;
     const int t = threadIdx.x;
     const int CQ = C >> 2;
+    const int lane = t & 63, wave = t >> 6;
+    const int sidx = blockIdx.x * 8 + wave;
+    // This kernel is a chain of dependent memory round trips (partials -> LDS -> weights -> store), not bandwidth: the weight row
+    // of this wave's hidden unit does not depend on the partial sums, so it is requested FIRST and is in flight while the sums are
+    // reduced (C <= 3840: at most 15 float4 per lane).
+    constexpr int WMAX = 15;
+    f32x4 wv[WMAX];
+    const f32x4* wr = reinterpret_cast<const f32x4*>(w1 + (long)(sidx < S ? sidx : 0) * C);
+#pragma unroll
+    for (int i = 0; i < WMAX; ++i) {
+        const int q = lane + 64 * i;
+        wv[i] = q < CQ ? wr[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const f32x4* pb = reinterpret_cast<const f32x4*>(partial + (long)b * P * C);
     for (int q = t; q < CQ; q += 512) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -330,13 +344,14 @@ __global__ __launch_bounds__(512) void se_fc1_kernel(const float* __restrict__ p
         reinterpret_cast<f32x4*>(mean)[q] = s * inv_hw;
     }
     __syncthreads();
-    const int lane = t & 63, wave = t >> 6;
-    const int sidx = blockIdx.x * 8 + wave;
     if (sidx >= S) return;
-    const f32x4* wr = reinterpret_cast<const f32x4*>(w1 + (long)sidx * C);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int q = lane; q < CQ; q += 64) acc += wr[q] * reinterpret_cast<const f32x4*>(mean)[q];
+#pragma unroll
+    for (int i = 0; i < WMAX; ++i) {
+        const int q = lane + 64 * i;
+        if (q < CQ) acc += wv[i] * reinterpret_cast<const f32x4*>(mean)[q];
+    }
+    for (int q = lane + 64 * WMAX; q < CQ; q += 64) acc += wr[q] * reinterpret_cast<const f32x4*>(mean)[q];     // (C > 3840: not in this network)
     float a = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
     if (lane == 0) hidden[(long)b * S + sidx] = act_silu_precise(a + b1[sidx]);
 }
@@ -344,10 +359,10 @@ __global__ __launch_bounds__(512) void se_fc1_kernel(const float* __restrict__ p
 // FOLD: additionally write the project weights scaled by this image's excitation, wb[b][n][c] = bf16(wp[n][c] * scale[b,c])
 // (FTC_FLAG_SE_FOLD).  The N rows are split over gridDim.z so that ~2 workgroups per CU share the copy; every z-slice
 // recomputes its 256 scale values (S coalesced loads per lane), slice 0 stores them.
-template <bool FOLD>
+template <bool FOLD, typename T>
 __global__ __launch_bounds__(256) void se_fc2_kernel(const float* __restrict__ hidden, const float* __restrict__ w2t,
                                                      const float* __restrict__ b2, float* __restrict__ scale, int C, int S,
-                                                     const __bf16* __restrict__ wp, __bf16* __restrict__ wb, int N) {
+                                                     const T* __restrict__ wp, T* __restrict__ wb, int N) {
     extern __shared__ __attribute__((aligned(16))) float hid[];    // [S] (+ [256] scale values when FOLD)
     const int b = blockIdx.y;
     for (int s = threadIdx.x; s < S; s += 256) hid[s] = hidden[(long)b * S + s];
@@ -373,14 +388,14 @@ __global__ __launch_bounds__(256) void se_fc2_kernel(const float* __restrict__ h
         for (int e = 0; e < 8; ++e) f[e] = lsc[chunk * 8 + e];
         const int rows = (N + gridDim.z - 1) / gridDim.z;
         const int n_lo = blockIdx.z * rows, n_hi = min(N, n_lo + rows);
-        __bf16* dst = wb + (long)b * N * C;
+        T* dst = wb + (long)b * N * C;
 #pragma unroll 4
         for (int n = n_lo + r0; n < n_hi; n += 8) {
             float x[8];
-            load16<__bf16>(wp + (long)n * C + cc, x);
+            load16<T>(wp + (long)n * C + cc, x);
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[e] *= f[e];
-            store16<__bf16>(dst + (long)n * C + cc, x);
+            store16<T>(dst + (long)n * C + cc, x);
         }
     }
 }
@@ -391,24 +406,32 @@ __global__ __launch_bounds__(256) void se_fc2_kernel(const float* __restrict__ h
 // (all of a lane's S/4 loads independent and unrolled), the four partial dots meet in LDS in fixed order, and the 64 scale values
 // then stream the [N][64] column block of the project weights: 8 lanes x 16 B per row, 32 rows per pass, rows split over gridDim.z.
 // Same arithmetic per element as se_fc2_kernel<true> except for the association of the S-sum (4 partial sums of S/4 terms).
+template <typename T>
 __global__ __launch_bounds__(256) void se_fc2_fold64_kernel(const float* __restrict__ hidden, const float* __restrict__ w2t,
                                                             const float* __restrict__ b2, float* __restrict__ scale, int C, int S,
-                                                            const __bf16* __restrict__ wp, __bf16* __restrict__ wb, int N) {
+                                                            const T* __restrict__ wp, T* __restrict__ wb, int N) {
     extern __shared__ __attribute__((aligned(16))) float lds_f[];      // [S] hidden | [4][64] partial dots | [64] scale
     float* hid = lds_f;
     float* part = lds_f + ((S + 3) & ~3);
     float* lsc = part + 256;
     const int b = blockIdx.y, t = threadIdx.x;
-    for (int s = t; s < S; s += 256) hid[s] = hidden[(long)b * S + s];
-    __syncthreads();
     const int cl = t & 63, sg = t >> 6;
     const int c = blockIdx.x * 64 + cl;
     const int s_lo = sg * ((S + 3) / 4), s_hi = min(S, s_lo + (S + 3) / 4);
+    // Dependent memory round trips, not bytes, bound this kernel (it takes ~9 us even when the fold writes 2 MB): the fc2 column of
+    // this lane does not depend on the hidden vector, so its S/4 loads are issued before the hidden vector is even requested
+    // (S <= 160: at most 40 per lane) and everything is in flight together.
+    constexpr int SMAX = 40;
+    float wreg[SMAX];
+#pragma unroll
+    for (int i = 0; i < SMAX; ++i) wreg[i] = (c < C && s_lo + i < s_hi) ? w2t[(long)(s_lo + i) * C + c] : 0.f;
+    for (int s = t; s < S; s += 256) hid[s] = hidden[(long)b * S + s];
+    __syncthreads();
     float acc = 0.f;
-    if (c < C) {
-#pragma unroll 8
-        for (int s = s_lo; s < s_hi; ++s) acc += hid[s] * w2t[(long)s * C + c];
-    }
+#pragma unroll
+    for (int i = 0; i < SMAX; ++i)
+        if (s_lo + i < s_hi) acc += hid[s_lo + i] * wreg[i];
+    for (int s = s_lo + SMAX; s < s_hi; ++s) acc += hid[s] * w2t[(long)s * C + c];      // (S > 160: not in this network)
     part[sg * 64 + cl] = acc;
     __syncthreads();
     if (t < 64) {
@@ -428,14 +451,14 @@ __global__ __launch_bounds__(256) void se_fc2_fold64_kernel(const float* __restr
     for (int e = 0; e < 8; ++e) f[e] = lsc[chunk * 8 + e];
     const int rows = (N + gridDim.z - 1) / gridDim.z;
     const int n_lo = blockIdx.z * rows, n_hi = min(N, n_lo + rows);
-    __bf16* dst = wb + (long)b * N * C;
+    T* dst = wb + (long)b * N * C;
 #pragma unroll 4
     for (int n = n_lo + r0; n < n_hi; n += 32) {
         float x[8];
-        load16<__bf16>(wp + (long)n * C + cc, x);
+        load16<T>(wp + (long)n * C + cc, x);
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] *= f[e];
-        store16<__bf16>(dst + (long)n * C + cc, x);
+        store16<T>(dst + (long)n * C + cc, x);
     }
 }
 
@@ -447,11 +470,18 @@ hipError_t launch_stem(const OpArgs& a, hipStream_t s) {
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     const size_t lds = (size_t)27 * o.Cout * sizeof(float);
     const int nchw = (o.flags & FTC_FLAG_IN_NCHW) ? 1 : 0;
-    if (o.out_dtype == FTC_F32)
-        hipLaunchKernelGGL(stem_kernel<float>, dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
+    // fp32 trunk output with an optional 16-bit copy in the plan's compute type (ftc_op.w_dtype: bf16 unless FTC_F16)
+    if (o.out_dtype == FTC_F32 && o.w_dtype == FTC_F16)
+        hipLaunchKernelGGL((stem_kernel<float, _Float16>), dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
+                           a.bias, (float*)a.out, (_Float16*)a.out2, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw);
+    else if (o.out_dtype == FTC_F32)
+        hipLaunchKernelGGL((stem_kernel<float, __bf16>), dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
                            a.bias, (float*)a.out, (__bf16*)a.out2, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw);
+    else if (o.out_dtype == FTC_F16)
+        hipLaunchKernelGGL((stem_kernel<_Float16, _Float16>), dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
+                           a.bias, (_Float16*)a.out, (_Float16*)nullptr, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw);
     else
-        hipLaunchKernelGGL(stem_kernel<__bf16>, dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
+        hipLaunchKernelGGL((stem_kernel<__bf16, __bf16>), dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
                            a.bias, (__bf16*)a.out, (__bf16*)nullptr, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw);
     return hipGetLastError();
 }
@@ -464,7 +494,7 @@ hipError_t launch_dwconv(const OpArgs& a, hipStream_t s) {
     if (P != o.aux0) return hipErrorInvalidValue;
     // Consecutive tiles per workgroup: the grid runs in ceil(workgroups / resident slots) rounds of `tpw` tile
     // times each; take the tpw that minimises rounds * tpw (ties: the larger, it amortises the tap loads).
-    const bool strip = o.in_dtype == FTC_BF16 && o.stride == 1 && !(o.flags & 0x100);
+    const bool strip = ftc_is16(o.in_dtype) && o.stride == 1 && !(o.flags & 0x100);
     const long slabs = (long)((o.Cin + 63) / 64) * o.B;
     const long slots = 256L * (strip ? 4 : o.in_dtype == FTC_F32 ? 3 : 2);     // workgroups resident on 256 CUs (VGPR-limited)
     int tpw = 1;
@@ -479,9 +509,13 @@ hipError_t launch_dwconv(const OpArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((dwconv_kernel<T, ST>), grid, dim3(256), 0, s, (const T*)a.in, (const float*)a.w, a.bias, \
                        (T*)a.out, a.aux, o.H, o.W, o.Ho, o.Wo, o.Cin, tilesX, P, tpw)
     if (o.in_dtype == FTC_F32) { if (o.stride == 1) DW_LAUNCH(float, 1); else DW_LAUNCH(float, 2); }
+    else if (o.stride == 1 && !(o.flags & 0x100) && o.in_dtype == FTC_F16)
+        hipLaunchKernelGGL(dwconv_strip_kernel<_Float16>, grid, dim3(256), 0, s, (const _Float16*)a.in, (const float*)a.w, a.bias,
+                           (_Float16*)a.out, a.aux, o.H, o.W, o.Cin, tilesX, P, tpw);
     else if (o.stride == 1 && !(o.flags & 0x100))
-        hipLaunchKernelGGL(dwconv_strip_kernel, grid, dim3(256), 0, s, (const __bf16*)a.in, (const float*)a.w, a.bias,
+        hipLaunchKernelGGL(dwconv_strip_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)a.in, (const float*)a.w, a.bias,
                            (__bf16*)a.out, a.aux, o.H, o.W, o.Cin, tilesX, P, tpw);
+    else if (o.in_dtype == FTC_F16) { if (o.stride == 1) DW_LAUNCH(_Float16, 1); else DW_LAUNCH(_Float16, 2); }
     else { if (o.stride == 1) DW_LAUNCH(__bf16, 1); else DW_LAUNCH(__bf16, 2); }
 #undef DW_LAUNCH
     return hipGetLastError();
@@ -500,16 +534,24 @@ hipError_t launch_se(const OpArgs& a, hipStream_t s) {
         int nz = (768 + cb * o.B - 1) / (cb * o.B);                  // ~3 workgroups per CU
         const int max_nz = (o.Cout_total + 31) / 32;
         nz = nz < 1 ? 1 : nz > max_nz ? max_nz : nz;
-        hipLaunchKernelGGL(se_fc2_fold64_kernel, dim3(cb, o.B, nz), dim3(256), (size_t)(((S + 3) & ~3) + 256 + 64) * sizeof(float), s, hidden,
-                           (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)a.in, (__bf16*)a.out2, o.Cout_total);
+        if (o.w_dtype == FTC_F16)
+            hipLaunchKernelGGL(se_fc2_fold64_kernel<_Float16>, dim3(cb, o.B, nz), dim3(256), (size_t)(((S + 3) & ~3) + 256 + 64) * sizeof(float), s, hidden,
+                               (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const _Float16*)a.in, (_Float16*)a.out2, o.Cout_total);
+        else
+            hipLaunchKernelGGL(se_fc2_fold64_kernel<__bf16>, dim3(cb, o.B, nz), dim3(256), (size_t)(((S + 3) & ~3) + 256 + 64) * sizeof(float), s, hidden,
+                               (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)a.in, (__bf16*)a.out2, o.Cout_total);
     } else if (o.flags & FTC_FLAG_SE_FOLD) {                         // 0x100: the first version (kept for A/B measurements)
         const int cb = (C + 255) / 256;
         int nz = 512 / (cb * o.B);
         nz = nz < 1 ? 1 : nz > 8 ? 8 : nz;
-        hipLaunchKernelGGL(se_fc2_kernel<true>, dim3(cb, o.B, nz), dim3(256), (size_t)(S + 256) * sizeof(float), s, hidden,
-                           (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)a.in, (__bf16*)a.out2, o.Cout_total);
+        if (o.w_dtype == FTC_F16)
+            hipLaunchKernelGGL((se_fc2_kernel<true, _Float16>), dim3(cb, o.B, nz), dim3(256), (size_t)(S + 256) * sizeof(float), s, hidden,
+                               (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const _Float16*)a.in, (_Float16*)a.out2, o.Cout_total);
+        else
+            hipLaunchKernelGGL((se_fc2_kernel<true, __bf16>), dim3(cb, o.B, nz), dim3(256), (size_t)(S + 256) * sizeof(float), s, hidden,
+                               (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)a.in, (__bf16*)a.out2, o.Cout_total);
     } else {
-        hipLaunchKernelGGL(se_fc2_kernel<false>, dim3((C + 255) / 256, o.B), dim3(256), (size_t)S * sizeof(float), s, hidden,
+        hipLaunchKernelGGL((se_fc2_kernel<false, __bf16>), dim3((C + 255) / 256, o.B), dim3(256), (size_t)S * sizeof(float), s, hidden,
                            (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)nullptr, (__bf16*)nullptr, 0);
     }
     return hipGetLastError();

@@ -11,18 +11,23 @@ hipError_t launch_conv_bf16_bb(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_bf16_fb(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_bf16_bf(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_bf16_ff(const ConvP& p, const ftc_op& o, hipStream_t s);
+hipError_t launch_conv_f16_hh(const ConvP& p, const ftc_op& o, hipStream_t s);
+hipError_t launch_conv_f16_fh(const ConvP& p, const ftc_op& o, hipStream_t s);
+hipError_t launch_conv_f16_hf(const ConvP& p, const ftc_op& o, hipStream_t s);
+hipError_t launch_conv_f16_ff(const ConvP& p, const ftc_op& o, hipStream_t s);
 
 void conv_kernel_label(const ftc_op& op, char* buf, int len) {
-    const char* dt[] = {"f32", "bf16"};
+    const char* dt[] = {"f32", "bf16", "f16", "?"};
     if (uses_halo(op)) {
-        snprintf(buf, len, (op.flags & FTC_FLAG_TOP_FUSE) ? "conv3x3_halo+top<%s,out=%s,tile=%dx16x16,bk=%d>" : "conv3x3_halo<%s,out=%s,tile=%dx16x16,bk=%d>", dt[op.w_dtype & 1], dt[op.out_dtype & 1], halo_sn(op) * 64,
-                 halo_cpr(op) * (op.w_dtype == FTC_BF16 ? 8 : 4));
+        const bool half_tile = hint_halo_half(op) && halo_cpr(op) == 4 && halo_sn(op) == 3 && ftc_is16(op.w_dtype);
+        snprintf(buf, len, (op.flags & FTC_FLAG_TOP_FUSE) ? "conv3x3_halo+top<%s,out=%s,tile=%dx%dx16,bk=%d>" : "conv3x3_halo<%s,out=%s,tile=%dx%dx16,bk=%d>", dt[op.w_dtype & 3],
+                 dt[op.out_dtype & 3], halo_sn(op) * 64, half_tile ? 8 : 16, halo_cpr(op) * (ftc_is16(op.w_dtype) ? 8 : 4));
         if (op.groups > 1) snprintf(buf + strlen(buf) - 1, len - strlen(buf) + 1, ",groups=%d>", op.groups);
         return;
     }
     const bool dma = uses_glds(op);
-    snprintf(buf, len, "conv_igemm%s<%s,in=%s,out=%s,tile=%s,bk=%d,nbuf=%d>", dma ? "_glds" : "", dt[op.w_dtype & 1], dt[op.in_dtype & 1],
-             dt[op.out_dtype & 1], kCfgName[select_cfg(op)], select_bk(op), dma ? glds_ring(op) : 1);
+    snprintf(buf, len, "conv_igemm%s<%s,in=%s,out=%s,tile=%s,bk=%d,nbuf=%d>", dma ? "_glds" : "", dt[op.w_dtype & 3], dt[op.in_dtype & 3],
+             dt[op.out_dtype & 3], kCfgName[select_cfg(op)], select_bk(op), dma ? glds_ring(op) : 1);
     if (!dma && hint_splitk(op) > 1) snprintf(buf + strlen(buf) - 1, len - strlen(buf) + 1, ",splitk=%d>", hint_splitk(op));
     if (op.groups > 1) snprintf(buf + strlen(buf) - 1, len - strlen(buf) + 1, ",groups=%d>", op.groups);
 }
@@ -30,6 +35,12 @@ void conv_kernel_label(const ftc_op& op, char* buf, int len) {
 const char* conv_validate(const ftc_op& op) {
     if (op.ksize != 1 && op.ksize != 3) return "conv: ksize must be 1 or 3";
     if (op.stride != 1 && op.stride != 2) return "conv: stride must be 1 or 2";
+    for (int dt : {op.w_dtype, op.in_dtype, op.out_dtype})
+        if (dt != FTC_F32 && dt != FTC_BF16 && dt != FTC_F16) return "conv: unknown dtype";
+    if (ftc_is16(op.w_dtype) && ((ftc_is16(op.in_dtype) && op.in_dtype != op.w_dtype) || (ftc_is16(op.out_dtype) && op.out_dtype != op.w_dtype)))
+        return "conv: 16-bit input / output must be in the compute type (bf16 and fp16 do not mix)";
+    if ((op.flags & FTC_FLAG_RESIDUAL) && ftc_is16(op.res_dtype) && op.res_dtype != (op.w_dtype == FTC_F16 ? FTC_F16 : FTC_BF16))
+        return "conv: a 16-bit residual must be in the compute type";
     const int E = op.w_dtype == FTC_F32 ? 4 : 8;
     const int Ein = op.in_dtype == FTC_F32 ? 4 : 8;
     if (op.w_dtype == FTC_F32 && (op.in_dtype != FTC_F32)) return "conv: fp32 compute needs fp32 input";
@@ -52,16 +63,16 @@ const char* conv_validate(const ftc_op& op) {
     if (!wset_legal(op)) return "conv: per-image weight sets need a pixel tile that divides Ho*Wo";
     if (op.flags & FTC_FLAG_UPCAT_IN) {
         const int bk = halo_cpr(op) * 8;
-        if (!uses_halo(op) || halo_sn(op) != 3 || op.w_dtype != FTC_BF16 || op.in_dtype != FTC_BF16 || op.out_dtype != FTC_BF16)
-            return "conv: UPCAT_IN needs the bf16 LDS-halo kernel with 192-channel tiles (aux0 = 65)";
+        if (!uses_halo(op) || halo_sn(op) != 3 || !ftc_is16(op.w_dtype) || op.in_dtype != op.w_dtype || op.out_dtype != op.w_dtype)
+            return "conv: UPCAT_IN needs the 16-bit LDS-halo kernel with 192-channel tiles (aux0 = 65)";
         if ((op.H | op.W) & 1 || op.cin_off != 0 || op.Cin_total <= 0 || op.Cin_total >= op.Cin || op.Cin_total % bk || (op.Cin - op.Cin_total) % bk)
             return "conv: UPCAT_IN needs even H, W and both channel parts multiples of the K block";
         if (op.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_SE_SCALE | FTC_FLAG_W_PER_IMAGE)) return "conv: UPCAT_IN excludes RESIDUAL / SE_SCALE / W_PER_IMAGE";
     }
     if (op.flags & FTC_FLAG_TOP_FUSE) {
-        if (!uses_halo(op) || halo_sn(op) != 3 || halo_cpr(op) != 8 || op.Cout != 192 || op.Cout_total != 192 || op.cout_off != 0 ||
-            op.w_dtype != FTC_BF16 || op.in_dtype != FTC_BF16 || op.out_dtype != FTC_BF16)
-            return "conv: TOP_FUSE needs the bf16 LDS-halo kernel with one 192-channel tile (aux0 = 65, Cin % 64 == 0, Cout = 192)";
+        if (!uses_halo(op) || halo_sn(op) != 3 || (halo_cpr(op) != 8 && !(hint_halo_half(op) && halo_cpr(op) == 4)) || op.Cout != 192 || op.Cout_total != 192 || op.cout_off != 0 ||
+            !ftc_is16(op.w_dtype) || op.in_dtype != op.w_dtype || op.out_dtype != op.w_dtype)
+            return "conv: TOP_FUSE needs the 16-bit LDS-halo kernel with one 192-channel tile (aux0 = 65, Cin % 64 == 0, Cout = 192)";
         if (op.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_GROUP_OUT_SLICE)) return "conv: TOP_FUSE excludes RESIDUAL / GROUP_OUT_SLICE";
         if (op.aux1 < 4 || op.aux1 > 32 || op.aux1 % 4) return "conv: TOP_FUSE output row width (aux1) must be a multiple of 4 in 4..32";
     }
@@ -72,8 +83,11 @@ const char* conv_validate(const ftc_op& op) {
     if (hint_halo(op) && !halo_legal(op)) return "conv: LDS-halo kernel is not legal for this op/tile";
     if (hint_splitk(op) > 1 && !splitk_legal(op, hint_splitk(op))) return "conv: split-K variant is not legal for this op/tile";
     if (op.aux0 < 0 || op.aux0 > 0xfff || hint_cfg(op) >= CFG_COUNT) return "conv: aux0 (tuned kernel choice) out of range";
-    if (hint_bk(op) && op.w_dtype == FTC_BF16 && (op.Cin % hint_bk(op)) && hint_bk(op) != 32) return "conv: tuned K step does not divide Cin";
-    if (hint_bk(op) == 128 && op.in_dtype != FTC_BF16) return "conv: K step 128 needs bf16 activations";
+    if ((op.aux0 & 128) && !hint_halo(op)) return "conv: aux0 bit 7 (half-height halo tile) needs bit 6 (LDS-halo kernel)";
+    if (hint_halo_half(op) && (halo_cpr(op) != 4 || halo_sn(op) != 3 || !ftc_is16(op.w_dtype) || op.out_dtype != op.w_dtype))
+        return "conv: the half-height halo tile exists for 16-bit 192-channel tiles with Cin % 32 == 0";
+    if (hint_bk(op) && ftc_is16(op.w_dtype) && (op.Cin % hint_bk(op)) && hint_bk(op) != 32) return "conv: tuned K step does not divide Cin";
+    if (hint_bk(op) == 128 && !ftc_is16(op.in_dtype)) return "conv: K step 128 needs 16-bit activations";
     if (hint_stage(op) >= 2 && !glds_legal(op)) return "conv: direct-to-LDS kernel is not legal for this op/tile";
     return nullptr;
 }
@@ -125,6 +139,12 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
         p.out2 = nullptr;
     }
     if (o.w_dtype == FTC_F32) return launch_conv_f32(p, o, s);
+    if (o.w_dtype == FTC_F16) {
+        if (o.in_dtype == FTC_F16 && o.out_dtype == FTC_F16) return launch_conv_f16_hh(p, o, s);
+        if (o.in_dtype == FTC_F32 && o.out_dtype == FTC_F16) return launch_conv_f16_fh(p, o, s);
+        if (o.in_dtype == FTC_F16 && o.out_dtype == FTC_F32) return launch_conv_f16_hf(p, o, s);
+        return launch_conv_f16_ff(p, o, s);
+    }
     if (o.in_dtype == FTC_BF16 && o.out_dtype == FTC_BF16) return launch_conv_bf16_bb(p, o, s);
     if (o.in_dtype == FTC_F32 && o.out_dtype == FTC_BF16) return launch_conv_bf16_fb(p, o, s);
     if (o.in_dtype == FTC_BF16 && o.out_dtype == FTC_F32) return launch_conv_bf16_bf(p, o, s);

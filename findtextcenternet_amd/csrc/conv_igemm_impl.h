@@ -97,6 +97,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const ConvP& p, in
 template <typename WT> struct Frag;
 template <> struct Frag<float> { using type = f32x4; };
 template <> struct Frag<__bf16> { using type = bf16x8; };
+template <> struct Frag<_Float16> { using type = f16x8; };
+
+// 32x32x16 MFMA on the two 16-bit operand formats (same rate, fp32 accumulation)
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 constexpr int OOB = 0x7ffffff0;      // byte offset beyond any buffer: the load returns zeros
 
@@ -116,6 +121,7 @@ __device__ __forceinline__ u32x4 load_act(__amdgpu_buffer_rsrc_t rin, int voff, 
         }
         return raw;
     } else {
+        using FragW = typename Frag<WT>::type;
         float f[8];
         if constexpr (sizeof(InT) == 4) {
             const f32x4 lo = __builtin_bit_cast(f32x4, bload(rin, voff, 0));
@@ -123,9 +129,10 @@ __device__ __forceinline__ u32x4 load_act(__amdgpu_buffer_rsrc_t rin, int voff, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = hi[e]; }
         } else {
+            static_assert(std::is_same<InT, WT>::value, "16-bit activations come in the compute type");
             const u32x4 raw = bload(rin, voff, 0);
             if (!use_se) return raw;
-            const bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+            const FragW v = __builtin_bit_cast(FragW, raw);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
         }
@@ -135,9 +142,9 @@ __device__ __forceinline__ u32x4 load_act(__amdgpu_buffer_rsrc_t rin, int voff, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) { f[e] *= s0[e]; f[4 + e] *= s1[e]; }
         }
-        bf16x8 r;
+        FragW r;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = (__bf16)f[e];
+        for (int e = 0; e < 8; ++e) r[e] = from_f32<WT>(f[e]);
         return __builtin_bit_cast(u32x4, r);
     }
 }
@@ -189,11 +196,11 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvP& p, f32x16 (&acc)
                     for (int e = 0; e < 4; ++e) v[e] = apply_act_sel<sizeof(WT) == 2>(v[e], p.act);
                     if (has_res) {
                         if (p.res_dtype == FTC_F32) v += load4<float>(reinterpret_cast<const float*>(p.res) + (size_t)m * p.Cout + n);
-                        else v += load4<__bf16>(reinterpret_cast<const __bf16*>(p.res) + (size_t)m * p.Cout + n);
+                        else v += load4<typename Half16<WT>::type>(reinterpret_cast<const typename Half16<WT>::type*>(p.res) + (size_t)m * p.Cout + n);
                     }
                     store4<OutT>(orow + n, v);
                     if constexpr (sizeof(OutT) == 4) {
-                        if (p.out2) store4<__bf16>(reinterpret_cast<__bf16*>(p.out2) + (size_t)m * p.Cout + n, v);
+                        if (p.out2) store4<typename Half16<WT>::type>(reinterpret_cast<typename Half16<WT>::type*>(p.out2) + (size_t)m * p.Cout + n, v);
                     }
                 } else {
 #pragma unroll
@@ -203,7 +210,7 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvP& p, f32x16 (&acc)
                         v = apply_act_sel<sizeof(WT) == 2>(v, p.act);
                         if (has_res) {
                             if (p.res_dtype == FTC_F32) v += reinterpret_cast<const float*>(p.res)[(size_t)m * p.Cout + n + e];
-                            else v += (float)reinterpret_cast<const __bf16*>(p.res)[(size_t)m * p.Cout + n + e];
+                            else v += (float)reinterpret_cast<const typename Half16<WT>::type*>(p.res)[(size_t)m * p.Cout + n + e];
                         }
                         orow[n + e] = from_f32<OutT>(v);
                     }
@@ -289,25 +296,25 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvP& p, f32x16 (&acc)[
             f32x4 v = __builtin_bit_cast(f32x4, raw);
             if (has_res) {
                 if (p.res_dtype == FTC_F32) v += load4<float>(reinterpret_cast<const float*>(p.res) + (size_t)m * p.Cout + n);
-                else v += load4<__bf16>(reinterpret_cast<const __bf16*>(p.res) + (size_t)m * p.Cout + n);
+                else v += load4<typename Half16<WT>::type>(reinterpret_cast<const typename Half16<WT>::type*>(p.res) + (size_t)m * p.Cout + n);
             }
             *reinterpret_cast<f32x4*>(outp + (size_t)m * p.CoutT + p.cout_off + n) = v;
-            if (p.out2) store4<__bf16>(reinterpret_cast<__bf16*>(p.out2) + (size_t)m * p.Cout + n, v);
+            if (p.out2) store4<typename Half16<WT>::type>(reinterpret_cast<typename Half16<WT>::type*>(p.out2) + (size_t)m * p.Cout + n, v);
         } else {
             if (has_res) {
                 float f[8], r[8];
-                load16<__bf16>(reinterpret_cast<const __bf16*>(&raw), f);
+                load16<OutT>(reinterpret_cast<const OutT*>(&raw), f);
                 if (p.res_dtype == FTC_F32) {
                     const f32x4 r0 = load4<float>(reinterpret_cast<const float*>(p.res) + (size_t)m * p.Cout + n);
                     const f32x4 r1 = load4<float>(reinterpret_cast<const float*>(p.res) + (size_t)m * p.Cout + n + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { r[e] = r0[e]; r[4 + e] = r1[e]; }
                 } else {
-                    load16<__bf16>(reinterpret_cast<const __bf16*>(p.res) + (size_t)m * p.Cout + n, r);
+                    load16<OutT>(reinterpret_cast<const OutT*>(p.res) + (size_t)m * p.Cout + n, r);
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) f[e] += r[e];
-                store16<__bf16>(reinterpret_cast<__bf16*>(outp) + (size_t)m * p.CoutT + p.cout_off + n, f);
+                store16<OutT>(outp + (size_t)m * p.CoutT + p.cout_off + n, f);
             } else {
                 *reinterpret_cast<u32x4*>(outp + (size_t)m * p.CoutT + p.cout_off + n) = raw;
             }
@@ -323,10 +330,10 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvP& p, f32x16 (&acc)[
 // while it sits in LDS (K = TN, 32 rows = 9*Co padded), so the 192-channel tensor (384 B/pixel) is never written:
 // only T (aux1 floats per pixel) leaves the CU, and FTC_OP_TAPSUM does the 9-point sum.
 // ------------------------------------------------------------------------------------------------
-template <int SN, int SM, int NTHREADS, int TN, int TM, typename RowFn>
+template <typename WT, int SN, int SM, int NTHREADS, int TN, int TM, typename RowFn>
 __device__ __forceinline__ void conv_epilogue_topfuse(const ConvP& p, f32x16 (&acc)[SN][SM], unsigned char* smem, int nw0, int pw0,
-                                                      int half, int l31, int wave, RowFn row_to_m) {
-    constexpr int PITCH = TN * 2;                           // bf16 image of the tile, [pixel][channel]
+                                                      int half, int l31, int lpix, int wave, RowFn row_to_m) {
+    constexpr int PITCH = TN * 2;                           // 16-bit image of the tile, [pixel][channel]
     constexpr int CH = TN / 8;                              // 16-byte chunks per row
     static_assert(PITCH % 128 == 0 && TM == 32 * (NTHREADS / 64), "one 32-pixel MFMA column block per wave");
     __syncthreads();
@@ -343,7 +350,7 @@ __device__ __forceinline__ void conv_epilogue_topfuse(const ConvP& p, f32x16 (&a
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < SM; ++j) {
-        const int prow = pw0 + j * 32 + l31;
+        const int prow = pw0 + j * 32 + lpix;           // pixel slot of this lane's accumulator column (see halo_pixel_slot)
         unsigned char* lrow = smem + prow * PITCH;
         const float* brow = lbias;
         if (p.flags & FTC_FLAG_BORDER_BIAS) {
@@ -364,7 +371,7 @@ __device__ __forceinline__ void conv_epilogue_topfuse(const ConvP& p, f32x16 (&a
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = apply_act_sel<true>(v[e], p.act);
                 const int chunk = (nl / 8) ^ (prow & 7);
-                store4<__bf16>(reinterpret_cast<__bf16*>(lrow + chunk * 16) + (nl % 8), v);
+                store4<WT>(reinterpret_cast<WT*>(lrow + chunk * 16) + (nl % 8), v);
             }
         }
     }
@@ -379,9 +386,10 @@ __device__ __forceinline__ void conv_epilogue_topfuse(const ConvP& p, f32x16 (&a
 #pragma unroll
     for (int g = 0; g < TN / 16; ++g) {
         const int c = g * 2 + half;
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(arow + ((c ^ (l31 & 7)) * 16));
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(brow + ((c ^ (prow & 7)) * 16));
-        t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, t, 0, 0, 0);
+        using FragW = typename Frag<WT>::type;
+        const FragW a = *reinterpret_cast<const FragW*>(arow + ((c ^ (l31 & 7)) * 16));
+        const FragW b = *reinterpret_cast<const FragW*>(brow + ((c ^ (prow & 7)) * 16));
+        t = mfma16(a, b, t);
     }
     const int m = row_to_m(prow);
     if (m >= 0) {
@@ -444,11 +452,11 @@ __device__ __forceinline__ void conv_epilogue_splitk(const ConvP& p, f32x16 (&ac
             for (int e = 0; e < 4; ++e) v[e] = apply_act_sel<sizeof(WT) == 2>(v[e], p.act);
             if (has_res) {
                 if (p.res_dtype == FTC_F32) v += load4<float>(reinterpret_cast<const float*>(p.res) + (size_t)m * p.Cout + n);
-                else v += load4<__bf16>(reinterpret_cast<const __bf16*>(p.res) + (size_t)m * p.Cout + n);
+                else v += load4<typename Half16<WT>::type>(reinterpret_cast<const typename Half16<WT>::type*>(p.res) + (size_t)m * p.Cout + n);
             }
             store4<OutT>(outp + (size_t)m * p.CoutT + p.cout_off + n, v);
             if constexpr (sizeof(OutT) == 4) {
-                if (p.out2) store4<__bf16>(reinterpret_cast<__bf16*>(p.out2) + (size_t)m * p.Cout + n, v);
+                if (p.out2) store4<typename Half16<WT>::type>(reinterpret_cast<typename Half16<WT>::type*>(p.out2) + (size_t)m * p.Cout + n, v);
             }
         } else {
 #pragma unroll
@@ -457,7 +465,7 @@ __device__ __forceinline__ void conv_epilogue_splitk(const ConvP& p, f32x16 (&ac
                 float x = apply_act_sel<sizeof(WT) == 2>(v[e] + brow[n + e], p.act);
                 if (has_res) {
                     if (p.res_dtype == FTC_F32) x += reinterpret_cast<const float*>(p.res)[(size_t)m * p.Cout + n + e];
-                    else x += (float)reinterpret_cast<const __bf16*>(p.res)[(size_t)m * p.Cout + n + e];
+                    else x += (float)reinterpret_cast<const typename Half16<WT>::type*>(p.res)[(size_t)m * p.Cout + n + e];
                 }
                 outp[(size_t)m * p.CoutT + p.cout_off + n + e] = from_f32<OutT>(x);
             }
@@ -634,8 +642,8 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(const ConvP p_laun
                 for (int i = 0; i < SN; ++i)
 #pragma unroll
                     for (int j = 0; j < SM; ++j) {
-                        if (DUAL && (g & 1)) accB[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], accB[i][j], 0, 0, 0);
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        if (DUAL && (g & 1)) accB[i][j] = mfma16(af[i], bf[j], accB[i][j]);
+                        else acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
                     }
             }
         }
@@ -848,8 +856,8 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p_laun
                 for (int i = 0; i < SN; ++i)
 #pragma unroll
                     for (int j = 0; j < SM; ++j) {
-                        if (DUAL && (g & 1)) accB[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], accB[i][j], 0, 0, 0);
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        if (DUAL && (g & 1)) accB[i][j] = mfma16(af[i], bf[j], accB[i][j]);
+                        else acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
                     }
             }
         }
@@ -914,18 +922,35 @@ __device__ __forceinline__ void wait_vmcnt_n(int n) {
     }
 }
 
+// Dynamic LDS of the halo kernel: 3 weight slots + 2 halo buffers; the half-height form also sizes for its epilogue images (the fused
+// tap epilogue needs tile image + 16 bias rows + tap matrix, more than its small operand buffers).
+template <typename WT, int CPR, int SN, bool TOPF, int WMQ>
+__host__ __device__ constexpr size_t halo_lds_bytes() {
+    constexpr int TN = 2 * SN * 32, TY = 4 * WMQ, NH = (TY + 2) * 18;
+    constexpr size_t ops = (size_t)3 * TN * CPR * 16 + (size_t)2 * NH * CPR * 16;
+    constexpr size_t topf = (size_t)TY * 16 * TN * 2 + (size_t)16 * TN * 4 + (size_t)32 * TN * 2;
+    constexpr size_t epi = (size_t)TY * 16 * TN * 2 + (size_t)16 * TN * 4;          // LDS-staged bf16 / fp16 output image + bias rows
+    return WMQ == 4 ? ops : (TOPF ? (ops > topf ? ops : topf) : (ops > epi ? ops : epi));
+}
+
 // (second launch bound = waves per SIMD: with 64-byte rows two workgroups fit the LDS of a CU, which needs <= 128 VGPRs)
-template <typename WT, typename OutT, int CPR, int SN, bool TOPF = false, bool UPIN = false>
-__global__ __launch_bounds__(512, (CPR == 4 && !UPIN && !TOPF) ? 4 : 2) void conv3x3_halo_kernel(const ConvP p_launch) {
+// WMQ = pixel quarters (waves along the pixel axis): 4 = the 16x16-pixel tile of 8 waves described above; 2 = a HALF-HEIGHT tile
+// (8 rows x 16 pixels, 4 waves, 256 threads) for the fused last-level kernels: with 64-byte rows its operand buffers + epilogue
+// image take 72 KB, so TWO workgroups share a CU with 256 VGPRs each -- one's per-K-step barrier wait, GELU / tap epilogue and
+// prologue overlap the other's MFMAs, which the one-workgroup-per-CU 16x16 form (156 KB, every wave at the same barrier) cannot do.
+// Cost: each workgroup streams its own copy of the weight slices (2x the weight bytes L2 -> LDS per CU).
+template <typename WT, typename OutT, int CPR, int SN, bool TOPF = false, bool UPIN = false, int WMQ = 4>
+__global__ __launch_bounds__(128 * WMQ, (WMQ == 2) ? 2 : (CPR == 4 && !UPIN && !TOPF) ? 4 : 2) void conv3x3_halo_kernel(const ConvP p_launch) {
     ConvP p = p_launch;
     constexpr int E = 16 / (int)sizeof(WT);
     constexpr int BK = CPR * E;
     constexpr int ROWB = CPR * 16;
-    constexpr int WN = 2, WM = 4, SM = 2;
+    constexpr int WN = 2, WM = WMQ, SM = 2;
+    constexpr int NT = 64 * WN * WM;                                         // threads per workgroup (512 | 256)
     constexpr int TN = WN * SN * 32;
-    constexpr int TY = 16, TX = 16, HW = TX + 2, NH = (TY + 2) * HW;        // 324 halo pixels
+    constexpr int TY = 4 * WM, TX = 16, HW = TX + 2, NH = (TY + 2) * HW;    // 324 (180) halo pixels
     constexpr int WCH = TN * CPR, HCH = NH * CPR;                            // 16-byte chunks per weight step / halo block
-    constexpr int NLW = (WCH + 511) / 512, NLH = (HCH + 511) / 512;          // DMA passes of the 512 threads
+    constexpr int NLW = (WCH + NT - 1) / NT, NLH = (HCH + NT - 1) / NT;      // DMA passes of the workgroup's threads
     constexpr int WSLOT = TN * ROWB, HBUF = NH * ROWB;
     static_assert(CPR == 8 || CPR == 4, "");
     static_assert(NLW + NLH <= 9 && NLH <= 8, "");
@@ -961,14 +986,14 @@ __global__ __launch_bounds__(512, (CPR == 4 && !UPIN && !TOPF) ? 4 : 2) void con
     int w_off[NLW], h_off[NLH];
 #pragma unroll
     for (int i = 0; i < NLW; ++i) {
-        const int q = i * 512 + t;
+        const int q = i * NT + t;
         const int row = q / CPR, kc = (q % CPR) ^ (CPR == 8 ? (row >> 1) & 7 : (row >> 2) & 3);
         const int n = n0 + row;
         w_off[i] = (q < WCH && n < p.Cout) ? (n * 9 * p.Cin + kc * E) * (int)sizeof(WT) : OOB;
     }
 #pragma unroll
     for (int i = 0; i < NLH; ++i) {
-        const int q = i * 512 + t;
+        const int q = i * NT + t;
         const int hr = q / CPR, kc = (q % CPR) ^ (CPR == 8 ? (hr >> 1) & 7 : (hr >> 2) & 3);
         const int iy = ty0 - 1 + hr / HW, ix = tx0 - 1 + hr % HW;
         const bool ok = q < HCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
@@ -984,9 +1009,9 @@ __global__ __launch_bounds__(512, (CPR == 4 && !UPIN && !TOPF) ? 4 : 2) void con
     // DMA instructions THIS wave issues per weight step / halo block (the last pass may cover fewer waves)
     int nlw = 0, nlh = 0;
 #pragma unroll
-    for (int i = 0; i < NLW; ++i) nlw += (i * 512 + wave * 64 < WCH) ? 1 : 0;
+    for (int i = 0; i < NLW; ++i) nlw += (i * NT + wave * 64 < WCH) ? 1 : 0;
 #pragma unroll
-    for (int i = 0; i < NLH; ++i) nlh += (i * 512 + wave * 64 < HCH) ? 1 : 0;
+    for (int i = 0; i < NLH; ++i) nlh += (i * NT + wave * 64 < HCH) ? 1 : 0;
 
     auto issue_w = [&](int k) {                              // weights of K step k -> ring slot k % 3
         const int cb = k / 9, tap = k - cb * 9;
@@ -994,9 +1019,9 @@ __global__ __launch_bounds__(512, (CPR == 4 && !UPIN && !TOPF) ? 4 : 2) void con
         unsigned char* slot = wbase + (k % 3) * WSLOT;
 #pragma unroll
         for (int i = 0; i < NLW; ++i) {
-            if (i * 512 + wave * 64 < WCH) {                 // wave-uniform
-                lds_void_t* dst = (lds_void_t*)(slot + (i * 512 + wave * 64) * 16);
-                if (i * 512 + t < WCH) glds16(rw, dst, w_off[i], soff);
+            if (i * NT + wave * 64 < WCH) {                 // wave-uniform
+                lds_void_t* dst = (lds_void_t*)(slot + (i * NT + wave * 64) * 16);
+                if (i * NT + t < WCH) glds16(rw, dst, w_off[i], soff);
             }
         }
     };
@@ -1005,9 +1030,9 @@ __global__ __launch_bounds__(512, (CPR == 4 && !UPIN && !TOPF) ? 4 : 2) void con
         unsigned char* buf = hbase + (cb & 1) * HBUF;
 #pragma unroll
         for (int i = 0; i < NLH; ++i) {
-            if (i * 512 + wave * 64 < HCH) {
-                lds_void_t* dst = (lds_void_t*)(buf + (i * 512 + wave * 64) * 16);
-                if (i * 512 + t < HCH) glds16(UPIN ? rin2 : rin, dst, h_off[i], soff);
+            if (i * NT + wave * 64 < HCH) {
+                lds_void_t* dst = (lds_void_t*)(buf + (i * NT + wave * 64) * 16);
+                if (i * NT + t < HCH) glds16(UPIN ? rin2 : rin, dst, h_off[i], soff);
             }
         }
     };
@@ -1026,9 +1051,16 @@ __global__ __launch_bounds__(512, (CPR == 4 && !UPIN && !TOPF) ? 4 : 2) void con
     int offA[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) offA[g] = (wn * SN * 32 + l31) * ROWB + (((g * 2 + half) ^ frA) << 4);
+    // Which of its sub-tile's 32 pixels (2 tile rows x 16) a lane owns.  ds_read_b128 services a wave in four groups of 16 lanes --
+    // {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32 (MI355X_MICROARCH.md, LDS) -- and the swizzled halo image is
+    // conflict-free for 16 CONSECUTIVE halo pixels (slot = halo row mod 16).  With the natural mapping (lane = pixel) a group mixes
+    // pixels of two tile rows whose halo rows are 18 apart, two of them collide mod 16 and every B-fragment read takes 8 LDS cycles
+    // instead of 4 (measured: SQ_LDS_BANK_CONFLICT = 29 % of the LDS cycles of this kernel, profiles/r02a).  So each lane group gets
+    // ONE tile row: group parity = popcount(lane >> 2) & 1, rank inside the group = (lane >> 3) * 4 + (lane & 3).
+    const int lpix = ((__builtin_popcount(l31 >> 2) & 1) << 4) | ((l31 >> 3) << 2) | (l31 & 3);
     int hr0[SM];                                             // halo row of this lane's pixel (tap 0,0) per sub-tile
 #pragma unroll
-    for (int j = 0; j < SM; ++j) hr0[j] = (wm * 4 + j * 2 + (l31 >> 4)) * HW + (l31 & 15);
+    for (int j = 0; j < SM; ++j) hr0[j] = (wm * 4 + j * 2 + (lpix >> 4)) * HW + (lpix & 15);
 
     auto compute = [&](int k) {
         const int cb = k / 9, tap = k - cb * 9;
@@ -1068,7 +1100,7 @@ __global__ __launch_bounds__(512, (CPR == 4 && !UPIN && !TOPF) ? 4 : 2) void con
                 for (int i = 0; i < SN; ++i)
 #pragma unroll
                     for (int j = 0; j < SM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][i], bf[s][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma16(af[s][i], bf[s][j], acc[i][j]);
             }
         }
     };
@@ -1084,7 +1116,7 @@ __global__ __launch_bounds__(512, (CPR == 4 && !UPIN && !TOPF) ? 4 : 2) void con
     if constexpr (UPIN) {
 #pragma unroll
         for (int i = 0; i < NLH; ++i) {
-            const int q = i * 512 + t;
+            const int q = i * NT + t;
             const int hr = q / CPR, kc = (q % CPR) ^ (CPR == 8 ? (hr >> 1) & 7 : (hr >> 2) & 3);
             const int iy = ty0 - 1 + hr / HW, ix = tx0 - 1 + hr % HW;
             const bool ok = q < HCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
@@ -1112,27 +1144,23 @@ __global__ __launch_bounds__(512, (CPR == 4 && !UPIN && !TOPF) ? 4 : 2) void con
             }
     };
     auto up_store = [&](int pass, int bufidx) {
-        static_assert(!UPIN || sizeof(WT) == 2, "in-loader upsample: bf16 only");
-        const int q = pass * 512 + t;
+        static_assert(!UPIN || sizeof(WT) == 2, "in-loader upsample: 16-bit operands only");
+        const int q = pass * NT + t;
         if (q >= HCH) return;
         float ly1 = 0.f, lx1 = 0.f;
 #pragma unroll
         for (int i = 0; i < NUP; ++i)
             if (i == pass) { ly1 = up_ly[i]; lx1 = up_lx[i]; }
         const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
-        float v[8];
+        if constexpr (sizeof(WT) == 2) {
+            float v[8];
+            const FragT c0 = __builtin_bit_cast(FragT, st[0]), c1 = __builtin_bit_cast(FragT, st[1]);
+            const FragT c2 = __builtin_bit_cast(FragT, st[2]), c3 = __builtin_bit_cast(FragT, st[3]);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {                        // bf16 pair of dword w: low half = even channel
-                const float a = __builtin_bit_cast(float, h ? (st[0][w] & 0xffff0000u) : (st[0][w] << 16));
-                const float b = __builtin_bit_cast(float, h ? (st[1][w] & 0xffff0000u) : (st[1][w] << 16));
-                const float c = __builtin_bit_cast(float, h ? (st[2][w] & 0xffff0000u) : (st[2][w] << 16));
-                const float d = __builtin_bit_cast(float, h ? (st[3][w] & 0xffff0000u) : (st[3][w] << 16));
-                v[2 * w + h] = ly0 * (lx0 * a + lx1 * b) + ly1 * (lx0 * c + lx1 * d);
-            }
+            for (int e = 0; e < 8; ++e)
+                v[e] = ly0 * (lx0 * (float)c0[e] + lx1 * (float)c1[e]) + ly1 * (lx0 * (float)c2[e] + lx1 * (float)c3[e]);
+            store16<WT>(reinterpret_cast<WT*>(hbase + bufidx * HBUF + q * 16), v);
         }
-        store16<__bf16>(reinterpret_cast<__bf16*>(hbase + bufidx * HBUF + q * 16), v);
     };
 
     const int nk = 9 * p.ncb;
@@ -1171,17 +1199,17 @@ __global__ __launch_bounds__(512, (CPR == 4 && !UPIN && !TOPF) ? 4 : 2) void con
     int mrow[SM];
 #pragma unroll
     for (int j = 0; j < SM; ++j) {
-        const int oy = ty0 + wm * 4 + j * 2 + (l31 >> 4), ox = tx0 + (l31 & 15);
+        const int oy = ty0 + wm * 4 + j * 2 + (lpix >> 4), ox = tx0 + (lpix & 15);
         mrow[j] = (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
     }
     if constexpr (TOPF) {
         static_assert(sizeof(WT) == 2 && sizeof(OutT) == 2, "");
-        conv_epilogue_topfuse<SN, SM, 512, TN, TY * TX>(p, acc, smem_raw, wn * SN * 32, wm * SM * 32, half, l31, wave, [&](int row) {
+        conv_epilogue_topfuse<WT, SN, SM, NT, TN, TY * TX>(p, acc, smem_raw, wn * SN * 32, wm * SM * 32, half, l31, lpix, wave, [&](int row) {
             const int oy = ty0 + (row >> 4), ox = tx0 + (row & 15);
             return (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
         });
-    } else if (epi_lds_ok<OutT>(p) && (size_t)TY * TX * epi_pitch<OutT>(TN) + (size_t)16 * TN * 4 <= (size_t)3 * WSLOT + 2 * HBUF) {
-        conv_epilogue_lds<WT, OutT, SN, SM, 512, TN, TY * TX>(p, acc, smem_raw, n0, wn * SN * 32, wm * SM * 32, half, l31, [&](int row) {
+    } else if (epi_lds_ok<OutT>(p) && (size_t)TY * TX * epi_pitch<OutT>(TN) + (size_t)16 * TN * 4 <= halo_lds_bytes<WT, CPR, SN, TOPF, WMQ>()) {
+        conv_epilogue_lds<WT, OutT, SN, SM, NT, TN, TY * TX>(p, acc, smem_raw, n0, wn * SN * 32, wm * SM * 32, half, lpix, [&](int row) {
             const int oy = ty0 + (row >> 4), ox = tx0 + (row & 15);
             return (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
         });
@@ -1191,13 +1219,14 @@ __global__ __launch_bounds__(512, (CPR == 4 && !UPIN && !TOPF) ? 4 : 2) void con
     if (tl_on) tl[43] = __builtin_amdgcn_s_memtime();
 }
 
-template <typename WT, typename OutT, int CPR, int SN, bool TOPF = false, bool UPIN = false>
+template <typename WT, typename OutT, int CPR, int SN, bool TOPF = false, bool UPIN = false, int WMQ = 4>
 hipError_t launch_halo(ConvP p, hipStream_t s) {
     constexpr int E = 16 / (int)sizeof(WT);
     constexpr int TN = 2 * SN * 32;
-    constexpr size_t lds_bytes = (size_t)3 * TN * CPR * 16 + (size_t)2 * 324 * CPR * 16;
-    static_assert(!TOPF || (size_t)256 * TN * 2 + 16 * TN * 4 + 32 * TN * 2 <= lds_bytes, "image + bias rows + tap matrix must fit the operand buffers");
-    auto kern = conv3x3_halo_kernel<WT, OutT, CPR, SN, TOPF, UPIN>;
+    constexpr int TY = 4 * WMQ;
+    constexpr size_t lds_bytes = halo_lds_bytes<WT, CPR, SN, TOPF, WMQ>();
+    static_assert(!TOPF || (size_t)TY * 16 * TN * 2 + 16 * TN * 4 + 32 * TN * 2 <= lds_bytes, "image + bias rows + tap matrix must fit");
+    auto kern = conv3x3_halo_kernel<WT, OutT, CPR, SN, TOPF, UPIN, WMQ>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -1207,9 +1236,9 @@ hipError_t launch_halo(ConvP p, hipStream_t s) {
     p.ncb = p.Cin / (CPR * E);
     p.nk = 9 * p.ncb;
     p.nN = (p.Cout + TN - 1) / TN;
-    p.nblk_g = p.nN * p.B * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16);
+    p.nblk_g = p.nN * p.B * ((p.Ho + TY - 1) / TY) * ((p.Wo + 15) / 16);
     p.nblk = p.nblk_g * (p.groups > 1 ? p.groups : 1);
-    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(512), lds_bytes, s, p);
+    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(128 * WMQ), lds_bytes, s, p);
     return hipGetLastError();
 }
 
@@ -1290,6 +1319,8 @@ hipError_t launch_cfg(const ConvP& p, hipStream_t s) {
 }
 
 // Tile configurations (output channels x output pixels per workgroup), in order of preference.
+// (tried in round 2 and removed: a 256x64 tile (4 waves side by side over N) for the wide MBConv expand GEMMs -- 0.6x the L2->LDS bytes
+//  per FLOP of the 64x64 tile -- never won in the tuner: gpurun_out/tuning_r2_1x1.log)
 enum { CFG_192x128 = 0, CFG_128x128, CFG_96x128, CFG_64x128, CFG_128x64, CFG_32x256, CFG_64x64, CFG_COUNT };
 static const char* const kCfgName[] = {"192x128", "128x128", "96x128", "64x128", "128x64", "32x256", "64x64"};
 static const int kCfgTN[] = {192, 128, 96, 64, 128, 32, 64};
@@ -1301,6 +1332,7 @@ static const int kCfgTM[] = {128, 128, 128, 128, 64, 256, 64};
 // (findtextcenternet_amd/tuning.py); every choice gives bit-identical results (same K order).
 inline int hint_cfg(const ftc_op& o) { return (o.aux0 & 15) - 1; }
 inline bool hint_halo(const ftc_op& o) { return (o.aux0 & 64) != 0; }         // bit 6: LDS-halo 3x3 kernel
+inline bool hint_halo_half(const ftc_op& o) { return (o.aux0 & 192) == 192; } // bits 6+7: its half-height, two-workgroups-per-CU form (fused 16-bit kernels)
 inline int hint_splitk(const ftc_op& o) { const int c = (o.aux0 >> 10) & 3; return c == 1 ? 2 : c == 2 ? 4 : 1; }   // bits 10-11
 inline int hint_stage(const ftc_op& o) { return (o.aux0 >> 4) & 3; }
 inline int hint_bk(const ftc_op& o) { const int b = (o.aux0 >> 8) & 3; return b == 1 ? 32 : b == 2 ? 64 : b == 3 ? 128 : 0; }
@@ -1331,7 +1363,7 @@ inline bool wset_legal(const ftc_op& o) {
 
 // K step: 64 for bf16 when the channel count allows (half the barriers per FLOP), else 32; 128 only by hint.
 inline int select_bk(const ftc_op& o) {
-    if (o.w_dtype != FTC_BF16) return 32;
+    if (!ftc_is16(o.w_dtype)) return 32;
     const int h = hint_bk(o);
     if (h) return h;
     return o.Cin % 64 == 0 ? 64 : 32;
@@ -1340,7 +1372,7 @@ inline bool glds_legal(const ftc_op& o) {
     if ((o.flags & FTC_FLAG_SE_SCALE) || o.in_dtype != o.w_dtype) return false;
     const int bk = select_bk(o);
     if (bk == 128) return false;
-    const int cpr = bk / (o.w_dtype == FTC_BF16 ? 8 : 4);
+    const int cpr = bk / (ftc_is16(o.w_dtype) ? 8 : 4);
     const int cfg = select_cfg(o);
     // tiles must be a whole number of workgroup-level DMA passes
     return ((kCfgTN[cfg] + kCfgTM[cfg]) * cpr) % 256 == 0 && (kCfgTN[cfg] * cpr) % 64 == 0;
@@ -1361,7 +1393,7 @@ inline int glds_ring(const ftc_op& o) { return hint_stage(o) == 3 ? 3 : 2; }
 // (64x64, 64x128, 128x64), and a K loop that divides evenly
 inline bool splitk_legal(const ftc_op& o, int kg) {
     if (kg == 1) return true;
-    if (o.w_dtype != FTC_BF16 || o.in_dtype != FTC_BF16 || select_bk(o) < 64) return false;
+    if (!ftc_is16(o.w_dtype) || o.in_dtype != o.w_dtype || select_bk(o) < 64) return false;
     const int cfg = select_cfg(o);
     if (!(cfg == CFG_64x64 || cfg == CFG_64x128 || cfg == CFG_128x64)) return false;
     const int bk = select_bk(o);
@@ -1376,6 +1408,7 @@ inline int halo_cpr(const ftc_op& o) {
     if (o.w_dtype == FTC_F32) return o.Cin % 32 == 0 ? 8 : 0;
     // 128-byte rows (K step 64) unless the channel count or the tuning hint (bk = 32) asks for 64-byte rows: those halve
     // the LDS footprint, so two workgroups share a CU and one's epilogue overlaps the other's K loop
+    if (hint_halo_half(o)) return (o.Cin % 32 == 0 && (!(o.flags & FTC_FLAG_UPCAT_IN) || o.Cin_total % 32 == 0)) ? 4 : 0;
     if (hint_bk(o) == 32 && hint_halo(o) && !(o.flags & (FTC_FLAG_TOP_FUSE | FTC_FLAG_UPCAT_IN))) return o.Cin % 32 == 0 ? 4 : 0;
     return o.Cin % 64 == 0 ? 8 : (o.Cin % 32 == 0 ? 4 : 0);
 }
@@ -1402,15 +1435,21 @@ hipError_t launch_halo_dispatch(const ConvP& p, const ftc_op& o, hipStream_t s) 
     const int sn = halo_sn(o), cpr = halo_cpr(o);
     if (o.flags & FTC_FLAG_TOP_FUSE) {
         if constexpr (sizeof(WT) == 2 && sizeof(OutT) == 2) {
+            if (hint_halo_half(o) && cpr == 4 && sn == 3)
+                return (o.flags & FTC_FLAG_UPCAT_IN) ? launch_halo<WT, OutT, 4, 3, true, true, 2>(p, s) : launch_halo<WT, OutT, 4, 3, true, false, 2>(p, s);
             if (cpr == 8 && sn == 3) return (o.flags & FTC_FLAG_UPCAT_IN) ? launch_halo<WT, OutT, 8, 3, true, true>(p, s) : launch_halo<WT, OutT, 8, 3, true>(p, s);
         }
         return hipErrorInvalidValue;
     }
     if (o.flags & FTC_FLAG_UPCAT_IN) {
         if constexpr (sizeof(WT) == 2 && sizeof(OutT) == 2) {
+            if (hint_halo_half(o) && cpr == 4 && sn == 3) return launch_halo<WT, OutT, 4, 3, false, true, 2>(p, s);
             if (sn == 3) return cpr == 8 ? launch_halo<WT, OutT, 8, 3, false, true>(p, s) : launch_halo<WT, OutT, 4, 3, false, true>(p, s);
         }
         return hipErrorInvalidValue;
+    }
+    if constexpr (sizeof(WT) == 2) {
+        if (hint_halo_half(o) && cpr == 4 && sn == 3) return launch_halo<WT, OutT, 4, 3, false, false, 2>(p, s);
     }
     if (cpr == 8) {
         if (sn == 3) return launch_halo<WT, OutT, 8, 3>(p, s);

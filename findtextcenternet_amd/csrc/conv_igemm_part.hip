@@ -8,7 +8,10 @@
 #define FTC_PART_OUT __bf16
 #define FTC_PART 1
 #endif
+#ifndef FTC_PART_W             // 16-bit compute / input type of the combination: __bf16 (default) or _Float16
+#define FTC_PART_W __bf16
+#endif
 
 hipError_t FTC_PART_FN(const convimpl::ConvP& p, const ftc_op& o, hipStream_t s) {
-    return convimpl::launch_part<__bf16, __bf16, FTC_PART_OUT, FTC_PART>(p, o, s);
+    return convimpl::launch_part<FTC_PART_W, FTC_PART_W, FTC_PART_OUT, FTC_PART>(p, o, s);
 }

@@ -164,6 +164,7 @@ hipError_t launch_upcat(const OpArgs& a, hipStream_t s) {
                        a.scale, a.shift, (T*)a.out, o.B, o.H, o.W, o.Ho, o.Wo, Cy, Ct, CyT, ry, rx, prev_gs, out_gs)
     // res_dtype = dtype of the backbone tap (the trunk stays fp32 in bf16 mode)
     if (o.in_dtype == FTC_F32) UPCAT_LAUNCH(float, float);
+    else if (o.in_dtype == FTC_F16) { if (o.res_dtype == FTC_F32) UPCAT_LAUNCH(_Float16, float); else UPCAT_LAUNCH(_Float16, _Float16); }
     else if (o.res_dtype == FTC_F32) UPCAT_LAUNCH(__bf16, float);
     else UPCAT_LAUNCH(__bf16, __bf16);
 #undef UPCAT_LAUNCH

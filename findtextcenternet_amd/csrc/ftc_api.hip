@@ -82,6 +82,7 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
     }
     case FTC_OP_DWCONV:
         if (!need(o.in, true, "in") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.bias, true, "bias") || !need(o.aux, true, "aux")) return why->c_str();
+        if (o.in_dtype != FTC_F32 && !ftc_is16(o.in_dtype)) return "dwconv: unknown dtype";
         if (o.Cin % (o.in_dtype == FTC_F32 ? 4 : 8) || o.Cin != o.Cout) return "dwconv: C must be a multiple of one 16-byte access (4 fp32 / 8 bf16) and Cin == Cout";
         if (o.stride != 1 && o.stride != 2) return "dwconv: stride must be 1 or 2";
         if (o.Ho != (o.H - 1) / o.stride + 1 || o.Wo != (o.W - 1) / o.stride + 1) return "dwconv: Ho/Wo inconsistent";
@@ -95,7 +96,7 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if ((size_t)o.Cin * 4 > 64000 || (size_t)o.aux0 * 4 > 64000) return "se: C or S too large for LDS";
         if (o.flags & FTC_FLAG_SE_FOLD) {
             if (!need(o.in, true, "in") || !need(o.out2, true, "out2")) return why->c_str();
-            if (o.Cin % 8 || o.Cout_total <= 0 || o.w_dtype != FTC_BF16) return "se: SE_FOLD needs a bf16 [Cout_total][C] matrix with C % 8 == 0";
+            if (o.Cin % 8 || o.Cout_total <= 0 || !ftc_is16(o.w_dtype)) return "se: SE_FOLD needs a 16-bit [Cout_total][C] matrix with C % 8 == 0";
         }
         return nullptr;
     case FTC_OP_UPCAT:
@@ -237,11 +238,11 @@ int ftc_op_kernel_label(const ftc_op* op, char* buf, int len) {
     case FTC_OP_STEM: std::snprintf(buf, len, "stem_kernel"); break;
     case FTC_OP_CONV: conv_kernel_label(*op, buf, len); break;
     case FTC_OP_DWCONV:
-        if (op->in_dtype == FTC_BF16 && op->stride == 1 && !(op->flags & 0x100)) std::snprintf(buf, len, "dwconv_strip_kernel<bf16,s1>");
-        else std::snprintf(buf, len, "dwconv_kernel<%s,s%d>", op->in_dtype == FTC_F32 ? "f32" : "bf16", op->stride);
+        if (ftc_is16(op->in_dtype) && op->stride == 1 && !(op->flags & 0x100)) std::snprintf(buf, len, "dwconv_strip_kernel<%s,s1>", ftc_dtname(op->in_dtype));
+        else std::snprintf(buf, len, "dwconv_kernel<%s,s%d>", ftc_dtname(op->in_dtype), op->stride);
         break;
     case FTC_OP_SE: std::snprintf(buf, len, "se_fc1+se_fc2"); break;
-    case FTC_OP_UPCAT: std::snprintf(buf, len, "upcat_kernel<%s>", op->in_dtype == FTC_F32 ? "f32" : "bf16"); break;
+    case FTC_OP_UPCAT: std::snprintf(buf, len, "upcat_kernel<%s>", ftc_dtname(op->in_dtype)); break;
     case FTC_OP_NMS: std::snprintf(buf, len, "nms_kernel"); break;
     case FTC_OP_TAPSUM: std::snprintf(buf, len, "tapsum_kernel"); break;
     default: return fail(FTC_ERR_INVALID, "ftc_op_kernel_label: unknown op kind");
@@ -373,8 +374,8 @@ int ftc_mask_compact(const unsigned char* mask, int64_t n, int32_t* sel_index, i
 int ftc_gather_rows(const float* features, const int32_t* sel_index, const int32_t* count, int64_t cap, int C, int c_pad, void* rows,
                     int out_dtype, void* stream) {
     if (!features || !sel_index || !rows) return fail(FTC_ERR_INVALID, "ftc_gather_rows: null pointer argument");
-    if (cap <= 0 || C <= 0 || (C & 3) || c_pad < C || (c_pad & 7) || (out_dtype != FTC_F32 && out_dtype != FTC_BF16))
-        return fail(FTC_ERR_INVALID, "ftc_gather_rows: need cap > 0, C % 4 == 0, c_pad >= C, c_pad % 8 == 0, out_dtype fp32 | bf16");
+    if (cap <= 0 || C <= 0 || (C & 3) || c_pad < C || (c_pad & 7) || (out_dtype != FTC_F32 && !ftc_is16(out_dtype)))
+        return fail(FTC_ERR_INVALID, "ftc_gather_rows: need cap > 0, C % 4 == 0, c_pad >= C, c_pad % 8 == 0, out_dtype fp32 | bf16 | fp16");
     hipError_t e = launch_gather_rows(features, sel_index, count, (long)cap, C, c_pad, rows, out_dtype, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(e, "ftc_gather_rows");
     return FTC_OK;

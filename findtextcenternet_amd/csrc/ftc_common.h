@@ -10,6 +10,16 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+
+// 16-bit storage / MFMA operand types: bf16 (speed mode) and IEEE half (fp16 mode).  Host-side helpers on ftc_dtype values.
+inline bool ftc_is16(int dt) { return dt == FTC_BF16 || dt == FTC_F16; }
+inline int ftc_esize(int dt) { return dt == FTC_F32 ? 4 : 2; }
+inline const char* ftc_dtname(int dt) { return dt == FTC_F32 ? "f32" : dt == FTC_BF16 ? "bf16" : "f16"; }
+// The 16-bit type that goes with a compute type: trunk copies (`out2`) and 16-bit residuals use it.
+template <typename WT> struct Half16 { using type = __bf16; };
+template <> struct Half16<_Float16> { using type = _Float16; };
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
@@ -38,6 +48,10 @@ template <> __device__ __forceinline__ float to_f32<__bf16>(__bf16 v) { return (
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+template <> __device__ __forceinline__ float to_f32<_Float16>(_Float16 v) { return (float)v; }
+// fp16 stores saturate (the format tops out at 65504; bf16 / fp32 activations of the same network do not overflow)
+__device__ __forceinline__ float f16_sat(float v) { return __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f); }
+template <> __device__ __forceinline__ _Float16 from_f32<_Float16>(float v) { return (_Float16)f16_sat(v); }
 
 // 4 consecutive elements <-> float4
 template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
@@ -47,11 +61,21 @@ template <> __device__ __forceinline__ f32x4 load4<__bf16>(const __bf16* p) {
     f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
     return r;
 }
+template <> __device__ __forceinline__ f32x4 load4<_Float16>(const _Float16* p) {
+    f16x4 v = *reinterpret_cast<const f16x4*>(p);
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+}
 template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
 template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 template <> __device__ __forceinline__ void store4<__bf16>(__bf16* p, f32x4 v) {
     bf16x4 r = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
     *reinterpret_cast<bf16x4*>(p) = r;
+}
+
+template <> __device__ __forceinline__ void store4<_Float16>(_Float16* p, f32x4 v) {
+    f16x4 r = {(_Float16)f16_sat(v[0]), (_Float16)f16_sat(v[1]), (_Float16)f16_sat(v[2]), (_Float16)f16_sat(v[3])};
+    *reinterpret_cast<f16x4*>(p) = r;
 }
 
 // V consecutive elements (16 bytes of storage: V = 4 fp32 | 8 bf16) <-> V floats
@@ -70,6 +94,11 @@ template <> __device__ __forceinline__ void load16<__bf16>(const __bf16* p, floa
         f[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u);
     }
 }
+template <> __device__ __forceinline__ void load16<_Float16>(const _Float16* p, float (&f)[8]) {
+    const f16x8 v = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+}
 template <typename T> __device__ __forceinline__ void store16(T* p, const float (&f)[16 / sizeof(T)]);
 template <> __device__ __forceinline__ void store16<float>(float* p, const float (&f)[4]) {
     f32x4 v = {f[0], f[1], f[2], f[3]};
@@ -80,6 +109,13 @@ template <> __device__ __forceinline__ void store16<__bf16>(__bf16* p, const flo
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (__bf16)f[e];
     *reinterpret_cast<bf16x8*>(p) = v;
+}
+
+template <> __device__ __forceinline__ void store16<_Float16>(_Float16* p, const float (&f)[8]) {
+    f16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (_Float16)f16_sat(f[e]);
+    *reinterpret_cast<f16x8*>(p) = v;
 }
 
 // Activations.  SiLU = x*sigmoid(x); GELU = exact erf form (nn.GELU default, detector.py:169).

@@ -131,6 +131,15 @@ inline uint16_t f32_to_bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
+inline uint16_t f32_to_f16_rne(float f) {           // IEEE half, round-to-nearest-even, saturating like the device stores
+    if (f > 65504.0f) f = 65504.0f;
+    if (f < -65504.0f) f = -65504.0f;
+    const _Float16 h = (_Float16)f;
+    uint16_t u;
+    std::memcpy(&u, &h, 2);
+    return u;
+}
+
 struct Blob {
     std::vector<uint8_t> bytes;
     std::map<std::string, int64_t> table;
@@ -145,11 +154,12 @@ struct Blob {
         for (int64_t i = 0; i < n; ++i) d[i] = (float)v[i];
     }
     void add_f32(const std::string& name, const float* v, int64_t n) { std::memcpy(add(name, n * 4), v, (size_t)n * 4); }
-    // MFMA compute type: fp32, or bf16 (double -> float -> bf16, both round-to-nearest-even)
-    void add_compute(const std::string& name, const double* v, int64_t n, bool bf16) {
-        if (!bf16) { add_f32(name, v, n); return; }
+    // MFMA compute type: fp32, or bf16 / fp16 (double -> float -> 16 bit, both steps round-to-nearest-even)
+    void add_compute(const std::string& name, const double* v, int64_t n, int dt) {
+        if (dt == FTC_F32) { add_f32(name, v, n); return; }
         uint16_t* d = reinterpret_cast<uint16_t*>(add(name, n * 2));
-        for (int64_t i = 0; i < n; ++i) d[i] = f32_to_bf16_rne((float)v[i]);
+        if (dt == FTC_BF16) for (int64_t i = 0; i < n; ++i) d[i] = f32_to_bf16_rne((float)v[i]);
+        else for (int64_t i = 0; i < n; ++i) d[i] = f32_to_f16_rne((float)v[i]);
     }
 };
 
@@ -254,14 +264,15 @@ bool env_on(const char* k) { const char* v = std::getenv(k); return v && *v && s
 
 // ---- weight packing (once per checkpoint) -------------------------------------------------------
 int pack_weights(ftc_model* m, Weights& w) {
-    const bool bf = m->precision == FTC_BF16;
+    const bool bf = m->precision != FTC_F32;      // a 16-bit speed mode (bf16 or fp16 operands): the fused / folded head variants exist
+    const int cdt = m->precision;                 // dtype of the MFMA operands
     Blob& bl = m->blob;
     bool ok = true;
     std::vector<double> wf, b;
     auto conv_bn = [&](const std::string& name, const std::string& conv_key, const std::string& bn, double eps, int O, int I, int k) {
         if (!fold(w, conv_key, bn, eps, O, I, k, &wf, &b)) { ok = false; return; }
         const std::vector<double> km = kmajor(wf, O, I, k);
-        bl.add_compute(name + ".w", km.data(), (int64_t)km.size(), bf);
+        bl.add_compute(name + ".w", km.data(), (int64_t)km.size(), cdt);
         bl.add_f32(name + ".b", b.data(), O);
     };
     const auto stages = backbone_blocks(m->size);
@@ -338,7 +349,7 @@ int pack_weights(ftc_model* m, Weights& w) {
                 for (int n = 0; n < FPN_DIM; ++n) b16_all[(size_t)idx * NHEADS * FPN_DIM + hi * FPN_DIM + n] = b16[(size_t)idx * FPN_DIM + n];
         }
         if (ok) {
-            bl.add_compute("heads.L0.w", wm_all.data(), (int64_t)wm_all.size(), bf);
+            bl.add_compute("heads.L0.w", wm_all.data(), (int64_t)wm_all.size(), cdt);
             bl.add_f32("heads.L0.b", b16_all.data(), (int64_t)b16_all.size());                         // [16][9*192]
         }
     }
@@ -366,7 +377,7 @@ int pack_weights(ftc_model* m, Weights& w) {
             ball.insert(ball.end(), b.begin(), b.end());
         }
         if (!ok) break;
-        bl.add_compute("heads.L" + std::to_string(i) + ".w", wall.data(), (int64_t)wall.size(), bf);
+        bl.add_compute("heads.L" + std::to_string(i) + ".w", wall.data(), (int64_t)wall.size(), cdt);
         bl.add_f32("heads.L" + std::to_string(i) + ".b", ball.data(), (int64_t)ball.size());
     }
     if (bf && ntap >= 2 && ok) {
@@ -393,7 +404,7 @@ int pack_weights(ftc_model* m, Weights& w) {
             std::copy(b16.begin(), b16.end(), ball.begin() + (size_t)hi * 16 * FPN_DIM);
         }
         if (ok) {
-            bl.add_compute("heads.L" + std::to_string(i) + "f.w", wall.data(), (int64_t)wall.size(), bf);
+            bl.add_compute("heads.L" + std::to_string(i) + "f.w", wall.data(), (int64_t)wall.size(), cdt);
             bl.add_f32("heads.L" + std::to_string(i) + "f.b", ball.data(), (int64_t)ball.size());         // [9][16][192]
         }
     }
@@ -411,7 +422,7 @@ int pack_weights(ftc_model* m, Weights& w) {
     std::vector<float> tb;
     for (int hi : {0, 1, 8}) {
         if (!ok || !top(HEADS[hi].name, HEADS[hi].out_dim, &km, &tb)) { ok = false; break; }
-        bl.add_compute(std::string(HEADS[hi].name) + ".top_conv.w", km.data(), (int64_t)km.size(), bf);
+        bl.add_compute(std::string(HEADS[hi].name) + ".top_conv.w", km.data(), (int64_t)km.size(), cdt);
         bl.add_f32(std::string(HEADS[hi].name) + ".top_conv.b", tb.data(), (int64_t)tb.size());
     }
     if (ok) {   // the six one-channel heads whose heat-map channels are consecutive (textline, separator, code1/2/4/8 -> channels 4..9)
@@ -423,7 +434,7 @@ int pack_weights(ftc_model* m, Weights& w) {
             b6.push_back(tb[0]);
         }
         if (ok) {
-            bl.add_compute("heads.top6.w", w6.data(), (int64_t)w6.size(), bf);
+            bl.add_compute("heads.top6.w", w6.data(), (int64_t)w6.size(), cdt);
             bl.add_f32("heads.top6.b", b6.data(), (int64_t)b6.size());
         }
     }
@@ -444,7 +455,7 @@ int pack_weights(ftc_model* m, Weights& w) {
             }
         }
         if (ok) {
-            bl.add_compute("heads.top8.wt", wt.data(), (int64_t)wt.size(), true);
+            bl.add_compute("heads.top8.wt", wt.data(), (int64_t)wt.size(), cdt);
             bl.add_f32("heads.top8.b", bias.data(), (int64_t)bias.size());
             std::memcpy(bl.add("heads.top8.map", (int64_t)omap.size() * 4), omap.data(), omap.size() * 4);
         }
@@ -467,11 +478,11 @@ int pack_weights(ftc_model* m, Weights& w) {
                 for (int c = 0; c < DECODER_MID; ++c) l1[(size_t)o * DECODER_MID + c] = (double)w1->data[(size_t)o * DECODER_MID + c] * a1.s[o];
             }
             for (size_t j = 0; j < l2.size(); ++j) l2[j] = (double)w2->data[j];
-            bl.add_compute(q + ".l0.w", l0.data(), (int64_t)l0.size(), bf);
+            bl.add_compute(q + ".l0.w", l0.data(), (int64_t)l0.size(), cdt);
             bl.add_f32(q + ".l0.b", a0.t.data(), DECODER_MID);
-            bl.add_compute(q + ".l1.w", l1.data(), (int64_t)l1.size(), bf);
+            bl.add_compute(q + ".l1.w", l1.data(), (int64_t)l1.size(), cdt);
             bl.add_f32(q + ".l1.b", a1.t.data(), DECODER_MID);
-            bl.add_compute(q + ".l2.w", l2.data(), (int64_t)l2.size(), bf);
+            bl.add_compute(q + ".l2.w", l2.data(), (int64_t)l2.size(), cdt);
             bl.add_f32(q + ".l2.b", b2->data, mod);
         }
         if (!ok) return ftc_set_error(FTC_ERR_INVALID, "ftc_create: decoder: " + (w.missing.empty() ? std::string("weight packing failed") : w.missing));
@@ -488,7 +499,9 @@ const TuneEntry kTuning[] = {
 
 std::string conv_signature(const ftc_op& o) {
     char buf[192];
-    int n = std::snprintf(buf, sizeof buf, "w%di%do%d_B%d_%dx%d_c%dof%d_n%dof%d_k%ds%d_f%d_a%d", o.w_dtype, o.in_dtype, o.out_dtype, o.B, o.H, o.W,
+    // fp16 operands run the same kernels at the same rate as bf16: they share the measured table (dtype 2 looks up as 1)
+    auto d = [](int dt) { return dt == FTC_F16 ? (int)FTC_BF16 : dt; };
+    int n = std::snprintf(buf, sizeof buf, "w%di%do%d_B%d_%dx%d_c%dof%d_n%dof%d_k%ds%d_f%d_a%d", d(o.w_dtype), d(o.in_dtype), d(o.out_dtype), o.B, o.H, o.W,
                           o.Cin, o.Cin_total, o.Cout, o.Cout_total, o.ksize, o.stride, o.flags, o.act);
     if (o.groups > 1) std::snprintf(buf + n, sizeof buf - n, "_g%d", o.groups);
     return buf;
@@ -499,10 +512,12 @@ void apply_tuning(std::vector<ftc_op>& ops) {
     static std::map<std::string, int> table;
     static std::once_flag once;
     std::call_once(once, [] { for (const TuneEntry* e = kTuning; e->sig; ++e) table[e->sig] = e->aux0; });
+    const char* hh = std::getenv("FTC_HALO_HALF");            // A/B switch for the half-height halo tile of the fused last-level kernels
     for (ftc_op& o : ops) {
         if (o.kind != FTC_OP_CONV) continue;
         auto it = table.find(conv_signature(o));
         if (it != table.end() && it->second) o.aux0 = it->second;
+        if (hh && (o.flags & FTC_FLAG_UPCAT_IN) && (o.aux0 & 64)) o.aux0 = std::strcmp(hh, "0") ? (o.aux0 | 128) : (o.aux0 & ~128);
     }
 }
 
@@ -528,8 +543,8 @@ struct ConvOpt {
 class Builder {
 public:
     Builder(ftc_model* m, int B, int H, int W, bool nchw) : m_(m), B(B), H(H), W(W), nchw_(nchw) {
-        bf_ = m->precision == FTC_BF16;
-        act_ = bf_ ? FTC_BF16 : FTC_F32;
+        bf_ = m->precision != FTC_F32;            // 16-bit speed mode (bf16 or fp16 operands)
+        act_ = m->precision;
         cdt_ = act_;
     }
     int build(ModelPlan* out);
@@ -593,7 +608,7 @@ int Builder::build(ModelPlan* out) {
     // the producing epilogue; the next GEMM reads the copy.
     const bool dual = bf_;
     const int G = dual ? A : T;                // dtype the GEMMs read the trunk in
-    auto trunk = [&](int64_t nelem, R* t, R* tb) { *t = buf(nelem, T); *tb = dual ? buf(nelem, FTC_BF16) : R(); };
+    auto trunk = [&](int64_t nelem, R* t, R* tb) { *t = buf(nelem, T); *tb = dual ? buf(nelem, A) : R(); };
 
     int h = (H - 1) / 2 + 1, w = (W - 1) / 2 + 1;
     R x, xb;
@@ -602,6 +617,7 @@ int Builder::build(ModelPlan* out) {
         SymOp s;
         ftc_op& o = s.o;
         o.kind = FTC_OP_STEM; o.flags = nchw_ ? FTC_FLAG_IN_NCHW : 0; o.act = FTC_ACT_SILU; o.in_dtype = FTC_F32; o.out_dtype = T;
+        o.w_dtype = dual ? A : 0;                  // STEM: dtype of the 16-bit trunk copy (out2)
         o.B = B; o.H = H; o.W = W; o.Ho = h; o.Wo = w; o.Cin = 3; o.Cout = c0; o.ksize = 3; o.stride = 2;
         s.in = {3, 0, 0}; s.out = x; s.out2 = xb; s.w = wref("stem.w"); s.bias = wref("stem.b");
         emit({"backbone.features.0", "stem", 2.0 * B * h * w * c0 * 27, (double)B * H * W * 3 * 4 + (double)B * h * w * c0 * (esize(T) + (dual ? 2 : 0))}, s);
@@ -645,11 +661,11 @@ int Builder::build(ModelPlan* out) {
                 // bf16 mode: the SE op also writes the project weights scaled per image, so that the project convolution streams both
                 // operands by DMA instead of rescaling activations while staging them.  Needs a 64-pixel tile that divides the image.
                 const bool foldse = dual && (ho * wo) % 64 == 0 && blk.exp % 8 == 0;
-                const R wb = foldse ? buf((int64_t)B * blk.cout * blk.exp, FTC_BF16) : R();
+                const R wb = foldse ? buf((int64_t)B * blk.cout * blk.exp, A) : R();
                 {
                     SymOp s;
                     ftc_op& o = s.o;
-                    o.kind = FTC_OP_SE; o.flags = foldse ? FTC_FLAG_SE_FOLD : 0; o.w_dtype = foldse ? FTC_BF16 : 0; o.B = B; o.H = ho; o.W = wo;
+                    o.kind = FTC_OP_SE; o.flags = foldse ? FTC_FLAG_SE_FOLD : 0; o.w_dtype = foldse ? A : 0; o.B = B; o.H = ho; o.W = wo;
                     o.Cin = blk.exp; o.Cout = blk.exp; o.Cout_total = foldse ? blk.cout : 0; o.aux0 = blk.squeeze; o.aux1 = P;
                     s.aux = part; s.out = sc; s.in2 = hid; s.w = wref(p + ".2.w1"); s.w2 = wref(p + ".2.w2t"); s.bias = wref(p + ".2.b1");
                     s.bias2 = wref(p + ".2.b2"); s.in = foldse ? wref(p + ".3.w") : R(); s.out2 = wb;
@@ -936,7 +952,7 @@ int ftc_create(const ftc_tensor* tensors, int n_tensors, const char* model_size,
     if (!tensors || n_tensors <= 0 || !out) return ftc_set_error(FTC_ERR_INVALID, "ftc_create: null/empty arguments");
     const std::string size = model_size && *model_size ? model_size : "xl";
     if (stage_rows(size).empty()) return ftc_set_error(FTC_ERR_INVALID, "ftc_create: model_size must be one of xl, l, m, s");
-    if (precision != FTC_F32 && precision != FTC_BF16) return ftc_set_error(FTC_ERR_INVALID, "ftc_create: precision must be FTC_F32 or FTC_BF16");
+    if (precision != FTC_F32 && precision != FTC_BF16 && precision != FTC_F16) return ftc_set_error(FTC_ERR_INVALID, "ftc_create: precision must be FTC_F32, FTC_BF16 or FTC_F16");
     Weights w;
     for (int i = 0; i < n_tensors; ++i) {
         const ftc_tensor& t = tensors[i];

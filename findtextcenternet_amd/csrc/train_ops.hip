@@ -316,6 +316,7 @@ hipError_t launch_gather_rows(const float* feat, const int32_t* sel_index, const
     const long total = cap * (Cpad / 4);
     const int nb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (out_dtype == FTC_F32) hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(nb), dim3(256), 0, s, feat, sel_index, count, cap, C, Cpad, (float*)rows);
+    else if (out_dtype == FTC_F16) hipLaunchKernelGGL(gather_rows_kernel<_Float16>, dim3(nb), dim3(256), 0, s, feat, sel_index, count, cap, C, Cpad, (_Float16*)rows);
     else hipLaunchKernelGGL(gather_rows_kernel<__bf16>, dim3(nb), dim3(256), 0, s, feat, sel_index, count, cap, C, Cpad, (__bf16*)rows);
     return hipGetLastError();
 }

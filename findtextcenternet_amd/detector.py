@@ -14,9 +14,10 @@ the reference); ``forward`` packs the weights once and enqueues the HIP plan thr
 built ``libftc_hip.so`` a call raises.
 
 Numeric modes (``precision`` argument, or env ``FTC_PRECISION``):
-``"fp32"`` (default; exact-f32 MFMA, the parity mode -- what the reference computes on CUDA/CPU) and
+``"fp32"`` (default; exact-f32 MFMA, the parity mode -- what the reference computes on CUDA/CPU),
 ``"bf16"`` (bf16 MFMA with fp32 accumulation, fp32 residual trunk and fp32 outputs -- the speed mode
-BASELINE.json's config 2 names).
+BASELINE.json's config 2 names) and ``"fp16"`` (the same plan with IEEE-half operands: same matrix rate,
+11-bit significands, so about 8x closer to the fp32 result; 16-bit activations saturate at +-65504).
 """
 from __future__ import annotations
 
@@ -30,7 +31,7 @@ import torch
 from torch import nn
 
 from . import _lib as L
-from .model import FtcModel
+from .model import PRECISIONS, TORCH_DTYPE, FtcModel
 from .schema import decoder_schema, detector_schema, feature_dim
 
 
@@ -174,8 +175,8 @@ class CenterNetDetection(nn.Module):
         self.model_size = model_size
         _populate(self, detector_schema(model_size))
         prec = precision or os.environ.get("FTC_PRECISION", "fp32")
-        if prec not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if prec not in PRECISIONS:
+            raise ValueError("precision must be 'fp32', 'bf16' or 'fp16'")
         object.__setattr__(self, "_engine", _HipEngine(prec, model_size, self))
         # pre_weights: the reference looks for efficientnetv2-xl-21k.npz next to detector.py and
         # silently continues when it is missing (models/detector.py:34-36, :129-130); use
@@ -186,8 +187,8 @@ class CenterNetDetection(nn.Module):
         return self._engine.precision
 
     def set_precision(self, precision: str) -> None:
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be 'fp32', 'bf16' or 'fp16'")
         if precision != self._engine.precision:
             self._engine.invalidate()
             self._engine.precision = precision
@@ -298,7 +299,7 @@ class TextDetectorModel(nn.Module):
         with torch.cuda.device(dev):
             eng.ensure_model(dev)
             n = feats.shape[0]
-            cdt = torch.float32 if eng.precision == "fp32" else torch.bfloat16
+            cdt = TORCH_DTYPE[eng.precision]
             if rows_ready:
                 rows = feats
             else:
@@ -326,11 +327,11 @@ class TextDetectorModel(nn.Module):
         dev = heat.device
         sel, cnt = mask_to_index(fmask)
         n = int(cnt.item())                                           # the reference's boolean indexing synchronises here as well
-        cdt = torch.float32 if self.detector.precision == "fp32" else torch.bfloat16
+        cdt = TORCH_DTYPE[self.detector.precision]
         rows = torch.empty((max(n, 1), 128), dtype=cdt, device=dev)
         with torch.cuda.device(dev):
             L.check(lib.ftc_gather_rows(feat.data_ptr(), sel.data_ptr(), cnt.data_ptr(), max(n, 1), feature_dim, 128, rows.data_ptr(),
-                                        L.F32 if cdt == torch.float32 else L.BF16, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                                        PRECISIONS[self.detector.precision], C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
                     "ftc_gather_rows")
         idx = torch.tensor([0, 2, 3, 4, 5, 6, 7, 8, 9], device=dev)
         heatmap = heat.index_select(3, idx).permute(0, 3, 1, 2)

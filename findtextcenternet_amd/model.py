@@ -16,6 +16,12 @@ import torch
 from . import _lib as L
 
 
+# numeric modes: fp32 = parity mode (exact-f32 MFMA); bf16 = speed mode (BASELINE config 2); fp16 = the speed-mode plan with IEEE-half
+# operands (same MFMA rate, 3 more mantissa bits: ~8x closer to the fp32 result, activations saturate at +-65504)
+PRECISIONS = {"fp32": L.F32, "bf16": L.BF16, "fp16": L.F16}
+TORCH_DTYPE = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+
+
 @dataclass
 class OpMeta:
     name: str
@@ -51,8 +57,8 @@ class FtcModel:
     """``ftc_create`` on a reference-style ``state_dict`` (``TextDetectorModel`` or ``CenterNetDetection`` keys)."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], precision: str = "fp32", model_size: str = "xl"):
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if precision not in PRECISIONS:
+            raise ValueError("precision must be 'fp32', 'bf16' or 'fp16'")
         lib = L.load()
         keep = []
         arr = (L.Tensor * len(state_dict))()
@@ -67,7 +73,7 @@ class FtcModel:
             for j, d in enumerate(t.shape):
                 arr[i].shape[j] = d
         h = C.c_void_p()
-        L.check(lib.ftc_create(arr, len(state_dict), model_size.encode(), L.F32 if precision == "fp32" else L.BF16, C.byref(h)), "ftc_create")
+        L.check(lib.ftc_create(arr, len(state_dict), model_size.encode(), PRECISIONS[precision], C.byref(h)), "ftc_create")
         self.handle: Optional[int] = h.value
         self.precision, self.model_size = precision, model_size
 

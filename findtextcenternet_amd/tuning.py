@@ -39,7 +39,8 @@ def describe(aux0: int) -> str:
     if aux0 == 0:
         return "default"
     if aux0 & 64:
-        return f"halo,channels={CFG_NAMES[(aux0 & 15) - 1].split('x')[0]}" + (",bk=32" if (aux0 >> 8) & 3 == 1 else "")
+        return (f"halo,channels={CFG_NAMES[(aux0 & 15) - 1].split('x')[0]}" + (",bk=32" if (aux0 >> 8) & 3 == 1 else "")
+                + (",half-height tile (2 WG/CU)" if aux0 & 128 else ""))
     sk = [1, 2, 4, 1][(aux0 >> 10) & 3]
     return (f"tile={CFG_NAMES[(aux0 & 15) - 1]},stage={['auto', 'reg', 'dma2', 'dma3'][(aux0 >> 4) & 3]},bk={[0, 32, 64, 128][(aux0 >> 8) & 3]}"
             + (f",splitk={sk}" if sk > 1 else ""))
@@ -86,6 +87,8 @@ def candidates(o) -> List[int]:
                 for sk in (2, 4):
                     out.append(encode(cfg, 1, bk, splitk=sk))
     if o.ksize == 3 and o.stride == 1:
+        if o.w_dtype != L.F32 and o.Cin % 32 == 0:        # ... its half-height form (4 waves, 64-byte rows, two workgroups per CU)
+            out.append(encode(0, 0, 0, halo=True) | 128)
         for cfg in (0, 1, 3):                             # LDS-halo kernel with 192 / 128 / 64 channel tiles
             out.append(encode(cfg, 0, 0, halo=True))
             if o.w_dtype == L.BF16 and o.Cin % 64 == 0:   # ... and with 64-byte rows (two workgroups per CU)
@@ -93,7 +96,7 @@ def candidates(o) -> List[int]:
     return out
 
 
-def tune_plan(engine, plan, reps: int = 5, verbose: bool = False) -> Dict[str, int]:
+def tune_plan(engine, plan, reps: int = 5, verbose: bool = False, only: str = "") -> Dict[str, int]:
     """engine: detector._HipEngine with weights + workspace resident and one forward already run; plan: model.PlanView built with
     FTC_NO_TUNING=1 (so that aux0 holds the untuned defaults)."""
     import numpy as np
@@ -116,6 +119,10 @@ def tune_plan(engine, plan, reps: int = 5, verbose: bool = False) -> Dict[str, i
         key = signature(o)
         if key in choices:
             continue
+        if only:
+            import re
+            if not re.search(only, key):
+                continue
         best, best_t, base_t = 0, 1e30, None
         one = (L.Op * 1)()
         for aux in [0] + candidates(o):
@@ -158,6 +165,7 @@ def main():
     ap.add_argument("--size", type=int, default=768)
     ap.add_argument("--out", default=TABLE_PATH)
     ap.add_argument("--merge", action="store_true", help="keep existing entries of --out")
+    ap.add_argument("--filter", default="", help="only re-measure conv signatures matching this regular expression (e.g. _k1s1_)")
     a = ap.parse_args()
     os.environ["FTC_NO_TUNING"] = "1"
     allc: Dict[str, int] = {}
@@ -174,7 +182,7 @@ def main():
                 det(x)
             eng = model.detector._engine
             plan = eng.plan(B, a.size, a.size, False)
-            ch = tune_plan(eng, plan, verbose=True)
+            ch = tune_plan(eng, plan, verbose=True, only=a.filter)
             allc.update(ch)
         del det, model
         torch.cuda.empty_cache()

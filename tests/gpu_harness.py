@@ -15,11 +15,16 @@ REF_FIELDS = ("in_", "in2", "out", "w", "w2", "bias", "bias2", "scale", "shift",
 def to_dev_bytes(t: torch.Tensor, dtype: int) -> torch.Tensor:
     """CPU fp32 tensor -> contiguous CPU tensor in the storage dtype."""
     t = t.contiguous()
-    return t.to(torch.bfloat16) if dtype == L.BF16 else t.float()
+    return t.to(torch.bfloat16) if dtype == L.BF16 else t.to(torch.float16) if dtype == L.F16 else t.float()
 
 
 def bf16_round(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.bfloat16).float()
+
+
+def round16(t: torch.Tensor, dtype: int) -> torch.Tensor:
+    """Round-trip through the 16-bit storage type (bf16 or IEEE half); identity for fp32."""
+    return t.to(torch.bfloat16).float() if dtype == L.BF16 else t.to(torch.float16).float() if dtype == L.F16 else t
 
 
 class Arena:
@@ -47,7 +52,7 @@ class Arena:
         buf = torch.full((self.size + 256,), fill, dtype=torch.uint8, device=self.device)
         for off, t in self.items:
             if t is not None:
-                raw = t.view(torch.uint8).reshape(-1) if t.dtype != torch.bfloat16 else t.view(torch.int16).view(torch.uint8).reshape(-1)
+                raw = t.view(torch.uint8).reshape(-1) if t.dtype not in (torch.bfloat16, torch.float16) else t.view(torch.int16).view(torch.uint8).reshape(-1)
                 buf[off:off + raw.numel()] = raw.to(self.device)
         self.buf = buf
         return buf
@@ -82,4 +87,4 @@ def run_op(fields: Dict, arena: Arena) -> None:
 
 
 def tdtype(d: int) -> torch.dtype:
-    return torch.float32 if d == L.F32 else torch.bfloat16
+    return torch.float32 if d == L.F32 else torch.bfloat16 if d == L.BF16 else torch.float16

@@ -345,3 +345,38 @@ def test_parameter_edits_are_noticed(sd):
         assert d2.detector._engine is not d.detector._engine and d2.detector._engine.model is None
         h3, _ = d2(x)
         assert torch.equal(h3, h2)
+
+
+def test_fp16_mode_same_plan_much_closer_to_the_reference(sd, golden_dir):
+    """precision='fp16': the speed-mode plan with IEEE-half MFMA operands (same matrix rate as bf16, 11-bit significands).
+    Against the reference golden it must beat the bf16 mode by a wide margin: heat-map / features within 0.15 % of range (bf16:
+    ~0.5 %), peak-set Jaccard >= 0.97."""
+    m = TextDetectorModel(pre_weights=False, precision="fp16")
+    m.load_state_dict(sd)
+    d = CenterNetDetector(m.detector).to("cuda").eval()
+    g = np.load(os.path.join(golden_dir, "g2_fwd768_page.npz"))
+    x = torch.from_numpy(synth.page_images(4242, 1, 768, 768)).permute(0, 3, 1, 2).to("cuda")
+    with torch.no_grad():
+        hm, ft = d(x)
+    hm, ft = hm.cpu().numpy(), ft.cpu().numpy()
+    gh = g["heatmap"]
+    both = np.isfinite(hm) & np.isfinite(gh)
+    rng = float(gh[np.isfinite(gh)].max() - gh[np.isfinite(gh)].min())
+    e = float(np.abs(hm[both] - gh[both]).max())
+    e_ft = float(np.abs(ft[0].reshape(100, -1)[:, g["feat_pos"]] - g["feat_at"]).max())
+    frng = float(g["feat_at"].max() - g["feat_at"].min())
+    ref, got = _peak_sets(gh)[0], _peak_sets(hm)[0]
+    jac, recall = len(ref & got) / max(1, len(ref | got)), len(ref & got) / max(1, len(ref))
+    _log(f"fp16 768 page: heatmap Linf {e:.3e} ({100 * e / rng:.3f}% of range)  features Linf {e_ft:.3e} ({100 * e_ft / frng:.3f}%)  "
+         f"peaks ref {len(ref)} fp16 {len(got)} jaccard {jac:.3f} recall {recall:.3f}")
+    assert e / rng < 0.0015 and e_ft / frng < 0.0015 and jac >= 0.97 and recall >= 0.98
+    # other geometries / batch sizes run the same code paths as bf16 (shared tuning table): quick agreement check with fp32
+    x2 = torch.from_numpy(synth.page_images(778, 3, 256, 192)).permute(0, 3, 1, 2).to("cuda")
+    m32 = TextDetectorModel(pre_weights=False, precision="fp32")
+    m32.load_state_dict(sd)
+    d32 = CenterNetDetector(m32.detector).to("cuda").eval()
+    with torch.no_grad():
+        h16, f16 = d(x2)
+        h32, f32_ = d32(x2)
+    fin = torch.isfinite(h16) & torch.isfinite(h32)
+    assert float((h16[fin] - h32[fin]).abs().max()) < 0.03 and float((f16 - f32_).abs().max()) < 0.05

@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from findtextcenternet_amd import _lib as L
-from gpu_harness import Arena, bf16_round, run_op, tdtype, to_dev_bytes
+from gpu_harness import round16, Arena, bf16_round, run_op, tdtype, to_dev_bytes
 
 pytestmark = pytest.mark.gpu
 
@@ -53,7 +53,9 @@ CONV_CASES = [
 ]
 # (mode name, w_dtype, in_dtype, out_dtype)
 CONV_MODES = [("f32", L.F32, L.F32, L.F32), ("bf16", L.BF16, L.BF16, L.BF16), ("bf16_f32in", L.BF16, L.F32, L.BF16),
-              ("bf16_f32out", L.BF16, L.BF16, L.F32), ("bf16_f32io", L.BF16, L.F32, L.F32)]
+              ("bf16_f32out", L.BF16, L.BF16, L.F32), ("bf16_f32io", L.BF16, L.F32, L.F32),
+              ("f16", L.F16, L.F16, L.F16), ("f16_f32in", L.F16, L.F32, L.F16), ("f16_f32out", L.F16, L.F16, L.F32), ("f16_f32io", L.F16, L.F32, L.F32)]
+TOL16 = {L.BF16: 1.5e-2, L.F16: 2.5e-3}          # relative error of a 16-bit-operand conv against the fp32 reference on the same rounded operands
 
 
 HALO_CASES = [c for c in CONV_CASES if c[10] == 3 and c[11] == 1] + [
@@ -62,8 +64,8 @@ HALO_CASES = [c for c in CONV_CASES if c[10] == 3 and c[11] == 1] + [
 ]
 
 
-@pytest.mark.parametrize("tile", [65, 66, 68], ids=["halo192", "halo128", "halo64"])
-@pytest.mark.parametrize("mode", [CONV_MODES[0], CONV_MODES[1], CONV_MODES[3]], ids=["f32", "bf16", "bf16_f32out"])
+@pytest.mark.parametrize("tile", [65, 66, 68, 193], ids=["halo192", "halo128", "halo64", "halo192_half"])
+@pytest.mark.parametrize("mode", [CONV_MODES[0], CONV_MODES[1], CONV_MODES[3], CONV_MODES[5], CONV_MODES[7]], ids=["f32", "bf16", "bf16_f32out", "f16", "f16_f32out"])
 @pytest.mark.parametrize("case", HALO_CASES, ids=[c[0] for c in HALO_CASES])
 def test_conv_halo_kernel(case, mode, tile):
     """The LDS-halo 3x3 kernel (ftc_op.aux0 bit 6) on every stride-1 3x3 case, all three channel tiles."""
@@ -71,6 +73,8 @@ def test_conv_halo_kernel(case, mode, tile):
         pytest.skip("halo kernel needs whole 32-element channel blocks")
     if mode[1] == L.F32 and case[4] % 32:
         pytest.skip("fp32 halo kernel needs Cin % 32 == 0")
+    if tile == 193 and (mode[1] == L.F32 or mode[3] != mode[1]):
+        pytest.skip("the half-height tile exists for 16-bit output in the compute type")
     _run_conv_case(case, mode, aux0=tile)
 
 
@@ -103,8 +107,8 @@ def test_conv(case, mode):
 def _run_conv_case(case, mode, aux0):
     name, B, H, W, Cin, CinT, cin_off, Cout, CoutT, cout_off, k, stride, act, residual, se = case
     mname, wdt, idt, odt = mode
-    if wdt == L.BF16 and Cin % 8:
-        pytest.skip("bf16 needs Cin % 8 == 0")
+    if wdt != L.F32 and Cin % 8:
+        pytest.skip("16-bit operands need Cin % 8 == 0")
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
     x_full = torch.randn(B, H, W, CinT, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
@@ -113,15 +117,12 @@ def _run_conv_case(case, mode, aux0):
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     res = torch.randn(B, Ho, Wo, Cout, generator=g) if residual else None
     sc = torch.rand(B, Cin, generator=g) + 0.25 if se else None
-    if idt == L.BF16:
-        x_full = bf16_round(x_full)
-    wq = bf16_round(w) if wdt == L.BF16 else w
+    x_full = round16(x_full, idt)
+    wq = round16(w, wdt)
     x = x_full[..., cin_off:cin_off + Cin]
     xin = x * sc[:, None, None, :] if se else x
-    if se and wdt == L.BF16:
-        xin = bf16_round(xin)                      # the kernel narrows the scaled activation to bf16
-    elif wdt == L.BF16 and idt == L.F32:
-        xin = bf16_round(xin)
+    if (se and wdt != L.F32) or (wdt != L.F32 and idt == L.F32):
+        xin = round16(xin, wdt)                    # the kernel narrows the (scaled) activation to the compute type
     ref = F.conv2d(xin.permute(0, 3, 1, 2), wq, None, stride, pad).permute(0, 2, 3, 1) + bias
     ref = ACT[act](ref)
     if residual:
@@ -143,7 +144,7 @@ def _run_conv_case(case, mode, aux0):
     out = full[..., cout_off:cout_off + Cout].float()
     err = _rel(out, ref)
     _log(f"conv {name:18s} {mname:12s} aux0={aux0} rel_err {err:.3e}")
-    tol = 2e-4 if wdt == L.F32 else 1.5e-2
+    tol = 2e-4 if wdt == L.F32 else TOL16[wdt]
     assert err < tol, (name, mname, err)
     if CoutT != Cout:      # untouched channels keep the 0xCD fill: the kernel wrote only its slice
         raw = ar.buf[o_out:o_out + B * Ho * Wo * CoutT * esz].cpu().view(B * Ho * Wo, CoutT * esz)
@@ -153,30 +154,31 @@ def _run_conv_case(case, mode, aux0):
 
 
 @pytest.mark.parametrize("aux0", [0, 5 + 32 + 512, 7 + 48 + 512, 7 + 16 + 512, 65], ids=["default", "128x64_dma2", "64x64_dma3", "64x64_reg", "halo"])
-@pytest.mark.parametrize("odt", [L.F32, L.BF16])
-def test_se_fold_then_per_image_weight_conv(odt, aux0):
+@pytest.mark.parametrize("odt,dt", [(L.F32, L.BF16), (L.BF16, L.BF16), (L.F32, L.F16), (L.F16, L.F16)], ids=["bf16_f32out", "bf16", "f16_f32out", "f16"])
+def test_se_fold_then_per_image_weight_conv(odt, dt, aux0):
     """bf16 mode of an MBConv tail: the SE op writes W_b = bf16(W * scale[b]) (FTC_FLAG_SE_FOLD) and the project
     convolution runs with one weight set per image (FTC_FLAG_W_PER_IMAGE) -- against project(x * scale) in fp32."""
     g = torch.Generator().manual_seed(23)
+    r16 = lambda t: round16(t, dt)
     B, H, W, Cc, N, S, P = 3, 8, 16, 256, 192, 16, 2
     k = 3 if aux0 == 65 else 1
-    x = bf16_round(torch.randn(B, H, W, Cc, generator=g))
+    x = r16(torch.randn(B, H, W, Cc, generator=g))
     part = torch.randn(B, P, Cc, generator=g) * 30
     w1 = torch.randn(S, Cc, generator=g) / Cc ** 0.5
     b1 = torch.randn(S, generator=g) * 0.3
     w2 = torch.randn(Cc, S, generator=g) / S ** 0.5
     b2 = torch.randn(Cc, generator=g) * 0.3
-    wp = bf16_round(torch.randn(N, Cc, k, k, generator=g) / (Cc * k * k) ** 0.5)
+    wp = r16(torch.randn(N, Cc, k, k, generator=g) / (Cc * k * k) ** 0.5)
     bias = torch.randn(N, generator=g) * 0.2
     res = torch.randn(B, H, W, N, generator=g)
     mean = part.sum(1) / (H * W)
     sc = torch.sigmoid(F.silu(mean @ w1.t() + b1) @ w2.t() + b2)                          # [B, C]
     ref = torch.stack([F.conv2d((x[b] * sc[b]).permute(2, 0, 1)[None], wp, bias, 1, (k - 1) // 2)[0].permute(1, 2, 0) for b in range(B)]) + res
     ar = Arena()
-    o_x = ar.put(to_dev_bytes(x, L.BF16))
+    o_x = ar.put(to_dev_bytes(x, dt))
     o_part = ar.put(part)
     o_w1, o_b1, o_w2t, o_b2 = ar.put(w1), ar.put(b1), ar.put(w2.t().contiguous()), ar.put(b2)
-    o_wp = ar.put(to_dev_bytes(wp.permute(0, 2, 3, 1).reshape(N, k * k * Cc), L.BF16))
+    o_wp = ar.put(to_dev_bytes(wp.permute(0, 2, 3, 1).reshape(N, k * k * Cc), dt))
     o_bias, o_res = ar.put(bias), ar.put(res)
     o_scale, o_hid = ar.reserve(B * Cc * 4), ar.reserve(B * S * 4)
     o_wb = ar.reserve(B * N * k * k * Cc * 2)
@@ -184,20 +186,20 @@ def test_se_fold_then_per_image_weight_conv(odt, aux0):
     o_out = ar.reserve(B * H * W * N * esz)
     ar.materialize()
     # the fold treats the weight matrix as [rows][C]: for the 3x3 variant of this test rows = N*9 (K-major layout)
-    run_op(dict(kind=L.OP_SE, flags=L.FLAG_SE_FOLD, w_dtype=L.BF16, B=B, H=H, W=W, Cin=Cc, Cout=Cc, Cout_total=N * k * k, aux0=S, aux1=P,
+    run_op(dict(kind=L.OP_SE, flags=L.FLAG_SE_FOLD, w_dtype=dt, B=B, H=H, W=W, Cin=Cc, Cout=Cc, Cout_total=N * k * k, aux0=S, aux1=P,
                 aux=o_part, out=o_scale, in2=o_hid, w=o_w1, w2=o_w2t, bias=o_b1, bias2=o_b2, in_=o_wp, out2=o_wb), ar)
     got_sc = ar.read(o_scale, (B, Cc), torch.float32)
     assert float((got_sc - sc).abs().max()) < 2e-6
-    wb = ar.read(o_wb, (B, N, k * k, Cc), torch.bfloat16).float()
-    want = bf16_round(wp.permute(0, 2, 3, 1).reshape(1, N, k * k, Cc) * got_sc[:, None, None, :])
-    assert float((wb - want).abs().max()) <= float(want.abs().max()) * 2 ** -8       # same product, at most one bf16 ulp apart
-    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_RESIDUAL | L.FLAG_W_PER_IMAGE, act=L.ACT_NONE, in_dtype=L.BF16, out_dtype=odt, w_dtype=L.BF16,
+    wb = ar.read(o_wb, (B, N, k * k, Cc), tdtype(dt)).float()
+    want = r16(wp.permute(0, 2, 3, 1).reshape(1, N, k * k, Cc) * got_sc[:, None, None, :])
+    assert float((wb - want).abs().max()) <= float(want.abs().max()) * (2 ** -8 if dt == L.BF16 else 2 ** -11)      # same product, at most one ulp of the 16-bit type apart
+    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_RESIDUAL | L.FLAG_W_PER_IMAGE, act=L.ACT_NONE, in_dtype=dt, out_dtype=odt, w_dtype=dt,
                 B=B, H=H, W=W, Ho=H, Wo=W, Cin=Cc, Cin_total=Cc, Cout=N, Cout_total=N, ksize=k, stride=1, res_dtype=L.F32, aux0=aux0,
                 in_=o_x, in2=o_res, out=o_out, w=o_wb, bias=o_bias), ar)
     out = ar.read(o_out, (B, H, W, N), tdtype(odt)).float()
     err = _rel(out, ref)
     _log(f"se_fold+per-image conv odt={odt} aux0={aux0} rel_err {err:.3e}")
-    assert err < 1.5e-2
+    assert err < TOL16[dt]
 
 
 @pytest.mark.parametrize("aux0", [0, 4 + 32 + 512, 2 + 16 + 512, 65, 68], ids=["default", "64x128_dma2", "128x128_reg", "halo192", "halo64"])
@@ -336,56 +338,62 @@ def _upcat_in_fuzz_shapes(n):
 
 @pytest.mark.parametrize("shape", [(2, 2, 16, 24, 192, 64), (3, 1, 22, 10, 64, 32), (1, 2, 40, 36, 192, 96), (2, 1, 8, 8, 128, 256)] + _upcat_in_fuzz_shapes(12),
                          ids=lambda s: "x".join(map(str, s)))
-def test_upcat_in_conv_equals_upsample_concat_conv(shape):
+@pytest.mark.parametrize("halo", [65, 193], ids=["tile16x16", "tile8x16_2perCU"])
+@pytest.mark.parametrize("dt", [L.BF16, L.F16], ids=["bf16", "f16"])
+def test_upcat_in_conv_equals_upsample_concat_conv(shape, dt, halo):
     """FTC_FLAG_UPCAT_IN: conv3x3(cat[bilinear_x2(prev), tapbn]) with the concatenation formed in the halo loader, against
     F.interpolate(align_corners=True) + cat + conv2d in fp32 (upsampled values rounded to bf16 as the kernel's LDS image is)."""
     G, B, H, W, Cy, Ct = shape
+    r16 = lambda t: round16(t, dt)
     g = torch.Generator().manual_seed(53)
-    prev = bf16_round(torch.randn(G, B, H // 2, W // 2, Cy, generator=g))
-    tap = bf16_round(torch.randn(G, B, H, W, Ct, generator=g))
+    prev = r16(torch.randn(G, B, H // 2, W // 2, Cy, generator=g))
+    tap = r16(torch.randn(G, B, H, W, Ct, generator=g))
     Cin, Cout = Cy + Ct, 192
-    w = bf16_round(torch.randn(G, Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    w = r16(torch.randn(G, Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
     bias = torch.randn(G, Cout, generator=g) * 0.3
     ref = []
     for i in range(G):
-        up = bf16_round(F.interpolate(prev[i].permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True))
+        up = r16(F.interpolate(prev[i].permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True))
         xin = torch.cat([up, tap[i].permute(0, 3, 1, 2)], 1)
         ref.append(F.gelu(F.conv2d(xin, w[i], bias[i], 1, 1)).permute(0, 2, 3, 1))
     ref = torch.stack(ref)
     ar = Arena()
-    o_prev = ar.put(to_dev_bytes(prev, L.BF16))
-    o_tap = ar.put(to_dev_bytes(tap, L.BF16))
-    o_w = ar.put(to_dev_bytes(w.permute(0, 1, 3, 4, 2).reshape(G, Cout, 9, Cin), L.BF16))
+    o_prev = ar.put(to_dev_bytes(prev, dt))
+    o_tap = ar.put(to_dev_bytes(tap, dt))
+    o_w = ar.put(to_dev_bytes(w.permute(0, 1, 3, 4, 2).reshape(G, Cout, 9, Cin), dt))
     o_b = ar.put(bias)
     o_out = ar.reserve(G * B * H * W * Cout * 2)
     ar.materialize()
-    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_UPCAT_IN, act=L.ACT_GELU, in_dtype=L.BF16, out_dtype=L.BF16, w_dtype=L.BF16, B=B, H=H, W=W, Ho=H,
-                Wo=W, Cin=Cin, Cin_total=Cy, Cout=Cout, Cout_total=Cout, ksize=3, stride=1, aux0=65, groups=G if G > 1 else 0,
+    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_UPCAT_IN, act=L.ACT_GELU, in_dtype=dt, out_dtype=dt, w_dtype=dt, B=B, H=H, W=W, Ho=H,
+                Wo=W, Cin=Cin, Cin_total=Cy, Cout=Cout, Cout_total=Cout, ksize=3, stride=1, aux0=halo, groups=G if G > 1 else 0,
                 in_=o_prev, in2=o_tap, out=o_out, w=o_w, bias=o_b), ar)
-    out = ar.read(o_out, (G, B, H, W, Cout), torch.bfloat16).float()
+    out = ar.read(o_out, (G, B, H, W, Cout), tdtype(dt)).float()
     err = _rel(out, ref)
     _log(f"upcat_in conv {shape} rel_err {err:.3e}")
-    assert err < 1.5e-2
+    assert err < TOL16[dt]
 
 
+@pytest.mark.parametrize("halo", [65, 193], ids=["tile16x16", "tile8x16_2perCU"])
+@pytest.mark.parametrize("dt", [L.BF16, L.F16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("top", [False, True], ids=["plain", "top_fuse"])
-def test_upcat_in_with_tap_batchnorm_folded_and_shared_tap(top):
+def test_upcat_in_with_tap_batchnorm_folded_and_shared_tap(top, dt, halo):
     """Last FPN level as the bf16 plan runs it: the nine heads read ONE backbone tap (FTC_FLAG_GROUP_IN2_SHARED); each head's input
     BatchNorm of the tap is folded into its weights and a 16-case border bias table (FTC_FLAG_BORDER_BIAS) -- against
     conv3x3(cat[upsample(prev_g), BN_g(tap)]) + GELU (then the 3x3 top convolution for the TOP_FUSE variant) in fp32."""
     G, B, H, W, Cy, Ct, Cm = 3, 2, 22, 36, 192, 64, 192
+    r16 = lambda t: round16(t, dt)
     g = torch.Generator().manual_seed(67)
-    prev = bf16_round(torch.randn(G, B, H // 2, W // 2, Cy, generator=g))
-    tap = bf16_round(torch.randn(B, H, W, Ct, generator=g))
+    prev = r16(torch.randn(G, B, H // 2, W // 2, Cy, generator=g))
+    tap = r16(torch.randn(B, H, W, Ct, generator=g))
     si, ti = torch.rand(G, Ct, generator=g) + 0.5, torch.randn(G, Ct, generator=g) * 0.5
     Cin = Cy + Ct
     w = torch.randn(G, Cm, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
     bo = torch.randn(G, Cm, generator=g) * 0.3
-    wt = bf16_round(torch.randn(G, 1, Cm, 3, 3, generator=g) / (Cm * 9) ** 0.5)
+    wt = r16(torch.randn(G, 1, Cm, 3, 3, generator=g) / (Cm * 9) ** 0.5)
     bt = torch.randn(G, 1, generator=g) * 0.2
     wm = w.clone()
     wm[:, :, Cy:] *= si[:, None, :, None, None]
-    wm = bf16_round(wm)
+    wm = r16(wm)
     b16 = torch.zeros(G, 16, Cm, dtype=torch.float64)
     for i in range(G):
         tmap = torch.einsum("ncrs,c->nrs", w[i, :, Cy:].double(), ti[i].double())
@@ -396,23 +404,23 @@ def test_upcat_in_with_tap_batchnorm_folded_and_shared_tap(top):
     # reference: the folded bf16 weights applied to (upsample, tap) plus what the shift contributes through the in-image taps
     ys = []
     for i in range(G):
-        up = bf16_round(F.interpolate(prev[i].permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True))
+        up = r16(F.interpolate(prev[i].permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True))
         xin = torch.cat([up, tap.permute(0, 3, 1, 2)], 1)
         shift = F.conv2d(torch.ones(B, Ct, H, W) * ti[i][None, :, None, None], w[i, :, Cy:], None, 1, 1)      # zero padded: border aware
         ys.append(F.gelu(F.conv2d(xin, wm[i], None, 1, 1) + shift + bo[i][None, :, None, None]))
     ar = Arena()
-    o_prev = ar.put(to_dev_bytes(prev, L.BF16))
-    o_tap = ar.put(to_dev_bytes(tap, L.BF16))
-    o_w = ar.put(to_dev_bytes(wm.permute(0, 1, 3, 4, 2).reshape(G, Cm, 9, Cin), L.BF16))
+    o_prev = ar.put(to_dev_bytes(prev, dt))
+    o_tap = ar.put(to_dev_bytes(tap, dt))
+    o_w = ar.put(to_dev_bytes(wm.permute(0, 1, 3, 4, 2).reshape(G, Cm, 9, Cin), dt))
     o_b = ar.put(b16.float())
     flags = L.FLAG_UPCAT_IN | L.FLAG_BORDER_BIAS | L.FLAG_GROUP_IN2_SHARED
     if not top:
         o_out = ar.reserve(G * B * H * W * Cm * 2)
         ar.materialize()
-        run_op(dict(kind=L.OP_CONV, flags=flags, act=L.ACT_GELU, in_dtype=L.BF16, out_dtype=L.BF16, w_dtype=L.BF16, B=B, H=H, W=W, Ho=H, Wo=W,
-                    Cin=Cin, Cin_total=Cy, Cout=Cm, Cout_total=Cm, ksize=3, stride=1, aux0=65, groups=G, in_=o_prev, in2=o_tap, out=o_out,
+        run_op(dict(kind=L.OP_CONV, flags=flags, act=L.ACT_GELU, in_dtype=dt, out_dtype=dt, w_dtype=dt, B=B, H=H, W=W, Ho=H, Wo=W,
+                    Cin=Cin, Cin_total=Cy, Cout=Cm, Cout_total=Cm, ksize=3, stride=1, aux0=halo, groups=G, in_=o_prev, in2=o_tap, out=o_out,
                     w=o_w, bias=o_b), ar)
-        out = ar.read(o_out, (G, B, H, W, Cm), torch.bfloat16).float()
+        out = ar.read(o_out, (G, B, H, W, Cm), tdtype(dt)).float()
         ref = torch.stack([y.permute(0, 2, 3, 1) for y in ys])
     else:
         TW = 12
@@ -420,27 +428,27 @@ def test_upcat_in_with_tap_batchnorm_folded_and_shared_tap(top):
         for i in range(G):
             for tp in range(9):
                 wt_mat[i, tp] = wt[i, 0, :, tp // 3, tp % 3]
-        o_wt = ar.put(to_dev_bytes(wt_mat, L.BF16))
+        o_wt = ar.put(to_dev_bytes(wt_mat, dt))
         o_map = ar.put(torch.tensor([(i, 0, 1, i) for i in range(G)], dtype=torch.int32))
         o_ob = ar.put(bt[:, 0].contiguous())
         o_T = ar.reserve(G * B * H * W * TW * 4)
         o_out = ar.reserve(B * H * W * G * 4)
         ar.materialize()
-        run_op(dict(kind=L.OP_CONV, flags=flags | L.FLAG_TOP_FUSE, act=L.ACT_GELU, in_dtype=L.BF16, out_dtype=L.BF16, w_dtype=L.BF16, B=B, H=H,
-                    W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cy, Cout=Cm, Cout_total=Cm, ksize=3, stride=1, aux0=65, aux1=TW, groups=G,
+        run_op(dict(kind=L.OP_CONV, flags=flags | L.FLAG_TOP_FUSE, act=L.ACT_GELU, in_dtype=dt, out_dtype=dt, w_dtype=dt, B=B, H=H,
+                    W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cy, Cout=Cm, Cout_total=Cm, ksize=3, stride=1, aux0=halo, aux1=TW, groups=G,
                     in_=o_prev, in2=o_tap, out=o_T, w=o_w, bias=o_b, w2=o_wt), ar)
         run_op(dict(kind=L.OP_TAPSUM, B=B, H=H, W=W, Ho=H, Wo=W, Cout_total=G, aux0=TW, aux1=G, groups=G, in_=o_T, out=o_out, w=o_map,
                     bias=o_ob), ar)
         out = ar.read(o_out, (B, H, W, G), torch.float32)
-        ref = torch.stack([F.conv2d(bf16_round(ys[i]), wt[i], bt[i], 1, 1)[:, 0] for i in range(G)], -1)
+        ref = torch.stack([F.conv2d(r16(ys[i]), wt[i], bt[i], 1, 1)[:, 0] for i in range(G)], -1)
     err = _rel(out, ref)
     _log(f"upcat_in + folded tap BN (top={top}) rel_err {err:.3e}")
-    assert err < 1.5e-2
+    assert err < TOL16[dt]
     # the image border is where a wrong border-bias case would show: same bound on the outermost ring alone
     ring = torch.ones(H, W, dtype=torch.bool)
     ring[1:-1, 1:-1] = False
     sel = (lambda a: a[:, :, ring]) if not top else (lambda a: a[:, ring])
-    assert float((sel(out) - sel(ref)).abs().max()) < 1.5e-2 * float(ref.abs().max())
+    assert float((sel(out) - sel(ref)).abs().max()) < TOL16[dt] * float(ref.abs().max())
 
 
 @pytest.mark.parametrize("dt", [L.F32, L.BF16])
@@ -500,7 +508,7 @@ def test_conv_dual_output_bf16_copy():
 
 
 @pytest.mark.parametrize("C0", [32, 24, 12])
-@pytest.mark.parametrize("odt", [L.F32, L.BF16])
+@pytest.mark.parametrize("odt", [L.F32, L.BF16, L.F16])
 @pytest.mark.parametrize("nchw", [False, True])
 def test_stem(nchw, odt, C0):
     g = torch.Generator().manual_seed(3)
@@ -523,14 +531,12 @@ def test_stem(nchw, odt, C0):
     assert err < (1e-5 if odt == L.F32 else 6e-3)
 
 
-@pytest.mark.parametrize("dt", [L.F32, L.BF16])
+@pytest.mark.parametrize("dt", [L.F32, L.BF16, L.F16])
 @pytest.mark.parametrize("shape", [(2, 48, 48, 192, 1), (2, 48, 48, 128, 2), (1, 21, 13, 72, 1), (1, 21, 13, 72, 2), (3, 24, 24, 3840, 1)])
 def test_dwconv_and_se(shape, dt):
     B, H, W, Cc, stride = shape
     g = torch.Generator().manual_seed(11)
-    x = torch.randn(B, H, W, Cc, generator=g)
-    if dt == L.BF16:
-        x = bf16_round(x)
+    x = round16(torch.randn(B, H, W, Cc, generator=g), dt)
     w = torch.randn(Cc, 1, 3, 3, generator=g) * 0.4
     bias = torch.randn(Cc, generator=g) * 0.2
     ref = F.silu(F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride, 1, 1, Cc)).permute(0, 2, 3, 1)
@@ -573,7 +579,8 @@ def test_dwconv_and_se(shape, dt):
     assert err_se < 2e-6
 
 
-@pytest.mark.parametrize("cfg", [("f32", L.F32, L.F32), ("bf16_f32tap", L.BF16, L.F32), ("bf16", L.BF16, L.BF16)], ids=lambda c: c[0])
+@pytest.mark.parametrize("cfg", [("f32", L.F32, L.F32), ("bf16_f32tap", L.BF16, L.F32), ("bf16", L.BF16, L.BF16), ("f16_f32tap", L.F16, L.F32),
+                                 ("f16", L.F16, L.F16)], ids=lambda c: c[0])
 @pytest.mark.parametrize("with_y", [True, False])
 def test_upcat(with_y, cfg):
     _, dt, tdt = cfg
@@ -582,10 +589,7 @@ def test_upcat(with_y, cfg):
     Ho, Wo = (2 * Hi, 2 * Wi) if with_y else (Hi, Wi)
     y = torch.randn(B, Hi, Wi, Cy, generator=g)
     tap = torch.randn(B, Ho, Wo, Ct, generator=g)
-    if dt == L.BF16:
-        y = bf16_round(y)
-    if tdt == L.BF16:
-        tap = bf16_round(tap)
+    y, tap = round16(y, dt), round16(tap, tdt)
     sc, sh = torch.rand(Ct, generator=g) + 0.5, torch.randn(Ct, generator=g)
     parts = []
     if with_y:

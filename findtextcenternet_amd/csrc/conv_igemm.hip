@@ -19,9 +19,8 @@ hipError_t launch_conv_f16_ff(const ConvP& p, const ftc_op& o, hipStream_t s);
 void conv_kernel_label(const ftc_op& op, char* buf, int len) {
     const char* dt[] = {"f32", "bf16", "f16", "?"};
     if (uses_halo(op)) {
-        const bool half_tile = hint_halo_half(op) && halo_cpr(op) == 4 && halo_sn(op) == 3 && ftc_is16(op.w_dtype);
-        snprintf(buf, len, (op.flags & FTC_FLAG_TOP_FUSE) ? "conv3x3_halo+top<%s,out=%s,tile=%dx%dx16,bk=%d>" : "conv3x3_halo<%s,out=%s,tile=%dx%dx16,bk=%d>", dt[op.w_dtype & 3],
-                 dt[op.out_dtype & 3], halo_sn(op) * 64, half_tile ? 8 : 16, halo_cpr(op) * (ftc_is16(op.w_dtype) ? 8 : 4));
+        snprintf(buf, len, (op.flags & FTC_FLAG_TOP_FUSE) ? "conv3x3_halo+top<%s,out=%s,tile=%dx16x16,bk=%d>" : "conv3x3_halo<%s,out=%s,tile=%dx16x16,bk=%d>", dt[op.w_dtype & 3],
+                 dt[op.out_dtype & 3], halo_sn(op) * 64, halo_cpr(op) * (ftc_is16(op.w_dtype) ? 8 : 4));
         if (op.groups > 1) snprintf(buf + strlen(buf) - 1, len - strlen(buf) + 1, ",groups=%d>", op.groups);
         return;
     }
@@ -70,7 +69,7 @@ const char* conv_validate(const ftc_op& op) {
         if (op.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_SE_SCALE | FTC_FLAG_W_PER_IMAGE)) return "conv: UPCAT_IN excludes RESIDUAL / SE_SCALE / W_PER_IMAGE";
     }
     if (op.flags & FTC_FLAG_TOP_FUSE) {
-        if (!uses_halo(op) || halo_sn(op) != 3 || (halo_cpr(op) != 8 && !(hint_halo_half(op) && halo_cpr(op) == 4)) || op.Cout != 192 || op.Cout_total != 192 || op.cout_off != 0 ||
+        if (!uses_halo(op) || halo_sn(op) != 3 || halo_cpr(op) != 8 || op.Cout != 192 || op.Cout_total != 192 || op.cout_off != 0 ||
             !ftc_is16(op.w_dtype) || op.in_dtype != op.w_dtype || op.out_dtype != op.w_dtype)
             return "conv: TOP_FUSE needs the 16-bit LDS-halo kernel with one 192-channel tile (aux0 = 65, Cin % 64 == 0, Cout = 192)";
         if (op.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_GROUP_OUT_SLICE)) return "conv: TOP_FUSE excludes RESIDUAL / GROUP_OUT_SLICE";
@@ -83,9 +82,7 @@ const char* conv_validate(const ftc_op& op) {
     if (hint_halo(op) && !halo_legal(op)) return "conv: LDS-halo kernel is not legal for this op/tile";
     if (hint_splitk(op) > 1 && !splitk_legal(op, hint_splitk(op))) return "conv: split-K variant is not legal for this op/tile";
     if (op.aux0 < 0 || op.aux0 > 0xfff || hint_cfg(op) >= CFG_COUNT) return "conv: aux0 (tuned kernel choice) out of range";
-    if ((op.aux0 & 128) && !hint_halo(op)) return "conv: aux0 bit 7 (half-height halo tile) needs bit 6 (LDS-halo kernel)";
-    if (hint_halo_half(op) && (halo_cpr(op) != 4 || halo_sn(op) != 3 || !ftc_is16(op.w_dtype) || op.out_dtype != op.w_dtype))
-        return "conv: the half-height halo tile exists for 16-bit 192-channel tiles with Cin % 32 == 0";
+    if (op.aux0 & 128) return "conv: aux0 bit 7 is reserved";
     if (hint_bk(op) && ftc_is16(op.w_dtype) && (op.Cin % hint_bk(op)) && hint_bk(op) != 32) return "conv: tuned K step does not divide Cin";
     if (hint_bk(op) == 128 && !ftc_is16(op.in_dtype)) return "conv: K step 128 needs 16-bit activations";
     if (hint_stage(op) >= 2 && !glds_legal(op)) return "conv: direct-to-LDS kernel is not legal for this op/tile";

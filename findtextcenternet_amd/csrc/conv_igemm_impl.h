@@ -934,11 +934,12 @@ __host__ __device__ constexpr size_t halo_lds_bytes() {
 }
 
 // (second launch bound = waves per SIMD: with 64-byte rows two workgroups fit the LDS of a CU, which needs <= 128 VGPRs)
-// WMQ = pixel quarters (waves along the pixel axis): 4 = the 16x16-pixel tile of 8 waves described above; 2 = a HALF-HEIGHT tile
-// (8 rows x 16 pixels, 4 waves, 256 threads) for the fused last-level kernels: with 64-byte rows its operand buffers + epilogue
-// image take 72 KB, so TWO workgroups share a CU with 256 VGPRs each -- one's per-K-step barrier wait, GELU / tap epilogue and
-// prologue overlap the other's MFMAs, which the one-workgroup-per-CU 16x16 form (156 KB, every wave at the same barrier) cannot do.
-// Cost: each workgroup streams its own copy of the weight slices (2x the weight bytes L2 -> LDS per CU).
+// WMQ = pixel quarters (waves along the pixel axis): 4 = the 16x16-pixel tile of 8 waves described above.  WMQ = 2 -- a HALF-HEIGHT
+// tile (8 x 16 pixels, 4 waves) whose 64-byte-row buffers + epilogue image take 72 KB so that TWO workgroups share a CU with 256 VGPRs
+// each -- was built and measured in round 2 for the fused last-level kernels (parity-green on every halo / UPCAT_IN / TOP_FUSE case):
+// 2.87 ms against 2.55 ms for the 16x16 form on the 8-head launch, 384 vs 346 us on the feature head.  The K step of 32 doubles the
+// barriers per FLOP and every workgroup streams its own copy of the weight slices (2x the weight bytes L2 -> LDS per CU), which costs
+// more than the inter-workgroup overlap returns.  The parameter stays; the variant is not instantiated.
 template <typename WT, typename OutT, int CPR, int SN, bool TOPF = false, bool UPIN = false, int WMQ = 4>
 __global__ __launch_bounds__(128 * WMQ, (WMQ == 2) ? 2 : (CPR == 4 && !UPIN && !TOPF) ? 4 : 2) void conv3x3_halo_kernel(const ConvP p_launch) {
     ConvP p = p_launch;
@@ -1332,7 +1333,6 @@ static const int kCfgTM[] = {128, 128, 128, 128, 64, 256, 64};
 // (findtextcenternet_amd/tuning.py); every choice gives bit-identical results (same K order).
 inline int hint_cfg(const ftc_op& o) { return (o.aux0 & 15) - 1; }
 inline bool hint_halo(const ftc_op& o) { return (o.aux0 & 64) != 0; }         // bit 6: LDS-halo 3x3 kernel
-inline bool hint_halo_half(const ftc_op& o) { return (o.aux0 & 192) == 192; } // bits 6+7: its half-height, two-workgroups-per-CU form (fused 16-bit kernels)
 inline int hint_splitk(const ftc_op& o) { const int c = (o.aux0 >> 10) & 3; return c == 1 ? 2 : c == 2 ? 4 : 1; }   // bits 10-11
 inline int hint_stage(const ftc_op& o) { return (o.aux0 >> 4) & 3; }
 inline int hint_bk(const ftc_op& o) { const int b = (o.aux0 >> 8) & 3; return b == 1 ? 32 : b == 2 ? 64 : b == 3 ? 128 : 0; }
@@ -1408,7 +1408,6 @@ inline int halo_cpr(const ftc_op& o) {
     if (o.w_dtype == FTC_F32) return o.Cin % 32 == 0 ? 8 : 0;
     // 128-byte rows (K step 64) unless the channel count or the tuning hint (bk = 32) asks for 64-byte rows: those halve
     // the LDS footprint, so two workgroups share a CU and one's epilogue overlaps the other's K loop
-    if (hint_halo_half(o)) return (o.Cin % 32 == 0 && (!(o.flags & FTC_FLAG_UPCAT_IN) || o.Cin_total % 32 == 0)) ? 4 : 0;
     if (hint_bk(o) == 32 && hint_halo(o) && !(o.flags & (FTC_FLAG_TOP_FUSE | FTC_FLAG_UPCAT_IN))) return o.Cin % 32 == 0 ? 4 : 0;
     return o.Cin % 64 == 0 ? 8 : (o.Cin % 32 == 0 ? 4 : 0);
 }
@@ -1435,21 +1434,15 @@ hipError_t launch_halo_dispatch(const ConvP& p, const ftc_op& o, hipStream_t s) 
     const int sn = halo_sn(o), cpr = halo_cpr(o);
     if (o.flags & FTC_FLAG_TOP_FUSE) {
         if constexpr (sizeof(WT) == 2 && sizeof(OutT) == 2) {
-            if (hint_halo_half(o) && cpr == 4 && sn == 3)
-                return (o.flags & FTC_FLAG_UPCAT_IN) ? launch_halo<WT, OutT, 4, 3, true, true, 2>(p, s) : launch_halo<WT, OutT, 4, 3, true, false, 2>(p, s);
             if (cpr == 8 && sn == 3) return (o.flags & FTC_FLAG_UPCAT_IN) ? launch_halo<WT, OutT, 8, 3, true, true>(p, s) : launch_halo<WT, OutT, 8, 3, true>(p, s);
         }
         return hipErrorInvalidValue;
     }
     if (o.flags & FTC_FLAG_UPCAT_IN) {
         if constexpr (sizeof(WT) == 2 && sizeof(OutT) == 2) {
-            if (hint_halo_half(o) && cpr == 4 && sn == 3) return launch_halo<WT, OutT, 4, 3, false, true, 2>(p, s);
             if (sn == 3) return cpr == 8 ? launch_halo<WT, OutT, 8, 3, false, true>(p, s) : launch_halo<WT, OutT, 4, 3, false, true>(p, s);
         }
         return hipErrorInvalidValue;
-    }
-    if constexpr (sizeof(WT) == 2) {
-        if (hint_halo_half(o) && cpr == 4 && sn == 3) return launch_halo<WT, OutT, 4, 3, false, false, 2>(p, s);
     }
     if (cpr == 8) {
         if (sn == 3) return launch_halo<WT, OutT, 8, 3>(p, s);

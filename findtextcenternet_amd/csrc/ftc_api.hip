@@ -45,64 +45,99 @@ int fail_hip(hipError_t e, const char* what) {
     return FTC_ERR_HIP;
 }
 
-bool ref_ok(const ftc_ref& r, const ftc_plan* pl, bool required, std::string* why) {
+// `extent` = bytes the op reads / writes from the operand's start (0 = unknown: only the start is checked).  The input / heat-map /
+// feature bases are caller buffers whose sizes the plan does not know (ftc_forward derives them from B, H, W).
+bool ref_ok(const ftc_ref& r, const ftc_plan* pl, bool required, int64_t extent, std::string* why) {
     if (r.base == FTC_BASE_NULL) {
         if (required) { *why = "missing required operand"; return false; }
         return true;
     }
     if (r.base < 0 || r.base >= FTC_NUM_BASES) { *why = "bad base id"; return false; }
     if (r.offset < 0 || (r.offset & 15)) { *why = "operand offset must be >= 0 and 16-byte aligned"; return false; }
-    if (r.base == FTC_BASE_WORKSPACE && r.offset >= pl->workspace_bytes) { *why = "workspace offset out of range"; return false; }
-    if (r.base == FTC_BASE_WEIGHTS && r.offset >= pl->weights_bytes) { *why = "weights offset out of range"; return false; }
+    if (extent < 0) { *why = "operand size overflows"; return false; }
+    const int64_t end = r.offset + (extent > 0 ? extent : 1);
+    if (r.base == FTC_BASE_WORKSPACE && end > pl->workspace_bytes) { *why = "workspace operand out of range (offset + extent > workspace_bytes)"; return false; }
+    if (r.base == FTC_BASE_WEIGHTS && end > pl->weights_bytes) { *why = "weights operand out of range (offset + extent > weights_bytes)"; return false; }
     return true;
 }
 
 const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
-    auto need = [&](const ftc_ref& r, bool req, const char* name) -> bool {
+    auto need = [&](const ftc_ref& r, bool req, const char* name, int64_t extent = 0) -> bool {
         std::string w;
-        if (!ref_ok(r, pl, req, &w)) { *why = std::string(name) + ": " + w; return false; }
+        if (!ref_ok(r, pl, req, extent, &w)) { *why = std::string(name) + ": " + w; return false; }
         return true;
     };
+    auto es = [](int dt) -> int64_t { return dt == FTC_F32 ? 4 : 2; };
+    const int64_t G = o.groups > 1 ? o.groups : 1;
+    const int64_t pin = (int64_t)o.B * o.H * o.W, pout = (int64_t)o.B * o.Ho * o.Wo;
     if (o.B <= 0 || o.H <= 0 || o.W <= 0) return "B/H/W must be positive";
     switch (o.kind) {
     case FTC_OP_STEM:
-        if (!need(o.in, true, "in") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.bias, true, "bias")) return why->c_str();
+        if (!need(o.in, true, "in") || !need(o.out, true, "out", pout * o.Cout * es(o.out_dtype)) || !need(o.w, true, "w", (int64_t)27 * o.Cout * 4) ||
+            !need(o.bias, true, "bias", (int64_t)o.Cout * 4)) return why->c_str();
         if (o.Cout % 4 || o.Cout > 256) return "stem: Cout must be a multiple of 4 (<= 256)";
         if ((long)o.B * o.Ho * o.Wo * (o.Cout / 4) >= 0x7fffffffL) return "stem: more than 2^31 output quads";
-        if (!need(o.out2, false, "out2")) return why->c_str();
-        if (o.out2.base != FTC_BASE_NULL && o.out_dtype != FTC_F32) return "stem: out2 (bf16 copy) needs an fp32 primary output";
+        if (!need(o.out2, false, "out2", pout * o.Cout * 2)) return why->c_str();
+        if (o.out2.base != FTC_BASE_NULL && o.out_dtype != FTC_F32) return "stem: out2 (16-bit copy) needs an fp32 primary output";
         if (o.Ho != (o.H - 1) / 2 + 1 || o.Wo != (o.W - 1) / 2 + 1) return "stem: Ho/Wo inconsistent";
         return nullptr;
     case FTC_OP_CONV: {
-        if (!need(o.in, true, "in") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.bias, true, "bias")) return why->c_str();
-        if (!need(o.in2, (o.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_UPCAT_IN)) != 0, "in2") || !need(o.scale, (o.flags & FTC_FLAG_SE_SCALE) != 0, "scale")) return why->c_str();
-        if (!need(o.out2, false, "out2")) return why->c_str();
+        if (o.Cin <= 0 || o.Cout <= 0 || o.Cin_total <= 0 || o.Cout_total <= 0 || o.Ho <= 0 || o.Wo <= 0 || o.ksize <= 0) return "conv: sizes must be positive";
+        const bool upin = (o.flags & FTC_FLAG_UPCAT_IN) != 0, topf = (o.flags & FTC_FLAG_TOP_FUSE) != 0;
+        const int64_t kk = (int64_t)o.ksize * o.ksize;
+        const int64_t in_ext = upin ? G * o.B * (o.H / 2) * (o.W / 2) * o.Cin_total * es(o.in_dtype) : G * pin * o.Cin_total * es(o.in_dtype);
+        const int64_t in2_ext = upin ? ((o.flags & FTC_FLAG_GROUP_IN2_SHARED) ? 1 : G) * pin * (o.Cin - o.Cin_total) * es(o.in_dtype)
+                                     : pout * o.Cout * es(o.res_dtype);
+        const int64_t w_ext = G * ((o.flags & FTC_FLAG_W_PER_IMAGE) ? o.B : 1) * o.Cout * kk * o.Cin * es(o.w_dtype);
+        const int64_t out_ext = topf ? G * pout * o.aux1 * 4 : ((o.flags & FTC_FLAG_GROUP_OUT_SLICE) ? 1 : G) * pout * o.Cout_total * es(o.out_dtype);
+        if (!need(o.in, true, "in", in_ext) || !need(o.out, true, "out", out_ext) || !need(o.w, true, "w", w_ext) ||
+            !need(o.bias, true, "bias", G * ((o.flags & FTC_FLAG_BORDER_BIAS) ? 16 : 1) * o.Cout * 4)) return why->c_str();
+        if (!need(o.in2, (o.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_UPCAT_IN)) != 0, "in2", in2_ext) ||
+            !need(o.scale, (o.flags & FTC_FLAG_SE_SCALE) != 0, "scale", (int64_t)o.B * o.Cin * 4)) return why->c_str();
+        if (!need(o.out2, false, "out2", pout * o.Cout * 2)) return why->c_str();
+        if (!need(o.w2, topf, "w2", G * 32 * o.Cout * 2)) return why->c_str();
         if (o.out2.base != FTC_BASE_NULL && (o.out_dtype != FTC_F32 || o.Cout % 4)) return "conv: out2 (bf16 copy) needs an fp32 primary output and Cout % 4 == 0";
         return conv_validate(o);
     }
     case FTC_OP_DWCONV:
-        if (!need(o.in, true, "in") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.bias, true, "bias") || !need(o.aux, true, "aux")) return why->c_str();
         if (o.in_dtype != FTC_F32 && !ftc_is16(o.in_dtype)) return "dwconv: unknown dtype";
+        if (o.Cin <= 0 || o.aux0 <= 0 || o.Ho <= 0 || o.Wo <= 0) return "dwconv: sizes must be positive";
+        if (!need(o.in, true, "in", pin * o.Cin * es(o.in_dtype)) || !need(o.out, true, "out", pout * o.Cin * es(o.in_dtype)) ||
+            !need(o.w, true, "w", (int64_t)9 * o.Cin * 4) || !need(o.bias, true, "bias", (int64_t)o.Cin * 4) ||
+            !need(o.aux, true, "aux", (int64_t)o.B * o.aux0 * o.Cin * 4)) return why->c_str();
+        // the bf16 / fp16 stride-1 strip kernel builds a 32-bit buffer resource per image
+        if (ftc_is16(o.in_dtype) && (int64_t)o.H * o.W * o.Cin * 2 >= 0x7fffffffLL) return "dwconv: one image exceeds the 2 GiB buffer-resource limit";
         if (o.Cin % (o.in_dtype == FTC_F32 ? 4 : 8) || o.Cin != o.Cout) return "dwconv: C must be a multiple of one 16-byte access (4 fp32 / 8 bf16) and Cin == Cout";
         if (o.stride != 1 && o.stride != 2) return "dwconv: stride must be 1 or 2";
         if (o.Ho != (o.H - 1) / o.stride + 1 || o.Wo != (o.W - 1) / o.stride + 1) return "dwconv: Ho/Wo inconsistent";
         if (o.in_dtype != o.out_dtype) return "dwconv: in/out dtype must match";
         return nullptr;
     case FTC_OP_SE:
-        if (!need(o.aux, true, "aux") || !need(o.out, true, "out") || !need(o.in2, true, "in2") || !need(o.w, true, "w") || !need(o.w2, true, "w2") ||
-            !need(o.bias, true, "bias") || !need(o.bias2, true, "bias2")) return why->c_str();
         if (o.aux0 <= 0 || o.aux1 <= 0 || o.Cin <= 0) return "se: C, S, P must be positive";
+        if (!need(o.aux, true, "aux", (int64_t)o.B * o.aux1 * o.Cin * 4) || !need(o.out, true, "out", (int64_t)o.B * o.Cin * 4) ||
+            !need(o.in2, true, "in2", (int64_t)o.B * o.aux0 * 4) || !need(o.w, true, "w", (int64_t)o.aux0 * o.Cin * 4) ||
+            !need(o.w2, true, "w2", (int64_t)o.aux0 * o.Cin * 4) || !need(o.bias, true, "bias", (int64_t)o.aux0 * 4) ||
+            !need(o.bias2, true, "bias2", (int64_t)o.Cin * 4)) return why->c_str();
         if (o.Cin % 4) return "se: C must be a multiple of 4";
         if ((size_t)o.Cin * 4 > 64000 || (size_t)o.aux0 * 4 > 64000) return "se: C or S too large for LDS";
         if (o.flags & FTC_FLAG_SE_FOLD) {
-            if (!need(o.in, true, "in") || !need(o.out2, true, "out2")) return why->c_str();
+            if (o.Cout_total <= 0) return "se: SE_FOLD needs Cout_total (rows of the folded matrix)";
+            if (!need(o.in, true, "in", (int64_t)o.Cout_total * o.Cin * 2) || !need(o.out2, true, "out2", (int64_t)o.B * o.Cout_total * o.Cin * 2)) return why->c_str();
             if (o.Cin % 8 || o.Cout_total <= 0 || !ftc_is16(o.w_dtype)) return "se: SE_FOLD needs a 16-bit [Cout_total][C] matrix with C % 8 == 0";
         }
         return nullptr;
     case FTC_OP_UPCAT:
-        if (!need(o.in, o.aux0 > 0, "in") || !need(o.in2, true, "in2") || !need(o.out, true, "out") || !need(o.scale, true, "scale") ||
-            !need(o.shift, true, "shift")) return why->c_str();
+        if (o.aux0 < 0 || o.aux1 <= 0 || o.Ho <= 0 || o.Wo <= 0) return "upcat: sizes must be positive";
+        {
+            const int64_t cyt = o.Cin_total > 0 ? o.Cin_total : o.aux0;
+            const int64_t in_ext = ((o.flags & FTC_FLAG_GROUP_IN_SLICE) ? 1 : G) * pin * cyt * es(o.in_dtype);
+            if (!need(o.in, o.aux0 > 0, "in", in_ext) || !need(o.in2, true, "in2", pout * o.aux1 * es(o.res_dtype)) ||
+                !need(o.out, true, "out", G * pout * (o.aux0 + o.aux1) * es(o.in_dtype)) || !need(o.scale, true, "scale", G * o.aux1 * 4) ||
+                !need(o.shift, true, "shift", G * o.aux1 * 4)) return why->c_str();
+        }
+        // 16-byte lanes: 4 fp32 / 8 16-bit channels per access, for the channel counts AND the slice of a wider upsampled tensor
         if (o.aux0 % (o.in_dtype == FTC_F32 ? 4 : 8) || o.aux1 % (o.in_dtype == FTC_F32 ? 4 : 8) || o.aux1 <= 0) return "upcat: channel counts must be multiples of one 16-byte access (4 fp32 / 8 bf16)";
+        if (o.aux0 > 0 && o.Cin_total > 0 && (o.Cin_total % (o.in_dtype == FTC_F32 ? 4 : 8) || o.cin_off % (o.in_dtype == FTC_F32 ? 4 : 8))) return "upcat: channel slice of the upsampled tensor is not 16-byte aligned";
         if (o.aux0 > 0 && o.Cin_total > 0 && (o.Cin_total % 4 || o.cin_off % 4 || o.cin_off + o.aux0 > o.Cin_total)) return "upcat: bad channel slice of the upsampled tensor";
         if (o.in_dtype != o.out_dtype) return "upcat: in/out dtype must match";
         if ((long)o.B * o.Ho * o.Wo * (o.aux0 + o.aux1) / 4 >= 0x7fffffffL) return "upcat: more than 2^31 output chunks per group";
@@ -110,7 +145,9 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if ((o.flags & FTC_FLAG_GROUP_IN_SLICE) && (o.groups <= 1 || o.cin_off + o.groups * o.aux0 > o.Cin_total)) return "upcat: GROUP_IN_SLICE channel slices out of range";
         return nullptr;
     case FTC_OP_TAPSUM:
-        if (!need(o.in, true, "in") || !need(o.out, true, "out") || !need(o.w, true, "w") || !need(o.bias, true, "bias")) return why->c_str();
+        if (o.aux0 <= 0 || o.aux1 <= 0) return "tapsum: bad aux0 / aux1";
+        if (!need(o.in, true, "in", G * pin * o.aux0 * 4) || !need(o.out, true, "out") || !need(o.w, true, "w", (int64_t)o.aux1 * 16) ||
+            !need(o.bias, true, "bias", (int64_t)o.aux1 * 4)) return why->c_str();
         if (o.aux0 < 4 || o.aux0 > 32 || o.aux0 % 4 || o.aux1 < 1 || o.aux1 > 64 || o.Cout_total < 1 || o.groups < 1) return "tapsum: bad aux0 / aux1 / Cout_total / groups";
         return nullptr;
     case FTC_OP_NMS:

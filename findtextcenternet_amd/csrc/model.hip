@@ -512,12 +512,10 @@ void apply_tuning(std::vector<ftc_op>& ops) {
     static std::map<std::string, int> table;
     static std::once_flag once;
     std::call_once(once, [] { for (const TuneEntry* e = kTuning; e->sig; ++e) table[e->sig] = e->aux0; });
-    const char* hh = std::getenv("FTC_HALO_HALF");            // A/B switch for the half-height halo tile of the fused last-level kernels
     for (ftc_op& o : ops) {
         if (o.kind != FTC_OP_CONV) continue;
         auto it = table.find(conv_signature(o));
         if (it != table.end() && it->second) o.aux0 = it->second;
-        if (hh && (o.flags & FTC_FLAG_UPCAT_IN) && (o.aux0 & 64)) o.aux0 = std::strcmp(hh, "0") ? (o.aux0 | 128) : (o.aux0 & ~128);
     }
 }
 

@@ -39,8 +39,7 @@ def describe(aux0: int) -> str:
     if aux0 == 0:
         return "default"
     if aux0 & 64:
-        return (f"halo,channels={CFG_NAMES[(aux0 & 15) - 1].split('x')[0]}" + (",bk=32" if (aux0 >> 8) & 3 == 1 else "")
-                + (",half-height tile (2 WG/CU)" if aux0 & 128 else ""))
+        return f"halo,channels={CFG_NAMES[(aux0 & 15) - 1].split('x')[0]}" + (",bk=32" if (aux0 >> 8) & 3 == 1 else "")
     sk = [1, 2, 4, 1][(aux0 >> 10) & 3]
     return (f"tile={CFG_NAMES[(aux0 & 15) - 1]},stage={['auto', 'reg', 'dma2', 'dma3'][(aux0 >> 4) & 3]},bk={[0, 32, 64, 128][(aux0 >> 8) & 3]}"
             + (f",splitk={sk}" if sk > 1 else ""))
@@ -87,8 +86,6 @@ def candidates(o) -> List[int]:
                 for sk in (2, 4):
                     out.append(encode(cfg, 1, bk, splitk=sk))
     if o.ksize == 3 and o.stride == 1:
-        if o.w_dtype != L.F32 and o.Cin % 32 == 0:        # ... its half-height form (4 waves, 64-byte rows, two workgroups per CU)
-            out.append(encode(0, 0, 0, halo=True) | 128)
         for cfg in (0, 1, 3):                             # LDS-halo kernel with 192 / 128 / 64 channel tiles
             out.append(encode(cfg, 0, 0, halo=True))
             if o.w_dtype == L.BF16 and o.Cin % 64 == 0:   # ... and with 64-byte rows (two workgroups per CU)

@@ -63,6 +63,24 @@ def test_plan_create_validates_ops():
                      (dict(good, kind=99), b"unknown op"), (dict(good, flags=L.FLAG_RESIDUAL), b"in2")]:
         assert lib.ftc_plan_create(_op(**bad), 1, 1 << 20, 0, C.byref(h)) == -1
         assert msg in lib.ftc_last_error(), (msg, lib.ftc_last_error())
+    # operand EXTENTS are checked, not just start offsets: an output that starts inside the workspace but runs past its end,
+    # a weight matrix larger than the blob, a fused top convolution without its tap matrix
+    ws = 1 << 20
+    out_bytes = 1 * 8 * 8 * 64 * 4
+    assert lib.ftc_plan_create(_op(**dict(good, out=ws - out_bytes)), 1, ws, 0, C.byref(h)) == 0
+    lib.ftc_plan_destroy(h)
+    assert lib.ftc_plan_create(_op(**dict(good, out=ws - out_bytes + 16)), 1, ws, 0, C.byref(h)) == -1 and b"offset + extent" in lib.ftc_last_error()
+    wop = _op(**good)
+    wop[0].w.base, wop[0].w.offset = L.BASE_WEIGHTS, 0
+    assert lib.ftc_plan_create(wop, 1, ws, 64 * 9 * 32 * 4, C.byref(h)) == 0
+    lib.ftc_plan_destroy(h)
+    assert lib.ftc_plan_create(wop, 1, ws, 64 * 9 * 32 * 4 - 16, C.byref(h)) == -1 and b"weights operand out of range" in lib.ftc_last_error()
+    top = dict(kind=L.OP_CONV, flags=L.FLAG_TOP_FUSE, act=L.ACT_GELU, in_dtype=L.BF16, out_dtype=L.BF16, w_dtype=L.BF16, B=1, H=16, W=16, Ho=16, Wo=16,
+               Cin=256, Cin_total=256, Cout=192, Cout_total=192, ksize=3, stride=1, aux0=65, aux1=12, in_=0, out=1 << 19, w=0, bias=0)
+    assert lib.ftc_plan_create(_op(**top), 1, 1 << 21, 0, C.byref(h)) == -1 and b"w2" in lib.ftc_last_error()
+    dw = dict(kind=L.OP_DWCONV, act=L.ACT_SILU, in_dtype=L.BF16, out_dtype=L.BF16, B=1, H=8, W=8, Ho=8, Wo=8, Cin=64, Cout=64, ksize=3, stride=1, aux0=1,
+              in_=0, out=8192, w=16384, bias=32768, aux=ws - 64 * 4 + 16)
+    assert lib.ftc_plan_create(_op(**dw), 1, ws, 0, C.byref(h)) == -1 and b"aux" in lib.ftc_last_error()
     # running without a device / with NULL bases is an error, not a crash
     assert lib.ftc_plan_create(_op(**good), 1, 1 << 20, 0, C.byref(h)) == 0
     bases = (C.c_void_p * L.NUM_BASES)()

@@ -64,7 +64,7 @@ HALO_CASES = [c for c in CONV_CASES if c[10] == 3 and c[11] == 1] + [
 ]
 
 
-@pytest.mark.parametrize("tile", [65, 66, 68, 193], ids=["halo192", "halo128", "halo64", "halo192_half"])
+@pytest.mark.parametrize("tile", [65, 66, 68], ids=["halo192", "halo128", "halo64"])
 @pytest.mark.parametrize("mode", [CONV_MODES[0], CONV_MODES[1], CONV_MODES[3], CONV_MODES[5], CONV_MODES[7]], ids=["f32", "bf16", "bf16_f32out", "f16", "f16_f32out"])
 @pytest.mark.parametrize("case", HALO_CASES, ids=[c[0] for c in HALO_CASES])
 def test_conv_halo_kernel(case, mode, tile):
@@ -73,8 +73,6 @@ def test_conv_halo_kernel(case, mode, tile):
         pytest.skip("halo kernel needs whole 32-element channel blocks")
     if mode[1] == L.F32 and case[4] % 32:
         pytest.skip("fp32 halo kernel needs Cin % 32 == 0")
-    if tile == 193 and (mode[1] == L.F32 or mode[3] != mode[1]):
-        pytest.skip("the half-height tile exists for 16-bit output in the compute type")
     _run_conv_case(case, mode, aux0=tile)
 
 
@@ -338,9 +336,8 @@ def _upcat_in_fuzz_shapes(n):
 
 @pytest.mark.parametrize("shape", [(2, 2, 16, 24, 192, 64), (3, 1, 22, 10, 64, 32), (1, 2, 40, 36, 192, 96), (2, 1, 8, 8, 128, 256)] + _upcat_in_fuzz_shapes(12),
                          ids=lambda s: "x".join(map(str, s)))
-@pytest.mark.parametrize("halo", [65, 193], ids=["tile16x16", "tile8x16_2perCU"])
 @pytest.mark.parametrize("dt", [L.BF16, L.F16], ids=["bf16", "f16"])
-def test_upcat_in_conv_equals_upsample_concat_conv(shape, dt, halo):
+def test_upcat_in_conv_equals_upsample_concat_conv(shape, dt):
     """FTC_FLAG_UPCAT_IN: conv3x3(cat[bilinear_x2(prev), tapbn]) with the concatenation formed in the halo loader, against
     F.interpolate(align_corners=True) + cat + conv2d in fp32 (upsampled values rounded to bf16 as the kernel's LDS image is)."""
     G, B, H, W, Cy, Ct = shape
@@ -365,7 +362,7 @@ def test_upcat_in_conv_equals_upsample_concat_conv(shape, dt, halo):
     o_out = ar.reserve(G * B * H * W * Cout * 2)
     ar.materialize()
     run_op(dict(kind=L.OP_CONV, flags=L.FLAG_UPCAT_IN, act=L.ACT_GELU, in_dtype=dt, out_dtype=dt, w_dtype=dt, B=B, H=H, W=W, Ho=H,
-                Wo=W, Cin=Cin, Cin_total=Cy, Cout=Cout, Cout_total=Cout, ksize=3, stride=1, aux0=halo, groups=G if G > 1 else 0,
+                Wo=W, Cin=Cin, Cin_total=Cy, Cout=Cout, Cout_total=Cout, ksize=3, stride=1, aux0=65, groups=G if G > 1 else 0,
                 in_=o_prev, in2=o_tap, out=o_out, w=o_w, bias=o_b), ar)
     out = ar.read(o_out, (G, B, H, W, Cout), tdtype(dt)).float()
     err = _rel(out, ref)
@@ -373,10 +370,9 @@ def test_upcat_in_conv_equals_upsample_concat_conv(shape, dt, halo):
     assert err < TOL16[dt]
 
 
-@pytest.mark.parametrize("halo", [65, 193], ids=["tile16x16", "tile8x16_2perCU"])
 @pytest.mark.parametrize("dt", [L.BF16, L.F16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("top", [False, True], ids=["plain", "top_fuse"])
-def test_upcat_in_with_tap_batchnorm_folded_and_shared_tap(top, dt, halo):
+def test_upcat_in_with_tap_batchnorm_folded_and_shared_tap(top, dt):
     """Last FPN level as the bf16 plan runs it: the nine heads read ONE backbone tap (FTC_FLAG_GROUP_IN2_SHARED); each head's input
     BatchNorm of the tap is folded into its weights and a 16-case border bias table (FTC_FLAG_BORDER_BIAS) -- against
     conv3x3(cat[upsample(prev_g), BN_g(tap)]) + GELU (then the 3x3 top convolution for the TOP_FUSE variant) in fp32."""
@@ -418,7 +414,7 @@ def test_upcat_in_with_tap_batchnorm_folded_and_shared_tap(top, dt, halo):
         o_out = ar.reserve(G * B * H * W * Cm * 2)
         ar.materialize()
         run_op(dict(kind=L.OP_CONV, flags=flags, act=L.ACT_GELU, in_dtype=dt, out_dtype=dt, w_dtype=dt, B=B, H=H, W=W, Ho=H, Wo=W,
-                    Cin=Cin, Cin_total=Cy, Cout=Cm, Cout_total=Cm, ksize=3, stride=1, aux0=halo, groups=G, in_=o_prev, in2=o_tap, out=o_out,
+                    Cin=Cin, Cin_total=Cy, Cout=Cm, Cout_total=Cm, ksize=3, stride=1, aux0=65, groups=G, in_=o_prev, in2=o_tap, out=o_out,
                     w=o_w, bias=o_b), ar)
         out = ar.read(o_out, (G, B, H, W, Cm), tdtype(dt)).float()
         ref = torch.stack([y.permute(0, 2, 3, 1) for y in ys])
@@ -435,7 +431,7 @@ def test_upcat_in_with_tap_batchnorm_folded_and_shared_tap(top, dt, halo):
         o_out = ar.reserve(B * H * W * G * 4)
         ar.materialize()
         run_op(dict(kind=L.OP_CONV, flags=flags | L.FLAG_TOP_FUSE, act=L.ACT_GELU, in_dtype=dt, out_dtype=dt, w_dtype=dt, B=B, H=H,
-                    W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cy, Cout=Cm, Cout_total=Cm, ksize=3, stride=1, aux0=halo, aux1=TW, groups=G,
+                    W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cy, Cout=Cm, Cout_total=Cm, ksize=3, stride=1, aux0=65, aux1=TW, groups=G,
                     in_=o_prev, in2=o_tap, out=o_T, w=o_w, bias=o_b, w2=o_wt), ar)
         run_op(dict(kind=L.OP_TAPSUM, B=B, H=H, W=W, Ho=H, Wo=W, Cout_total=G, aux0=TW, aux1=G, groups=G, in_=o_T, out=o_out, w=o_map,
                     bias=o_ob), ar)

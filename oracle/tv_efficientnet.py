@@ -236,8 +236,28 @@ class EfficientNet(nn.Module):
         return self.classifier(torch.flatten(x, 1))
 
 
-def _unavailable(*_a, **_k):
-    raise RuntimeError("efficientnet_v2_{s,m,l} factories are outside the xl hot path")
+# torchvision's published EfficientNetV2 configurations (models/efficientnet.py `_efficientnet_conf`), used by the reference for
+# model_size 's' / 'm' / 'l' (models/detector.py:131-136): (block, expand_ratio, kernel, stride, in, out, layers), last_channel 1280,
+# norm_layer = BatchNorm2d(eps=1e-3), dropout 0.2 / 0.3 / 0.4, stochastic depth 0.2.
+_V2_CONF = {
+    "s": ([("f", 1, 3, 1, 24, 24, 2), ("f", 4, 3, 2, 24, 48, 4), ("f", 4, 3, 2, 48, 64, 4), ("m", 4, 3, 2, 64, 128, 6), ("m", 6, 3, 1, 128, 160, 9),
+           ("m", 6, 3, 2, 160, 256, 15)], 0.2),
+    "m": ([("f", 1, 3, 1, 24, 24, 3), ("f", 4, 3, 2, 24, 48, 5), ("f", 4, 3, 2, 48, 80, 5), ("m", 4, 3, 2, 80, 160, 7), ("m", 6, 3, 1, 160, 176, 14),
+           ("m", 6, 3, 2, 176, 304, 18), ("m", 6, 3, 1, 304, 512, 5)], 0.3),
+    "l": ([("f", 1, 3, 1, 32, 32, 4), ("f", 4, 3, 2, 32, 64, 7), ("f", 4, 3, 2, 64, 96, 7), ("m", 4, 3, 2, 96, 192, 10), ("m", 6, 3, 1, 192, 224, 19),
+           ("m", 6, 3, 2, 224, 384, 25), ("m", 6, 3, 1, 384, 640, 7)], 0.4),
+}
+
+
+def _v2_factory(size):
+    def make(weights=None, progress=True, **kwargs):
+        if weights is not None:
+            raise RuntimeError("pretrained torchvision weights are not available offline")
+        rows, dropout = _V2_CONF[size]
+        setting = [(FusedMBConvConfig if b == "f" else MBConvConfig)(e, k, s_, i, o, n) for b, e, k, s_, i, o, n in rows]
+        from functools import partial
+        return EfficientNet(setting, dropout, last_channel=1280, norm_layer=partial(nn.BatchNorm2d, eps=1e-03), **kwargs)
+    return make
 
 
 def install_as_torchvision() -> None:
@@ -257,9 +277,9 @@ def install_as_torchvision() -> None:
     eff.MBConvConfig = MBConvConfig
     eff.FusedMBConvConfig = FusedMBConvConfig
     models.efficientnet = eff
-    models.efficientnet_v2_s = _unavailable
-    models.efficientnet_v2_m = _unavailable
-    models.efficientnet_v2_l = _unavailable
+    models.efficientnet_v2_s = _v2_factory("s")
+    models.efficientnet_v2_m = _v2_factory("m")
+    models.efficientnet_v2_l = _v2_factory("l")
     tv.models = models
     sys.modules["torchvision"] = tv
     sys.modules["torchvision.models"] = models

@@ -358,9 +358,28 @@ def gen_validation_step(model):
     save("g7_validation_step.npz", **out)
 
 
+def gen_small_models():
+    """g8: the reference's detector for model_size 's' and 'm' (models/detector.py:131-136, 149-158: torchvision's EfficientNetV2-S / -M
+    tables, other tap widths) at 128x128, batch 1 -- pins the library's non-XL plans."""
+    for size, seed in (("s", 11), ("m", 12)):
+        torch.manual_seed(0)
+        model = ref_detector.TextDetectorModel(pre_weights=False, model_size=size)
+        model.load_state_dict(deterministic_state_dict(SEED_W, model_size=size))
+        det = ref_detector.CenterNetDetector(model.detector)
+        det.eval()
+        x = synth.page_images(seed, 1, 128, 128)
+        with torch.no_grad():
+            hm, ft = det(torch.from_numpy(x).permute(0, 3, 1, 2))
+        save(f"g8_fwd128_{size}.npz", heatmap=hm.numpy(), features=ft.numpy(), seed=np.array(seed),
+             n_keys=np.array(len(model.state_dict())), backbone_params=np.array(sum(p.numel() for p in model.detector.backbone.parameters())))
+
+
 def main():
     if "--adamw-only" in sys.argv:
         gen_adamw()
+        return
+    if "--small-only" in sys.argv:
+        gen_small_models()
         return
     if "--validation-only" in sys.argv:
         torch.manual_seed(0)
@@ -385,6 +404,7 @@ def main():
     gen_decode()
     gen_adamw()
     gen_validation_step(model)
+    gen_small_models()
 
 
 if __name__ == "__main__":

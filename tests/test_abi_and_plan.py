@@ -279,3 +279,20 @@ def test_adamw_schedulefree_host_schedule_matches_reference_fixture():
             want = gold[f"c{ci}_sched"][step]
             assert [group["scheduled_lr"], group["lr_max"], group["weight_sum"]] == list(want)
             assert 0 < sc["bias_correction2"] <= 1 and sc["lr"] == group["scheduled_lr"]
+
+
+@pytest.mark.parametrize("size", ["s", "m", "l"])
+def test_library_builds_plans_for_the_other_model_sizes(size):
+    """ftc_create + plan construction for the EfficientNetV2-S / -M / -L variants the reference can instantiate
+    (models/detector.py:131-136): other stage depths, tap widths (Leafmap.in_dims :151-158) and, for 's', one stage fewer."""
+    from findtextcenternet_amd.schema import STAGES
+    sd_ = deterministic_state_dict(0, model_size=size, prefix_detector=False, with_decoder=False)
+    for mode in ("fp32", "bf16"):
+        m = FtcModel(sd_, mode, size)
+        pl = m.plan(2, 128, 160)
+        kinds = [x.kind for x in pl.meta]
+        n_mb = sum(r[6] for r in STAGES[size] if r[0] == "mb")
+        assert kinds.count("dwconv3x3") == n_mb == kinds.count("se") and kinds[0] == "stem" and kinds[-1] == "nms"
+        assert pl.h == 32 and pl.w == 40
+    with pytest.raises(L.FtcError, match="shape|missing"):
+        FtcModel(sd_, "fp32", "xl")                          # a checkpoint of another size is rejected, not mis-read

@@ -380,3 +380,32 @@ def test_fp16_mode_same_plan_much_closer_to_the_reference(sd, golden_dir):
         h32, f32_ = d32(x2)
     fin = torch.isfinite(h16) & torch.isfinite(h32)
     assert float((h16[fin] - h32[fin]).abs().max()) < 0.03 and float((f16 - f32_).abs().max()) < 0.05
+
+
+@pytest.mark.parametrize("size", ["s", "m"])
+def test_other_model_sizes_match_the_reference(golden_dir, size):
+    """TextDetectorModel(model_size='s' | 'm') on the GPU against the reference's own outputs for those sizes (g8)."""
+    g = np.load(os.path.join(golden_dir, f"g8_fwd128_{size}.npz"))
+    sd_ = deterministic_state_dict(0, model_size=size)
+    x = torch.from_numpy(synth.page_images(int(g["seed"]), 1, 128, 128)).permute(0, 3, 1, 2).to("cuda")
+    outs = {}
+    for prec in ("fp32", "fp16", "bf16"):
+        m = TextDetectorModel(pre_weights=False, model_size=size, precision=prec)
+        m.load_state_dict(sd_)
+        d = CenterNetDetector(m.detector).to("cuda").eval()
+        with torch.no_grad():
+            hm, ft = d(x)
+        outs[prec] = (hm.cpu().numpy(), ft.cpu().numpy())
+    hm, ft = outs["fp32"]
+    fin = np.isfinite(g["heatmap"])
+    assert np.array_equal(np.isfinite(hm), fin)
+    e, ef = float(np.abs(hm[fin] - g["heatmap"][fin]).max()), float(np.abs(ft - g["features"]).max())
+    _log(f"model_size={size} 128x128 fp32: heatmap Linf {e:.3e} features Linf {ef:.3e}")
+    assert e < TOL and ef < TOL
+    rng = float(g["heatmap"][fin].max() - g["heatmap"][fin].min())
+    for prec, lim in (("fp16", 0.004), ("bf16", 0.03)):
+        h2, f2 = outs[prec]
+        both = np.isfinite(h2) & fin
+        e2 = float(np.abs(h2[both] - g["heatmap"][both]).max()) / rng
+        _log(f"model_size={size} 128x128 {prec}: heatmap Linf {100 * e2:.3f}% of range")
+        assert e2 < lim

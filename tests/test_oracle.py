@@ -168,3 +168,19 @@ def test_validation_step_oracle_matches_reference():
         got = cov(vals)
         assert abs(got - float(g["cov_loss"][step])) < 2e-6 * max(1.0, abs(got)), (step, got, g["cov_loss"][step])
         assert np.abs(cov.alphas - g["cov_alphas"][step]).max() < 2e-6
+
+
+@pytest.mark.parametrize("size", ["s", "m"])
+def test_small_model_sizes_match_reference(size):
+    """model_size 's' / 'm' (models/detector.py:131-136, 149-158): the schema loads strictly into the reference's own modules (the
+    fixture was generated that way), and the oracle reproduces the reference's outputs (tests/golden/g8_fwd128_<size>.npz)."""
+    g = np.load(os.path.join(G, f"g8_fwd128_{size}.npz"))
+    assert int(g["n_keys"]) == len(schema.text_detector_schema(size))
+    sd_ = deterministic_state_dict(0, model_size=size, prefix_detector=False, with_decoder=False)
+    n_backbone = sum(int(np.prod(v.shape)) for k, v in sd_.items() if k.startswith("backbone.") and "running" not in k and "num_batches" not in k)
+    assert n_backbone == int(g["backbone_params"])
+    x = torch.from_numpy(synth.page_images(int(g["seed"]), 1, 128, 128)).permute(0, 3, 1, 2)
+    hm, ft = detector_oracle.detector_forward(sd_, x)
+    fin = np.isfinite(g["heatmap"])
+    assert np.array_equal(np.isfinite(hm.numpy()), fin)
+    assert np.abs(hm.numpy()[fin] - g["heatmap"][fin]).max() < 1e-4 and np.abs(ft.numpy() - g["features"]).max() < 1e-4

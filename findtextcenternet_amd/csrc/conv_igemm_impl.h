@@ -1182,7 +1182,7 @@ __global__ __launch_bounds__(128 * WMQ, (WMQ == 2) ? 2 : (CPR == 4 && !UPIN && !
         const bool halo_prev = kp >= 0 && (kp % 9) == 0 && (kp / 9 + 1) < (UPIN ? nb_dma : p.ncb);
         if (p.flags & 0x100) wait_vmcnt<0>(); else wait_vmcnt_n((k + 1 < nk ? nlw : 0) + (halo_prev ? nlh : 0));
         if (!(p.flags & 0x800)) wg_barrier();                        // 0x800: ablation, no barrier
-        if (!(p.flags & 0x100)) {                                    // 0x100/0x200: ablation switches of tools/conv_bench.py
+        auto produce = [&]() {
             const int cbj = k / 9, tapj = k - cbj * 9, nxt = cbj + 1;
             if (tapj == 0 && nxt < (UPIN ? nb_dma : p.ncb)) issue_h(nxt);   // other halo buffer: last read 9 steps ago
             if constexpr (UPIN) {
@@ -1192,7 +1192,13 @@ __global__ __launch_bounds__(128 * WMQ, (WMQ == 2) ? 2 : (CPR == 4 && !UPIN && !
                 }
             }
             if (k + 2 < nk) issue_w(k + 2);                              // slot (k+2)%3 was read in step k-1
-        }
+        };
+        // Round-2 timeline of this loop (tools/conv_bench.py --timeline --ablate N, s_memtime per K step, last FPN level, 1536 = the
+        // MFMA-bound step): MFMA + LDS reads alone 1510-1565 | + barrier 2064 | DMA + barrier alone 1229 | everything 2697.  The
+        // compute part alone runs AT the matrix-pipe limit; the per-step barrier (pipe drains, every wave re-reads LDS before its first
+        // MFMA) costs ~550 and the concurrent DMA stream ~630 more.  WHERE in the step a wave issues its DMA pieces does not matter:
+        // before / after its MFMAs staggered between the two waves of a SIMD, after K group 0 / 1 / 2 -- all 2660-2840 (measured, removed).
+        if (!(p.flags & 0x100)) produce();                            // 0x100/0x200: ablation switches of tools/conv_bench.py
         if (!(p.flags & 0x200)) compute(k);
     }
 

@@ -18,6 +18,11 @@ hipError_t launch_conv_f16_ff(const ConvP& p, const ftc_op& o, hipStream_t s);
 
 void conv_kernel_label(const ftc_op& op, char* buf, int len) {
     const char* dt[] = {"f32", "bf16", "f16", "?"};
+    if (uses_halo(op) && hint_wl1(op) && (op.flags & FTC_FLAG_W_FRAG)) {
+        snprintf(buf, len, (op.flags & FTC_FLAG_TOP_FUSE) ? "conv3x3_wl1+top<%s,tile=192x16x16,bk=64>" : "conv3x3_wl1<%s,tile=192x16x16,bk=64>", dt[op.w_dtype & 3]);
+        if (op.groups > 1) snprintf(buf + strlen(buf) - 1, len - strlen(buf) + 1, ",groups=%d>", op.groups);
+        return;
+    }
     if (uses_halo(op)) {
         snprintf(buf, len, (op.flags & FTC_FLAG_TOP_FUSE) ? "conv3x3_halo+top<%s,out=%s,tile=%dx16x16,bk=%d>" : "conv3x3_halo<%s,out=%s,tile=%dx16x16,bk=%d>", dt[op.w_dtype & 3],
                  dt[op.out_dtype & 3], halo_sn(op) * 64, halo_cpr(op) * (ftc_is16(op.w_dtype) ? 8 : 4));
@@ -82,7 +87,13 @@ const char* conv_validate(const ftc_op& op) {
     if (hint_halo(op) && !halo_legal(op)) return "conv: LDS-halo kernel is not legal for this op/tile";
     if (hint_splitk(op) > 1 && !splitk_legal(op, hint_splitk(op))) return "conv: split-K variant is not legal for this op/tile";
     if (op.aux0 < 0 || op.aux0 > 0xfff || hint_cfg(op) >= CFG_COUNT) return "conv: aux0 (tuned kernel choice) out of range";
-    if (op.aux0 & 128) return "conv: aux0 bit 7 is reserved";
+    if ((op.aux0 & 128) || (op.flags & FTC_FLAG_W_FRAG)) {
+        if (!hint_wl1(op) || !(op.flags & FTC_FLAG_W_FRAG)) return "conv: aux0 bit 7 (weights-through-L1 kernel) and FTC_FLAG_W_FRAG go together (with bit 6)";
+        if (op.ksize != 3 || op.stride != 1 || !ftc_is16(op.w_dtype) || op.in_dtype != op.w_dtype || op.out_dtype != op.w_dtype || op.Cout != 192 ||
+            op.Cout_total != 192 || op.cout_off != 0 || op.Cin % 64 || halo_sn(op) != 3 || halo_cpr(op) != 8 || (op.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_SE_SCALE | FTC_FLAG_W_PER_IMAGE)))
+            return "conv: the weights-through-L1 kernel needs 3x3 stride 1, 16-bit operands, one 192-channel tile, Cin % 64 == 0 (aux0 = 193)";
+        if (!(op.flags & FTC_FLAG_UPCAT_IN) && (op.Cin_total != op.Cin || op.cin_off != 0)) return "conv: the weights-through-L1 kernel reads whole input tensors";
+    }
     if (hint_bk(op) && ftc_is16(op.w_dtype) && (op.Cin % hint_bk(op)) && hint_bk(op) != 32) return "conv: tuned K step does not divide Cin";
     if (hint_bk(op) == 128 && !ftc_is16(op.in_dtype)) return "conv: K step 128 needs 16-bit activations";
     if (hint_stage(op) >= 2 && !glds_legal(op)) return "conv: direct-to-LDS kernel is not legal for this op/tile";

@@ -335,7 +335,7 @@ __device__ __forceinline__ void conv_epilogue_topfuse(const ConvP& p, f32x16 (&a
                                                       int half, int l31, int lpix, int wave, RowFn row_to_m) {
     constexpr int PITCH = TN * 2;                           // 16-bit image of the tile, [pixel][channel]
     constexpr int CH = TN / 8;                              // 16-byte chunks per row
-    static_assert(PITCH % 128 == 0 && TM == 32 * (NTHREADS / 64), "one 32-pixel MFMA column block per wave");
+    static_assert(PITCH % 128 == 0 && TM <= 32 * (NTHREADS / 64), "one 32-pixel MFMA column block per wave (surplus waves idle)");
     __syncthreads();
     const int nrows = (p.flags & FTC_FLAG_BORDER_BIAS) ? 16 : 1;   // 16 border cases when a BatchNorm of the input is folded in
     float* lbias = reinterpret_cast<float*>(smem + TM * PITCH);
@@ -377,6 +377,7 @@ __device__ __forceinline__ void conv_epilogue_topfuse(const ConvP& p, f32x16 (&a
     }
     __syncthreads();
     // wave w: pixels 32w .. 32w+31 of the tile;  A = tap matrix rows, B = image rows, K = TN in steps of 16
+    if (wave * 32 >= TM) return;
     const int prow = wave * 32 + l31;
     f32x16 t;
 #pragma unroll
@@ -1249,6 +1250,269 @@ hipError_t launch_halo(ConvP p, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution, 192-channel tile, WEIGHTS THROUGH L1 ("wl1"): round-2 successor of conv3x3_halo_kernel for the
+// fused last FPN level.
+//
+// The s_memtime timeline of conv3x3_halo_kernel showed its MFMA + LDS-read part running AT the matrix-pipe limit (1540 cycles per
+// K step) and the rest of the 2700 going to the per-step barrier (weights ring: every wave must see every wave's DMA) and to the
+// weight DMA stream competing with the fragment reads for LDS.  Here the weights never touch LDS:
+//   * 12 waves = 6 channel blocks of 32 x 2 pixel halves of 128; a wave's A operand (its 32 channels x the step's 64 K) is 4
+//     register fragments per step, fetched straight from global memory one full step ahead (double-buffered in VGPRs).  The two
+//     pixel halves request the same lines (L1 hits); the weights are packed FRAGMENT-MAJOR (FTC_FLAG_W_FRAG: one fully
+//     coalesced 1 KiB per wave-load: [row block][tap][channel block][K group][lane][8]) so a load touches 8 lines, not 32;
+//   * only the activation halo (18x18 pixels x 64 channels, shared by all 12 waves, reused by the 9 taps) lives in LDS, double
+//     buffered and refilled by DMA once per channel block -- so the workgroup synchronises once per NINE K steps instead of
+//     every step, and in between the waves drift freely (one's fragment reads overlap another's MFMAs);
+//   * LDS traffic per step: 12 waves x 16 B-fragment reads (192 KB) instead of 160 KB of A + B, no DMA writes except the halo.
+// Same UPCAT_IN loader, TOP_FUSE / LDS-staged epilogues, pixel-slot mapping and output layout as conv3x3_halo_kernel.
+// ------------------------------------------------------------------------------------------------
+// WMH = pixel halves per workgroup.  2 (used): 12 waves, 16x16-pixel tile, one workgroup per CU (the epilogue image needs 120 KB).
+// 1: 6 waves, 8x16-pixel tile, 72 KB -> TWO workgroups per CU with the same fragment loads per MFMA -- built and measured
+// (parity-green): a workgroup then takes 96 k cycles for HALF the pixels against 107 k for the full tile, i.e. the CU is already
+// saturated by 12 waves either way and the extra halo rows and L1 misses make it slower end to end (497 vs 532 img/s).  Not instantiated.
+template <typename WT, bool TOPF, int WMH>
+__host__ __device__ constexpr size_t wl1_lds_bytes() {
+    constexpr int TY = 8 * WMH;
+    constexpr size_t halo = (size_t)2 * (TY + 2) * 18 * 128;
+    constexpr size_t epi = (size_t)TY * 16 * 192 * 2 + (size_t)16 * 192 * 4 + (TOPF ? (size_t)32 * 192 * 2 : 0);
+    return halo > epi ? halo : epi;
+}
+
+template <typename WT, typename OutT, bool TOPF = false, bool UPIN = false, int WMH = 2>
+__global__ __launch_bounds__(384 * WMH, 3) void conv3x3_wl1_kernel(const ConvP p_launch) {
+    ConvP p = p_launch;
+    static_assert(sizeof(WT) == 2 && sizeof(OutT) == 2, "16-bit operands");
+    constexpr int E = 8, CPR = 8, BK = 64, ROWB = 128, G = 4;
+    constexpr int SM = 4, NT = 384 * WMH, TN = 192;
+    constexpr int TY = 8 * WMH, TX = 16, HW = TX + 2, NH = (TY + 2) * HW;     // 324 | 180 halo pixels
+    constexpr int HCH = NH * CPR, NLH = (HCH + NT - 1) / NT;                  // 2592 | 1440 chunks, 4 DMA passes
+    constexpr int HBUF = NH * ROWB;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char* const hbase = smem_raw;                   // 2 halo buffers
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wn = wave / WMH, wm = wave % WMH;              // (the pixel halves of a channel block are neighbours: same lines, same time)
+    const int half = lane >> 5, l31 = lane & 31;
+
+    int bid = blockIdx.x;
+    {
+        const int q = p.nblk >> 3, r = p.nblk & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    bid = enter_group(p, bid);
+    int sp = bid;
+    const int tilesX = (p.Wo + TX - 1) / TX, tilesY = (p.Ho + TY - 1) / TY;
+    const int img = sp / (tilesX * tilesY);
+    sp -= img * tilesX * tilesY;
+    const int ty0 = (sp / tilesX) * TY, tx0 = (sp % tilesX) * TX;
+    constexpr int n0 = 0;
+
+    const __amdgpu_buffer_rsrc_t rw = weight_rsrc(p, img * p.Ho * p.Wo);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+
+    int h_off[NLH];
+#pragma unroll
+    for (int i = 0; i < NLH; ++i) {
+        const int q = i * NT + t;
+        const int hr = q / CPR, kc = (q % CPR) ^ ((hr >> 1) & 7);
+        const int iy = ty0 - 1 + hr / HW, ix = tx0 - 1 + hr % HW;
+        const bool ok = q < HCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        if constexpr (UPIN) h_off[i] = ok ? (((img * p.H + iy) * p.W + ix) * (p.Cin - p.Cy) + kc * E) * 2 : OOB;
+        else h_off[i] = ok ? (((img * p.H + iy) * p.W + ix) * p.CinT + p.cin_off + kc * E) * 2 : OOB;
+    }
+    const int ncb_up = UPIN ? p.Cy / BK : 0;
+    const int nb_dma = p.ncb - ncb_up;
+    const __amdgpu_buffer_rsrc_t rin2 = UPIN ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in2u), 0, p.in2u_bytes, 0x00020000) : rin;
+    auto phys_cb = [&](int j) { return UPIN ? (j < nb_dma ? ncb_up + j : j - nb_dma) : j; };
+
+    auto issue_h = [&](int cb) {                             // halo of channel block cb -> buffer cb & 1
+        const int soff = cb * BK * 2;
+        unsigned char* buf = hbase + (cb & 1) * HBUF;
+#pragma unroll
+        for (int i = 0; i < NLH; ++i) {
+            if (i * NT + wave * 64 < HCH) {
+                lds_void_t* dst = (lds_void_t*)(buf + (i * NT + wave * 64) * 16);
+                if (i * NT + t < HCH) glds16(UPIN ? rin2 : rin, dst, h_off[i], soff);
+            }
+        }
+    };
+
+    using FragT = typename Frag<WT>::type;
+    // A operand: fragment-major weights.  Fragment (row block rb, tap, channel block cb, K group g) = 1 KiB at
+    // (((rb * 9 + tap) * ncb + cb) * G + g) * 1024; lane L reads its 16 bytes at L * 16.
+    const int a_voff = lane * 16;
+    auto loadA = [&](int k, FragT (&dst)[G]) {
+        const int cb = k / 9, tap = k - cb * 9;
+        const int soff = (((wn * 9 + tap) * p.ncb + phys_cb(cb)) * G) * 1024;
+#pragma unroll
+        for (int g = 0; g < G; ++g) dst[g] = __builtin_bit_cast(FragT, bload(rw, a_voff, soff + g * 1024));
+    };
+
+    f32x16 acc[1][SM];
+#pragma unroll
+    for (int j = 0; j < SM; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.0f;
+
+    const int lpix = ((__builtin_popcount(l31 >> 2) & 1) << 4) | ((l31 >> 3) << 2) | (l31 & 3);      // see conv3x3_halo_kernel
+    int hr0[SM];
+#pragma unroll
+    for (int j = 0; j < SM; ++j) hr0[j] = (wm * 8 + j * 2 + (lpix >> 4)) * HW + (lpix & 15);
+
+    FragT a_cur[G], a_nxt[G];
+    auto compute = [&](int k) {
+        const int cb = k / 9, tap = k - cb * 9;
+        const int d = (tap / 3) * HW + (tap % 3);
+        const unsigned char* hb = hbase + (cb & 1) * HBUF;
+        int rowB[SM], f4[SM];
+#pragma unroll
+        for (int j = 0; j < SM; ++j) {
+            const int hr = hr0[j] + d;
+            rowB[j] = hr * ROWB;
+            f4[j] = ((hr >> 1) & 7) << 4;
+        }
+        FragT bf[2][SM];
+        auto ldfrag = [&](int g, int s) {
+#pragma unroll
+            for (int j = 0; j < SM; ++j) bf[s][j] = *reinterpret_cast<const FragT*>(hb + rowB[j] + ((((g * 2 + half) << 4)) ^ f4[j]));
+        };
+        ldfrag(0, 0);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int s = g & 1;
+            if (g + 1 < G) ldfrag(g + 1, s ^ 1);
+#pragma unroll
+            for (int j = 0; j < SM; ++j) acc[0][j] = mfma16(a_cur[g], bf[s][j], acc[0][j]);
+        }
+    };
+
+    // ---- UPIN: identical to conv3x3_halo_kernel (one 16-byte chunk of the halo image per thread and pass) ----
+    constexpr int NUP = UPIN ? NLH : 1;
+    int up_off[NUP][4];
+    float up_ly[NUP], up_lx[NUP];
+    if constexpr (UPIN) {
+#pragma unroll
+        for (int i = 0; i < NLH; ++i) {
+            const int q = i * NT + t;
+            const int hr = q / CPR, kc = (q % CPR) ^ ((hr >> 1) & 7);
+            const int iy = ty0 - 1 + hr / HW, ix = tx0 - 1 + hr % HW;
+            const bool ok = q < HCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const float sy = p.ry * (float)iy, sx = p.rx * (float)ix;
+            const int y0 = ok ? (int)sy : 0, x0 = ok ? (int)sx : 0;
+            const int y1 = y0 + (y0 < p.Hi - 1 ? 1 : 0), x1 = x0 + (x0 < p.Wi - 1 ? 1 : 0);
+            up_ly[i] = sy - (float)y0;
+            up_lx[i] = sx - (float)x0;
+            const int r0 = (img * p.Hi + y0) * p.Wi, r1 = (img * p.Hi + y1) * p.Wi;
+            const int pb = p.Cy * 2, cbase = kc * E * 2;
+            up_off[i][0] = ok ? (r0 + x0) * pb + cbase : OOB;
+            up_off[i][1] = ok ? (r0 + x1) * pb + cbase : OOB;
+            up_off[i][2] = ok ? (r1 + x0) * pb + cbase : OOB;
+            up_off[i][3] = ok ? (r1 + x1) * pb + cbase : OOB;
+        }
+    }
+    u32x4 st[4] = {};
+    auto up_load = [&](int pass, int ub) {
+        const int soff = ub * BK * 2;
+#pragma unroll
+        for (int i = 0; i < NUP; ++i)
+            if (i == pass) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) st[c] = bload(rin, up_off[i][c], soff);
+            }
+    };
+    auto up_store = [&](int pass, int bufidx) {
+        const int q = pass * NT + t;
+        if (q >= HCH) return;
+        float ly1 = 0.f, lx1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NUP; ++i)
+            if (i == pass) { ly1 = up_ly[i]; lx1 = up_lx[i]; }
+        const float ly0 = 1.0f - ly1, lx0 = 1.0f - lx1;
+        float v[8];
+        const FragT c0 = __builtin_bit_cast(FragT, st[0]), c1 = __builtin_bit_cast(FragT, st[1]);
+        const FragT c2 = __builtin_bit_cast(FragT, st[2]), c3 = __builtin_bit_cast(FragT, st[3]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = ly0 * (lx0 * (float)c0[e] + lx1 * (float)c1[e]) + ly1 * (lx0 * (float)c2[e] + lx1 * (float)c3[e]);
+        store16<WT>(reinterpret_cast<WT*>(hbase + bufidx * HBUF + q * 16), v);
+    };
+
+    const int nk = 9 * p.ncb;
+    // 0x1000: timeline of wave 0 of the first 512 workgroups into p.res (tools/conv_bench.py --timeline)
+    const bool tl_on = (p.flags & 0x1000) && blockIdx.x < 512 && t == 0;
+    unsigned long long* tl = reinterpret_cast<unsigned long long*>(const_cast<void*>(p.res)) + (size_t)blockIdx.x * 64;
+    if (tl_on) tl[0] = __builtin_amdgcn_s_memtime();
+    issue_h(0);
+    loadA(0, a_cur);
+    if (tl_on) tl[1] = __builtin_amdgcn_s_memtime();
+    for (int k = 0; k < nk; ++k) {
+        if (tl_on && k < 40) tl[2 + k] = __builtin_amdgcn_s_memtime();
+        const int cbj = k / 9, tapj = k - cbj * 9, nxt = cbj + 1;
+        if (tapj == 0) {
+            // channel-block boundary: this block's halo has landed (this wave's pieces: vmcnt; everyone's: barrier) and every wave is
+            // done reading the other buffer, which the next block's halo is about to overwrite.  LDS writes of the in-loader upsample
+            // retire in order with the fragment reads that followed them.
+            wait_vmcnt<0>();
+            wg_barrier();
+            if (nxt < (UPIN ? nb_dma : p.ncb)) issue_h(nxt);
+        }
+        if constexpr (UPIN) {
+            if (nxt < p.ncb && nxt >= nb_dma) {                      // next block is upsampled: produce its halo pass by pass
+                if (tapj >= 1 && tapj - 1 < NLH) up_store(tapj - 1, nxt & 1);
+                if (tapj < NLH) up_load(tapj, nxt - nb_dma);
+            }
+        }
+        if (k + 1 < nk) loadA(k + 1, a_nxt);                         // one full step ahead
+        compute(k);
+#pragma unroll
+        for (int g = 0; g < G; ++g) a_cur[g] = a_nxt[g];
+    }
+
+    if (tl_on) tl[42] = __builtin_amdgcn_s_memtime();
+    int mrow[SM];
+#pragma unroll
+    for (int j = 0; j < SM; ++j) {
+        const int oy = ty0 + wm * 8 + j * 2 + (lpix >> 4), ox = tx0 + (lpix & 15);
+        mrow[j] = (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
+    }
+    auto row_to_m = [&](int row) {
+        const int oy = ty0 + (row >> 4), ox = tx0 + (row & 15);
+        return (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
+    };
+    if constexpr (TOPF) {
+        conv_epilogue_topfuse<WT, 1, SM, NT, TN, TY * TX>(p, acc, smem_raw, wn * 32, wm * SM * 32, half, l31, lpix, wave, row_to_m);
+    } else if (epi_lds_ok<OutT>(p)) {
+        conv_epilogue_lds<WT, OutT, 1, SM, NT, TN, TY * TX>(p, acc, smem_raw, n0, wn * 32, wm * SM * 32, half, lpix, row_to_m);
+    } else {
+        conv_epilogue_rows<WT, OutT, 1, SM>(p, acc, mrow, n0 + wn * 32, half);
+    }
+    if (tl_on) tl[43] = __builtin_amdgcn_s_memtime();
+}
+
+template <typename WT, typename OutT, bool TOPF = false, bool UPIN = false, int WMH = 2>
+hipError_t launch_wl1(ConvP p, hipStream_t s) {
+    constexpr size_t lds_bytes = wl1_lds_bytes<WT, TOPF, WMH>();
+    constexpr int TY = 8 * WMH;
+    auto kern = conv3x3_wl1_kernel<WT, OutT, TOPF, UPIN, WMH>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    p.ncb = p.Cin / 64;
+    p.nk = 9 * p.ncb;
+    p.nN = 1;
+    p.nblk_g = p.B * ((p.Ho + TY - 1) / TY) * ((p.Wo + 15) / 16);
+    p.nblk = p.nblk_g * (p.groups > 1 ? p.groups : 1);
+    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(384 * WMH), lds_bytes, s, p);
+    return hipGetLastError();
+}
+
 template <typename WT, typename InT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF, bool SE, int KG = 1>
 hipError_t launch_cfg2(ConvP p, hipStream_t s) {
     constexpr int E = 16 / (int)sizeof(WT);
@@ -1339,6 +1603,7 @@ static const int kCfgTM[] = {128, 128, 128, 128, 64, 256, 64};
 // (findtextcenternet_amd/tuning.py); every choice gives bit-identical results (same K order).
 inline int hint_cfg(const ftc_op& o) { return (o.aux0 & 15) - 1; }
 inline bool hint_halo(const ftc_op& o) { return (o.aux0 & 64) != 0; }         // bit 6: LDS-halo 3x3 kernel
+inline bool hint_wl1(const ftc_op& o) { return (o.aux0 & 192) == 192; }       // bits 6+7: its weights-through-L1 successor (needs FTC_FLAG_W_FRAG weights)
 inline int hint_splitk(const ftc_op& o) { const int c = (o.aux0 >> 10) & 3; return c == 1 ? 2 : c == 2 ? 4 : 1; }   // bits 10-11
 inline int hint_stage(const ftc_op& o) { return (o.aux0 >> 4) & 3; }
 inline int hint_bk(const ftc_op& o) { const int b = (o.aux0 >> 8) & 3; return b == 1 ? 32 : b == 2 ? 64 : b == 3 ? 128 : 0; }
@@ -1438,6 +1703,13 @@ hipError_t launch_tiles(const ConvP& p, int cfg, hipStream_t s) {
 template <typename WT, typename OutT>
 hipError_t launch_halo_dispatch(const ConvP& p, const ftc_op& o, hipStream_t s) {
     const int sn = halo_sn(o), cpr = halo_cpr(o);
+    if constexpr (sizeof(WT) == 2 && sizeof(OutT) == 2) {
+        if (hint_wl1(o) && (o.flags & FTC_FLAG_W_FRAG) && cpr == 8 && sn == 3) {
+            const bool up = (o.flags & FTC_FLAG_UPCAT_IN) != 0;
+            if (o.flags & FTC_FLAG_TOP_FUSE) return up ? launch_wl1<WT, OutT, true, true>(p, s) : launch_wl1<WT, OutT, true, false>(p, s);
+            return up ? launch_wl1<WT, OutT, false, true>(p, s) : launch_wl1<WT, OutT, false, false>(p, s);
+        }
+    }
     if (o.flags & FTC_FLAG_TOP_FUSE) {
         if constexpr (sizeof(WT) == 2 && sizeof(OutT) == 2) {
             if (cpr == 8 && sn == 3) return (o.flags & FTC_FLAG_UPCAT_IN) ? launch_halo<WT, OutT, 8, 3, true, true>(p, s) : launch_halo<WT, OutT, 8, 3, true>(p, s);

@@ -406,6 +406,27 @@ int pack_weights(ftc_model* m, Weights& w) {
         if (ok) {
             bl.add_compute("heads.L" + std::to_string(i) + "f.w", wall.data(), (int64_t)wall.size(), cdt);
             bl.add_f32("heads.L" + std::to_string(i) + "f.b", ball.data(), (int64_t)ball.size());         // [9][16][192]
+            if (cin % 64 == 0) {
+                // the same weights FRAGMENT-MAJOR for the weights-through-L1 kernel (FTC_FLAG_W_FRAG): per head
+                // [6 row blocks][9 taps][cin/64][4 K groups][64 lanes][8]: lane L, element e = W[32 rb + (L & 31)][tap][64 cb + 16 g + 8 (L >> 5) + e]
+                const int ncb = cin / 64;
+                std::vector<double> wf2(wall.size());
+                const size_t per_head = (size_t)FPN_DIM * 9 * cin;
+                for (int hi = 0; hi < NHEADS; ++hi) {
+                    const double* km = wall.data() + hi * per_head;
+                    double* dst = wf2.data() + hi * per_head;
+                    for (int rb = 0; rb < 6; ++rb)
+                        for (int t = 0; t < 9; ++t)
+                            for (int cb = 0; cb < ncb; ++cb)
+                                for (int g = 0; g < 4; ++g)
+                                    for (int L = 0; L < 64; ++L) {
+                                        const size_t src = ((size_t)(rb * 32 + (L & 31)) * 9 + t) * cin + cb * 64 + g * 16 + (L >> 5) * 8;
+                                        const size_t d = (((((size_t)rb * 9 + t) * ncb + cb) * 4 + g) * 64 + L) * 8;
+                                        for (int e = 0; e < 8; ++e) dst[d + e] = km[src + e];
+                                    }
+                }
+                bl.add_compute("heads.L" + std::to_string(i) + "f.wfrag", wf2.data(), (int64_t)wf2.size(), cdt);
+            }
         }
     }
     // top convolutions (3x3, with bias, no BN): K-major [co][9][192]
@@ -762,10 +783,13 @@ int Builder::build(ModelPlan* out) {
             s.w = wref(wname + ".w", (int64_t)g0 * wsz);
             s.bias = wref(wname + ".b", (int64_t)g0 * brows * FPN_DIM * 4);
             int flags = 0;
+            // weights-through-L1 kernel for the fused last level (fragment-major copy of the folded weights); FTC_NO_WL1=1: the LDS-ring halo kernel
+            const bool wl1 = bn_fold && has_w(lf + ".wfrag") && !env_on("FTC_NO_WL1");
             if (bn_fold) {
                 flags |= FTC_FLAG_UPCAT_IN | FTC_FLAG_BORDER_BIAS | FTC_FLAG_GROUP_IN2_SHARED;
                 o.Cin_total = cy; o.aux0 = 65;
                 s.in = sub(y, (int64_t)g0 * B * yh * yw * cy * 2); s.in2 = tapbn;
+                if (wl1) { flags |= FTC_FLAG_W_FRAG; s.w = wref(lf + ".wfrag", (int64_t)g0 * wsz); }
             } else if (up_in) {
                 flags |= FTC_FLAG_UPCAT_IN;
                 o.Cin_total = cy; o.aux0 = 65;
@@ -788,6 +812,7 @@ int Builder::build(ModelPlan* out) {
                 byt += (double)ng * M * FPN_DIM * esize(A);
             }
             o.flags = flags;
+            if (wl1) o.aux0 |= 128;
             emit({name, "conv3x3", flops, byt}, s);
         };
         if (last && fuse_top) {

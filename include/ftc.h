@@ -113,6 +113,10 @@ enum {
                                   both channel counts multiples of the kernel's K block (64, or 32 when Cin % 64 != 0) */
     FTC_FLAG_GROUP_IN2_SHARED = 0x200000, /* CONV + UPCAT_IN with groups > 1: in2 is ONE tensor [B,H,W,Cin-Cin_total] read by every group
                                   (the backbone tap; its per-head BatchNorm folded into the weights and a BORDER_BIAS table) */
+    FTC_FLAG_W_FRAG = 0x400000, /* CONV 3x3 stride 1, 16-bit, Cout = 192, Cin % 64 == 0, aux0 bits 6+7 (weights-through-L1 kernel): `w` is packed
+                                  FRAGMENT-MAJOR -- [groups][6 row blocks of 32][9 taps][Cin/64][4 K groups of 16][64 lanes][8]: element e of
+                                  lane L = W[32*rb + (L & 31)][tap][64*cb + 16*g + 8*(L >> 5) + e] -- so that a wave reads an MFMA A fragment
+                                  as one coalesced 1 KiB load straight from global memory (the weights never touch LDS) */
     FTC_FLAG_SE_FOLD = 32      /* SE: besides scale[b,c], write out2[b][n][c] = bf16(in[n][c] * scale[b,c]) for the
                                   bf16 matrix `in` [Cout_total][C] -- the following 1x1 convolution then runs with
                                   FTC_FLAG_W_PER_IMAGE on unscaled activations (both operands by DMA) */

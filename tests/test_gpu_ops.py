@@ -370,9 +370,18 @@ def test_upcat_in_conv_equals_upsample_concat_conv(shape, dt):
     assert err < TOL16[dt]
 
 
+def _frag_major(wk):
+    """[G, Cout=192, 9, Cin] K-major weights -> FTC_FLAG_W_FRAG layout [G][6 row blocks][9][Cin/64][4][64 lanes][8]."""
+    G, Co, T, Ci = wk.shape
+    assert Co == 192 and T == 9 and Ci % 64 == 0
+    w = wk.reshape(G, 6, 32, 9, Ci // 64, 4, 2, 8)              # g, rb, l31, tap, cb, kg, half, e
+    return w.permute(0, 1, 3, 4, 5, 6, 2, 7).contiguous().reshape(G, -1)   # g, rb, tap, cb, kg, (half, l31), e
+
+
+@pytest.mark.parametrize("kern", ["halo", "wl1"])
 @pytest.mark.parametrize("dt", [L.BF16, L.F16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("top", [False, True], ids=["plain", "top_fuse"])
-def test_upcat_in_with_tap_batchnorm_folded_and_shared_tap(top, dt):
+def test_upcat_in_with_tap_batchnorm_folded_and_shared_tap(top, dt, kern):
     """Last FPN level as the bf16 plan runs it: the nine heads read ONE backbone tap (FTC_FLAG_GROUP_IN2_SHARED); each head's input
     BatchNorm of the tap is folded into its weights and a 16-case border bias table (FTC_FLAG_BORDER_BIAS) -- against
     conv3x3(cat[upsample(prev_g), BN_g(tap)]) + GELU (then the 3x3 top convolution for the TOP_FUSE variant) in fp32."""
@@ -407,14 +416,17 @@ def test_upcat_in_with_tap_batchnorm_folded_and_shared_tap(top, dt):
     ar = Arena()
     o_prev = ar.put(to_dev_bytes(prev, dt))
     o_tap = ar.put(to_dev_bytes(tap, dt))
-    o_w = ar.put(to_dev_bytes(wm.permute(0, 1, 3, 4, 2).reshape(G, Cm, 9, Cin), dt))
+    wk = wm.permute(0, 1, 3, 4, 2).reshape(G, Cm, 9, Cin)
+    # "wl1": the weights-through-L1 kernel (aux0 bits 6+7) on fragment-major weights; "halo": the LDS-ring kernel on K-major weights
+    o_w = ar.put(to_dev_bytes(_frag_major(wk) if kern == "wl1" else wk, dt))
+    aux0 = 193 if kern == "wl1" else 65
     o_b = ar.put(b16.float())
-    flags = L.FLAG_UPCAT_IN | L.FLAG_BORDER_BIAS | L.FLAG_GROUP_IN2_SHARED
+    flags = L.FLAG_UPCAT_IN | L.FLAG_BORDER_BIAS | L.FLAG_GROUP_IN2_SHARED | (L.FLAG_W_FRAG if kern == "wl1" else 0)
     if not top:
         o_out = ar.reserve(G * B * H * W * Cm * 2)
         ar.materialize()
         run_op(dict(kind=L.OP_CONV, flags=flags, act=L.ACT_GELU, in_dtype=dt, out_dtype=dt, w_dtype=dt, B=B, H=H, W=W, Ho=H, Wo=W,
-                    Cin=Cin, Cin_total=Cy, Cout=Cm, Cout_total=Cm, ksize=3, stride=1, aux0=65, groups=G, in_=o_prev, in2=o_tap, out=o_out,
+                    Cin=Cin, Cin_total=Cy, Cout=Cm, Cout_total=Cm, ksize=3, stride=1, aux0=aux0, groups=G, in_=o_prev, in2=o_tap, out=o_out,
                     w=o_w, bias=o_b), ar)
         out = ar.read(o_out, (G, B, H, W, Cm), tdtype(dt)).float()
         ref = torch.stack([y.permute(0, 2, 3, 1) for y in ys])
@@ -431,7 +443,7 @@ def test_upcat_in_with_tap_batchnorm_folded_and_shared_tap(top, dt):
         o_out = ar.reserve(B * H * W * G * 4)
         ar.materialize()
         run_op(dict(kind=L.OP_CONV, flags=flags | L.FLAG_TOP_FUSE, act=L.ACT_GELU, in_dtype=dt, out_dtype=dt, w_dtype=dt, B=B, H=H,
-                    W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cy, Cout=Cm, Cout_total=Cm, ksize=3, stride=1, aux0=65, aux1=TW, groups=G,
+                    W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cy, Cout=Cm, Cout_total=Cm, ksize=3, stride=1, aux0=aux0, aux1=TW, groups=G,
                     in_=o_prev, in2=o_tap, out=o_T, w=o_w, bias=o_b, w2=o_wt), ar)
         run_op(dict(kind=L.OP_TAPSUM, B=B, H=H, W=W, Ho=H, Wo=W, Cout_total=G, aux0=TW, aux1=G, groups=G, in_=o_T, out=o_out, w=o_map,
                     bias=o_ob), ar)

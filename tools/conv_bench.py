@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--ablate", type=int, default=0, help="halo kernel ablation: 1 = no DMA in the K loop, 2 = no MFMA/LDS reads (wrong results; timing only)")
     ap.add_argument("--nbuf", type=int, default=0, help="tuning hints (ftc_op.aux0): 4 = no direct-to-LDS, 8 = 3-deep DMA ring, 16 = force direct-to-LDS")
     ap.add_argument("--no-se", action="store_true", help="drop the SE-scale flag (what-if: scale folded into per-image weights)")
+    ap.add_argument("--wl1", action="store_true", help="3x3 192-channel layers: the weights-through-L1 kernel (FTC_FLAG_W_FRAG; weight values are random anyway)")
     ap.add_argument("--sweep", action="store_true", help="try every tuner candidate for the layer and print the five fastest")
     a = ap.parse_args()
     lib = L.load()
@@ -90,6 +91,9 @@ def main():
         o.Cout = o.Cout_total = Cout
         o.ksize, o.stride = k, stride
         o.aux0 = a.nbuf
+        if a.wl1:
+            o.flags |= L.FLAG_W_FRAG
+            o.aux0 = 193
         for fld, key in (("in_", "in"), ("w", "w"), ("bias", "bias"), ("out", "out")):
             r = getattr(o, fld); r.base, r.offset = L.BASE_WORKSPACE, off[key]
         if res or a.timeline:

@@ -17,23 +17,6 @@ ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 FLAG_RESIDUAL, FLAG_SE_SCALE, FLAG_IN_NCHW, FLAG_BORDER_BIAS, FLAG_W_PER_IMAGE, FLAG_SE_FOLD = 1, 2, 4, 8, 16, 32
 FLAG_GROUP_IN_SLICE, FLAG_GROUP_OUT_SLICE = 64, 128
 FLAG_TOP_FUSE, FLAG_UPCAT_IN, FLAG_GROUP_IN2_SHARED, FLAG_W_FRAG = 0x10000, 0x20000, 0x200000, 0x400000
-# pointwise-GEMM kernel variants (csrc/conv_igemm_impl.h kPw): (channels, pixels, waves, ring depth) of variant 1..12; ftc_op.aux0 =
-# variant << 12 | (K splits - 1) << 16
-PW_VARIANTS = [None, (64, 64, 4, 4), (128, 128, 4, 4), (128, 128, 8, 4), (192, 256, 8, 2), (128, 256, 8, 3), (256, 128, 8, 3), (128, 192, 8, 3),
-               (256, 192, 8, 2), (192, 128, 8, 3), (96, 128, 4, 4), (64, 128, 4, 4), (128, 64, 4, 4)]
-
-
-def pw_encode(variant: int, split: int = 1) -> int:
-    return (variant << 12) | ((split - 1) << 16)
-
-
-def pw_aux_bytes(Cout: int, M: int, variant: int, split: int) -> int:
-    """Bytes of the `aux` operand (arrival counters + partial tiles) of a K-split pointwise conv (0 when split == 1)."""
-    if split <= 1:
-        return 0
-    tn, tm = PW_VARIANTS[variant][:2]
-    tiles = -(-Cout // tn) * -(-M // tm)
-    return (tiles * 4 + 255) // 256 * 256 + tiles * split * tn * tm * 4
 
 EXPORTS = ["ftc_abi_version", "ftc_last_error", "ftc_device_info", "ftc_plan_create", "ftc_plan_destroy",
            "ftc_plan_num_ops", "ftc_plan_run", "ftc_plan_profile", "ftc_op_kernel_label", "ftc_decode_scratch_bytes", "ftc_decode", "ftc_tile_gather", "ftc_paste_maps",

@@ -15,18 +15,9 @@ hipError_t launch_conv_f16_hh(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_f16_fh(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_f16_hf(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_f16_ff(const ConvP& p, const ftc_op& o, hipStream_t s);
-hipError_t launch_pw_bf16_b(const ConvP& p, const ftc_op& o, hipStream_t s);
-hipError_t launch_pw_bf16_f(const ConvP& p, const ftc_op& o, hipStream_t s);
-hipError_t launch_pw_f16_h(const ConvP& p, const ftc_op& o, hipStream_t s);
-hipError_t launch_pw_f16_f(const ConvP& p, const ftc_op& o, hipStream_t s);
 
 void conv_kernel_label(const ftc_op& op, char* buf, int len) {
     const char* dt[] = {"f32", "bf16", "f16", "?"};
-    if (uses_pw(op) && hint_pw(op) <= PW_COUNT) {
-        const PwVariant& v = kPw[hint_pw(op)];
-        snprintf(buf, len, "pw_gemm<%s,out=%s,tile=%dx%d,waves=%d,nbuf=%d,splitk=%d>", dt[op.w_dtype & 3], dt[op.out_dtype & 3], v.tn, v.tm, v.wn * v.wm, v.nbuf, hint_pw_split(op));
-        return;
-    }
     if (uses_halo(op) && hint_wl1(op) && (op.flags & FTC_FLAG_W_FRAG)) {
         snprintf(buf, len, (op.flags & FTC_FLAG_TOP_FUSE) ? "conv3x3_wl1+top<%s,tile=192x16x16,bk=64>" : "conv3x3_wl1<%s,tile=192x16x16,bk=64>", dt[op.w_dtype & 3]);
         if (op.groups > 1) snprintf(buf + strlen(buf) - 1, len - strlen(buf) + 1, ",groups=%d>", op.groups);
@@ -73,8 +64,6 @@ const char* conv_validate(const ftc_op& op) {
     const long w_bytes = (long)op.Cout * op.ksize * op.ksize * op.Cin * (op.w_dtype == FTC_F32 ? 4 : 2);
     if (in_bytes >= 0x7ff00000L || w_bytes >= 0x7ff00000L) return "conv: operand larger than 2 GiB (split the batch)";
     if ((op.flags & FTC_FLAG_W_PER_IMAGE) && (op.flags & (FTC_FLAG_SE_SCALE | FTC_FLAG_BORDER_BIAS))) return "conv: per-image weight sets exclude SE_SCALE / BORDER_BIAS";
-    if (op.aux0 < 0 || op.aux0 > 0x7ffff) return "conv: aux0 (tuned kernel choice) out of range";
-    if (uses_pw(op)) return pw_illegal(op);
     if (!wset_legal(op)) return "conv: per-image weight sets need a pixel tile that divides Ho*Wo";
     if (op.flags & FTC_FLAG_UPCAT_IN) {
         const int bk = halo_cpr(op) * 8;
@@ -97,7 +86,7 @@ const char* conv_validate(const ftc_op& op) {
     if (op.groups > 1 && (long)op.groups * op.B * op.Ho * op.Wo > 0x7fffffffL / 4) return "conv: too many output pixels over all groups";
     if (hint_halo(op) && !halo_legal(op)) return "conv: LDS-halo kernel is not legal for this op/tile";
     if (hint_splitk(op) > 1 && !splitk_legal(op, hint_splitk(op))) return "conv: split-K variant is not legal for this op/tile";
-    if (hint_cfg(op) >= CFG_COUNT) return "conv: aux0 (tuned kernel choice) out of range";
+    if (op.aux0 < 0 || op.aux0 > 0xfff || hint_cfg(op) >= CFG_COUNT) return "conv: aux0 (tuned kernel choice) out of range";
     if ((op.aux0 & 128) || (op.flags & FTC_FLAG_W_FRAG)) {
         if (!hint_wl1(op) || !(op.flags & FTC_FLAG_W_FRAG)) return "conv: aux0 bit 7 (weights-through-L1 kernel) and FTC_FLAG_W_FRAG go together (with bit 6)";
         if (op.ksize != 3 || op.stride != 1 || !ftc_is16(op.w_dtype) || op.in_dtype != op.w_dtype || op.out_dtype != op.w_dtype || op.Cout != 192 ||
@@ -156,17 +145,6 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
         p.w2 = a.w2; p.w2_gs = (long)32 * o.Cout * 2; p.Tw = o.aux1;
         p.out_gs = (long)o.B * o.Ho * o.Wo * o.aux1 * 4;       // `out` holds T [G][B,Ho,Wo][aux1] fp32
         p.out2 = nullptr;
-    }
-    p.pw_ws = nullptr; p.pw_cnt = nullptr; p.pw_split = 1;
-    if (uses_pw(o)) {
-        p.pw_split = hint_pw_split(o);
-        if (p.pw_split > 1) {
-            if (!a.aux) return hipErrorInvalidValue;
-            p.pw_cnt = reinterpret_cast<int*>(a.aux);
-            p.pw_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(a.aux) + pw_cnt_bytes(o));
-        }
-        if (o.w_dtype == FTC_F16) return o.out_dtype == FTC_F32 ? launch_pw_f16_f(p, o, s) : launch_pw_f16_h(p, o, s);
-        return o.out_dtype == FTC_F32 ? launch_pw_bf16_f(p, o, s) : launch_pw_bf16_b(p, o, s);
     }
     if (o.w_dtype == FTC_F32) return launch_conv_f32(p, o, s);
     if (o.w_dtype == FTC_F16) {

@@ -69,11 +69,6 @@ struct ConvP {
     long in2u_gs;
     int Cy, Hi, Wi;
     float ry, rx;
-    // pointwise-GEMM kernel (pw_gemm_impl.h): K split over `pw_split` workgroups per tile; partial tiles and the per-tile arrival
-    // counters live in the op's `aux` operand
-    float* pw_ws;
-    int* pw_cnt;
-    int pw_split;
 };
 
 // Turns the launch-wide parameter block into the one of the group that owns workgroup `bid`; returns the
@@ -1612,53 +1607,6 @@ inline bool hint_wl1(const ftc_op& o) { return (o.aux0 & 192) == 192; }       //
 inline int hint_splitk(const ftc_op& o) { const int c = (o.aux0 >> 10) & 3; return c == 1 ? 2 : c == 2 ? 4 : 1; }   // bits 10-11
 inline int hint_stage(const ftc_op& o) { return (o.aux0 >> 4) & 3; }
 inline int hint_bk(const ftc_op& o) { const int b = (o.aux0 >> 8) & 3; return b == 1 ? 32 : b == 2 ? 64 : b == 3 ? 128 : 0; }
-
-// ---- pointwise-GEMM kernel (pw_gemm_impl.h): aux0 bits 12-15 = variant (1..PW_COUNT, 0 = not used), bits 16-18 = K splits - 1 ----
-struct PwVariant { int tn, tm, wn, wm, sn, sm, nbuf; };      // tile = tn channels x tm pixels, wn x wm waves of sn x sm 32x32 sub-tiles
-constexpr int PW_COUNT = 12;
-static const PwVariant kPw[PW_COUNT + 1] = {
-    {0, 0, 0, 0, 0, 0, 0},
-    {64, 64, 2, 2, 1, 1, 4},       //  1
-    {128, 128, 2, 2, 2, 2, 4},     //  2
-    {128, 128, 2, 4, 2, 1, 4},     //  3  (8 waves from here on unless noted)
-    {192, 256, 2, 4, 3, 2, 2},     //  4
-    {128, 256, 2, 4, 2, 2, 3},     //  5
-    {256, 128, 4, 2, 2, 2, 3},     //  6
-    {128, 192, 4, 2, 1, 3, 3},     //  7
-    {256, 192, 4, 2, 2, 3, 2},     //  8
-    {192, 128, 2, 4, 3, 1, 3},     //  9
-    {96, 128, 1, 4, 3, 1, 4},      // 10  (4 waves)
-    {64, 128, 2, 2, 1, 2, 4},      // 11  (4 waves)
-    {128, 64, 2, 2, 2, 1, 4},      // 12  (4 waves)
-};
-inline int hint_pw(const ftc_op& o) { return (o.aux0 >> 12) & 15; }
-inline int hint_pw_split(const ftc_op& o) { return ((o.aux0 >> 16) & 7) + 1; }
-inline long pw_tiles(const ftc_op& o) {
-    const PwVariant& v = kPw[hint_pw(o)];
-    return (long)((o.Cout + v.tn - 1) / v.tn) * (((long)o.B * o.Ho * o.Wo + v.tm - 1) / v.tm);
-}
-inline long pw_cnt_bytes(const ftc_op& o) { return (pw_tiles(o) * 4 + 255) / 256 * 256; }
-// bytes of the `aux` operand of a split launch: arrival counters (zero before the first launch; the kernel leaves them zero), partial tiles
-inline long pw_aux_bytes(const ftc_op& o) {
-    if (!hint_pw(o) || hint_pw_split(o) <= 1) return 0;
-    const PwVariant& v = kPw[hint_pw(o)];
-    return pw_cnt_bytes(o) + pw_tiles(o) * hint_pw_split(o) * v.tn * v.tm * 4;
-}
-inline const char* pw_illegal(const ftc_op& o) {
-    const int vi = hint_pw(o);
-    if (vi < 1 || vi > PW_COUNT) return "conv: unknown pointwise-GEMM variant (aux0 bits 12-15)";
-    const PwVariant& v = kPw[vi];
-    if (o.ksize != 1 || o.stride != 1 || !ftc_is16(o.w_dtype) || o.in_dtype != o.w_dtype || (o.out_dtype != o.w_dtype && o.out_dtype != FTC_F32))
-        return "conv: the pointwise-GEMM kernel takes 1x1 stride-1 convs with 16-bit weights and activations";
-    if (o.Cin % 64) return "conv: the pointwise-GEMM kernel needs Cin % 64 == 0";
-    if (o.groups > 1 || (o.flags & (FTC_FLAG_SE_SCALE | FTC_FLAG_BORDER_BIAS | FTC_FLAG_UPCAT_IN | FTC_FLAG_TOP_FUSE | FTC_FLAG_W_FRAG)))
-        return "conv: the pointwise-GEMM kernel excludes groups / SE_SCALE / BORDER_BIAS / UPCAT_IN / TOP_FUSE";
-    if ((o.flags & FTC_FLAG_W_PER_IMAGE) && (o.Ho * o.Wo) % v.tm) return "conv: per-image weight sets need a pixel tile that divides Ho*Wo";
-    if (hint_pw_split(o) > o.Cin / 64) return "conv: more K splits than K steps";
-    if (o.aux0 & 0xfff) return "conv: pointwise-GEMM variant excludes the other tuning hints (aux0 bits 0-11)";
-    return nullptr;
-}
-inline bool uses_pw(const ftc_op& o) { return hint_pw(o) != 0; }
 
 inline int default_cfg(int n, int M) {
     if (n <= 32) return CFG_32x256;

@@ -5,7 +5,6 @@
 #include <string>
 #include <vector>
 
-#include "conv_igemm_impl.h"          // pointwise-GEMM scratch sizes (host helpers only)
 #include "ftc_common.h"
 #include "ftc_host.h"
 
@@ -97,8 +96,6 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
             !need(o.scale, (o.flags & FTC_FLAG_SE_SCALE) != 0, "scale", (int64_t)o.B * o.Cin * 4)) return why->c_str();
         if (!need(o.out2, false, "out2", pout * o.Cout * 2)) return why->c_str();
         if (!need(o.w2, topf, "w2", G * 32 * o.Cout * 2)) return why->c_str();
-        if (o.aux0 >= 0 && o.aux0 <= 0x7ffff && convimpl::hint_pw(o) >= 1 && convimpl::hint_pw(o) <= convimpl::PW_COUNT && convimpl::hint_pw_split(o) > 1 &&
-            !need(o.aux, true, "aux", convimpl::pw_aux_bytes(o))) return why->c_str();
         if (o.out2.base != FTC_BASE_NULL && (o.out_dtype != FTC_F32 || o.Cout % 4)) return "conv: out2 (bf16 copy) needs an fp32 primary output and Cout % 4 == 0";
         return conv_validate(o);
     }
@@ -165,26 +162,6 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
 inline void* resolve(const ftc_ref& r, void* const bases[FTC_NUM_BASES]) {
     if (r.base == FTC_BASE_NULL) return nullptr;
     return static_cast<char*>(bases[r.base]) + r.offset;
-}
-
-// Split pointwise GEMMs count workgroup arrivals per tile in the head of their `aux` operand and leave the counters at zero; they
-// are zeroed here once per run (they start as arbitrary caller memory, and an aborted run may leave them mid-count).
-hipError_t zero_arrival_counters(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], int first, int last, hipStream_t s) {
-    std::vector<std::pair<char*, size_t>> done;
-    for (int i = first; i <= last; ++i) {
-        const ftc_op& o = plan->ops[i];
-        if (o.kind != FTC_OP_CONV || !convimpl::uses_pw(o) || convimpl::hint_pw_split(o) <= 1 || o.aux.base == FTC_BASE_NULL) continue;
-        char* ptr = static_cast<char*>(bases[o.aux.base]) + o.aux.offset;
-        const size_t n = (size_t)convimpl::pw_cnt_bytes(o);
-        bool covered = false;
-        for (auto& d : done)
-            if (d.first == ptr && d.second >= n) covered = true;
-        if (covered) continue;
-        hipError_t e = hipMemsetAsync(ptr, 0, n, s);
-        if (e != hipSuccess) return e;
-        done.emplace_back(ptr, n);
-    }
-    return hipSuccess;
 }
 
 hipError_t run_one(const ftc_op& o, void* const bases[FTC_NUM_BASES], hipStream_t s) {
@@ -281,7 +258,6 @@ int ftc_plan_run(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], void* s
     int rc = check_bases(plan, bases, first_op, last_op);
     if (rc != FTC_OK) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipError_t e = zero_arrival_counters(plan, bases, first_op, last_op, s); e != hipSuccess) return fail_hip(e, "ftc_plan_run: zeroing arrival counters");
     for (int i = first_op; i <= last_op; ++i) {
         hipError_t e = run_one(plan->ops[i], bases, s);
         if (e != hipSuccess) {
@@ -320,10 +296,9 @@ int ftc_plan_profile(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], voi
     std::vector<hipEvent_t> ev(n + 1);
     for (auto& e : ev)
         if (hipEventCreate(&e) != hipSuccess) return fail(FTC_ERR_HIP, "ftc_plan_profile: hipEventCreate failed");
-    int ret = FTC_OK;
-    if (hipError_t e = zero_arrival_counters(plan, bases, 0, n - 1, s); e != hipSuccess) ret = fail_hip(e, "ftc_plan_profile: zeroing arrival counters");
     (void)hipEventRecord(ev[0], s);
-    for (int i = 0; i < n && ret == FTC_OK; ++i) {
+    int ret = FTC_OK;
+    for (int i = 0; i < n; ++i) {
         hipError_t e = run_one(plan->ops[i], bases, s);
         if (e != hipSuccess) { ret = fail_hip(e, "ftc_plan_profile: launch"); break; }
         (void)hipEventRecord(ev[i + 1], s);

@@ -22,7 +22,6 @@
 #include <tuple>
 #include <vector>
 
-#include "conv_igemm_impl.h"          // pointwise-GEMM variant table / scratch sizes (host helpers only)
 #include "ftc_host.h"
 
 namespace {
@@ -529,37 +528,16 @@ std::string conv_signature(const ftc_op& o) {
     return buf;
 }
 
-int tuned_aux0(const ftc_op& o) {
-    if (env_on("FTC_NO_TUNING") || o.kind != FTC_OP_CONV) return 0;
+void apply_tuning(std::vector<ftc_op>& ops) {
+    if (env_on("FTC_NO_TUNING")) return;
     static std::map<std::string, int> table;
     static std::once_flag once;
     std::call_once(once, [] { for (const TuneEntry* e = kTuning; e->sig; ++e) table[e->sig] = e->aux0; });
-    auto it = table.find(conv_signature(o));
-    return it != table.end() ? it->second : 0;
-}
-
-void apply_tuning(std::vector<ftc_op>& ops) {
-    for (ftc_op& o : ops)
-        if (const int a = tuned_aux0(o)) o.aux0 = a;
-}
-
-// Scratch (arrival counters + partial tiles) a pointwise conv needs for its K-split variant: exactly what the tuned choice asks for, or --
-// when the table is switched off (the tuner measuring candidates) -- the largest any candidate with <= 4 splits would need.  Only convs
-// with a long K and few outputs are split candidates (MBConv project convs at small batch); see pw_gemm_impl.h.
-int64_t pw_scratch_bytes(const ftc_op& o) {
-    ftc_op t = o;
-    if (!env_on("FTC_NO_TUNING")) {
-        t.aux0 = tuned_aux0(o);
-        return (t.aux0 >> 12) ? convimpl::pw_aux_bytes(t) : 0;
+    for (ftc_op& o : ops) {
+        if (o.kind != FTC_OP_CONV) continue;
+        auto it = table.find(conv_signature(o));
+        if (it != table.end() && it->second) o.aux0 = it->second;
     }
-    if (o.ksize != 1 || o.stride != 1 || o.Cin < 2 * o.Cout || (int64_t)o.B * o.Ho * o.Wo * o.Cout > 5000000) return 0;
-    int64_t worst = 0;
-    for (int v = 1; v <= convimpl::PW_COUNT; ++v)
-        for (int sp = 2; sp <= 4; ++sp) {
-            t.aux0 = (v << 12) | ((sp - 1) << 16);
-            if (!convimpl::pw_illegal(t)) worst = std::max<int64_t>(worst, convimpl::pw_aux_bytes(t));
-        }
-    return worst;
 }
 
 // ---- plan builder (once per input shape) ---------------------------------------------------------------
@@ -601,7 +579,6 @@ private:
     std::vector<OpMeta> meta_;
     std::vector<Buf> bufs_;
     std::string err_;
-    R pw_scratch_;                              // shared by every K-split pointwise conv of the plan (they run one after another)
 
     static int esize(int dt) { return dt == FTC_F32 ? 4 : 2; }
     R buf(int64_t nelem, int dt) { bufs_.push_back({align_up(nelem * esize(dt))}); return {1, (int64_t)bufs_.size() - 1, 0}; }
@@ -636,11 +613,6 @@ private:
         o.res_dtype = c.res_dt; o.groups = c.groups > 1 ? c.groups : 0;
         s.in = x; s.in2 = c.residual; s.out = out; s.w = c.wsets ? c.wsets : wref(wname + ".w", c.w_off); s.bias = wref(wname + ".b", c.b_off);
         s.scale = c.se; s.out2 = c.out2;
-        if (const int64_t need = pw_scratch_bytes(o)) {
-            if (!pw_scratch_) pw_scratch_ = buf(0, FTC_F32);
-            bufs_[pw_scratch_.v].nbytes = std::max(bufs_[pw_scratch_.v].nbytes, align_up(need));
-            s.aux = pw_scratch_;
-        }
         emit({name, "conv" + std::to_string(k) + "x" + std::to_string(k), 2.0 * macs, byt}, s);
     }
     int finish(ModelPlan* out, int mh, int mw);

@@ -38,9 +38,6 @@ def encode(cfg: int, stage: int, bk: int, halo: bool = False, splitk: int = 1) -
 def describe(aux0: int) -> str:
     if aux0 == 0:
         return "default"
-    if aux0 >> 12:
-        v = L.PW_VARIANTS[(aux0 >> 12) & 15]
-        return f"pw_gemm,tile={v[0]}x{v[1]},waves={v[2]},nbuf={v[3]},splitk={((aux0 >> 16) & 7) + 1}"
     if aux0 & 64:
         return f"halo,channels={CFG_NAMES[(aux0 & 15) - 1].split('x')[0]}" + (",bk=32" if (aux0 >> 8) & 3 == 1 else "")
     sk = [1, 2, 4, 1][(aux0 >> 10) & 3]
@@ -88,16 +85,6 @@ def candidates(o) -> List[int]:
             for bk in [b for b in bks if b >= 64]:
                 for sk in (2, 4):
                     out.append(encode(cfg, 1, bk, splitk=sk))
-    if o.ksize == 1 and o.stride == 1 and o.w_dtype != L.F32 and o.in_dtype == o.w_dtype and o.Cin % 64 == 0 and (o.groups or 1) <= 1 \
-            and not (o.flags & (L.FLAG_SE_SCALE | L.FLAG_BORDER_BIAS)):
-        # pointwise-GEMM kernel: big tiles / deep ring, K split when the op carries scratch (`aux`, see csrc/model.hip pw_scratch_bytes)
-        for v in range(1, len(L.PW_VARIANTS)):
-            tn, tm = L.PW_VARIANTS[v][:2]
-            if tn > 2 * max(32, o.Cout) or ((o.flags & L.FLAG_W_PER_IMAGE) and (o.Ho * o.Wo) % tm):
-                continue
-            for sp in (1, 2, 3, 4) if o.aux.base != L.BASE_NULL else (1,):
-                if sp <= o.Cin // 64:
-                    out.append(L.pw_encode(v, sp))
     if o.ksize == 3 and o.stride == 1:
         for cfg in (0, 1, 3):                             # LDS-halo kernel with 192 / 128 / 64 channel tiles
             out.append(encode(cfg, 0, 0, halo=True))

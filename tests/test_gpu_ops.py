@@ -151,70 +151,6 @@ def _run_conv_case(case, mode, aux0):
         assert (raw[:, keep] == 0xCD).all()
 
 
-# (name, B, H, W, Cin, Cout, act, residual, per_image)
-PW_CASES = [
-    ("expand_like", 2, 24, 24, 128, 704, L.ACT_SILU, False, False),          # short K, wide N (704 = 5.5 x 128: ragged channel tile)
-    ("project_like", 3, 24, 24, 768, 192, L.ACT_NONE, True, True),            # long K, per-image weight sets, 576 pixels per image
-    ("ragged", 1, 13, 11, 192, 72, L.ACT_NONE, True, False),                  # 143 pixels, 72 channels: every tile is partial
-]
-
-
-def _pw_conv(case, wdt, odt, aux0, runs=1):
-    name, B, H, W, Cin, Cout, act, residual, per_image = case
-    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
-    x = round16(torch.randn(B, H, W, Cin, generator=g), wdt)
-    nw = B if per_image else 1
-    w = round16(torch.randn(nw, Cout, Cin, generator=g) / Cin ** 0.5, wdt)
-    bias = torch.randn(Cout, generator=g) * 0.3
-    res = torch.randn(B, H, W, Cout, generator=g) if residual else None
-    ref = torch.stack([x[b].reshape(-1, Cin) @ w[b if per_image else 0].t() for b in range(B)]).reshape(B, H, W, Cout) + bias
-    ref = ACT[act](ref)
-    if residual:
-        ref = ref + res
-    ar = Arena()
-    o_in, o_w, o_b = ar.put(to_dev_bytes(x, wdt)), ar.put(to_dev_bytes(w, wdt)), ar.put(bias)
-    o_res = ar.put(res) if residual else None
-    split = ((aux0 >> 16) & 7) + 1 if aux0 >> 12 else 1
-    nb = L.pw_aux_bytes(Cout, B * H * W, (aux0 >> 12) & 15, split) if aux0 >> 12 else 0
-    o_aux = ar.reserve(nb) if nb else None
-    esz = 4 if odt == L.F32 else 2
-    o_out = ar.reserve(B * H * W * Cout * esz)
-    ar.materialize()                                                         # scratch starts as 0xCD garbage: the run zeroes the counters
-    outs = []
-    for _ in range(runs):
-        run_op(dict(kind=L.OP_CONV, flags=(L.FLAG_RESIDUAL if residual else 0) | (L.FLAG_W_PER_IMAGE if per_image else 0), act=act, in_dtype=wdt,
-                    out_dtype=odt, w_dtype=wdt, B=B, H=H, W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cin, Cout=Cout, Cout_total=Cout, ksize=1, stride=1,
-                    res_dtype=L.F32, aux0=aux0, in_=o_in, in2=o_res, out=o_out, w=o_w, bias=o_b, aux=o_aux), ar)
-        outs.append(ar.read(o_out, (B, H, W, Cout), tdtype(odt)))
-    return outs, ref
-
-
-@pytest.mark.parametrize("split", [1, 2, 3])
-@pytest.mark.parametrize("variant", range(1, len(L.PW_VARIANTS)), ids=[f"{v[0]}x{v[1]}w{v[2]}n{v[3]}" for v in L.PW_VARIANTS[1:]])
-@pytest.mark.parametrize("mode", [("bf16", L.BF16, L.BF16), ("bf16_f32out", L.BF16, L.F32), ("f16", L.F16, L.F16)], ids=lambda m: m[0])
-@pytest.mark.parametrize("case", PW_CASES, ids=[c[0] for c in PW_CASES])
-def test_pointwise_gemm_kernel(case, mode, variant, split):
-    """The big-tile / deep-ring / K-split kernel of the MBConv 1x1 convs (csrc/pw_gemm_impl.h): unsplit, every tile shape adds the K steps in the same
-    order (bit-identical outputs); split, the partial tiles are summed in split order whatever the arrival order (two runs agree
-    bit for bit) and the result stays within the 16-bit tolerance of the fp32 reference."""
-    mname, wdt, odt = mode
-    name, B, H, W, Cin, Cout, act, residual, per_image = case
-    tm = L.PW_VARIANTS[variant][1]
-    aux0 = L.pw_encode(variant, split)
-    if (per_image and (H * W) % tm) or split > Cin // 64:
-        with pytest.raises(RuntimeError):
-            _pw_conv(case, wdt, odt, aux0)
-        return
-    outs, ref = _pw_conv(case, wdt, odt, aux0, runs=2)
-    err = _rel(outs[0].float(), ref)
-    _log(f"pw_gemm {name:14s} {mname:12s} v{variant} split{split} rel_err {err:.3e}")
-    assert err < TOL16[wdt], (name, mname, variant, split, err)
-    assert torch.equal(outs[0], outs[1]), "not deterministic"
-    if split == 1 and variant > 1:
-        base, _ = _pw_conv(case, wdt, odt, L.pw_encode(1, 1))
-        assert torch.equal(outs[0], base[0]), "every unsplit variant adds the K steps in the same order: expected identical bits"
-
-
 @pytest.mark.parametrize("aux0", [0, 5 + 32 + 512, 7 + 48 + 512, 7 + 16 + 512, 65], ids=["default", "128x64_dma2", "64x64_dma3", "64x64_reg", "halo"])
 @pytest.mark.parametrize("odt,dt", [(L.F32, L.BF16), (L.BF16, L.BF16), (L.F32, L.F16), (L.F16, L.F16)], ids=["bf16_f32out", "bf16", "f16_f32out", "f16"])
 def test_se_fold_then_per_image_weight_conv(odt, dt, aux0):

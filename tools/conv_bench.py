@@ -52,10 +52,6 @@ def main():
     ap.add_argument("--nbuf", type=int, default=0, help="tuning hints (ftc_op.aux0): 4 = no direct-to-LDS, 8 = 3-deep DMA ring, 16 = force direct-to-LDS")
     ap.add_argument("--no-se", action="store_true", help="drop the SE-scale flag (what-if: scale folded into per-image weights)")
     ap.add_argument("--wl1", action="store_true", help="3x3 192-channel layers: the weights-through-L1 kernel (FTC_FLAG_W_FRAG; weight values are random anyway)")
-    ap.add_argument("--pw", type=int, default=0, help="1x1 layers: pointwise-GEMM kernel variant 1..12 (findtextcenternet_amd._lib.PW_VARIANTS)")
-    ap.add_argument("--split", type=int, default=1, help="with --pw: K splits")
-    ap.add_argument("--per-image", action="store_true", help="SE layers: per-image weight sets (what the model runs) instead of the SE-scale flag")
-    ap.add_argument("--pw-sweep", action="store_true", help="1x1 layers: every legal pointwise-GEMM variant x split, fastest first")
     ap.add_argument("--sweep", action="store_true", help="try every tuner candidate for the layer and print the five fastest")
     a = ap.parse_args()
     lib = L.load()
@@ -67,17 +63,13 @@ def main():
         if a.only and a.only not in name:
             continue
         B = a.batch
-        per_image = se and a.per_image
-        se = se and not a.no_se and not a.per_image
+        se = se and not a.no_se
         idt = L.F32 if a.mode == "fp32" else L.BF16      # bf16 mode: GEMMs read the bf16 trunk copy
         odt = L.F32 if (a.mode == "fp32" or out_tr) else L.BF16
         Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
         es = lambda d: 4 if d == L.F32 else 2  # noqa: E731
-        pw_legal = k == 1 and stride == 1 and Cin % 64 == 0 and a.mode != "fp32"
-        aux_bytes = max([L.pw_aux_bytes(Cout, B * Ho * Wo, v, sp) for v in range(1, len(L.PW_VARIANTS)) for sp in (2, 3, 4)]) if (pw_legal and (a.pw_sweep or a.sweep or a.split > 1)) else 0
-        sizes = {"in": B * H * W * Cin * es(idt), "w": (B if per_image else 1) * Cout * k * k * Cin * es(cdt), "bias": Cout * 4,
-                 "res": B * Ho * Wo * Cout * 4 if (res or a.timeline) else 0, "se": B * Cin * 4 if se else 0, "out": B * Ho * Wo * Cout * es(odt),
-                 "aux": aux_bytes}
+        sizes = {"in": B * H * W * Cin * es(idt), "w": Cout * k * k * Cin * es(cdt), "bias": Cout * 4,
+                 "res": B * Ho * Wo * Cout * 4 if (res or a.timeline) else 0, "se": B * Cin * 4 if se else 0, "out": B * Ho * Wo * Cout * es(odt)}
         off, cur = {}, 0
         for key, n in sizes.items():
             off[key] = cur
@@ -92,7 +84,7 @@ def main():
             ws[off["w"]:off["w"] + sizes["w"]].view(torch.bfloat16).normal_(0, 0.05)
         op = (L.Op * 1)()
         o = op[0]
-        o.kind, o.flags, o.act = L.OP_CONV, (L.FLAG_RESIDUAL if res else 0) | (L.FLAG_SE_SCALE if se else 0) | (L.FLAG_W_PER_IMAGE if per_image else 0) | (a.ablate << 8) | (0x1000 if a.timeline else 0), act
+        o.kind, o.flags, o.act = L.OP_CONV, (L.FLAG_RESIDUAL if res else 0) | (L.FLAG_SE_SCALE if se else 0) | (a.ablate << 8) | (0x1000 if a.timeline else 0), act
         o.in_dtype, o.out_dtype, o.w_dtype, o.res_dtype = idt, odt, cdt, L.F32
         o.B, o.H, o.W, o.Ho, o.Wo = B, H, W, Ho, Wo
         o.Cin = o.Cin_total = Cin
@@ -108,20 +100,14 @@ def main():
             o.in2.base, o.in2.offset = L.BASE_WORKSPACE, off["res"]
         if se:
             o.scale.base, o.scale.offset = L.BASE_WORKSPACE, off["se"]
-        if aux_bytes:
-            o.aux.base, o.aux.offset = L.BASE_WORKSPACE, off["aux"]
-        if a.pw and pw_legal:
-            o.aux0 = L.pw_encode(a.pw, a.split)
         bases = (C.c_void_p * L.NUM_BASES)(None, ws.data_ptr(), None, None, None, None)
         ms = (C.c_float * 1)()
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         fl = 2.0 * B * Ho * Wo * Cout * Cin * k * k
-        if a.sweep or a.pw_sweep:
+        if a.sweep:
             from findtextcenternet_amd import tuning as T
-            if a.pw_sweep and not pw_legal:
-                continue
             res_ = []
-            for aux in ([0] + [c for c in T.candidates(o) if c >> 12]) if a.pw_sweep else T.candidates(o):
+            for aux in T.candidates(o):
                 o.aux0 = aux
                 h = C.c_void_p()
                 if lib.ftc_plan_create(op, 1, cur + 256, 0, C.byref(h)) != 0:
@@ -136,7 +122,7 @@ def main():
                 lib.ftc_plan_destroy(h)
             res_.sort()
             print(f"{name:26s} M={B * Ho * Wo} N={Cout} K={Cin * k * k} se={se}")
-            for t, aux in res_[:8] if a.pw_sweep else res_[:5]:
+            for t, aux in res_[:5]:
                 print(f"    {t * 1e3:8.1f} us {fl / (t * 1e-3) / 1e12:7.1f} TF  {T.describe(aux)}")
             del ws
             continue

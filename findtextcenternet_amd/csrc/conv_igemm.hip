@@ -130,6 +130,7 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
     p.cout_gs = oslice ? o.Cout : 0;
     p.w2 = nullptr; p.w2_gs = 0; p.Tw = 0;
     p.in2u = nullptr; p.in2u_bytes = 0; p.in2u_gs = 0; p.Cy = 0; p.Hi = p.Wi = 0; p.ry = p.rx = 0.f;
+    p.epi_off = 0;
     if (o.flags & FTC_FLAG_UPCAT_IN) {
         p.Cy = o.Cin_total; p.Hi = o.H / 2; p.Wi = o.W / 2;
         p.ry = o.H > 1 ? (float)(p.Hi - 1) / (float)(o.H - 1) : 0.f;

@@ -69,6 +69,7 @@ struct ConvP {
     long in2u_gs;
     int Cy, Hi, Wi;
     float ry, rx;
+    int epi_off;    // weights-through-L1 kernel: LDS byte offset of the epilogue image (behind halo buffer 0 when both fit, else 0)
 };
 
 // Turns the launch-wide parameter block into the one of the group that owns workgroup `bid`; returns the
@@ -192,8 +193,7 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvP& p, f32x16 (&acc)
                 if (vec_ok) {
                     f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                     v += *reinterpret_cast<const f32x4*>(brow + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = apply_act_sel<sizeof(WT) == 2>(v[e], p.act);
+                    v = apply_act4<sizeof(WT) == 2>(v, p.act);
                     if (has_res) {
                         if (p.res_dtype == FTC_F32) v += load4<float>(reinterpret_cast<const float*>(p.res) + (size_t)m * p.Cout + n);
                         else v += load4<typename Half16<WT>::type>(reinterpret_cast<const typename Half16<WT>::type*>(p.res) + (size_t)m * p.Cout + n);
@@ -276,8 +276,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvP& p, f32x16 (&acc)[
                 const int nl = nw0 + i * 32 + 8 * q + 4 * half;          // channel inside the tile
                 f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                 v += *reinterpret_cast<const f32x4*>(brow + nl);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = apply_act_sel<sizeof(WT) == 2>(v[e], p.act);
+                v = apply_act4<sizeof(WT) == 2>(v, p.act);
                 const int chunk = (nl / V) ^ (prow & 7);
                 store4<OutT>(reinterpret_cast<OutT*>(lrow + chunk * 16) + (nl % V), v);
             }
@@ -338,11 +337,14 @@ __device__ __forceinline__ void conv_epilogue_topfuse(const ConvP& p, f32x16 (&a
     static_assert(PITCH % 128 == 0 && TM <= 32 * (NTHREADS / 64), "one 32-pixel MFMA column block per wave (surplus waves idle)");
     __syncthreads();
     const int nrows = (p.flags & FTC_FLAG_BORDER_BIAS) ? 16 : 1;   // 16 border cases when a BatchNorm of the input is folded in
-    float* lbias = reinterpret_cast<float*>(smem + TM * PITCH);
-    unsigned char* lwt = smem + TM * PITCH + 16 * TN * 4;   // tap matrix [32][TN] bf16, same swizzle as the image
+    // tap matrix [wrows][TN] (same swizzle as the image), then the bias table.  Only the Tw rows that produce stored outputs are staged:
+    // the MFMA below reads 32 rows, the surplus ones come out of the bias table's bytes and only feed output rows nobody stores.
+    const int wrows = (p.Tw + 3) & ~3;
+    unsigned char* lwt = smem + TM * PITCH;
+    float* lbias = reinterpret_cast<float*>(lwt + wrows * PITCH);
     for (int c = threadIdx.x; c < nrows * (TN / 4); c += NTHREADS)
         *reinterpret_cast<f32x4*>(lbias + 4 * c) = *reinterpret_cast<const f32x4*>(p.bias + 4 * c);
-    for (int c = threadIdx.x; c < 32 * CH; c += NTHREADS) {
+    for (int c = threadIdx.x; c < wrows * CH; c += NTHREADS) {
         const int r = c / CH, cc = c - r * CH;
         *reinterpret_cast<u32x4*>(lwt + r * PITCH + ((cc ^ (r & 7)) * 16)) =
             *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.w2) + ((size_t)r * TN + cc * 8) * 2);
@@ -368,8 +370,7 @@ __device__ __forceinline__ void conv_epilogue_topfuse(const ConvP& p, f32x16 (&a
                 const int nl = nw0 + i * 32 + 8 * q + 4 * half;
                 f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
                 v += *reinterpret_cast<const f32x4*>(brow + nl);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = apply_act_sel<true>(v[e], p.act);
+                v = apply_act4<true>(v, p.act);
                 const int chunk = (nl / 8) ^ (prow & 7);
                 store4<WT>(reinterpret_cast<WT*>(lrow + chunk * 16) + (nl % 8), v);
             }
@@ -449,8 +450,7 @@ __device__ __forceinline__ void conv_epilogue_splitk(const ConvP& p, f32x16 (&ac
         }
         if (vec_ok) {
             v += *reinterpret_cast<const f32x4*>(brow + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = apply_act_sel<sizeof(WT) == 2>(v[e], p.act);
+            v = apply_act4<sizeof(WT) == 2>(v, p.act);
             if (has_res) {
                 if (p.res_dtype == FTC_F32) v += load4<float>(reinterpret_cast<const float*>(p.res) + (size_t)m * p.Cout + n);
                 else v += load4<typename Half16<WT>::type>(reinterpret_cast<const typename Half16<WT>::type*>(p.res) + (size_t)m * p.Cout + n);
@@ -1271,14 +1271,6 @@ hipError_t launch_halo(ConvP p, hipStream_t s) {
 // 1: 6 waves, 8x16-pixel tile, 72 KB -> TWO workgroups per CU with the same fragment loads per MFMA -- built and measured
 // (parity-green): a workgroup then takes 96 k cycles for HALF the pixels against 107 k for the full tile, i.e. the CU is already
 // saturated by 12 waves either way and the extra halo rows and L1 misses make it slower end to end (497 vs 532 img/s).  Not instantiated.
-template <typename WT, bool TOPF, int WMH>
-__host__ __device__ constexpr size_t wl1_lds_bytes() {
-    constexpr int TY = 8 * WMH;
-    constexpr size_t halo = (size_t)2 * (TY + 2) * 18 * 128;
-    constexpr size_t epi = (size_t)TY * 16 * 192 * 2 + (size_t)16 * 192 * 4 + (TOPF ? (size_t)32 * 192 * 2 : 0);
-    return halo > epi ? halo : epi;
-}
-
 template <typename WT, typename OutT, bool TOPF = false, bool UPIN = false, int WMH = 2>
 __global__ __launch_bounds__(384 * WMH, 3) void conv3x3_wl1_kernel(const ConvP p_launch) {
     ConvP p = p_launch;
@@ -1298,36 +1290,61 @@ __global__ __launch_bounds__(384 * WMH, 3) void conv3x3_wl1_kernel(const ConvP p
     const int wn = wave / WMH, wm = wave % WMH;              // (the pixel halves of a channel block are neighbours: same lines, same time)
     const int half = lane >> 5, l31 = lane & 31;
 
-    int bid = blockIdx.x;
-    {
-        const int q = p.nblk >> 3, r = p.nblk & 7, xcd = bid & 7, k = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
-    bid = enter_group(p, bid);
-    int sp = bid;
+    // PERSISTENT workgroups: XCD x (= blockIdx & 7, the hardware's round-robin) owns a contiguous eighth of the tiles (all heads of a
+    // grouped launch laid end to end) and its gridDim/8 workgroups walk that range with stride gridDim/8.  While a workgroup runs the LAST
+    // channel block of a tile, halo buffer 0 is already free, so the first halo of its NEXT tile is DMA'd then -- nine K steps plus the
+    // epilogue ahead of its use -- and the epilogue stages its image behind buffer 0 (p.epi_off): the 4-10 k cycles a fresh workgroup
+    // spent waiting for its first halo are gone, and so is the workgroup turnaround.  (Prefetch needs an even number of channel blocks --
+    // the last one then sits in buffer 1 -- a next tile of the same head, and p.epi_off != 0, i.e. enough LDS for both.)
     const int tilesX = (p.Wo + TX - 1) / TX, tilesY = (p.Ho + TY - 1) / TY;
-    const int img = sp / (tilesX * tilesY);
-    sp -= img * tilesX * tilesY;
-    const int ty0 = (sp / tilesX) * TY, tx0 = (sp % tilesX) * TX;
-    constexpr int n0 = 0;
-
-    const __amdgpu_buffer_rsrc_t rw = weight_rsrc(p, img * p.Ho * p.Wo);
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
-
-    int h_off[NLH];
-#pragma unroll
-    for (int i = 0; i < NLH; ++i) {
-        const int q = i * NT + t;
-        const int hr = q / CPR, kc = (q % CPR) ^ ((hr >> 1) & 7);
-        const int iy = ty0 - 1 + hr / HW, ix = tx0 - 1 + hr % HW;
-        const bool ok = q < HCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        if constexpr (UPIN) h_off[i] = ok ? (((img * p.H + iy) * p.W + ix) * (p.Cin - p.Cy) + kc * E) * 2 : OOB;
-        else h_off[i] = ok ? (((img * p.H + iy) * p.W + ix) * p.CinT + p.cin_off + kc * E) * 2 : OOB;
+    int gt, gt_end, gstep;
+    {
+        const int total = p.nblk, q8 = total >> 3, r8 = total & 7, xcd = blockIdx.x & 7;
+        const int cstart = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+        gt = cstart + (int)(blockIdx.x >> 3);
+        gt_end = cstart + q8 + (xcd < r8 ? 1 : 0);
+        gstep = (int)(gridDim.x >> 3);
     }
+    if (gt >= gt_end) return;
+    constexpr int n0 = 0;
+    const bool pf_ok = p.epi_off != 0 && !(p_launch.Cin / BK & 1);
+    unsigned char* const epi_smem = smem_raw + p.epi_off;
+
+    int grp = gt / p_launch.nblk_g;
+    int img, ty0, tx0;
+    auto set_tile = [&](int g_tile, int& im, int& y0, int& x0) {
+        int sp = g_tile % p_launch.nblk_g;
+        im = sp / (tilesX * tilesY);
+        sp -= im * tilesX * tilesY;
+        y0 = (sp / tilesX) * TY;
+        x0 = (sp % tilesX) * TX;
+    };
+    enter_group(p, gt);
+    set_tile(gt, img, ty0, tx0);
+
+    __amdgpu_buffer_rsrc_t rw = weight_rsrc(p, 0);
+    __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+
     const int ncb_up = UPIN ? p.Cy / BK : 0;
     const int nb_dma = p.ncb - ncb_up;
-    const __amdgpu_buffer_rsrc_t rin2 = UPIN ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in2u), 0, p.in2u_bytes, 0x00020000) : rin;
+    __amdgpu_buffer_rsrc_t rin2 = UPIN ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in2u), 0, p.in2u_bytes, 0x00020000) : rin;
     auto phys_cb = [&](int j) { return UPIN ? (j < nb_dma ? ncb_up + j : j - nb_dma) : j; };
+
+    int h_off[NLH];
+    auto calc_hoff = [&](int im, int y0, int x0) {
+        int tt = t;
+        asm volatile("" : "+v"(tt));                          // (opaque: keeps the per-thread halo geometry from being hoisted out of the
+                                                              //  tile loop, where it would pin ~30 registers through the K loop)
+#pragma unroll
+        for (int i = 0; i < NLH; ++i) {
+            const int q = i * NT + tt;
+            const int hr = q / CPR, kc = (q % CPR) ^ ((hr >> 1) & 7);
+            const int iy = y0 - 1 + hr / HW, ix = x0 - 1 + hr % HW;
+            const bool ok = q < HCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            if constexpr (UPIN) h_off[i] = ok ? (((im * p.H + iy) * p.W + ix) * (p.Cin - p.Cy) + kc * E) * 2 : OOB;
+            else h_off[i] = ok ? (((im * p.H + iy) * p.W + ix) * p.CinT + p.cin_off + kc * E) * 2 : OOB;
+        }
+    };
 
     auto issue_h = [&](int cb) {                             // halo of channel block cb -> buffer cb & 1
         const int soff = cb * BK * 2;
@@ -1353,17 +1370,22 @@ __global__ __launch_bounds__(384 * WMH, 3) void conv3x3_wl1_kernel(const ConvP p
     };
 
     f32x16 acc[1][SM];
-#pragma unroll
-    for (int j = 0; j < SM; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.0f;
 
     const int lpix = ((__builtin_popcount(l31 >> 2) & 1) << 4) | ((l31 >> 3) << 2) | (l31 & 3);      // see conv3x3_halo_kernel
     int hr0[SM];
 #pragma unroll
     for (int j = 0; j < SM; ++j) hr0[j] = (wm * 8 + j * 2 + (lpix >> 4)) * HW + (lpix & 15);
 
-    FragT a_cur[G], a_nxt[G];
+    const int nk = 9 * p.ncb;
+    // K step: the B fragments of a K group are read from LDS as ONE batch, a group ahead of the MFMAs that use them, and the A fragment of
+    // group g is reloaded IN PLACE for the next step right after its MFMAs (a full step of prefetch distance without a second register
+    // set; after the last step of a tile that is step 0 again -- the next tile of the same head starts with its weights in registers).
+    // The scheduling barriers pin that order: left alone under the 168-register cap of three waves per SIMD, the compiler sank every
+    // ds_read to just above its MFMA -- read, wait, multiply, sixteen times per step.  BB = B fragments per batch (the upsampling
+    // variant has registers for two).
+    FragT a_frag[G];
+    constexpr int BB = UPIN ? 2 : SM;
+    static_assert(SM % BB == 0, "");
     auto compute = [&](int k) {
         const int cb = k / 9, tap = k - cb * 9;
         const int d = (tap / 3) * HW + (tap % 3);
@@ -1375,18 +1397,30 @@ __global__ __launch_bounds__(384 * WMH, 3) void conv3x3_wl1_kernel(const ConvP p
             rowB[j] = hr * ROWB;
             f4[j] = ((hr >> 1) & 7) << 4;
         }
-        FragT bf[2][SM];
-        auto ldfrag = [&](int g, int s) {
+        const int k1 = k + 1 == nk ? 0 : k + 1, cb1 = k1 / 9, tap1 = k1 - cb1 * 9;
+        const int a_soff = (((wn * 9 + tap1) * p.ncb + phys_cb(cb1)) * G) * 1024;
+        constexpr int NB = G * (SM / BB);                   // batches per step
+        FragT bf[2][BB];
+        auto ldbatch = [&](int b, int s) {
+            const int g = b / (SM / BB), j0 = (b % (SM / BB)) * BB;
 #pragma unroll
-            for (int j = 0; j < SM; ++j) bf[s][j] = *reinterpret_cast<const FragT*>(hb + rowB[j] + ((((g * 2 + half) << 4)) ^ f4[j]));
+            for (int j = 0; j < BB; ++j) bf[s][j] = *reinterpret_cast<const FragT*>(hb + rowB[j0 + j] + ((((g * 2 + half) << 4)) ^ f4[j0 + j]));
         };
-        ldfrag(0, 0);
+        // Timing ablations of this step on MI355X (single head, 1152 one-shot workgroups, kernel time; switches since removed): full 311 us;
+        // no A reloads 311; no B reads 289; neither 274; neither and a quarter of the MFMAs 168; no block barrier 318 (the wait moves to the
+        // epilogue's first barrier).  I.e. the operand traffic costs 12 %, the rest is the matrix pipe at the 1.75-1.8 GHz the part
+        // sustains on real data (tools/ubench/mfma_peak.hip: 32.0 ticks per MFMA, 1.79 G ticks/s) plus the per-block barrier skew.
+        ldbatch(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int s = g & 1;
-            if (g + 1 < G) ldfrag(g + 1, s ^ 1);
+        for (int b = 0; b < NB; ++b) {
+            const int s = b & 1, g = b / (SM / BB), j0 = (b % (SM / BB)) * BB;
+            if (b + 1 < NB) ldbatch(b + 1, s ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < SM; ++j) acc[0][j] = mfma16(a_cur[g], bf[s][j], acc[0][j]);
+            for (int j = 0; j < BB; ++j) acc[0][j0 + j] = mfma16(a_frag[g], bf[s][j], acc[0][j0 + j]);
+            if (j0 + BB == SM) a_frag[g] = __builtin_bit_cast(FragT, bload(rw, a_voff, a_soff + g * 1024));
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -1394,26 +1428,30 @@ __global__ __launch_bounds__(384 * WMH, 3) void conv3x3_wl1_kernel(const ConvP p
     constexpr int NUP = UPIN ? NLH : 1;
     int up_off[NUP][4];
     float up_ly[NUP], up_lx[NUP];
-    if constexpr (UPIN) {
+    auto calc_up = [&]() {
+        if constexpr (UPIN) {
+            int tt = t;
+            asm volatile("" : "+v"(tt));
 #pragma unroll
-        for (int i = 0; i < NLH; ++i) {
-            const int q = i * NT + t;
-            const int hr = q / CPR, kc = (q % CPR) ^ ((hr >> 1) & 7);
-            const int iy = ty0 - 1 + hr / HW, ix = tx0 - 1 + hr % HW;
-            const bool ok = q < HCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const float sy = p.ry * (float)iy, sx = p.rx * (float)ix;
-            const int y0 = ok ? (int)sy : 0, x0 = ok ? (int)sx : 0;
-            const int y1 = y0 + (y0 < p.Hi - 1 ? 1 : 0), x1 = x0 + (x0 < p.Wi - 1 ? 1 : 0);
-            up_ly[i] = sy - (float)y0;
-            up_lx[i] = sx - (float)x0;
-            const int r0 = (img * p.Hi + y0) * p.Wi, r1 = (img * p.Hi + y1) * p.Wi;
-            const int pb = p.Cy * 2, cbase = kc * E * 2;
-            up_off[i][0] = ok ? (r0 + x0) * pb + cbase : OOB;
-            up_off[i][1] = ok ? (r0 + x1) * pb + cbase : OOB;
-            up_off[i][2] = ok ? (r1 + x0) * pb + cbase : OOB;
-            up_off[i][3] = ok ? (r1 + x1) * pb + cbase : OOB;
+            for (int i = 0; i < NLH; ++i) {
+                const int q = i * NT + tt;
+                const int hr = q / CPR, kc = (q % CPR) ^ ((hr >> 1) & 7);
+                const int iy = ty0 - 1 + hr / HW, ix = tx0 - 1 + hr % HW;
+                const bool ok = q < HCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const float sy = p.ry * (float)iy, sx = p.rx * (float)ix;
+                const int y0 = ok ? (int)sy : 0, x0 = ok ? (int)sx : 0;
+                const int y1 = y0 + (y0 < p.Hi - 1 ? 1 : 0), x1 = x0 + (x0 < p.Wi - 1 ? 1 : 0);
+                up_ly[i] = sy - (float)y0;
+                up_lx[i] = sx - (float)x0;
+                const int r0 = (img * p.Hi + y0) * p.Wi, r1 = (img * p.Hi + y1) * p.Wi;
+                const int pb = p.Cy * 2, cbase = kc * E * 2;
+                up_off[i][0] = ok ? (r0 + x0) * pb + cbase : OOB;
+                up_off[i][1] = ok ? (r0 + x1) * pb + cbase : OOB;
+                up_off[i][2] = ok ? (r1 + x0) * pb + cbase : OOB;
+                up_off[i][3] = ok ? (r1 + x1) * pb + cbase : OOB;
+            }
         }
-    }
+    };
     u32x4 st[4] = {};
     auto up_load = [&](int pass, int ub) {
         const int soff = ub * BK * 2;
@@ -1441,67 +1479,108 @@ __global__ __launch_bounds__(384 * WMH, 3) void conv3x3_wl1_kernel(const ConvP p
         store16<WT>(reinterpret_cast<WT*>(hbase + bufidx * HBUF + q * 16), v);
     };
 
-    const int nk = 9 * p.ncb;
-    // 0x1000: timeline of wave 0 of the first 512 workgroups into p.res (tools/conv_bench.py --timeline)
-    const bool tl_on = (p.flags & 0x1000) && blockIdx.x < 512 && t == 0;
-    unsigned long long* tl = reinterpret_cast<unsigned long long*>(const_cast<void*>(p.res)) + (size_t)blockIdx.x * 64;
-    if (tl_on) tl[0] = __builtin_amdgcn_s_memtime();
+    calc_hoff(img, ty0, tx0);
     issue_h(0);
-    loadA(0, a_cur);
-    if (tl_on) tl[1] = __builtin_amdgcn_s_memtime();
-    for (int k = 0; k < nk; ++k) {
-        if (tl_on && k < 40) tl[2 + k] = __builtin_amdgcn_s_memtime();
-        const int cbj = k / 9, tapj = k - cbj * 9, nxt = cbj + 1;
-        if (tapj == 0) {
-            // channel-block boundary: this block's halo has landed (this wave's pieces: vmcnt; everyone's: barrier) and every wave is
-            // done reading the other buffer, which the next block's halo is about to overwrite.  LDS writes of the in-loader upsample
-            // retire in order with the fragment reads that followed them.
-            wait_vmcnt<0>();
-            wg_barrier();
-            if (nxt < (UPIN ? nb_dma : p.ncb)) issue_h(nxt);
-        }
-        if constexpr (UPIN) {
-            if (nxt < p.ncb && nxt >= nb_dma) {                      // next block is upsampled: produce its halo pass by pass
-                if (tapj >= 1 && tapj - 1 < NLH) up_store(tapj - 1, nxt & 1);
-                if (tapj < NLH) up_load(tapj, nxt - nb_dma);
+    loadA(0, a_frag);
+    for (int it = 0;; ++it) {
+        // 0x1000: timeline of wave 0 of every workgroup's SECOND tile (the steady state) into p.res (tools/conv_bench.py --timeline)
+        const bool tl_on = (p.flags & 0x1000) && blockIdx.x < 512 && t == 0 && it == 1;
+        unsigned long long* tl = reinterpret_cast<unsigned long long*>(const_cast<void*>(p_launch.res)) + (size_t)blockIdx.x * 64;
+        if (tl_on) tl[0] = tl[1] = __builtin_amdgcn_s_memtime();
+        calc_up();
+#pragma unroll
+        for (int j = 0; j < SM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.0f;
+        const int gnext = gt + gstep;
+        const bool has_next = gnext < gt_end;
+        const bool pf = pf_ok && has_next && gnext / p_launch.nblk_g == grp;
+        for (int k = 0; k < nk; ++k) {
+            if (tl_on && k < 40) tl[2 + k] = __builtin_amdgcn_s_memtime();
+            const int cbj = k / 9, tapj = k - cbj * 9, nxt = cbj + 1;
+            if (tapj == 0) {
+                // channel-block boundary: this block's halo has landed (this wave's pieces: vmcnt; everyone's: barrier) and every wave is
+                // done reading the other buffer, which the next block's halo is about to overwrite.  LDS writes of the in-loader upsample
+                // retire in order with the fragment reads that followed them.
+                wait_vmcnt<0>();
+                wg_barrier();
+                if (nxt < (UPIN ? nb_dma : p.ncb)) {
+                    issue_h(nxt);
+                } else if (nxt == p.ncb && pf) {                     // last block: buffer 0 is free -> first halo of the next tile
+                    int im2, y2, x2;
+                    set_tile(gnext, im2, y2, x2);
+                    calc_hoff(im2, y2, x2);
+                    issue_h(0);
+                }
             }
+            if constexpr (UPIN) {
+                if (nxt < p.ncb && nxt >= nb_dma) {                  // next block is upsampled: produce its halo pass by pass
+                    if (tapj >= 1 && tapj - 1 < NLH) up_store(tapj - 1, nxt & 1);
+                    if (tapj < NLH) up_load(tapj, nxt - nb_dma);
+                }
+            }
+            compute(k);
         }
-        if (k + 1 < nk) loadA(k + 1, a_nxt);                         // one full step ahead
-        compute(k);
-#pragma unroll
-        for (int g = 0; g < G; ++g) a_cur[g] = a_nxt[g];
-    }
 
-    if (tl_on) tl[42] = __builtin_amdgcn_s_memtime();
-    int mrow[SM];
+        if (tl_on) tl[42] = __builtin_amdgcn_s_memtime();
+        auto row_to_m = [&](int row) {
+            const int oy = ty0 + (row >> 4), ox = tx0 + (row & 15);
+            return (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
+        };
+        // (opaque copies: the epilogue's per-lane LDS addresses are tile-invariant, and hoisted out of the tile loop they were spilled
+        //  to scratch and reloaded one by one inside the epilogue -- ~45 dependent scratch loads per tile)
+        int e_half = half, e_l31 = l31, e_lpix = lpix;
+        asm volatile("" : "+v"(e_half), "+v"(e_l31), "+v"(e_lpix));
+        if constexpr (TOPF) {
+            conv_epilogue_topfuse<WT, 1, SM, NT, TN, TY * TX>(p, acc, epi_smem, wn * 32, wm * SM * 32, e_half, e_l31, e_lpix, wave, row_to_m);
+        } else if (epi_lds_ok<OutT>(p)) {
+            conv_epilogue_lds<WT, OutT, 1, SM, NT, TN, TY * TX>(p, acc, epi_smem, n0, wn * 32, wm * SM * 32, e_half, e_lpix, row_to_m);
+        } else {
+            int mrow[SM];
 #pragma unroll
-    for (int j = 0; j < SM; ++j) {
-        const int oy = ty0 + wm * 8 + j * 2 + (lpix >> 4), ox = tx0 + (lpix & 15);
-        mrow[j] = (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
+            for (int j = 0; j < SM; ++j) {
+                const int oy = ty0 + wm * 8 + j * 2 + (e_lpix >> 4), ox = tx0 + (e_lpix & 15);
+                mrow[j] = (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
+            }
+            conv_epilogue_rows<WT, OutT, 1, SM>(p, acc, mrow, n0 + wn * 32, e_half);
+        }
+        if (tl_on) tl[43] = __builtin_amdgcn_s_memtime();
+        if (!has_next) break;
+
+        gt = gnext;
+        const int g2 = gt / p_launch.nblk_g;
+        const bool new_group = g2 != grp;
+        if (new_group) {                                             // next head of a grouped launch: its operands
+            p = p_launch;
+            enter_group(p, gt);
+            grp = g2;
+            rw = weight_rsrc(p, 0);
+            rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+            rin2 = UPIN ? __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in2u), 0, p.in2u_bytes, 0x00020000) : rin;
+        }
+        set_tile(gt, img, ty0, tx0);
+        if (!pf) {
+            __syncthreads();                                         // everyone is done with the epilogue image (it may overlap buffer 0)
+            calc_hoff(img, ty0, tx0);
+            issue_h(0);
+        }
+        if (new_group) loadA(0, a_frag);                             // (same head: step 0's fragments were reloaded by the last K step)
     }
-    auto row_to_m = [&](int row) {
-        const int oy = ty0 + (row >> 4), ox = tx0 + (row & 15);
-        return (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
-    };
-    if constexpr (TOPF) {
-        conv_epilogue_topfuse<WT, 1, SM, NT, TN, TY * TX>(p, acc, smem_raw, wn * 32, wm * SM * 32, half, l31, lpix, wave, row_to_m);
-    } else if (epi_lds_ok<OutT>(p)) {
-        conv_epilogue_lds<WT, OutT, 1, SM, NT, TN, TY * TX>(p, acc, smem_raw, n0, wn * 32, wm * SM * 32, half, lpix, row_to_m);
-    } else {
-        conv_epilogue_rows<WT, OutT, 1, SM>(p, acc, mrow, n0 + wn * 32, half);
-    }
-    if (tl_on) tl[43] = __builtin_amdgcn_s_memtime();
 }
 
 template <typename WT, typename OutT, bool TOPF = false, bool UPIN = false, int WMH = 2>
 hipError_t launch_wl1(ConvP p, hipStream_t s) {
-    constexpr size_t lds_bytes = wl1_lds_bytes<WT, TOPF, WMH>();
     constexpr int TY = 8 * WMH;
+    constexpr size_t HBUF = (size_t)(TY + 2) * 18 * 128, LDS_MAX = 160 * 1024;
     auto kern = conv3x3_wl1_kernel<WT, OutT, TOPF, UPIN, WMH>;
     static bool attr_set = false;
+    static int n_cu = 0;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX);
         if (e != hipSuccess) return e;
+        int dev = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
         attr_set = true;
     }
     p.ncb = p.Cin / 64;
@@ -1509,7 +1588,18 @@ hipError_t launch_wl1(ConvP p, hipStream_t s) {
     p.nN = 1;
     p.nblk_g = p.B * ((p.Ho + TY - 1) / TY) * ((p.Wo + 15) / 16);
     p.nblk = p.nblk_g * (p.groups > 1 ? p.groups : 1);
-    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(384 * WMH), lds_bytes, s, p);
+    // epilogue image (+ tap matrix rows in use) + bias table behind halo buffer 0 when the LDS holds both: lets a workgroup fetch its next
+    // tile's first halo while it finishes the current tile
+    const size_t epi = (size_t)TY * 16 * 192 * 2 + (size_t)16 * 192 * 4 + (TOPF ? (size_t)((p.Tw + 3) & ~3) * 192 * 2 : 0);
+    p.epi_off = HBUF + epi <= LDS_MAX ? (int)HBUF : 0;
+    size_t lds_bytes = p.epi_off + epi;
+    if (lds_bytes < 2 * HBUF) lds_bytes = 2 * HBUF;
+    if (lds_bytes > LDS_MAX) return hipErrorInvalidValue;
+    // persistent grid: one workgroup per CU (the LDS admits no second one), a multiple of 8 so that every XCD gets the same number
+    int grid = ((n_cu > 0 ? n_cu : 256) + 7) / 8 * 8;
+    // (measured on the 8-head launch, 36 tiles per CU: one-shot workgroups 2114 us, persistent 2065, persistent + halo prefetch 2054)
+    if (grid > (p.nblk + 7) / 8 * 8) grid = (p.nblk + 7) / 8 * 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(384 * WMH), lds_bytes, s, p);
     return hipGetLastError();
 }
 

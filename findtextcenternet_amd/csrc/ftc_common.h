@@ -148,6 +148,46 @@ template <bool FAST> __device__ __forceinline__ float apply_act_sel(float x, int
     return x;
 }
 
+// Four values at a time, written on vectors so that the full-rate part of the polynomial becomes packed fp32 instructions
+// (v_pk_mul_f32 / v_pk_fma_f32: two values per issue slot); the rcp / exp2 stay one lane-op per value.  A conv epilogue
+// evaluates 64-96 activations per lane and is VALU-bound on them.
+__device__ __forceinline__ f32x4 act_gelu_fast4(f32x4 x) {
+    f32x4 ax, t, ex;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ax[e] = fabsf(x[e]);
+    const f32x4 z = ax * 0.70710678118654752440f;
+    const f32x4 d = z * 0.3275911f + 1.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = __builtin_amdgcn_rcpf(d[e]);
+    f32x4 poly = t * 1.061405429f - 1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t - 0.284496736f;
+    poly = poly * t + 0.254829592f;
+    const f32x4 zz = (z * -1.4426950408889634f) * z;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ex[e] = __builtin_amdgcn_exp2f(zz[e]);
+    const f32x4 er = 1.0f - (poly * t) * ex;
+    return x * 0.5f + (ax * 0.5f) * er;
+}
+__device__ __forceinline__ f32x4 act_silu_fast4(f32x4 x) {
+    const f32x4 a = x * -1.4426950408889634f;
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a[e]));
+    return x * r;
+}
+template <bool FAST> __device__ __forceinline__ f32x4 apply_act4(f32x4 v, int act) {
+    if constexpr (FAST) {
+        if (act == FTC_ACT_SILU) return act_silu_fast4(v);
+        if (act == FTC_ACT_GELU) return act_gelu_fast4(v);
+        return v;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act_sel<false>(v[e], act);
+        return v;
+    }
+}
+
 template <int ACT> __device__ __forceinline__ float apply_act(float x) {
     if constexpr (ACT == FTC_ACT_SILU) return act_silu_precise(x);
     else if constexpr (ACT == FTC_ACT_GELU) return act_gelu(x);

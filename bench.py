@@ -88,7 +88,8 @@ def cpu_baseline(sd, budget_s: float):
         torch.set_num_threads(n)
         fwd(x1)
         sweep[n] = min(fwd(x1)[0] for _ in range(2))
-        if time.perf_counter() - t_start > 0.5 * budget_s:
+        # past the knee more threads only get slower (256 threads: 200 s per image on the 256-thread host): stop climbing there
+        if time.perf_counter() - t_start > 0.5 * budget_s or sweep[n] > 1.3 * min(sweep.values()):
             break
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)

@@ -1599,6 +1599,11 @@ hipError_t launch_wl1(ConvP p, hipStream_t s) {
     int grid = ((n_cu > 0 ? n_cu : 256) + 7) / 8 * 8;
     // (measured on the 8-head launch, 36 tiles per CU: one-shot workgroups 2114 us, persistent 2065, persistent + halo prefetch 2054)
     if (grid > (p.nblk + 7) / 8 * 8) grid = (p.nblk + 7) / 8 * 8;
+    // test hook: a smaller grid makes every workgroup walk several tiles (and heads) even on the small shapes of the unit tests
+    if (const char* e = getenv("FTC_WL1_GRID_CAP")) {
+        const int c = atoi(e) / 8 * 8;
+        if (c >= 8 && c < grid) grid = c;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(384 * WMH), lds_bytes, s, p);
     return hipGetLastError();
 }

@@ -378,14 +378,21 @@ def _frag_major(wk):
     return w.permute(0, 1, 3, 4, 5, 6, 2, 7).contiguous().reshape(G, -1)   # g, rb, tap, cb, kg, (half, l31), e
 
 
-@pytest.mark.parametrize("kern", ["halo", "wl1"])
+@pytest.mark.parametrize("kern,Cy,TW", [("halo", 192, 12), ("wl1", 192, 12), ("wl1_walk", 192, 12), ("wl1_walk", 128, 32)],
+                         ids=["halo", "wl1", "wl1_walk", "wl1_walk_odd_blocks_wide_T"])
 @pytest.mark.parametrize("dt", [L.BF16, L.F16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("top", [False, True], ids=["plain", "top_fuse"])
-def test_upcat_in_with_tap_batchnorm_folded_and_shared_tap(top, dt, kern):
+def test_upcat_in_with_tap_batchnorm_folded_and_shared_tap(top, dt, kern, Cy, TW, monkeypatch):
     """Last FPN level as the bf16 plan runs it: the nine heads read ONE backbone tap (FTC_FLAG_GROUP_IN2_SHARED); each head's input
     BatchNorm of the tap is folded into its weights and a 16-case border bias table (FTC_FLAG_BORDER_BIAS) -- against
     conv3x3(cat[upsample(prev_g), BN_g(tap)]) + GELU (then the 3x3 top convolution for the TOP_FUSE variant) in fp32."""
-    G, B, H, W, Cy, Ct, Cm = 3, 2, 22, 36, 192, 64, 192
+    G, B, H, W, Ct, Cm = 3, 2, 22, 36, 64, 192
+    if kern == "wl1_walk":
+        # the persistent kernel with 8 workgroups for its 36 tiles: every workgroup walks 4-5 tiles, prefetches the next tile's halo
+        # (even number of channel blocks, narrow T) or not (3 blocks / 32-float T rows: no room behind halo buffer 0), and crosses
+        # from one head's operands to the next
+        monkeypatch.setenv("FTC_WL1_GRID_CAP", "8")
+        kern = "wl1"
     r16 = lambda t: round16(t, dt)
     g = torch.Generator().manual_seed(67)
     prev = r16(torch.randn(G, B, H // 2, W // 2, Cy, generator=g))
@@ -431,7 +438,6 @@ def test_upcat_in_with_tap_batchnorm_folded_and_shared_tap(top, dt, kern):
         out = ar.read(o_out, (G, B, H, W, Cm), tdtype(dt)).float()
         ref = torch.stack([y.permute(0, 2, 3, 1) for y in ys])
     else:
-        TW = 12
         wt_mat = torch.zeros(G, 32, Cm)
         for i in range(G):
             for tp in range(9):

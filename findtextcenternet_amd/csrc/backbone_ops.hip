@@ -488,7 +488,6 @@ hipError_t launch_stem(const OpArgs& a, hipStream_t s) {
 
 hipError_t launch_dwconv(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
-    if (o.flags & FTC_FLAG_EXPAND_IN) return launch_mbfused(a, s);
     const int TH = o.stride == 1 ? 8 : 4, TW = 8;
     const int tilesX = (o.Wo + TW - 1) / TW, tilesY = (o.Ho + TH - 1) / TH;
     const int P = tilesX * tilesY;

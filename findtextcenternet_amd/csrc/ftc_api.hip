@@ -100,17 +100,6 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         return conv_validate(o);
     }
     case FTC_OP_DWCONV:
-        if (o.flags & FTC_FLAG_EXPAND_IN) {
-            int P = 0;
-            if (!ftc_is16(o.in_dtype) || o.in_dtype != o.out_dtype || o.stride != 1 || o.Ho != o.H || o.Wo != o.W) return "dwconv+expand: 16-bit, stride 1 only";
-            if (o.Cin <= 0 || o.Cin != o.Cout || o.Cin % 128 || o.Cin_total <= 0 || o.Cin_total % 32) return "dwconv+expand: C % 128 == 0 and Cin_total % 32 == 0 required";
-            if (ftc_mbfused_rows(o.H, o.W, &P) <= 0 || P != o.aux0) return "dwconv+expand: aux0 must be the number of row bands (ftc_mbfused_rows), (rows + 2) * W <= 352";
-            if (pin * o.Cin_total * 2 >= 0x7fffffffLL || (int64_t)o.Cin * o.Cin_total * 2 >= 0x7fffffffLL) return "dwconv+expand: operand exceeds the 2 GiB buffer-resource limit";
-            if (!need(o.in, true, "in", pin * o.Cin_total * 2) || !need(o.out, true, "out", pout * o.Cin * 2) || !need(o.w, true, "w", (int64_t)9 * o.Cin * 4) ||
-                !need(o.bias, true, "bias", (int64_t)o.Cin * 4) || !need(o.w2, true, "w2", (int64_t)o.Cin * o.Cin_total * 2) ||
-                !need(o.bias2, true, "bias2", (int64_t)o.Cin * 4) || !need(o.aux, true, "aux", (int64_t)o.B * o.aux0 * o.Cin * 4)) return why->c_str();
-            return nullptr;
-        }
         if (o.in_dtype != FTC_F32 && !ftc_is16(o.in_dtype)) return "dwconv: unknown dtype";
         if (o.Cin <= 0 || o.aux0 <= 0 || o.Ho <= 0 || o.Wo <= 0) return "dwconv: sizes must be positive";
         if (!need(o.in, true, "in", pin * o.Cin * es(o.in_dtype)) || !need(o.out, true, "out", pout * o.Cin * es(o.in_dtype)) ||
@@ -286,8 +275,7 @@ int ftc_op_kernel_label(const ftc_op* op, char* buf, int len) {
     case FTC_OP_STEM: std::snprintf(buf, len, "stem_kernel"); break;
     case FTC_OP_CONV: conv_kernel_label(*op, buf, len); break;
     case FTC_OP_DWCONV:
-        if (op->flags & FTC_FLAG_EXPAND_IN) std::snprintf(buf, len, "mb_expand_dw_kernel<%s>", ftc_dtname(op->in_dtype));
-        else if (ftc_is16(op->in_dtype) && op->stride == 1 && !(op->flags & 0x100)) std::snprintf(buf, len, "dwconv_strip_kernel<%s,s1>", ftc_dtname(op->in_dtype));
+        if (ftc_is16(op->in_dtype) && op->stride == 1 && !(op->flags & 0x100)) std::snprintf(buf, len, "dwconv_strip_kernel<%s,s1>", ftc_dtname(op->in_dtype));
         else std::snprintf(buf, len, "dwconv_kernel<%s,s%d>", ftc_dtname(op->in_dtype), op->stride);
         break;
     case FTC_OP_SE: std::snprintf(buf, len, "se_fc1+se_fc2"); break;

@@ -23,16 +23,6 @@ template <> struct Half16<_Float16> { using type = _Float16; };
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
-// FTC_FLAG_EXPAND_IN (mbconv_fused.hip): rows of the band a workgroup owns and (*P) bands per image for an H x W map; 0 = not applicable.
-// A band plus one halo row above and below, full width, must fit the kernel's 352-pixel LDS image.
-inline int ftc_mbfused_rows(int H, int W, int* P) {
-    if (H <= 0 || W <= 0 || 3 * W > 352) return 0;
-    const int tymax = 352 / W - 2;
-    const int p = (H + tymax - 1) / tymax;
-    *P = p;
-    return (H + p - 1) / p;
-}
-
 // Resolved (absolute-pointer) form of an ftc_op, what the launchers consume.
 struct OpArgs {
     const ftc_op* op;
@@ -219,7 +209,6 @@ __device__ __forceinline__ float wave_sum(float v) {
 hipError_t launch_stem(const OpArgs& a, hipStream_t s);
 hipError_t launch_conv(const OpArgs& a, hipStream_t s);
 hipError_t launch_dwconv(const OpArgs& a, hipStream_t s);
-hipError_t launch_mbfused(const OpArgs& a, hipStream_t s);
 hipError_t launch_se(const OpArgs& a, hipStream_t s);
 hipError_t launch_upcat(const OpArgs& a, hipStream_t s);
 hipError_t launch_nms(const OpArgs& a, hipStream_t s);

@@ -22,7 +22,6 @@
 #include <tuple>
 #include <vector>
 
-#include "ftc_common.h"
 #include "ftc_host.h"
 
 namespace {
@@ -662,26 +661,13 @@ int Builder::build(ModelPlan* out) {
                 conv(p + ".0", gin, G, h, w, blk.cin, blk.cin, 0, p + ".0", blk.exp, 3, blk.stride, FTC_ACT_SILU, e, A);
                 conv(p + ".1", e, A, ho, wo, blk.exp, blk.exp, 0, p + ".1", blk.cout, 1, 1, FTC_ACT_NONE, y, T, tail);
             } else {
-                // 16-bit modes, low-resolution stride-1 blocks: expand conv + depthwise conv + squeeze sums in one kernel (mbconv_fused.hip);
-                // the expanded tensor never reaches HBM
-                int Pf = 0;
-                const bool fuse_head = dual && blk.stride == 1 && blk.cin % 32 == 0 && blk.exp % 128 == 0 && ftc_mbfused_rows(h, w, &Pf) > 0 &&
-                                       (h * w <= 576 || env_on("FTC_MBFUSE_ALL")) && !env_on("FTC_NO_MBFUSE");
-                const R e = fuse_head ? R() : buf((int64_t)B * h * w * blk.exp, A);
-                if (!fuse_head) conv(p + ".0", gin, G, h, w, blk.cin, blk.cin, 0, p + ".0", blk.exp, 1, 1, FTC_ACT_SILU, e, A);
+                const R e = buf((int64_t)B * h * w * blk.exp, A);
+                conv(p + ".0", gin, G, h, w, blk.cin, blk.cin, 0, p + ".0", blk.exp, 1, 1, FTC_ACT_SILU, e, A);
                 const int th = blk.stride == 1 ? 8 : 4;
-                const int P = fuse_head ? Pf : ((ho + th - 1) / th) * ((wo + 7) / 8);
+                const int P = ((ho + th - 1) / th) * ((wo + 7) / 8);
                 const R d = buf((int64_t)B * ho * wo * blk.exp, A);
                 const R part = buf((int64_t)B * P * blk.exp, FTC_F32);
-                if (fuse_head) {
-                    SymOp s;
-                    ftc_op& o = s.o;
-                    o.kind = FTC_OP_DWCONV; o.flags = FTC_FLAG_EXPAND_IN; o.act = FTC_ACT_SILU; o.in_dtype = A; o.out_dtype = A; o.w_dtype = A;
-                    o.B = B; o.H = h; o.W = w; o.Ho = ho; o.Wo = wo; o.Cin = blk.exp; o.Cout = blk.exp; o.Cin_total = blk.cin; o.ksize = 3; o.stride = 1; o.aux0 = P;
-                    s.in = gin; s.out = d; s.w = wref(p + ".1.w"); s.bias = wref(p + ".1.b"); s.w2 = wref(p + ".0.w"); s.bias2 = wref(p + ".0.b"); s.aux = part;
-                    emit({p + ".0-1", "mbhead", 2.0 * B * h * w * blk.exp * (blk.cin + 9.0),
-                          (double)B * h * w * (blk.cin + blk.exp) * esize(A) + (double)blk.exp * blk.cin * esize(A) + blk.exp * 44.0}, s);
-                } else {
+                {
                     SymOp s;
                     ftc_op& o = s.o;
                     o.kind = FTC_OP_DWCONV; o.act = FTC_ACT_SILU; o.in_dtype = A; o.out_dtype = A; o.B = B; o.H = h; o.W = w; o.Ho = ho; o.Wo = wo;

@@ -117,12 +117,6 @@ enum {
                                   FRAGMENT-MAJOR -- [groups][6 row blocks of 32][9 taps][Cin/64][4 K groups of 16][64 lanes][8]: element e of
                                   lane L = W[32*rb + (L & 31)][tap][64*cb + 16*g + 8*(L >> 5) + e] -- so that a wave reads an MFMA A fragment
                                   as one coalesced 1 KiB load straight from global memory (the weights never touch LDS) */
-    FTC_FLAG_EXPAND_IN = 0x800000, /* DWCONV stride 1, 16-bit: the input of the depthwise conv is the MBConv expand convolution of `in`, computed
-                                  in the same kernel and never stored: in = x [B,H,W,Cin_total] (16-bit), w2 = expand weights [C][Cin_total]
-                                  (K-major, 16-bit, BatchNorm folded), bias2 = its bias fp32 [C]; SiLU after both convolutions.  C % 128 == 0,
-                                  Cin_total % 32 == 0; a workgroup holds a band of rows (+1 halo row each side, full width) of one image:
-                                  (rows + 2) * W <= 352, and aux0 = number of bands per image = rows of partial sums (csrc/ftc_common.h
-                                  ftc_mbfused_rows) */
     FTC_FLAG_SE_FOLD = 32      /* SE: besides scale[b,c], write out2[b][n][c] = bf16(in[n][c] * scale[b,c]) for the
                                   bf16 matrix `in` [Cout_total][C] -- the following 1x1 convolution then runs with
                                   FTC_FLAG_W_PER_IMAGE on unscaled activations (both operands by DMA) */

@@ -593,53 +593,6 @@ def test_dwconv_and_se(shape, dt):
     assert err_se < 2e-6
 
 
-def _mbfused_rows(H, W):
-    tymax = 352 // W - 2
-    P = -(-H // tymax)
-    return -(-H // P), P
-
-
-@pytest.mark.parametrize("dt", [L.BF16, L.F16], ids=["bf16", "f16"])
-@pytest.mark.parametrize("shape", [(8, 24, 24, 512, 256), (2, 24, 24, 64, 384), (3, 7, 5, 96, 128), (1, 4, 4, 32, 128), (2, 31, 20, 160, 256)],
-                         ids=["stage6_like", "24x24", "7x5", "4x4", "31x20_ragged_bands"])
-def test_fused_expand_depthwise_equals_the_two_kernel_path(shape, dt):
-    """FTC_FLAG_EXPAND_IN (csrc/mbconv_fused.hip): expand 1x1 conv + SiLU -> depthwise 3x3 + SiLU -> squeeze sums in one kernel, against
-    the same two ops run one after the other (the expanded tensor rounded to the 16-bit type in both): outputs bit-identical, channel
-    sums equal up to the order of the fp32 additions; and both against fp32 torch."""
-    B, H, W, Cin, C = shape
-    g = torch.Generator().manual_seed(H * 131 + W)
-    x = round16(torch.randn(B, H, W, Cin, generator=g), dt)
-    we = round16(torch.randn(C, Cin, generator=g) / Cin ** 0.5, dt)
-    be = torch.randn(C, generator=g) * 0.3
-    wd = torch.randn(9, C, generator=g) / 3.0
-    bd = torch.randn(C, generator=g) * 0.2
-    e_ref = round16(F.silu(x.reshape(-1, Cin) @ we.t() + be).reshape(B, H, W, C), dt)
-    ref = F.silu(F.conv2d(e_ref.permute(0, 3, 1, 2), wd.t().reshape(C, 1, 3, 3), bd, 1, 1, 1, C)).permute(0, 2, 3, 1)
-    TY, Pf = _mbfused_rows(H, W)
-    P2 = -(-H // 8) * -(-W // 8)
-    ar = Arena()
-    o_x, o_we, o_be, o_wd, o_bd = ar.put(to_dev_bytes(x, dt)), ar.put(to_dev_bytes(we, dt)), ar.put(be), ar.put(wd), ar.put(bd)
-    o_e = ar.reserve(B * H * W * C * 2)
-    o_d1, o_d2 = ar.reserve(B * H * W * C * 2), ar.reserve(B * H * W * C * 2)
-    o_p1, o_p2 = ar.reserve(B * Pf * C * 4), ar.reserve(B * P2 * C * 4)
-    ar.materialize()
-    run_op(dict(kind=L.OP_DWCONV, flags=L.FLAG_EXPAND_IN, act=L.ACT_SILU, in_dtype=dt, out_dtype=dt, w_dtype=dt, B=B, H=H, W=W, Ho=H, Wo=W, Cin=C,
-                Cout=C, Cin_total=Cin, ksize=3, stride=1, aux0=Pf, in_=o_x, out=o_d1, w=o_wd, bias=o_bd, w2=o_we, bias2=o_be, aux=o_p1), ar)
-    run_op(dict(kind=L.OP_CONV, act=L.ACT_SILU, in_dtype=dt, out_dtype=dt, w_dtype=dt, B=B, H=H, W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cin, Cout=C,
-                Cout_total=C, ksize=1, stride=1, in_=o_x, out=o_e, w=o_we, bias=o_be), ar)
-    run_op(dict(kind=L.OP_DWCONV, act=L.ACT_SILU, in_dtype=dt, out_dtype=dt, B=B, H=H, W=W, Ho=H, Wo=W, Cin=C, Cout=C, ksize=3, stride=1, aux0=P2,
-                in_=o_e, out=o_d2, w=o_wd, bias=o_bd, aux=o_p2), ar)
-    d1 = ar.read(o_d1, (B, H, W, C), tdtype(dt))
-    d2 = ar.read(o_d2, (B, H, W, C), tdtype(dt))
-    err = _rel(d1.float(), ref)
-    _log(f"fused expand+dw {shape} dt={dt} rel_err {err:.3e} identical {bool(torch.equal(d1, d2))}")
-    assert err < 8e-3
-    assert torch.equal(d1, d2)
-    s1 = ar.read(o_p1, (B, Pf, C), torch.float32).sum(1)
-    s2 = ar.read(o_p2, (B, P2, C), torch.float32).sum(1)
-    assert float((s1 - s2).abs().max()) <= 1e-4 * float(s2.abs().max())
-
-
 @pytest.mark.parametrize("cfg", [("f32", L.F32, L.F32), ("bf16_f32tap", L.BF16, L.F32), ("bf16", L.BF16, L.BF16), ("f16_f32tap", L.F16, L.F32),
                                  ("f16", L.F16, L.F16)], ids=lambda c: c[0])
 @pytest.mark.parametrize("with_y", [True, False])

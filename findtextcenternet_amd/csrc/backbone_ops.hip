@@ -15,7 +15,7 @@ namespace {
 template <typename OutT, typename CopyT>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                    const float* __restrict__ bias, OutT* __restrict__ out, CopyT* __restrict__ out2,
-                                                   int B, int H, int W, int Ho, int Wo, int C0, int nchw) {
+                                                   int B, int H, int W, int Ho, int Wo, int C0, int nchw, int act) {
     extern __shared__ __attribute__((aligned(16))) float sw[];   // [27][C0]
     for (int i = threadIdx.x; i < 27 * C0; i += blockDim.x) sw[i] = w[i];
     __syncthreads();
@@ -47,8 +47,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
                 }
             }
         }
+        if (act) {                                          // (act 0: the raw convolution, for the training-mode forward)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = act_silu_precise(acc[e]);
+            for (int e = 0; e < 4; ++e) acc[e] = act_silu_precise(acc[e]);
+        }
         store4<OutT>(out + (long)pix * C0 + cq * 4, acc);
         if (out2) store4<CopyT>(out2 + (long)pix * C0 + cq * 4, acc);
     }
@@ -65,7 +67,7 @@ template <typename T, int STRIDE>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, const float* __restrict__ w,
                                                      const float* __restrict__ bias, T* __restrict__ out,
                                                      float* __restrict__ partial, int H, int W, int Ho, int Wo,
-                                                     int C, int tilesX, int P, int tiles_per_wg) {
+                                                     int C, int tilesX, int P, int tiles_per_wg, int act) {
     constexpr int V = 16 / (int)sizeof(T);      // channels per lane = one 16-byte access (4 fp32 | 8 bf16)
     constexpr int LPP = 64 / V;                 // lanes per pixel of the 64-channel slab (16 | 8)
     constexpr int SLOTS = 256 / LPP;            // pixel slots per workgroup (16 | 32)
@@ -168,8 +170,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, c
                     for (int e = 0; e < V; ++e) acc[e] = fmaf(wv[r * 3 + s][e], x[e], acc[e]);
                 }
             if (cok && oy < Ho && ox < Wo) {
+                if (act) {
 #pragma unroll
-                for (int e = 0; e < V; ++e) acc[e] = sizeof(T) == 2 ? act_silu_fast(acc[e]) : act_silu_precise(acc[e]);
+                    for (int e = 0; e < V; ++e) acc[e] = sizeof(T) == 2 ? act_silu_fast(acc[e]) : act_silu_precise(acc[e]);
+                }
                 store16<T>(out + (((long)b * Ho + oy) * Wo + ox) * C + c, acc);
 #pragma unroll
                 for (int e = 0; e < V; ++e) sum[e] += acc[e];
@@ -473,16 +477,16 @@ hipError_t launch_stem(const OpArgs& a, hipStream_t s) {
     // fp32 trunk output with an optional 16-bit copy in the plan's compute type (ftc_op.w_dtype: bf16 unless FTC_F16)
     if (o.out_dtype == FTC_F32 && o.w_dtype == FTC_F16)
         hipLaunchKernelGGL((stem_kernel<float, _Float16>), dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
-                           a.bias, (float*)a.out, (_Float16*)a.out2, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw);
+                           a.bias, (float*)a.out, (_Float16*)a.out2, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw, o.act != FTC_ACT_NONE ? 1 : 0);
     else if (o.out_dtype == FTC_F32)
         hipLaunchKernelGGL((stem_kernel<float, __bf16>), dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
-                           a.bias, (float*)a.out, (__bf16*)a.out2, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw);
+                           a.bias, (float*)a.out, (__bf16*)a.out2, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw, o.act != FTC_ACT_NONE ? 1 : 0);
     else if (o.out_dtype == FTC_F16)
         hipLaunchKernelGGL((stem_kernel<_Float16, _Float16>), dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
-                           a.bias, (_Float16*)a.out, (_Float16*)nullptr, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw);
+                           a.bias, (_Float16*)a.out, (_Float16*)nullptr, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw, o.act != FTC_ACT_NONE ? 1 : 0);
     else
         hipLaunchKernelGGL((stem_kernel<__bf16, __bf16>), dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
-                           a.bias, (__bf16*)a.out, (__bf16*)nullptr, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw);
+                           a.bias, (__bf16*)a.out, (__bf16*)nullptr, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw, o.act != FTC_ACT_NONE ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -494,7 +498,7 @@ hipError_t launch_dwconv(const OpArgs& a, hipStream_t s) {
     if (P != o.aux0) return hipErrorInvalidValue;
     // Consecutive tiles per workgroup: the grid runs in ceil(workgroups / resident slots) rounds of `tpw` tile
     // times each; take the tpw that minimises rounds * tpw (ties: the larger, it amortises the tap loads).
-    const bool strip = ftc_is16(o.in_dtype) && o.stride == 1 && !(o.flags & 0x100);
+    const bool strip = ftc_is16(o.in_dtype) && o.stride == 1 && !(o.flags & 0x100) && o.act != FTC_ACT_NONE;
     const long slabs = (long)((o.Cin + 63) / 64) * o.B;
     const long slots = 256L * (strip ? 4 : o.in_dtype == FTC_F32 ? 3 : 2);     // workgroups resident on 256 CUs (VGPR-limited)
     int tpw = 1;
@@ -507,12 +511,12 @@ hipError_t launch_dwconv(const OpArgs& a, hipStream_t s) {
     dim3 grid((o.Cin + 63) / 64, (P + tpw - 1) / tpw, o.B);
 #define DW_LAUNCH(T, ST)                                                                                      \
     hipLaunchKernelGGL((dwconv_kernel<T, ST>), grid, dim3(256), 0, s, (const T*)a.in, (const float*)a.w, a.bias, \
-                       (T*)a.out, a.aux, o.H, o.W, o.Ho, o.Wo, o.Cin, tilesX, P, tpw)
+                       (T*)a.out, a.aux, o.H, o.W, o.Ho, o.Wo, o.Cin, tilesX, P, tpw, o.act != FTC_ACT_NONE ? 1 : 0)
     if (o.in_dtype == FTC_F32) { if (o.stride == 1) DW_LAUNCH(float, 1); else DW_LAUNCH(float, 2); }
-    else if (o.stride == 1 && !(o.flags & 0x100) && o.in_dtype == FTC_F16)
+    else if (strip && o.in_dtype == FTC_F16)
         hipLaunchKernelGGL(dwconv_strip_kernel<_Float16>, grid, dim3(256), 0, s, (const _Float16*)a.in, (const float*)a.w, a.bias,
                            (_Float16*)a.out, a.aux, o.H, o.W, o.Cin, tilesX, P, tpw);
-    else if (o.stride == 1 && !(o.flags & 0x100))
+    else if (strip)
         hipLaunchKernelGGL(dwconv_strip_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)a.in, (const float*)a.w, a.bias,
                            (__bf16*)a.out, a.aux, o.H, o.W, o.Cin, tilesX, P, tpw);
     else if (o.in_dtype == FTC_F16) { if (o.stride == 1) DW_LAUNCH(_Float16, 1); else DW_LAUNCH(_Float16, 2); }

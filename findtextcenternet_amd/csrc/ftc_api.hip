@@ -150,6 +150,29 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
             !need(o.bias, true, "bias", (int64_t)o.aux1 * 4)) return why->c_str();
         if (o.aux0 < 4 || o.aux0 > 32 || o.aux0 % 4 || o.aux1 < 1 || o.aux1 > 64 || o.Cout_total < 1 || o.groups < 1) return "tapsum: bad aux0 / aux1 / Cout_total / groups";
         return nullptr;
+    case FTC_OP_BNSTAT: {
+        if (o.Cin <= 0) return "bnstat: Cin must be positive";
+        if (o.in_dtype != FTC_F32 && !ftc_is16(o.in_dtype)) return "bnstat: unknown dtype";
+        const int64_t M = pin;
+        if (!need(o.in, true, "in", M * o.Cin * es(o.in_dtype)) || !need(o.out, true, "out", (int64_t)2 * o.Cin * 4) || !need(o.w, true, "w", (int64_t)o.Cin * 4) ||
+            !need(o.bias, true, "bias", (int64_t)o.Cin * 4) || !need(o.aux, false, "aux", (int64_t)2 * o.Cin * 4) ||
+            !need(o.in2, true, "in2", (int64_t)ftc_bnstat_chunks(M) * 2 * o.Cin * 8)) return why->c_str();
+        return nullptr;
+    }
+    case FTC_OP_BNACT: {
+        if (o.Cin <= 0 || o.aux0 < 0 || o.aux0 > 65535) return "bnact: bad Cin / aux0";
+        if ((o.in_dtype != FTC_F32 && !ftc_is16(o.in_dtype)) || (o.out_dtype != FTC_F32 && !ftc_is16(o.out_dtype))) return "bnact: unknown dtype";
+        const int tc = o.w_dtype == FTC_F16 ? FTC_F16 : FTC_BF16;
+        if ((ftc_is16(o.in_dtype) && o.in_dtype != tc) || (ftc_is16(o.out_dtype) && o.out_dtype != tc)) return "bnact: 16-bit tensors must be in the plan's 16-bit type (w_dtype)";
+        if ((o.flags & FTC_FLAG_RESIDUAL) && o.res_dtype != FTC_F32 && o.res_dtype != tc) return "bnact: residual must be fp32 or the plan's 16-bit type";
+        if (o.act != FTC_ACT_NONE && o.act != FTC_ACT_SILU && o.act != FTC_ACT_GELU) return "bnact: unknown activation";
+        if (!need(o.in, true, "in", pin * o.Cin * es(o.in_dtype)) || !need(o.out, true, "out", pin * o.Cin * es(o.out_dtype)) ||
+            !need(o.scale, true, "scale", (int64_t)o.Cin * 4) || !need(o.shift, true, "shift", (int64_t)o.Cin * 4) ||
+            !need(o.in2, (o.flags & FTC_FLAG_RESIDUAL) != 0, "in2", pin * o.Cin * es(o.res_dtype)) || !need(o.w2, false, "w2", (int64_t)o.B * 4) ||
+            !need(o.out2, false, "out2", pin * o.Cin * 2) || !need(o.aux, false, "aux", (int64_t)o.B * (o.aux0 > 0 ? o.aux0 : 1) * o.Cin * 4)) return why->c_str();
+        if (o.out2.base != FTC_BASE_NULL && o.out_dtype != FTC_F32) return "bnact: out2 (16-bit copy) needs an fp32 primary output";
+        return nullptr;
+    }
     case FTC_OP_NMS:
         if (!need(o.out, true, "out")) return why->c_str();
         if (o.Cout_total < 2) return "nms: heat-map needs >= 2 channels";
@@ -186,6 +209,8 @@ hipError_t run_one(const ftc_op& o, void* const bases[FTC_NUM_BASES], hipStream_
     case FTC_OP_UPCAT: return launch_upcat(a, s);
     case FTC_OP_NMS: return launch_nms(a, s);
     case FTC_OP_TAPSUM: return launch_tapsum(a, s);
+    case FTC_OP_BNSTAT: return launch_bnstat(a, s);
+    case FTC_OP_BNACT: return launch_bnact(a, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -275,13 +300,15 @@ int ftc_op_kernel_label(const ftc_op* op, char* buf, int len) {
     case FTC_OP_STEM: std::snprintf(buf, len, "stem_kernel"); break;
     case FTC_OP_CONV: conv_kernel_label(*op, buf, len); break;
     case FTC_OP_DWCONV:
-        if (ftc_is16(op->in_dtype) && op->stride == 1 && !(op->flags & 0x100)) std::snprintf(buf, len, "dwconv_strip_kernel<%s,s1>", ftc_dtname(op->in_dtype));
+        if (ftc_is16(op->in_dtype) && op->stride == 1 && !(op->flags & 0x100) && op->act != FTC_ACT_NONE) std::snprintf(buf, len, "dwconv_strip_kernel<%s,s1>", ftc_dtname(op->in_dtype));
         else std::snprintf(buf, len, "dwconv_kernel<%s,s%d>", ftc_dtname(op->in_dtype), op->stride);
         break;
     case FTC_OP_SE: std::snprintf(buf, len, "se_fc1+se_fc2"); break;
     case FTC_OP_UPCAT: std::snprintf(buf, len, "upcat_kernel<%s>", ftc_dtname(op->in_dtype)); break;
     case FTC_OP_NMS: std::snprintf(buf, len, "nms_kernel"); break;
     case FTC_OP_TAPSUM: std::snprintf(buf, len, "tapsum_kernel"); break;
+    case FTC_OP_BNSTAT: std::snprintf(buf, len, "bnstat_partial+final<%s>", ftc_dtname(op->in_dtype)); break;
+    case FTC_OP_BNACT: std::snprintf(buf, len, "bnact_kernel<%s,%s>", ftc_dtname(op->in_dtype), ftc_dtname(op->out_dtype)); break;
     default: return fail(FTC_ERR_INVALID, "ftc_op_kernel_label: unknown op kind");
     }
     return FTC_OK;

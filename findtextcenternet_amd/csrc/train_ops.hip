@@ -8,6 +8,8 @@
 //
 // Everything here is bandwidth-trivial (a few MB per step); the kernels are written for determinism: integer histograms,
 // fixed-order two-stage reductions (per-workgroup partials summed in index order in float64), no floating-point atomics.
+#include <cstring>
+
 #include "ftc_common.h"
 
 namespace {
@@ -301,7 +303,136 @@ __global__ void cov_step_kernel(const float* __restrict__ L, int n, int iter, fl
     *out_loss = loss;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Training-mode BatchNorm (FTC_OP_BNSTAT / FTC_OP_BNACT): the BN-refresh pass of the reference (train1.py:203-211) runs the model in
+// train() mode without gradients, so that every BatchNorm normalises with the statistics of the batch and moves its running
+// statistics.  Statistics are summed in float64 in a fixed order: per (row chunk, channel) partial sums, then one thread per channel.
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bnstat_partial_kernel(const T* __restrict__ x, double* __restrict__ part, long M, int C, int nchunk) {
+    __shared__ double red[2][4][64];
+    const int t = threadIdx.x, cl = t & 63, rl = t >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int chunk = blockIdx.y;
+    const long rows = (M + nchunk - 1) / nchunk;
+    const long r0 = (long)chunk * rows, r1 = r0 + rows < M ? r0 + rows : M;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (long r = r0 + rl; r < r1; r += 4) {
+            const double v = (double)to_f32<T>(x[r * C + c]);
+            s1 += v;
+            s2 += v * v;
+        }
+    red[0][rl][cl] = s1;
+    red[1][rl][cl] = s2;
+    __syncthreads();
+    if (t < 64 && c < C) {
+        part[((long)chunk * 2 + 0) * C + c] = (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
+        part[((long)chunk * 2 + 1) * C + c] = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bnstat_final_kernel(const double* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ running, float* __restrict__ out, long M, int C, int nchunk, float eps,
+                                                           float momentum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        s1 += part[((long)k * 2 + 0) * C + c];
+        s2 += part[((long)k * 2 + 1) * C + c];
+    }
+    const double mean = s1 / (double)M;
+    double var = s2 / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double sc = (double)gamma[c] / sqrt(var + (double)eps);
+    out[c] = (float)sc;
+    out[C + c] = (float)((double)beta[c] - mean * sc);
+    if (running) {
+        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running[c] = (float)((1.0 - (double)momentum) * (double)running[c] + (double)momentum * mean);
+        running[C + c] = (float)((1.0 - (double)momentum) * (double)running[C + c] + (double)momentum * unb);
+    }
+}
+
+// grid (C/64, row chunks P, B): 64 channels x 4 row lanes; the activation in fp32 exactly as the inference epilogues apply it
+template <typename TI, typename TO, typename TC>
+__global__ __launch_bounds__(256) void bnact_kernel(const TI* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                    const void* __restrict__ res, int res_dtype, const float* __restrict__ keep, TO* __restrict__ out,
+                                                    TC* __restrict__ out2, float* __restrict__ sums, int HW, int C, int P, int act) {
+    __shared__ float red[4][64];
+    const int t = threadIdx.x, cl = t & 63, rl = t >> 6;
+    const int c = blockIdx.x * 64 + cl, p = blockIdx.y, b = blockIdx.z;
+    const int rows = (HW + P - 1) / P;
+    const int r0 = p * rows, r1 = min(HW, r0 + rows);
+    float acc = 0.f;
+    if (c < C) {
+        const float sc = scale[c], sh = shift[c];
+        const float kp = keep ? keep[b] : 1.0f;
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const long i = ((long)b * HW + r) * C + c;
+            float v = to_f32<TI>(x[i]) * sc + sh;
+            v = apply_act_rt(v, act);
+            if (res) v = v * kp + (res_dtype == FTC_F32 ? reinterpret_cast<const float*>(res)[i] : to_f32<TC>(reinterpret_cast<const TC*>(res)[i]));
+            out[i] = from_f32<TO>(v);
+            if (out2) out2[i] = from_f32<TC>(v);
+            acc += v;
+        }
+    }
+    if (sums) {
+        red[rl][cl] = acc;
+        __syncthreads();
+        if (t < 64 && c < C) sums[((long)b * P + p) * C + c] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    }
+}
+
 }  // namespace
+
+hipError_t launch_bnstat(const OpArgs& a, hipStream_t s) {
+    const ftc_op& o = *a.op;
+    const long M = (long)o.B * o.H * o.W;
+    const int C = o.Cin, nchunk = ftc_bnstat_chunks(M);
+    double* part = reinterpret_cast<double*>(const_cast<void*>(a.in2));
+    float eps, mom;
+    memcpy(&eps, &o.aux0, 4);
+    memcpy(&mom, &o.aux1, 4);
+    const dim3 grid((C + 63) / 64, nchunk);
+    if (o.in_dtype == FTC_F32) hipLaunchKernelGGL(bnstat_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)a.in, part, M, C, nchunk);
+    else if (o.in_dtype == FTC_F16) hipLaunchKernelGGL(bnstat_partial_kernel<_Float16>, grid, dim3(256), 0, s, (const _Float16*)a.in, part, M, C, nchunk);
+    else hipLaunchKernelGGL(bnstat_partial_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)a.in, part, M, C, nchunk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bnstat_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, (const float*)a.w, a.bias, a.aux, (float*)a.out, M, C, nchunk, eps, mom);
+    return hipGetLastError();
+}
+
+namespace {
+template <typename TI, typename TO, typename TC>
+hipError_t launch_bnact_t(const OpArgs& a, hipStream_t s) {
+    const ftc_op& o = *a.op;
+    const int HW = o.H * o.W, C = o.Cin, P = o.aux0 > 0 ? o.aux0 : 1;
+    const bool has_res = (o.flags & FTC_FLAG_RESIDUAL) != 0;
+    hipLaunchKernelGGL((bnact_kernel<TI, TO, TC>), dim3((C + 63) / 64, P, o.B), dim3(256), 0, s, (const TI*)a.in, a.scale, a.shift, has_res ? a.in2 : nullptr,
+                       o.res_dtype, has_res ? static_cast<const float*>(a.w2) : nullptr, (TO*)a.out, (TC*)a.out2, a.aux, HW, C, P, o.act);
+    return hipGetLastError();
+}
+template <typename TI, typename TC>
+hipError_t launch_bnact_i(const OpArgs& a, hipStream_t s) {
+    if (a.op->out_dtype == FTC_F32) return launch_bnact_t<TI, float, TC>(a, s);
+    return launch_bnact_t<TI, TC, TC>(a, s);
+}
+}  // namespace
+
+hipError_t launch_bnact(const OpArgs& a, hipStream_t s) {
+    const ftc_op& o = *a.op;
+    // TC = the plan's 16-bit type (w_dtype: bf16 unless fp16): 16-bit outputs, copies and residuals come in it
+    if (o.w_dtype == FTC_F16) {
+        if (o.in_dtype == FTC_F32) return launch_bnact_i<float, _Float16>(a, s);
+        return launch_bnact_i<_Float16, _Float16>(a, s);
+    }
+    if (o.in_dtype == FTC_F32) return launch_bnact_i<float, __bf16>(a, s);
+    return launch_bnact_i<__bf16, __bf16>(a, s);
+}
 
 hipError_t launch_topk_mask(const float* vals, long n, long k, unsigned char* mask, int32_t* sel_index, int32_t* count, hipStream_t s) {
     hipLaunchKernelGGL(topk_mask_kernel, dim3(1), dim3(1024), 0, s, vals, n, k, mask, sel_index, count);

@@ -593,6 +593,57 @@ def test_dwconv_and_se(shape, dt):
     assert err_se < 2e-6
 
 
+def _fbits(v):
+    import struct
+    return struct.unpack("<i", struct.pack("<f", v))[0]
+
+
+@pytest.mark.parametrize("cfg", [("f32", L.F32, L.F32, L.BF16), ("f32_to_bf16", L.F32, L.BF16, L.BF16), ("bf16", L.BF16, L.BF16, L.BF16), ("f16_to_f32", L.F16, L.F32, L.F16)],
+                         ids=lambda c: c[0])
+@pytest.mark.parametrize("shape", [(2, 12, 10, 96), (3, 5, 7, 200), (8, 24, 24, 64)], ids=["12x10x96", "5x7x200", "24x24x64"])
+def test_training_mode_batchnorm_ops(shape, cfg):
+    """FTC_OP_BNSTAT + FTC_OP_BNACT (csrc/train_ops.hip) against torch.nn.functional.batch_norm(training=True): normalised output with
+    activation, StochasticDepth keep-scale and residual, the SE squeeze sums, and the running statistics (momentum, unbiased variance)."""
+    _, idt, odt, tc = cfg
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(B * 100 + C)
+    x = round16(torch.randn(B, H, W, C, generator=g) * 1.7 + 0.4, idt)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    rm, rv = torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5
+    res = torch.randn(B, H, W, C, generator=g)
+    keep = torch.tensor([0.0 if b % 3 == 1 else 1.25 for b in range(B)])
+    eps, mom = 1e-3, 0.1
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = F.batch_norm(x.permute(0, 3, 1, 2), rm_ref, rv_ref, gamma, beta, True, mom, eps)
+    ref = F.silu(y).permute(0, 2, 3, 1) * keep[:, None, None, None] + res
+    M = B * H * W
+    nchunk = max(1, min(64, -(-M // 256)))
+    P = 3
+    ar = Arena()
+    o_x, o_g, o_b, o_res, o_keep = ar.put(to_dev_bytes(x, idt)), ar.put(gamma), ar.put(beta), ar.put(res), ar.put(keep)
+    o_run = ar.put(torch.stack([rm, rv]))
+    o_ss, o_part = ar.reserve(2 * C * 4), ar.reserve(nchunk * 2 * C * 8)
+    o_out = ar.reserve(M * C * (4 if odt == L.F32 else 2))
+    o_out2 = ar.reserve(M * C * 2) if odt == L.F32 else None
+    o_sums = ar.reserve(B * P * C * 4)
+    ar.materialize()
+    run_op(dict(kind=L.OP_BNSTAT, in_dtype=idt, B=B, H=H, W=W, Cin=C, aux0=_fbits(eps), aux1=_fbits(mom), in_=o_x, w=o_g, bias=o_b, aux=o_run,
+                out=o_ss, in2=o_part), ar)
+    run_op(dict(kind=L.OP_BNACT, flags=L.FLAG_RESIDUAL, act=L.ACT_SILU, in_dtype=idt, out_dtype=odt, w_dtype=tc, res_dtype=L.F32, B=B, H=H, W=W, Cin=C,
+                aux0=P, in_=o_x, scale=o_ss, shift=o_ss + C * 4, in2=o_res, w2=o_keep, out=o_out, out2=o_out2, aux=o_sums), ar)
+    run = ar.read(o_run, (2, C), torch.float32)
+    assert float((run[0] - rm_ref).abs().max()) < 2e-6 and float((run[1] - rv_ref).abs().max()) < 2e-5
+    out = ar.read(o_out, (B, H, W, C), tdtype(odt)).float()
+    err = _rel(out, ref)
+    _log(f"bnstat+bnact {shape} {cfg[0]} rel_err {err:.3e}")
+    assert err < (5e-6 if odt == L.F32 else TOL16[odt])
+    if o_out2 is not None:
+        c2 = ar.read(o_out2, (B, H, W, C), tdtype(tc)).float()
+        assert torch.equal(c2, round16(out, tc))
+    sums = ar.read(o_sums, (B, P, C), torch.float32).sum(1)
+    assert float((sums - ref.sum((1, 2))).abs().max()) < 2e-3 * float(ref.sum((1, 2)).abs().max() + 1)
+
+
 @pytest.mark.parametrize("cfg", [("f32", L.F32, L.F32), ("bf16_f32tap", L.BF16, L.F32), ("bf16", L.BF16, L.BF16), ("f16_f32tap", L.F16, L.F32),
                                  ("f16", L.F16, L.F16)], ids=lambda c: c[0])
 @pytest.mark.parametrize("with_y", [True, False])

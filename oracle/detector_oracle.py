@@ -154,3 +154,139 @@ def detector_forward(sd, x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         sd = {k[len("detector."):]: v for k, v in sd.items() if k.startswith("detector.")}
     maps, feat = detection_forward(sd, x)
     return nms_forward(maps), feat
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Training-mode forward without gradients: what the reference's end-of-epoch BN-refresh pass runs (train1.py:203-211 calls
+# train_step under torch.no_grad() with the model in train()): every BatchNorm normalises with the statistics of the batch and
+# moves its running statistics (momentum 0.1, unbiased variance), and the residual branches go through torchvision's
+# StochasticDepth("row"): branch * keep[b] with keep[b] in {0, 1/(1-p)}.  The random draw is an INPUT here (`keep`: block
+# prefix -> [B] tensor; missing = ones), so that a test can feed the reference and the GPU the same draw.
+# ----------------------------------------------------------------------------------------------------------------------
+class TrainCtx:
+    def __init__(self, keep=None, momentum: float = 0.1):
+        self.keep = keep or {}
+        self.momentum = momentum
+        self.new_stats: Dict[str, torch.Tensor] = {}
+
+
+def _bn_t(sd, p, x, eps, ctx: TrainCtx):
+    rm, rv = sd[p + ".running_mean"].clone(), sd[p + ".running_var"].clone()
+    y = F.batch_norm(x, rm, rv, sd[p + ".weight"], sd[p + ".bias"], True, ctx.momentum, eps)
+    ctx.new_stats[p + ".running_mean"], ctx.new_stats[p + ".running_var"] = rm, rv
+    return y
+
+
+def _cna_t(sd, p, x, ctx, stride=1, groups=1, act=True):
+    w = sd[p + ".0.weight"]
+    x = F.conv2d(x, w, None, stride, (w.shape[-1] - 1) // 2, 1, groups)
+    x = _bn_t(sd, p + ".1", x, BACKBONE_EPS, ctx)
+    return F.silu(x) if act else x
+
+
+def _block_t(sd, p, x, ctx):
+    b = p + ".block"
+    stride = 2 if _mb_stride2(sd, p) else 1
+    if f"{b}.2.fc1.weight" in sd:
+        dw = sd[b + ".1.0.weight"]
+        y = _cna_t(sd, b + ".0", x, ctx)
+        y = _cna_t(sd, b + ".1", y, ctx, stride=stride, groups=dw.shape[0])
+        s = F.adaptive_avg_pool2d(y, 1)
+        s = F.silu(F.conv2d(s, sd[b + ".2.fc1.weight"], sd[b + ".2.fc1.bias"]))
+        s = torch.sigmoid(F.conv2d(s, sd[b + ".2.fc2.weight"], sd[b + ".2.fc2.bias"]))
+        y = _cna_t(sd, b + ".3", s * y, ctx, act=False)
+        cout = sd[b + ".3.0.weight"].shape[0]
+    elif f"{b}.1.0.weight" in sd:
+        y = _cna_t(sd, b + ".0", x, ctx, stride=stride)
+        y = _cna_t(sd, b + ".1", y, ctx, act=False)
+        cout = sd[b + ".1.0.weight"].shape[0]
+    else:
+        y = _cna_t(sd, b + ".0", x, ctx, stride=stride)
+        cout = sd[b + ".0.0.weight"].shape[0]
+    if stride == 1 and x.shape[1] == cout:
+        k = ctx.keep.get(p)
+        if k is not None:
+            y = y * k.to(y.dtype).reshape(-1, 1, 1, 1)
+        y = y + x
+    return y
+
+
+def residual_blocks(sd, prefix="backbone.features") -> List[str]:
+    """Prefixes of the blocks that have a residual connection (and therefore a StochasticDepth draw), in network order."""
+    out = []
+    i = 1
+    while f"{prefix}.{i}.0.block.0.0.weight" in sd:
+        for p in _stage_blocks(sd, f"{prefix}.{i}"):
+            b = p + ".block"
+            last = ".3" if f"{b}.2.fc1.weight" in sd else (".1" if f"{b}.1.0.weight" in sd else ".0")
+            cout, cin = sd[b + last + ".0.weight"].shape[0], sd[b + ".0.0.weight"].shape[1]
+            if not _mb_stride2(sd, p) and cin == cout:
+                out.append(p)
+        i += 1
+    return out
+
+
+def stochastic_depth_probs(sd, prefix="backbone.features", p_total: float = 0.2) -> Dict[str, float]:
+    """torchvision EfficientNet.__init__: sd_prob = stochastic_depth_prob * block_id / total_blocks, block_id counting every block."""
+    blocks = []
+    i = 1
+    while f"{prefix}.{i}.0.block.0.0.weight" in sd:
+        blocks += _stage_blocks(sd, f"{prefix}.{i}")
+        i += 1
+    return {p: p_total * j / len(blocks) for j, p in enumerate(blocks)}
+
+
+def leafmap_forward_train(sd, name, taps, ctx):
+    y = None
+    n = len(taps)
+    for i, x in enumerate(reversed(taps)):
+        x = _bn_t(sd, f"{name}.in_bn.{n - 1 - i}", x, HEAD_EPS, ctx)
+        if y is not None:
+            x = torch.cat([y, x], dim=1)
+        y = F.conv2d(x, sd[f"{name}.upsamplers.{i}.0.weight"], None, 1, 1)
+        y = F.gelu(_bn_t(sd, f"{name}.upsamplers.{i}.1", y, HEAD_EPS, ctx))
+        if i < n - 1:
+            y = F.interpolate(y, scale_factor=2, mode="bilinear", align_corners=True)
+    return F.conv2d(y, sd[f"{name}.top_conv.0.weight"], sd[f"{name}.top_conv.0.bias"], 1, 1)
+
+
+@torch.no_grad()
+def detection_forward_train(sd, x: torch.Tensor, keep=None, momentum: float = 0.1):
+    """CenterNetDetection.forward in train() mode -> (maps [B,9,h,w], features [B,100,h,w], {running-stat key: new value})."""
+    sd = {k: v for k, v in sd.items()}
+    if any(k.startswith("detector.") for k in sd):
+        keep = {k[len("detector."):] if k.startswith("detector.") else k: v for k, v in (keep or {}).items()}
+        sd = {k[len("detector."):]: v for k, v in sd.items() if k.startswith("detector.")}
+    ctx = TrainCtx(keep, momentum)
+    prefix = "backbone.features"
+    x = x * 2 - 1
+    taps = []
+    x = _cna_t(sd, f"{prefix}.0", x, ctx, stride=2)
+    i = 1
+    while f"{prefix}.{i}.0.block.0.0.weight" in sd:
+        for p in _stage_blocks(sd, f"{prefix}.{i}"):
+            x = _block_t(sd, p, x, ctx)
+        if i in (2, 3, 5):
+            taps.append(x)
+        i += 1
+    taps.append(_cna_t(sd, f"{prefix}.{i}", x, ctx))
+    maps = torch.cat([leafmap_forward_train(sd, h, taps, ctx) for h in HEAD_NAMES], dim=1)
+    return maps, leafmap_forward_train(sd, "feature", taps, ctx), ctx.new_stats
+
+
+@torch.no_grad()
+def decoder_forward_train(sd, rows: torch.Tensor, momentum: float = 0.1, prefix="decoder."):
+    """SimpleDecoder.forward in train() mode (models/detector.py:232-254): Linear -> BatchNorm1d (batch stats) -> GELU, twice, Linear."""
+    outs, new = [], {}
+    j = 0
+    while f"{prefix}blocks.{j}.0.weight" in sd:
+        b = f"{prefix}blocks.{j}"
+        y = rows
+        for li, bi in ((0, 1), (3, 4)):
+            y = F.linear(y, sd[f"{b}.{li}.weight"])
+            rm, rv = sd[f"{b}.{bi}.running_mean"].clone(), sd[f"{b}.{bi}.running_var"].clone()
+            y = F.gelu(F.batch_norm(y, rm, rv, sd[f"{b}.{bi}.weight"], sd[f"{b}.{bi}.bias"], True, momentum, 1e-5))
+            new[f"{b}.{bi}.running_mean"], new[f"{b}.{bi}.running_var"] = rm, rv
+        outs.append(F.linear(y, sd[f"{b}.6.weight"], sd[f"{b}.6.bias"]))
+        j += 1
+    return outs, new

@@ -374,7 +374,68 @@ def gen_small_models():
              n_keys=np.array(len(model.state_dict())), backbone_params=np.array(sum(p.numel() for p in model.detector.backbone.parameters())))
 
 
+def gen_train_forward(model):
+    """g9: the reference's TextDetectorModel in train() mode without gradients -- what its BN-refresh pass runs (train1.py:203-211) --
+    at 128x128, batch 3, CPU fp32: batch-statistics BatchNorm everywhere (momentum 0.1) and StochasticDepth with a SEEDED draw that
+    is saved with the outputs (the stand-in StochasticDepth of oracle/tv_efficientnet.py multiplies by the supplied keep-scale
+    instead of drawing its own; same arithmetic).  Outputs: maps, features, decoder logits of the masked rows, and the new running
+    statistics of a spread of BatchNorm layers."""
+    from oracle import tv_efficientnet as tv
+    B, H, W = 3, 128, 128
+    x = synth.page_images(929, B, H, W)
+    label, _ = synth.train_labels(930, B, H // 4, W // 4)
+    rng = np.random.Generator(np.random.PCG64(931))
+    sds = [(n, m) for n, m in model.named_modules() if isinstance(m, tv.StochasticDepth)]
+    keep = {}
+    for n, m in sds:
+        pfx = n[: -len(".stochastic_depth")]
+        surv = 1.0 - m.p
+        k = (rng.random(B) < surv).astype(np.float32) / np.float32(surv)
+        keep[pfx] = torch.from_numpy(k)
+    orig = tv.StochasticDepth.forward
+    by_id = {id(m): keep[n[: -len(".stochastic_depth")]] for n, m in sds}
+
+    def fwd(self, t):
+        if not self.training or self.p == 0.0:
+            return t
+        return t * by_id[id(self)].reshape(-1, 1, 1, 1)
+    tv.StochasticDepth.forward = fwd
+    try:
+        before = {k: v.clone() for k, v in model.state_dict().items()}
+        model.train()
+        with torch.no_grad():
+            fmask = model.get_fmask(torch.from_numpy(label), None)
+            maps, dec = model(torch.from_numpy(x).permute(0, 3, 1, 2), fmask)
+            feats = None
+        after = {k: v.clone() for k, v in model.state_dict().items()}
+    finally:
+        tv.StochasticDepth.forward = orig
+        model.load_state_dict(before)
+        model.eval()
+    # residual blocks only carry a draw that matters; keep the ones the model has, by prefix
+    names = sorted(keep)
+    changed = [k for k in after if k.endswith("running_mean") or k.endswith("running_var")]
+    pick = changed[:: max(1, len(changed) // 120)]
+    out = {"maps": maps.numpy(), "keep_names": np.array(names), "keep": np.stack([keep[n].numpy() for n in names]),
+           "fmask": np.packbits(fmask.numpy()), "stat_names": np.array(pick), "n_changed": np.array(len(changed))}
+    for i, k in enumerate(pick):
+        out[f"stat{i}"] = after[k].numpy()
+    rows = np.random.Generator(np.random.PCG64(6)).choice(int(fmask.sum()), 64, replace=False)
+    out["dec_rows"] = rows
+    for j in range(3):
+        d = dec[j].numpy()
+        out[f"dec{j}_at"] = d[rows]
+        out[f"dec{j}_lse"] = torch.logsumexp(dec[j], 1).numpy()
+    save("g9_train_forward.npz", **out)
+
+
 def main():
+    if "--train-only" in sys.argv:
+        torch.manual_seed(0)
+        model = ref_detector.TextDetectorModel(pre_weights=False)
+        model.load_state_dict(deterministic_state_dict(SEED_W))
+        gen_train_forward(model)
+        return
     if "--adamw-only" in sys.argv:
         gen_adamw()
         return
@@ -404,6 +465,7 @@ def main():
     gen_decode()
     gen_adamw()
     gen_validation_step(model)
+    gen_train_forward(model)
     gen_small_models()
 
 

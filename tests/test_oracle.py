@@ -184,3 +184,38 @@ def test_small_model_sizes_match_reference(size):
     fin = np.isfinite(g["heatmap"])
     assert np.array_equal(np.isfinite(hm.numpy()), fin)
     assert np.abs(hm.numpy()[fin] - g["heatmap"][fin]).max() < 1e-4 and np.abs(ft.numpy() - g["features"]).max() < 1e-4
+
+
+def test_train_mode_oracle_matches_reference():
+    """oracle/detector_oracle.py's training-mode forward (batch-statistics BatchNorm, StochasticDepth with the saved draw) and
+    SimpleDecoder in train() against the reference's own modules run in train() under no_grad (g9) -- the BN-refresh pass."""
+    from oracle import loss_oracle
+    g = np.load(os.path.join(G, "g9_train_forward.npz"))
+    B, H, W = 3, 128, 128
+    sd_full = deterministic_state_dict(0)
+    x = torch.from_numpy(synth.page_images(929, B, H, W)).permute(0, 3, 1, 2)
+    label, _ = synth.train_labels(930, B, H // 4, W // 4)
+    fmask = loss_oracle.get_fmask(torch.from_numpy(label))
+    assert np.array_equal(np.packbits(fmask.numpy()), g["fmask"])
+    keep = {str(n): torch.from_numpy(k) for n, k in zip(g["keep_names"], g["keep"])}
+    # every block the reference gave a StochasticDepth module that multiplies (p > 0, residual) is one of ours
+    sd_det = {k[len("detector."):]: v for k, v in sd_full.items() if k.startswith("detector.")}
+    res_blocks = set("detector." + p for p in detector_oracle.residual_blocks(sd_det))
+    assert res_blocks <= set(keep)
+    probs = detector_oracle.stochastic_depth_probs(sd_det)
+    for n, k in keep.items():
+        p = probs[n[len("detector."):]]
+        assert all(abs(float(v)) < 1e-9 or abs(float(v) - 1.0 / (1.0 - p)) < 1e-5 for v in k)
+    maps, feat, new = detector_oracle.detection_forward_train(sd_full, x, keep)
+    assert float((maps - torch.from_numpy(g["maps"])).abs().max()) < 2e-4
+    rows = feat.permute(0, 2, 3, 1).flatten(0, -2)[fmask]
+    dec, new_dec = detector_oracle.decoder_forward_train(sd_full, rows)
+    new = {"detector." + k: v for k, v in new.items()}
+    new.update(new_dec)
+    assert int(g["n_changed"]) == len(new)
+    for i, k in enumerate(g["stat_names"]):
+        want = torch.from_numpy(g[f"stat{i}"])
+        assert float((new[str(k)] - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), k
+    for j in range(3):
+        assert float((dec[j][torch.from_numpy(g["dec_rows"])] - torch.from_numpy(g[f"dec{j}_at"])).abs().max()) < 5e-3
+        assert float((torch.logsumexp(dec[j], 1) - torch.from_numpy(g[f"dec{j}_lse"])).abs().max()) < 5e-3

@@ -270,6 +270,7 @@ class TextDetectorModel(nn.Module):
     def __getstate__(self):
         st = dict(self.__dict__)
         st["_engine"] = None
+        st.pop("_train_forward", None)
         return st
 
     def __setstate__(self, st):
@@ -282,7 +283,7 @@ class TextDetectorModel(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k != "_engine":
+            if k not in ("_engine", "_train_forward"):
                 new.__dict__[k] = copy.deepcopy(v, memo)
         new._bind()
         return new
@@ -320,7 +321,17 @@ class TextDetectorModel(nn.Module):
         """(heatmap [B,9,h,w], [dec0, dec1, dec2]) -- detector forward, boolean-mask gather of the flattened NHWC feature map
         (``features.permute(0,2,3,1).flatten(0,-2)[fmask]``, models/detector.py:265-266) on the GPU, decoder on the gathered rows."""
         if self.training:
-            raise NotImplementedError("findtextcenternet_amd implements the eval-mode forward only; call .eval()")
+            # train() mode: batch-statistics BatchNorm + StochasticDepth, running statistics updated -- forward only (the reference's
+            # BN-refresh pass, train1.py:203-211, runs exactly this under torch.no_grad()).  There is no backward pass.
+            if torch.is_grad_enabled():
+                raise NotImplementedError("findtextcenternet_amd has no backward pass: the train()-mode forward runs under torch.no_grad() only "
+                                          "(BatchNorm refresh); call .eval() for inference")
+            from .train_forward import TrainForward
+            tf = self.__dict__.get("_train_forward")
+            if tf is None or tf.precision != self.detector.precision:
+                tf = TrainForward(self, self.detector.precision)
+                self.__dict__["_train_forward"] = tf
+            return tf.forward(x, fmask, keep=self.__dict__.get("stochastic_depth_keep"))
         from .loss_func import mask_to_index
         lib = L.load()
         heat, feat = self.detector.forward_nhwc(x, with_nms=False)

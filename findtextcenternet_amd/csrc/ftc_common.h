@@ -212,7 +212,7 @@ hipError_t launch_dwconv(const OpArgs& a, hipStream_t s);
 hipError_t launch_bnstat(const OpArgs& a, hipStream_t s);
 hipError_t launch_bnact(const OpArgs& a, hipStream_t s);
 // FTC_OP_BNSTAT: number of row chunks the partial sums are split into
-inline int ftc_bnstat_chunks(long M) { const long n = (M + 255) / 256; return (int)(n < 1 ? 1 : n > 64 ? 64 : n); }
+inline int ftc_bnstat_chunks(long M) { const long n = (M + 255) / 256; return (int)(n < 1 ? 1 : n > 512 ? 512 : n); }
 hipError_t launch_se(const OpArgs& a, hipStream_t s);
 hipError_t launch_upcat(const OpArgs& a, hipStream_t s);
 hipError_t launch_nms(const OpArgs& a, hipStream_t s);

@@ -152,15 +152,17 @@ class TrainForward:
         # BatchNorm with batch statistics (+ activation, keep-scale * branch + residual, SE sums) on z [B,h,w,c] fp32
         def bn(self, z, h, w, c, bn_name, eps, act, residual=None, keep=None, sums_p=0):
             M = self.B * h * w
-            nchunk = max(1, min(64, -(-M // 256)))
+            nchunk = max(1, min(512, -(-M // 256)))
             ss = ("ws", self.buf(2 * c * 4), 0)
             part = ("ws", self.buf(nchunk * 2 * c * 8), 0)
             self.emit(kind=L.OP_BNSTAT, in_dtype=L.F32, B=self.B, H=h, W=w, Cin=c, aux0=_fbits(eps), aux1=_fbits(0.1), in_=z, w=self.w(bn_name + ".weight"),
                       bias=self.w(bn_name + ".bias"), aux=self.w(bn_name + ".running"), out=ss, in2=part)
             y = ("ws", self.buf(M * c * 4), 0)
             sums = ("ws", self.buf(self.B * sums_p * c * 4), 0) if sums_p else None
+            # row chunks per image: few when the SE op has to read the partial sums, else enough workgroups to fill the GPU
+            rows_p = sums_p if sums_p else max(1, min(2048, (h * w) // 64))
             self.emit(kind=L.OP_BNACT, flags=L.FLAG_RESIDUAL if residual is not None else 0, act=act, in_dtype=L.F32, out_dtype=L.F32,
-                      w_dtype=L.F16 if self.tf.cdt == L.F16 else L.BF16, res_dtype=L.F32, B=self.B, H=h, W=w, Cin=c, aux0=sums_p, in_=z, scale=ss,
+                      w_dtype=L.F16 if self.tf.cdt == L.F16 else L.BF16, res_dtype=L.F32, B=self.B, H=h, W=w, Cin=c, aux0=rows_p, in_=z, scale=ss,
                       shift=("ws", ss[1], c * 4), in2=residual, w2=keep, out=y, aux=sums)
             return y, sums, ss
 
@@ -244,7 +246,7 @@ class TrainForward:
                 ti = n - 1 - lvl
                 # the head's input BatchNorm of the tap: statistics here, the affine applied by the upsample+concat kernel
                 M = B * th_ * tw_
-                nchunk = max(1, min(64, -(-M // 256)))
+                nchunk = max(1, min(512, -(-M // 256)))
                 ss = ("ws", g.buf(2 * tc * 4), 0)
                 g.emit(kind=L.OP_BNSTAT, in_dtype=L.F32, B=B, H=th_, W=tw_, Cin=tc, aux0=_fbits(HEAD_EPS), aux1=_fbits(0.1), in_=tx,
                        w=g.w(f"{hp}.in_bn.{ti}.weight"), bias=g.w(f"{hp}.in_bn.{ti}.bias"), aux=g.w(f"{hp}.in_bn.{ti}.running"), out=ss,

@@ -83,13 +83,13 @@ typedef enum ftc_op_kind {
        for FTC_OP_BNACT, and the running statistics aux = fp32 [2][Cin] (mean | var) updated in place:
        r = (1 - momentum) * r + momentum * batch value (the variance unbiased, as torch.nn.BatchNorm2d does).
        w = gamma, bias = beta (fp32 [Cin]); aux0 / aux1 = the bit patterns of the floats eps / momentum; in2 = scratch for the partial sums,
-       float64 [aux chunks = min(64, ceil(B*H*W / 256))][2][Cin] (2 launches: partial sums, finalize) */
+       float64 [chunks = min(512, ceil(B*H*W / 256))][2][Cin] (2 launches: partial sums, finalize) */
     FTC_OP_BNSTAT = 8,
     /* Training-mode BatchNorm, second half + activation (+ stochastic depth + residual): out[b,y,x,c] = act(in * scale[c] + shift[c]);
        with FTC_FLAG_RESIDUAL: out = out * w2[b] + in2 (w2 = fp32 [B] keep-scales of torchvision's StochasticDepth "row" mode, may be NULL = 1).
        in: fp32 or 16-bit [B,H,W,Cin]; scale / shift: fp32 [Cin] (the two halves of BNSTAT's output); out: out_dtype; out2: optional 16-bit
-       copy (w_dtype) when out is fp32; aux: optional fp32 [B][aux0][Cin] per-image partial channel sums of the result for the SE squeeze
-       (aux0 row chunks per image) */
+       copy (w_dtype) when out is fp32; aux0 = row chunks per image (the launch is B x aux0 x Cin/64 workgroups); aux: optional
+       fp32 [B][aux0][Cin] per-image partial channel sums of the result for the SE squeeze */
     FTC_OP_BNACT = 9,
     FTC_OP_TAPSUM = 7          /* second half of a 3x3 convolution split as per-pixel taps + 9-point sum (FTC_FLAG_TOP_FUSE):
                                   out[b,y,x,ch_j] = bias[j] + sum_{r,s} in[g_j][b,y+r-1,x+s-1][(3r+s)*co_j + o_j] (zero outside),

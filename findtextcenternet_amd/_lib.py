@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libftc_hip.so")
 
-FTC_ABI_VERSION = 3
+FTC_ABI_VERSION = 4
 F32, BF16, F16 = 0, 1, 2
 (BASE_NULL, BASE_WORKSPACE, BASE_WEIGHTS, BASE_INPUT, BASE_HEATMAP, BASE_FEATURES, NUM_BASES) = range(7)
 OP_STEM, OP_CONV, OP_DWCONV, OP_SE, OP_UPCAT, OP_NMS, OP_TAPSUM, OP_BNSTAT, OP_BNACT = 1, 2, 3, 4, 5, 6, 7, 8, 9

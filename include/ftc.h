@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define FTC_ABI_VERSION 3
+/* 4: FTC_OP_BNSTAT / FTC_OP_BNACT (training-mode BatchNorm); FTC_OP_STEM and FTC_OP_DWCONV honour act = FTC_ACT_NONE (they applied SiLU
+   unconditionally before); FTC_FLAG_W_FRAG */
+#define FTC_ABI_VERSION 4
 
 typedef enum ftc_status {
     FTC_OK = 0,

@@ -16,7 +16,9 @@ EXE = os.path.join(ROOT, "tests", "c_abi", "ftc_c_smoke")
 
 
 def _exe():
-    if not os.path.exists(EXE):
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ftc.h")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c_abi", "ftc_c_smoke.c")
+    if not os.path.exists(EXE) or any(os.path.exists(f) and os.path.getmtime(f) > os.path.getmtime(EXE) for f in (hdr, src)):
         import __graft_entry__
         __graft_entry__.build_c_client()
     return EXE

@@ -217,3 +217,35 @@ def test_train_mode_forward_matches_oracle_and_reference(precision, tol_maps, to
     with torch.no_grad():
         hm, _ = m(x, fmask)
     assert torch.isfinite(hm).all()
+
+
+@pytest.mark.parametrize("size", ["s", "m"])
+def test_train_mode_forward_small_models_vs_oracle(size):
+    """The training-mode op list is built from the state_dict alone: EfficientNetV2-S / -M backbones (other stage tables and tap widths,
+    models/detector.py:131-136) against the CPU oracle, fp32, random StochasticDepth draw supplied to both."""
+    from oracle import detector_oracle
+    B, H, W = 2, 128, 128
+    sd = deterministic_state_dict(0, model_size=size)
+    m = TextDetectorModel(pre_weights=False, precision="fp32", model_size=size)
+    m.load_state_dict(sd)
+    m = m.to("cuda").train()
+    x_cpu = torch.from_numpy(synth.page_images(31, B, H, W)).permute(0, 3, 1, 2)
+    label, _ = synth.train_labels(32, B, H // 4, W // 4)
+    sd_det = {k[len("detector."):]: v for k, v in sd.items() if k.startswith("detector.")}
+    probs = detector_oracle.stochastic_depth_probs(sd_det)
+    g = torch.Generator().manual_seed(33)
+    keep = {p: (torch.rand(B, generator=g) < 1.0 - probs[p]).float() / (1.0 - probs[p]) for p in detector_oracle.residual_blocks(sd_det)}
+    m.stochastic_depth_keep = keep
+    with torch.no_grad():
+        fmask = m.get_fmask(torch.from_numpy(label).cuda(), None)
+        maps, dec = m(x_cpu.cuda(), fmask)
+    o_maps, o_feat, new = detector_oracle.detection_forward_train(sd, x_cpu, {"detector." + k: v for k, v in keep.items()})
+    scale = float(o_maps.abs().max())
+    assert float((maps.cpu() - o_maps).abs().max()) < 1e-4 * max(1.0, scale)
+    got = {k: v.cpu() for k, v in m.state_dict().items()}
+    for k, v in new.items():
+        assert float((got["detector." + k] - v).abs().max()) <= 2e-4 * max(1.0, float(v.abs().max())), k
+    rows = o_feat.permute(0, 2, 3, 1).flatten(0, -2)[fmask.cpu()]
+    o_dec, _ = detector_oracle.decoder_forward_train(sd, rows)
+    for j in range(3):
+        assert float((dec[j].cpu() - o_dec[j]).abs().max()) < 2e-2 * max(1.0, float(o_dec[j].abs().max()))

@@ -12,23 +12,28 @@ namespace {
 // Stem: y = SiLU(conv3x3_s2(x*2-1, W') + b'), W'/b' = BN-folded.  Cin = 3, so K = 27: direct
 // convolution on the VALU; lanes = (pixel, channel quad) so a wave writes 1 KiB contiguous.
 // ------------------------------------------------------------------------------------------
-template <typename OutT, typename CopyT>
+// NQ = channel quads per lane: with 4 (C0 % 16 == 0) a lane loads the 27 input values once for 16 output channels instead of once per
+// quad (the kernel is load-instruction bound: 8 lanes per pixel re-read the same taps through L1).  FAST = the exp2/rcp SiLU of the 16-bit
+// modes (3e-7 relative); the fp32 parity mode keeps libm's expf.  The per-channel order of the 27 multiply-adds is the same in all forms.
+template <typename OutT, typename CopyT, int NQ, bool FAST>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                    const float* __restrict__ bias, OutT* __restrict__ out, CopyT* __restrict__ out2,
                                                    int B, int H, int W, int Ho, int Wo, int C0, int nchw, int act) {
     extern __shared__ __attribute__((aligned(16))) float sw[];   // [27][C0]
     for (int i = threadIdx.x; i < 27 * C0; i += blockDim.x) sw[i] = w[i];
     __syncthreads();
-    const int CQ = C0 >> 2;
-    const unsigned total = (unsigned)B * Ho * Wo * CQ;          // 32-bit index arithmetic (validated)
+    const int CG = C0 / (4 * NQ);
+    const unsigned total = (unsigned)B * Ho * Wo * CG;          // 32-bit index arithmetic (validated)
     for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const unsigned pix = idx / (unsigned)CQ;
-        const int cq = (int)(idx - pix * CQ);
+        const unsigned pix = idx / (unsigned)CG;
+        const int c0 = (int)(idx - pix * CG) * 4 * NQ;
         const unsigned row = pix / (unsigned)Wo;
         const int ox = (int)(pix - row * Wo);
         const int b = (int)(row / (unsigned)Ho);
         const int oy = (int)(row - (unsigned)b * Ho);
-        f32x4 acc = *reinterpret_cast<const f32x4*>(bias + cq * 4);
+        f32x4 acc[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = *reinterpret_cast<const f32x4*>(bias + c0 + 4 * q);
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int iy = oy * 2 - 1 + r;
@@ -41,18 +46,24 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ in,
                         const float v = nchw ? in[(((long)b * 3 + c) * H + iy) * W + ix]
                                              : in[(((long)b * H + iy) * W + ix) * 3 + c];
                         const float xv = v * 2.0f - 1.0f;                       // detector.py:218
-                        const f32x4 wv = *reinterpret_cast<const f32x4*>(sw + ((r * 3 + s) * 3 + c) * C0 + cq * 4);
-                        acc += xv * wv;
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) acc[q] += xv * *reinterpret_cast<const f32x4*>(sw + ((r * 3 + s) * 3 + c) * C0 + c0 + 4 * q);
                     }
                 }
             }
         }
-        if (act) {                                          // (act 0: the raw convolution, for the training-mode forward)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = act_silu_precise(acc[e]);
+        for (int q = 0; q < NQ; ++q) {
+            if (act) {                                      // (act 0: the raw convolution, for the training-mode forward)
+                if constexpr (FAST) acc[q] = act_silu_fast4(acc[q]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[q][e] = act_silu_precise(acc[q][e]);
+                }
+            }
+            store4<OutT>(out + (long)pix * C0 + c0 + 4 * q, acc[q]);
+            if (out2) store4<CopyT>(out2 + (long)pix * C0 + c0 + 4 * q, acc[q]);
         }
-        store4<OutT>(out + (long)pix * C0 + cq * 4, acc);
-        if (out2) store4<CopyT>(out2 + (long)pix * C0 + cq * 4, acc);
     }
 }
 
@@ -470,23 +481,25 @@ __global__ __launch_bounds__(256) void se_fc2_fold64_kernel(const float* __restr
 
 hipError_t launch_stem(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
-    const long total = (long)o.B * o.Ho * o.Wo * (o.Cout / 4);
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    const bool wide = o.Cout % 16 == 0;
+    const long total = (long)o.B * o.Ho * o.Wo * (o.Cout / (wide ? 16 : 4));
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     const size_t lds = (size_t)27 * o.Cout * sizeof(float);
     const int nchw = (o.flags & FTC_FLAG_IN_NCHW) ? 1 : 0;
-    // fp32 trunk output with an optional 16-bit copy in the plan's compute type (ftc_op.w_dtype: bf16 unless FTC_F16)
-    if (o.out_dtype == FTC_F32 && o.w_dtype == FTC_F16)
-        hipLaunchKernelGGL((stem_kernel<float, _Float16>), dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
-                           a.bias, (float*)a.out, (_Float16*)a.out2, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw, o.act != FTC_ACT_NONE ? 1 : 0);
-    else if (o.out_dtype == FTC_F32)
-        hipLaunchKernelGGL((stem_kernel<float, __bf16>), dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
-                           a.bias, (float*)a.out, (__bf16*)a.out2, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw, o.act != FTC_ACT_NONE ? 1 : 0);
-    else if (o.out_dtype == FTC_F16)
-        hipLaunchKernelGGL((stem_kernel<_Float16, _Float16>), dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
-                           a.bias, (_Float16*)a.out, (_Float16*)nullptr, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw, o.act != FTC_ACT_NONE ? 1 : 0);
-    else
-        hipLaunchKernelGGL((stem_kernel<__bf16, __bf16>), dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w,
-                           a.bias, (__bf16*)a.out, (__bf16*)nullptr, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw, o.act != FTC_ACT_NONE ? 1 : 0);
+    const int act = o.act != FTC_ACT_NONE ? 1 : 0;
+#define STEM_LAUNCH(OT, CT, NQ, FAST)                                                                                                        \
+    hipLaunchKernelGGL((stem_kernel<OT, CT, NQ, FAST>), dim3(blocks), dim3(256), lds, s, (const float*)a.in, (const float*)a.w, a.bias, (OT*)a.out, \
+                       (CT*)a.out2, o.B, o.H, o.W, o.Ho, o.Wo, o.Cout, nchw, act)
+#define STEM_WIDTH(OT, CT, FAST) do { if (wide) STEM_LAUNCH(OT, CT, 4, FAST); else STEM_LAUNCH(OT, CT, 1, FAST); } while (0)
+    // fp32 trunk output with an optional 16-bit copy in the plan's compute type (ftc_op.w_dtype: bf16 unless FTC_F16); a plan without
+    // a 16-bit copy or type is the fp32 parity mode (or the training-mode forward): libm's expf
+    if (o.out_dtype == FTC_F32 && o.w_dtype == FTC_F16) STEM_WIDTH(float, _Float16, true);
+    else if (o.out_dtype == FTC_F32 && a.out2) STEM_WIDTH(float, __bf16, true);
+    else if (o.out_dtype == FTC_F32) STEM_WIDTH(float, __bf16, false);
+    else if (o.out_dtype == FTC_F16) STEM_WIDTH(_Float16, _Float16, true);
+    else STEM_WIDTH(__bf16, __bf16, true);
+#undef STEM_WIDTH
+#undef STEM_LAUNCH
     return hipGetLastError();
 }
 

@@ -9,14 +9,16 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libftc_hip.so")
 
-FTC_ABI_VERSION = 4
+FTC_ABI_VERSION = 5
 F32, BF16, F16 = 0, 1, 2
-(BASE_NULL, BASE_WORKSPACE, BASE_WEIGHTS, BASE_INPUT, BASE_HEATMAP, BASE_FEATURES, NUM_BASES) = range(7)
+(BASE_NULL, BASE_WORKSPACE, BASE_WEIGHTS, BASE_INPUT, BASE_HEATMAP, BASE_FEATURES, BASE_GRADS, NUM_BASES) = range(8)
 OP_STEM, OP_CONV, OP_DWCONV, OP_SE, OP_UPCAT, OP_NMS, OP_TAPSUM, OP_BNSTAT, OP_BNACT = 1, 2, 3, 4, 5, 6, 7, 8, 9
+(OP_GATHER_ROWS, OP_LOSSES, OP_LOSS_BWD, OP_SCATTER_ROWS, OP_BNBWD, OP_WGRAD, OP_DWBWD, OP_SEBWD, OP_UPCATBWD, OP_DILATE, OP_TOPDGRAD, OP_COLSUM,
+ OP_STEMWGRAD, OP_FILL) = range(10, 24)
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 FLAG_RESIDUAL, FLAG_SE_SCALE, FLAG_IN_NCHW, FLAG_BORDER_BIAS, FLAG_W_PER_IMAGE, FLAG_SE_FOLD = 1, 2, 4, 8, 16, 32
 FLAG_GROUP_IN_SLICE, FLAG_GROUP_OUT_SLICE = 64, 128
-FLAG_TOP_FUSE, FLAG_UPCAT_IN, FLAG_GROUP_IN2_SHARED, FLAG_W_FRAG = 0x10000, 0x20000, 0x200000, 0x400000
+FLAG_TOP_FUSE, FLAG_UPCAT_IN, FLAG_GROUP_IN2_SHARED, FLAG_W_FRAG, FLAG_ACCUM = 0x10000, 0x20000, 0x200000, 0x400000, 0x800000
 
 EXPORTS = ["ftc_abi_version", "ftc_last_error", "ftc_device_info", "ftc_plan_create", "ftc_plan_destroy",
            "ftc_plan_num_ops", "ftc_plan_run", "ftc_plan_profile", "ftc_op_kernel_label", "ftc_decode_scratch_bytes", "ftc_decode", "ftc_tile_gather", "ftc_paste_maps",
@@ -24,7 +26,7 @@ EXPORTS = ["ftc_abi_version", "ftc_last_error", "ftc_device_info", "ftc_plan_cre
            "ftc_create", "ftc_destroy", "ftc_weights_bytes", "ftc_weights_host", "ftc_weights_offset", "ftc_workspace_bytes", "ftc_forward",
            "ftc_model_plan", "ftc_model_op_info", "ftc_plan_op",
            "ftc_topk_mask", "ftc_mask_compact", "ftc_gather_rows", "ftc_decoder_workspace_bytes", "ftc_decoder_forward",
-           "ftc_losses_scratch_bytes", "ftc_losses", "ftc_cov_weighting_step"]
+           "ftc_losses_scratch_bytes", "ftc_losses", "ftc_cov_weighting_step", "ftc_pack_train_weights", "ftc_wgrad_splits"]
 
 
 class FtcLibraryError(RuntimeError):
@@ -61,6 +63,11 @@ class OpInfo(C.Structure):
 
 class MtChunk(C.Structure):
     _fields_ = [("y", C.c_void_p), ("g", C.c_void_p), ("v", C.c_void_p), ("z", C.c_void_p), ("n", C.c_int32), ("reserved", C.c_int32)]
+
+
+class PackEntry(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("fwd", C.c_void_p), ("dgrad", C.c_void_p)] + [
+        (n, C.c_int32) for n in ("Cout", "Cin", "kk", "cin_pad", "cout_pad", "dtype", "reserved0", "reserved1")]
 
 
 class Tile(C.Structure):
@@ -128,6 +135,8 @@ def load():
     lib.ftc_losses_scratch_bytes.restype = i64
     lib.ftc_losses.argtypes = [vp, C.POINTER(i64), vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp, vp, vp]
     lib.ftc_cov_weighting_step.argtypes = [vp, i32, i32, vp, vp, vp]
+    lib.ftc_pack_train_weights.argtypes = [vp, i32, i64, vp]
+    lib.ftc_wgrad_splits.argtypes = [i32] * 6
     if lib.ftc_abi_version() != FTC_ABI_VERSION:
         raise FtcLibraryError(f"ABI mismatch: library {lib.ftc_abi_version()} vs binding {FTC_ABI_VERSION}")
     _lib = lib

@@ -32,6 +32,19 @@ hipError_t launch_losses(const float* heat, const long* hstrides, const float* l
 hipError_t launch_cov_step(const float* L, int n, int iter, float* state, float* out_loss, hipStream_t s);
 
 namespace {
+// FTC_OP_LOSSES: ftc_losses on the NHWC [B,H,W,9] map block of the training plan
+hipError_t launch_losses_op(const OpArgs& a, hipStream_t s) {
+    const ftc_op& o = *a.op;
+    const long hs[4] = {(long)o.H * o.W * 9, 1, (long)o.W * 9, 9};
+    static const int mod[3] = {1091, 1093, 1097};                   // util_func.py:5 modulo_list
+    const float* dec[3] = {(const float*)a.w2, a.bias, a.bias2};
+    const bool has_dec = a.w2 && a.bias && a.bias2 && o.aux0 > 0;
+    return launch_losses((const float*)a.in, hs, (const float*)a.in2, (const int32_t*)a.w, o.B, o.H, o.W, has_dec ? dec : nullptr, mod,
+                         (const int32_t*)a.scale, nullptr, (long)o.aux0, (float*)a.out, a.aux, s);
+}
+}  // namespace
+
+namespace {
 
 thread_local std::string g_err;
 
@@ -154,7 +167,7 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if (o.Cin <= 0) return "bnstat: Cin must be positive";
         if (o.in_dtype != FTC_F32 && !ftc_is16(o.in_dtype)) return "bnstat: unknown dtype";
         const int64_t M = pin;
-        if (!need(o.in, true, "in", M * o.Cin * es(o.in_dtype)) || !need(o.out, true, "out", (int64_t)2 * o.Cin * 4) || !need(o.w, true, "w", (int64_t)o.Cin * 4) ||
+        if (!need(o.in, true, "in", M * o.Cin * es(o.in_dtype)) || !need(o.out, true, "out", (int64_t)4 * o.Cin * 4) || !need(o.w, true, "w", (int64_t)o.Cin * 4) ||
             !need(o.bias, true, "bias", (int64_t)o.Cin * 4) || !need(o.aux, false, "aux", (int64_t)2 * o.Cin * 4) ||
             !need(o.in2, true, "in2", (int64_t)ftc_bnstat_chunks(M) * 2 * o.Cin * 8)) return why->c_str();
         return nullptr;
@@ -176,6 +189,94 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
     case FTC_OP_NMS:
         if (!need(o.out, true, "out")) return why->c_str();
         if (o.Cout_total < 2) return "nms: heat-map needs >= 2 channels";
+        return nullptr;
+    case FTC_OP_GATHER_ROWS:
+        if (o.aux0 <= 0 || o.Cin <= 0 || (o.Cin & 3) || o.Cout_total < o.Cin || (o.Cout_total & 7)) return "gather_rows: need aux0 > 0, Cin % 4 == 0, Cout_total >= Cin, Cout_total % 8 == 0";
+        if (!need(o.in, true, "in", pin * o.Cin * 4) || !need(o.in2, true, "in2", (int64_t)o.aux0 * 4) || !need(o.out, true, "out", (int64_t)o.aux0 * o.Cout_total * 4)) return why->c_str();
+        return nullptr;
+    case FTC_OP_LOSSES:
+    case FTC_OP_LOSS_BWD: {
+        const int64_t hw = (int64_t)o.H * o.W;
+        if (!need(o.in, true, "in", pin * 9 * 4) || !need(o.in2, true, "in2", o.B * 5 * hw * 4) || !need(o.w, true, "w", o.B * 2 * hw * 4)) return why->c_str();
+        if (o.aux0 < 0) return "losses: aux0 (selected rows) must be >= 0";
+        if (o.aux0 > 0 && (!need(o.w2, true, "w2", (int64_t)o.aux0 * 1091 * 4) || !need(o.bias, true, "bias", (int64_t)o.aux0 * 1093 * 4) ||
+                           !need(o.bias2, true, "bias2", (int64_t)o.aux0 * 1097 * 4) || !need(o.scale, true, "scale", (int64_t)o.aux0 * 4))) return why->c_str();
+        if (o.kind == FTC_OP_LOSSES) {
+            if (!need(o.out, true, "out", 64) || !need(o.aux, true, "aux", ftc_losses_scratch_bytes())) return why->c_str();
+        } else {
+            if (!need(o.out, true, "out", pin * 9 * 4) || !need(o.shift, true, "shift", 36) || !need(o.aux, true, "aux", 64)) return why->c_str();
+            if (o.aux0 > 0 && (o.aux1 < 1097 || (o.aux1 & 3) || !need(o.out2, true, "out2", (int64_t)3 * o.aux0 * o.aux1 * 4))) return "loss_bwd: out2 / aux1 (padded logit row >= 1097, % 4 == 0)";
+        }
+        return nullptr;
+    }
+    case FTC_OP_SCATTER_ROWS:
+        if (o.aux0 <= 0 || o.Cout_total <= 0 || (o.Cout_total & 3)) return "scatter_rows: need aux0 > 0 and Cout_total % 4 == 0";
+        if (!need(o.in, true, "in", (int64_t)o.aux0 * o.Cout_total * 4) || !need(o.in2, true, "in2", (int64_t)o.aux0 * 4) || !need(o.out, true, "out", pin * o.Cout_total * 4)) return why->c_str();
+        return nullptr;
+    case FTC_OP_BNBWD: {
+        if (o.Cin <= 0 || (o.Cin & 3)) return "bnbwd: Cin must be a positive multiple of 4";
+        const int64_t gs = o.Cin_total > 0 ? o.Cin_total : o.Cin;
+        if ((gs & 3) || (o.cin_off & 3) || o.cin_off + o.Cin > gs) return "bnbwd: bad channel slice of the incoming gradient";
+        if (o.act != FTC_ACT_NONE && o.act != FTC_ACT_SILU && o.act != FTC_ACT_GELU) return "bnbwd: unknown activation";
+        if (!need(o.in, true, "in", pin * gs * 4) || !need(o.in2, true, "in2", pin * o.Cin * 4) || !need(o.scale, true, "scale", (int64_t)4 * o.Cin * 4) ||
+            !need(o.out, true, "out", pin * o.Cin * 4) || !need(o.w, false, "w", (int64_t)o.Cin * 4) || !need(o.shift, false, "shift", (int64_t)o.Cin * 4) ||
+            !need(o.w2, false, "w2", (int64_t)o.B * 4) || !need(o.bias, false, "bias", (int64_t)o.B * o.Cin * 4) || !need(o.bias2, false, "bias2", (int64_t)o.B * o.Cin * 4) ||
+            !need(o.aux, true, "aux", (int64_t)ftc_bnstat_chunks(pin) * 2 * o.Cin * 8 + (int64_t)2 * o.Cin * 4)) return why->c_str();
+        return nullptr;
+    }
+    case FTC_OP_WGRAD: {
+        if (o.Cin <= 0 || o.Cout <= 0 || o.Ho <= 0 || o.Wo <= 0 || (o.ksize != 1 && o.ksize != 3) || (o.stride != 1 && o.stride != 2)) return "wgrad: bad sizes";
+        if (o.w_dtype != FTC_F32 && !ftc_is16(o.w_dtype)) return "wgrad: unknown compute type";
+        const int pad = (o.ksize - 1) / 2;
+        if (o.Ho != (o.H + 2 * pad - o.ksize) / o.stride + 1 || o.Wo != (o.W + 2 * pad - o.ksize) / o.stride + 1) return "wgrad: Ho/Wo inconsistent";
+        const int64_t cit = o.Cin_total > 0 ? o.Cin_total : o.Cin, cot = o.Cout_total > 0 ? o.Cout_total : o.Cout;
+        if (o.cin_off + o.Cin > cit || o.cout_off + o.Cout > cot || o.aux0 < 1 || o.aux0 > 4096) return "wgrad: channel slices / splits out of range";
+        const int64_t kk = (int64_t)o.ksize * o.ksize;
+        if (!need(o.in, true, "in", pin * cit * 4) || !need(o.in2, true, "in2", pout * cot * 4) || !need(o.out, true, "out", kk * o.Cout * o.Cin * 4) ||
+            !need(o.aux, true, "aux", (int64_t)o.aux0 * kk * o.Cout * o.Cin * 4) || !need(o.scale, (o.flags & FTC_FLAG_SE_SCALE) != 0, "scale", (int64_t)o.B * o.Cin * 4)) return why->c_str();
+        return nullptr;
+    }
+    case FTC_OP_DWBWD:
+        if (o.Cin <= 0 || (o.Cin & 3) || (o.stride != 1 && o.stride != 2)) return "dwbwd: Cin % 4 == 0, stride 1 | 2";
+        if (o.Ho != (o.H - 1) / o.stride + 1 || o.Wo != (o.W - 1) / o.stride + 1) return "dwbwd: Ho/Wo inconsistent";
+        if (!need(o.in, true, "in", pin * o.Cin * 4) || !need(o.in2, true, "in2", pout * o.Cin * 4) || !need(o.w, true, "w", (int64_t)9 * o.Cin * 4) ||
+            !need(o.out, true, "out", pin * o.Cin * 4) || !need(o.out2, true, "out2", (int64_t)9 * o.Cin * 4) ||
+            !need(o.aux, true, "aux", (int64_t)ftc_bnstat_chunks(pout) * 9 * o.Cin * 8)) return why->c_str();
+        return nullptr;
+    case FTC_OP_SEBWD:
+        if (o.Cin <= 0 || o.aux0 <= 0 || o.aux1 <= 0) return "sebwd: C, S, P must be positive";
+        if ((size_t)(2 * o.Cin + 2 * o.aux0) * 4 > 64000) return "sebwd: C / S too large for LDS";
+        if (!need(o.in, true, "in", pin * o.Cin * 4) || !need(o.in2, true, "in2", pin * o.Cin * 4) || !need(o.scale, true, "scale", (int64_t)o.B * o.Cin * 4) ||
+            !need(o.aux, true, "aux", (int64_t)o.B * o.aux1 * o.Cin * 4) || !need(o.w, true, "w", (int64_t)o.aux0 * o.Cin * 4) || !need(o.w2, true, "w2", (int64_t)o.aux0 * o.Cin * 4) ||
+            !need(o.bias, true, "bias", (int64_t)o.aux0 * 4) || !need(o.out, true, "out", ((int64_t)4 * o.B * o.Cin + (int64_t)2 * o.B * o.aux0) * 4) ||
+            !need(o.out2, true, "out2", ((int64_t)2 * o.aux0 * o.Cin + o.aux0 + o.Cin) * 4)) return why->c_str();
+        return nullptr;
+    case FTC_OP_UPCATBWD:
+        if (o.aux0 <= 0 || (o.aux0 & 3) || o.Cin_total < o.aux0 || (o.Cin_total & 3) || o.Ho <= 0 || o.Wo <= 0) return "upcatbwd: bad channel counts";
+        if (!need(o.in, true, "in", pout * o.Cin_total * 4) || !need(o.out, true, "out", pin * o.aux0 * 4)) return why->c_str();
+        return nullptr;
+    case FTC_OP_DILATE:
+        if (o.Cin <= 0 || (o.Cin & 3) || o.Ho != 2 * o.H || o.Wo != 2 * o.W) return "dilate: Cin % 4 == 0, Ho = 2H, Wo = 2W";
+        if (!need(o.in, true, "in", pin * o.Cin * 4) || !need(o.out, true, "out", pout * o.Cin * 4)) return why->c_str();
+        return nullptr;
+    case FTC_OP_TOPDGRAD:
+        if (o.Cin <= 0 || o.Cin > 8 || o.Cout <= 0 || (o.Cout & 3) || o.cin_off + o.Cin > o.Cin_total) return "topdgrad: 1..8 gradient channels, Cout % 4 == 0";
+        if (!need(o.in, true, "in", pin * o.Cin_total * 4) || !need(o.w, true, "w", (int64_t)o.Cin * 9 * o.Cout * es(o.w_dtype)) || !need(o.out, true, "out", pin * o.Cout * 4)) return why->c_str();
+        return nullptr;
+    case FTC_OP_COLSUM: {
+        const int64_t ct = o.Cin_total > 0 ? o.Cin_total : o.Cin;
+        if (o.Cin <= 0 || o.cin_off + o.Cin > ct) return "colsum: bad column slice";
+        if (!need(o.in, true, "in", pin * ct * 4) || !need(o.out, true, "out", (int64_t)o.Cin * 4) || !need(o.aux, true, "aux", (int64_t)ftc_bnstat_chunks(pin) * o.Cin * 8)) return why->c_str();
+        return nullptr;
+    }
+    case FTC_OP_STEMWGRAD:
+        if (o.Cout <= 0 || o.Cout > 32 || o.Ho != (o.H - 1) / 2 + 1 || o.Wo != (o.W - 1) / 2 + 1) return "stemwgrad: Cout <= 32, Ho/Wo of a stride-2 3x3";
+        if (!need(o.in, true, "in") || !need(o.in2, true, "in2", pout * o.Cout * 4) || !need(o.out, true, "out", (int64_t)27 * o.Cout * 4) ||
+            !need(o.aux, true, "aux", (int64_t)ftc_stemwgrad_chunks(pout) * 27 * o.Cout * 8)) return why->c_str();
+        return nullptr;
+    case FTC_OP_FILL:
+        if (o.Cin <= 0) return "fill: Cin must be positive";
+        if (!need(o.out, true, "out", pin * o.Cin * 4)) return why->c_str();
         return nullptr;
     default:
         return "unknown op kind";
@@ -211,6 +312,20 @@ hipError_t run_one(const ftc_op& o, void* const bases[FTC_NUM_BASES], hipStream_
     case FTC_OP_TAPSUM: return launch_tapsum(a, s);
     case FTC_OP_BNSTAT: return launch_bnstat(a, s);
     case FTC_OP_BNACT: return launch_bnact(a, s);
+    case FTC_OP_GATHER_ROWS: return launch_gather_rows_op(a, s);
+    case FTC_OP_LOSSES: return launch_losses_op(a, s);
+    case FTC_OP_LOSS_BWD: return launch_loss_bwd(a, s);
+    case FTC_OP_SCATTER_ROWS: return launch_scatter_rows(a, s);
+    case FTC_OP_BNBWD: return launch_bnbwd(a, s);
+    case FTC_OP_WGRAD: return launch_wgrad(a, s);
+    case FTC_OP_DWBWD: return launch_dwbwd(a, s);
+    case FTC_OP_SEBWD: return launch_sebwd(a, s);
+    case FTC_OP_UPCATBWD: return launch_upcatbwd(a, s);
+    case FTC_OP_DILATE: return launch_dilate(a, s);
+    case FTC_OP_TOPDGRAD: return launch_topdgrad(a, s);
+    case FTC_OP_COLSUM: return launch_colsum(a, s);
+    case FTC_OP_STEMWGRAD: return launch_stemwgrad(a, s);
+    case FTC_OP_FILL: return launch_fill(a, s);
     default: return hipErrorInvalidValue;
     }
 }
@@ -309,6 +424,20 @@ int ftc_op_kernel_label(const ftc_op* op, char* buf, int len) {
     case FTC_OP_TAPSUM: std::snprintf(buf, len, "tapsum_kernel"); break;
     case FTC_OP_BNSTAT: std::snprintf(buf, len, "bnstat_partial+final<%s>", ftc_dtname(op->in_dtype)); break;
     case FTC_OP_BNACT: std::snprintf(buf, len, "bnact_kernel<%s,%s>", ftc_dtname(op->in_dtype), ftc_dtname(op->out_dtype)); break;
+    case FTC_OP_GATHER_ROWS: std::snprintf(buf, len, "gather_rows_kernel"); break;
+    case FTC_OP_LOSSES: std::snprintf(buf, len, "map_loss+id_loss+finish"); break;
+    case FTC_OP_LOSS_BWD: std::snprintf(buf, len, "maploss_bwd+idloss_bwd"); break;
+    case FTC_OP_SCATTER_ROWS: std::snprintf(buf, len, "scatter_rows_kernel"); break;
+    case FTC_OP_BNBWD: std::snprintf(buf, len, "bnbwd_partial+final+apply"); break;
+    case FTC_OP_WGRAD: std::snprintf(buf, len, "wgrad_kernel<%s,k%d,s%d>+reduce", ftc_dtname(op->w_dtype), op->ksize, op->stride); break;
+    case FTC_OP_DWBWD: std::snprintf(buf, len, "dwbwd_data+weight<s%d>", op->stride); break;
+    case FTC_OP_SEBWD: std::snprintf(buf, len, "sebwd_ds+mlp+w"); break;
+    case FTC_OP_UPCATBWD: std::snprintf(buf, len, "upcatbwd_kernel"); break;
+    case FTC_OP_DILATE: std::snprintf(buf, len, "dilate_kernel"); break;
+    case FTC_OP_TOPDGRAD: std::snprintf(buf, len, "topdgrad_kernel<%s>", ftc_dtname(op->w_dtype)); break;
+    case FTC_OP_COLSUM: std::snprintf(buf, len, "colsum_partial+final"); break;
+    case FTC_OP_STEMWGRAD: std::snprintf(buf, len, "stemwgrad_partial+final"); break;
+    case FTC_OP_FILL: std::snprintf(buf, len, "memset"); break;
     default: return fail(FTC_ERR_INVALID, "ftc_op_kernel_label: unknown op kind");
     }
     return FTC_OK;
@@ -443,6 +572,18 @@ int ftc_gather_rows(const float* features, const int32_t* sel_index, const int32
     hipError_t e = launch_gather_rows(features, sel_index, count, (long)cap, C, c_pad, rows, out_dtype, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(e, "ftc_gather_rows");
     return FTC_OK;
+}
+
+int ftc_pack_train_weights(const ftc_pack_entry* entries_dev, int n_entries, int64_t max_elems, void* stream) {
+    if (!entries_dev || n_entries <= 0 || n_entries > 65535 || max_elems <= 0) return fail(FTC_ERR_INVALID, "ftc_pack_train_weights: need 1..65535 entries and max_elems > 0");
+    hipError_t e = launch_pack_train(entries_dev, n_entries, (long)max_elems, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "ftc_pack_train_weights");
+    return FTC_OK;
+}
+
+int ftc_wgrad_splits(int B, int Ho, int Wo, int Cout, int Cin, int ksize) {
+    if (B <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return 1;
+    return ftc_wgrad_splits_impl(B, Ho, Wo, Cout, Cin, ksize);
 }
 
 int64_t ftc_losses_scratch_bytes(void) { return (int64_t)(512 * 9 + 512 * 4) * 8; }

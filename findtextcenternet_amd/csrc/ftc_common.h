@@ -213,6 +213,23 @@ hipError_t launch_bnstat(const OpArgs& a, hipStream_t s);
 hipError_t launch_bnact(const OpArgs& a, hipStream_t s);
 // FTC_OP_BNSTAT: number of row chunks the partial sums are split into
 inline int ftc_bnstat_chunks(long M) { const long n = (M + 255) / 256; return (int)(n < 1 ? 1 : n > 512 ? 512 : n); }
+inline int ftc_stemwgrad_chunks(long M) { const long n = (M + 255) / 256; return (int)(n < 1 ? 1 : n > 2048 ? 2048 : n); }
+// train step (bwd_ops.hip, wgrad.hip)
+hipError_t launch_bnbwd(const OpArgs& a, hipStream_t s);
+hipError_t launch_wgrad(const OpArgs& a, hipStream_t s);
+hipError_t launch_dwbwd(const OpArgs& a, hipStream_t s);
+hipError_t launch_sebwd(const OpArgs& a, hipStream_t s);
+hipError_t launch_upcatbwd(const OpArgs& a, hipStream_t s);
+hipError_t launch_dilate(const OpArgs& a, hipStream_t s);
+hipError_t launch_topdgrad(const OpArgs& a, hipStream_t s);
+hipError_t launch_colsum(const OpArgs& a, hipStream_t s);
+hipError_t launch_stemwgrad(const OpArgs& a, hipStream_t s);
+hipError_t launch_fill(const OpArgs& a, hipStream_t s);
+hipError_t launch_gather_rows_op(const OpArgs& a, hipStream_t s);
+hipError_t launch_scatter_rows(const OpArgs& a, hipStream_t s);
+hipError_t launch_loss_bwd(const OpArgs& a, hipStream_t s);
+hipError_t launch_pack_train(const ftc_pack_entry* entries, int n, long max_elems, hipStream_t s);
+int ftc_wgrad_splits_impl(int B, int Ho, int Wo, int Cout, int Cin, int ksize);
 hipError_t launch_se(const OpArgs& a, hipStream_t s);
 hipError_t launch_upcat(const OpArgs& a, hipStream_t s);
 hipError_t launch_nms(const OpArgs& a, hipStream_t s);

@@ -213,7 +213,7 @@ struct IdLossP {
 __global__ __launch_bounds__(256) void id_loss_kernel(IdLossP p, double* __restrict__ partial /* [gridDim.x][4] */) {
     __shared__ double red[4][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long n = *p.count < p.cap ? *p.count : p.cap;
+    const long n = p.count ? (*p.count < p.cap ? *p.count : p.cap) : p.cap;       // count == NULL: all `cap` rows are selected
     double a_ce = 0.0, a_w = 0.0, a_ok = 0.0, a_tot = 0.0;
     for (long r = (long)blockIdx.x * 4 + wave; r < n; r += (long)gridDim.x * 4) {
         const long px = p.sel_index[r];
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void id_loss_kernel(IdLossP p, double* __restr
     if (threadIdx.x < 4) partial[(long)blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
 }
 
-// out[0..13) = loss, keymap, size, textline, separator, id, code1, code2, code4, code8, correct, total, reserved
+// out[0..14) = loss, keymap, size, textline, separator, id, code1, code2, code4, code8, correct, total, max(1, sum w1), max(1, sum w3)
 __global__ void finish_losses_kernel(const double* __restrict__ map_partial, int n_map, const double* __restrict__ id_partial, int n_id,
                                      double n_pixels, float* __restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -271,7 +271,9 @@ __global__ void finish_losses_kernel(const double* __restrict__ map_partial, int
     float total = keymap + size + textline + sep + idl;
     for (int k = 0; k < 4; ++k) { out[6 + k] = (float)(s[5 + k] / n_pixels); total += out[6 + k]; }
     out[0] = total; out[1] = keymap; out[2] = size; out[3] = textline; out[4] = sep; out[5] = idl;
-    out[10] = (float)d[2]; out[11] = (float)d[3]; out[12] = 0.f;
+    out[10] = (float)d[2]; out[11] = (float)d[3];
+    out[12] = (float)fmax(1.0, s[2]);                               // the two normalisers, for FTC_OP_LOSS_BWD
+    out[13] = n_id > 0 ? (float)fmax(1.0, d[1]) : 1.0f;
 }
 
 // CoVWeightingLoss.forward (loss_func.py:24-72) for n <= 16 losses; state = [mean_L, mean_l, S_l, std_l][16] floats + alphas[16].
@@ -348,6 +350,8 @@ __global__ __launch_bounds__(256) void bnstat_final_kernel(const double* __restr
     const double sc = (double)gamma[c] / sqrt(var + (double)eps);
     out[c] = (float)sc;
     out[C + c] = (float)((double)beta[c] - mean * sc);
+    out[2 * C + c] = (float)mean;                                   // for FTC_OP_BNBWD
+    out[3 * C + c] = (float)(1.0 / sqrt(var + (double)eps));
     if (running) {
         const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
         running[c] = (float)((1.0 - (double)momentum) * (double)running[c] + (double)momentum * mean);
@@ -462,7 +466,7 @@ hipError_t launch_losses(const float* heat, const long* hstrides, const float* l
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     int nb_id = 0;
-    if (dec && sel_index && count && cap > 0) {
+    if (dec && sel_index && cap > 0) {
         IdLossP ip{{dec[0], dec[1], dec[2]}, {mod[0], mod[1], mod[2]}, sel_index, count, cap, label, idmap, (long)h * w};
         nb_id = (int)((cap + 3) / 4 < 512 ? (cap + 3) / 4 : 512);
         hipLaunchKernelGGL(id_loss_kernel, dim3(nb_id), dim3(256), 0, s, ip, id_partial);

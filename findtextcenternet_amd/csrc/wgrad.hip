@@ -1,0 +1,270 @@
+// FTC_OP_WGRAD: weight gradient of a dense 1x1 / 3x3 convolution (stride 1 | 2) on the matrix cores -- the half of
+// `loss.backward()` (/root/reference/train1.py:170-179) that autograd spends in conv2d's weight gradient.
+//
+//   dW[co][tap][ci] = sum over output pixels p of  dZ[p][co] * X[p @ tap][ci]          (X zero outside the image)
+//
+// A GEMM whose CONTRACTION runs over pixels, i.e. over the slow axis of both NHWC operands ("TN" form).  The operands are fp32 in
+// HBM (the training-mode plan keeps activations fp32), so they are register-staged anyway: a lane loads 4 consecutive channels of 8
+// consecutive pixels, narrows them to the MFMA operand type and writes four 16-byte, pixel-contiguous rows into LDS -- the transpose
+// happens in the registers of the staging pass, and the MFMA fragments are plain ds_read_b128 of [channel][8 pixels].
+// Grid = (Cout tiles, Cin tiles x taps, pixel splits): every workgroup reduces its pixel range for one (tile, tap) and writes an
+// fp32 partial tile; wgrad_reduce_kernel sums the splits in a fixed order (deterministic) and ADDS the result to the gradient buffer
+// in the PyTorch layout [Cout][Cin][k][k].
+#include "ftc_common.h"
+
+namespace {
+
+template <typename WT> struct WFrag;
+template <> struct WFrag<__bf16> { using type = bf16x8; };
+template <> struct WFrag<_Float16> { using type = f16x8; };
+
+struct WgradP {
+    const float* x; const float* dz; const float* se; float* part;
+    int B, H, W, Ho, Wo, Cin, CinT, cin_off, Cout, CoutT, cout_off, KS, stride, pad;
+    long P;          // B * Ho * Wo
+    long chunk;      // pixels per split (multiple of BK)
+};
+
+template <typename WT> __device__ __forceinline__ WT narrow(float v);
+template <> __device__ __forceinline__ float narrow<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 narrow<__bf16>(float v) { return (__bf16)v; }
+template <> __device__ __forceinline__ _Float16 narrow<_Float16>(float v) { return (_Float16)f16_sat(v); }
+
+// 4 consecutive channels c..c+3 of row `row` (channel stride CT, offset off), zero beyond C
+__device__ __forceinline__ f32x4 load_ch4(const float* base, long row, int CT, int off, int c, int C, bool vec_ok) {
+    const float* q = base + row * CT + off + c;
+    if (vec_ok && c + 3 < C) return *reinterpret_cast<const f32x4*>(q);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (c + e < C) v[e] = q[e];
+    return v;
+}
+
+// component j of 8 staged pixels -> 8 consecutive K elements of one LDS row (16-byte stores)
+__device__ __forceinline__ void put8(float* dst, const f32x4 (&r)[8], int j) {
+    *reinterpret_cast<f32x4*>(dst) = f32x4{r[0][j], r[1][j], r[2][j], r[3][j]};
+    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{r[4][j], r[5][j], r[6][j], r[7][j]};
+}
+__device__ __forceinline__ void put8(__bf16* dst, const f32x4 (&r)[8], int j) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (__bf16)r[i][j];
+    *reinterpret_cast<bf16x8*>(dst) = v;
+}
+__device__ __forceinline__ void put8(_Float16* dst, const f32x4 (&r)[8], int j) {
+    f16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (_Float16)f16_sat(r[i][j]);
+    *reinterpret_cast<f16x8*>(dst) = v;
+}
+
+template <typename WT, int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
+    constexpr int BK = sizeof(WT) == 4 ? 32 : 64;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int LD = BK + 16 / (int)sizeof(WT);             // row stride in elements: 144 bytes -> conflict-free ds_read_b128 fragments
+    constexpr int OCT = BK / 8;                                // pixel octets per K step
+    __shared__ __attribute__((aligned(16))) WT As[BM * LD];
+    __shared__ __attribute__((aligned(16))) WT Bs[BN * LD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int KK = p.KS * p.KS;
+    const int mt = blockIdx.x, nt = blockIdx.y / KK, tap = blockIdx.y - nt * KK, split = blockIdx.z;
+    const int tr = tap / p.KS, ts = tap - tr * p.KS;
+    const long k0 = (long)split * p.chunk, k1 = k0 + p.chunk < p.P ? k0 + p.chunk : p.P;
+    const bool a_vec = (p.CoutT % 4 == 0) && (p.cout_off % 4 == 0);
+    const bool b_vec = (p.CinT % 4 == 0) && (p.cin_off % 4 == 0);
+    const bool plain = p.KS == 1 && p.stride == 1;
+    const int HoWo = p.Ho * p.Wo;
+    // staging tasks: (channel quad, pixel octet); one per thread at most (BM, BN <= 128)
+    const bool a_on = t < (BM / 4) * OCT, b_on = t < (BN / 4) * OCT;
+    const int a_cq = t % (BM / 4), a_po = t / (BM / 4);
+    const int b_cq = t % (BN / 4), b_po = t / (BN / 4);
+    const int m0 = mt * BM + a_cq * 4, n0 = nt * BN + b_cq * 4;
+    f32x4 ra[8], rb[8];
+
+    auto fetch = [&](long kb) {
+        if (a_on) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long pix = kb + a_po * 8 + i;
+                ra[i] = (pix < k1 && m0 < p.Cout) ? load_ch4(p.dz, pix, p.CoutT, p.cout_off, m0, p.Cout, a_vec) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        if (b_on) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long pix = kb + b_po * 8 + i;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (pix < k1 && n0 < p.Cin) {
+                    long row;
+                    int b;
+                    bool ok = true;
+                    if (plain) {
+                        row = pix;
+                        b = (int)(pix / HoWo);
+                    } else {
+                        b = (int)(pix / HoWo);
+                        const int rem = (int)(pix - (long)b * HoWo);
+                        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                        const int iy = oy * p.stride + tr - p.pad, ix = ox * p.stride + ts - p.pad;
+                        ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                        row = ((long)b * p.H + iy) * p.W + ix;
+                    }
+                    if (ok) {
+                        v = load_ch4(p.x, row, p.CinT, p.cin_off, n0, p.Cin, b_vec);
+                        if (p.se) v *= load_ch4(p.se, b, p.Cin, 0, n0, p.Cin, (p.Cin & 3) == 0);
+                    }
+                }
+                rb[i] = v;
+            }
+        }
+    };
+    auto stage = [&]() {
+        if (a_on) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) put8(As + (a_cq * 4 + j) * LD + a_po * 8, ra, j);
+        }
+        if (b_on) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) put8(Bs + (b_cq * 4 + j) * LD + b_po * 8, rb, j);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fr = lane & 31, fk = (lane >> 5) * 8;
+    if (k0 < k1) fetch(k0);
+    for (long kb = k0; kb < k1; kb += BK) {
+        stage();
+        __syncthreads();
+        if (kb + BK < k1) fetch(kb + BK);                       // in flight behind the MFMAs of this step
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            if constexpr (sizeof(WT) == 4) {
+                f32x4 af[TM][2], bf[TN][2];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float* q = As + ((wm * TM + i) * 32 + fr) * LD + kk * 16 + fk;
+                    af[i][0] = *reinterpret_cast<const f32x4*>(q);
+                    af[i][1] = *reinterpret_cast<const f32x4*>(q + 4);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float* q = Bs + ((wn * TN + j) * 32 + fr) * LD + kk * 16 + fk;
+                    bf[j][0] = *reinterpret_cast<const f32x4*>(q);
+                    bf[j][1] = *reinterpret_cast<const f32x4*>(q + 4);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e >> 2][e & 3], bf[j][e >> 2][e & 3], acc[i][j], 0, 0, 0);
+            } else {
+                using F = typename WFrag<WT>::type;
+                F af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const F*>(As + ((wm * TM + i) * 32 + fr) * LD + kk * 16 + fk);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const F*>(Bs + ((wn * TN + j) * 32 + fr) * LD + kk * 16 + fk);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (sizeof(WT) == 2 && __is_same(WT, __bf16)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    // partial tile -> part[((split * KK + tap) * Cout + m) * Cin + n]; accumulator element e of a lane: row 8*(e/4) + 4*(lane/32) + e%4, column lane%32
+    float* pp = p.part + ((long)split * KK + tap) * p.Cout * p.Cin;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nt * BN + (wn * TN + j) * 32 + (lane & 31);
+            if (n >= p.Cin) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mt * BM + (wm * TM + i) * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+                if (m < p.Cout) pp[(long)m * p.Cin + n] = acc[i][j][e];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int S, int KK, int Cout, int Cin) {
+    const long per = (long)KK * Cout * Cin;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += part[(long)k * per + i];
+        const int ci = (int)(i % Cin);
+        const long t = i / Cin;
+        const int co = (int)(t % Cout), tap = (int)(t / Cout);
+        out[((long)co * Cin + ci) * KK + tap] += s;
+    }
+}
+
+struct WgCfg { int id, BM, BN; };
+inline WgCfg wgrad_cfg(int Cout, int Cin) {
+    if (Cout <= 32) return {0, 32, 128};
+    if (Cout <= 64 || Cin <= 64) return {1, 64, 64};
+    return {2, 128, 128};
+}
+
+template <typename WT>
+void launch_cfg(const WgradP& p, int cfg, dim3 grid, hipStream_t s) {
+    if (cfg == 0) hipLaunchKernelGGL((wgrad_kernel<WT, 1, 1, 1, 4>), grid, dim3(256), 0, s, p);
+    else if (cfg == 1) hipLaunchKernelGGL((wgrad_kernel<WT, 1, 1, 2, 2>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<WT, 2, 2, 2, 2>), grid, dim3(256), 0, s, p);
+}
+
+}  // namespace
+
+int ftc_wgrad_splits_impl(int B, int Ho, int Wo, int Cout, int Cin, int ksize) {
+    const WgCfg c = wgrad_cfg(Cout, Cin);
+    const long tiles = (long)((Cout + c.BM - 1) / c.BM) * ((Cin + c.BN - 1) / c.BN) * ksize * ksize;
+    const long P = (long)B * Ho * Wo;
+    long S = (1536 + tiles - 1) / tiles;                          // ~6 workgroups per CU in flight
+    const long smax = (P + 255) / 256;                            // at least 256 pixels per split
+    if (S > smax) S = smax;
+    if (S < 1) S = 1;
+    if (S > 4096) S = 4096;
+    return (int)S;
+}
+
+hipError_t launch_wgrad(const OpArgs& a, hipStream_t s) {
+    const ftc_op& o = *a.op;
+    WgradP p;
+    p.x = (const float*)a.in; p.dz = (const float*)a.in2; p.se = (o.flags & FTC_FLAG_SE_SCALE) ? a.scale : nullptr; p.part = a.aux;
+    p.B = o.B; p.H = o.H; p.W = o.W; p.Ho = o.Ho; p.Wo = o.Wo;
+    p.Cin = o.Cin; p.CinT = o.Cin_total > 0 ? o.Cin_total : o.Cin; p.cin_off = o.cin_off;
+    p.Cout = o.Cout; p.CoutT = o.Cout_total > 0 ? o.Cout_total : o.Cout; p.cout_off = o.cout_off;
+    p.KS = o.ksize; p.stride = o.stride; p.pad = (o.ksize - 1) / 2;
+    p.P = (long)o.B * o.Ho * o.Wo;
+    const int S = o.aux0 > 0 ? o.aux0 : 1;
+    const int BK = o.w_dtype == FTC_F32 ? 32 : 64;
+    p.chunk = ((p.P + S - 1) / S + BK - 1) / BK * BK;
+    const WgCfg c = wgrad_cfg(o.Cout, o.Cin);
+    const int KK = o.ksize * o.ksize;
+    const dim3 grid((o.Cout + c.BM - 1) / c.BM, ((o.Cin + c.BN - 1) / c.BN) * KK, S);
+    if (o.w_dtype == FTC_F32) launch_cfg<float>(p, c.id, grid, s);
+    else if (o.w_dtype == FTC_F16) launch_cfg<_Float16>(p, c.id, grid, s);
+    else launch_cfg<__bf16>(p, c.id, grid, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const long per = (long)KK * o.Cout * o.Cin;
+    const long nb = (per + 255) / 256;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, s, a.aux, (float*)a.out, S, KK, o.Cout, o.Cin);
+    return hipGetLastError();
+}

@@ -31,8 +31,10 @@ extern "C" {
 #endif
 
 /* 4: FTC_OP_BNSTAT / FTC_OP_BNACT (training-mode BatchNorm); FTC_OP_STEM and FTC_OP_DWCONV honour act = FTC_ACT_NONE (they applied SiLU
-   unconditionally before); FTC_FLAG_W_FRAG */
-#define FTC_ABI_VERSION 4
+   unconditionally before); FTC_FLAG_W_FRAG
+   5: the train step (BASELINE configs[4]): FTC_BASE_GRADS, FTC_OP_GATHER_ROWS .. FTC_OP_FILL (backward kernels), FTC_OP_BNSTAT writes
+      [4][Cin] (scale, shift, mean, 1/std), ftc_losses out[12..13] = the two weight normalisers, ftc_pack_train_weights */
+#define FTC_ABI_VERSION 5
 
 typedef enum ftc_status {
     FTC_OK = 0,
@@ -52,7 +54,8 @@ typedef enum ftc_base {
     FTC_BASE_INPUT = 3,        /* image batch */
     FTC_BASE_HEATMAP = 4,      /* [B,h,w,10] fp32 output */
     FTC_BASE_FEATURES = 5,     /* [B,h,w,100] fp32 output */
-    FTC_NUM_BASES = 6
+    FTC_BASE_GRADS = 6,        /* train step: the flat fp32 gradient buffer (every parameter's .grad is a view into it) */
+    FTC_NUM_BASES = 7
 } ftc_base;
 
 typedef struct ftc_ref {
@@ -81,8 +84,8 @@ typedef enum ftc_op_kind {
        detector.py:291-296) */
     FTC_OP_NMS = 6,
     /* Training-mode BatchNorm, first half (BN-refresh pass, train1.py:203-211): per-channel batch statistics of `in` [B*H*W][Cin]
-       (fp32 or 16-bit; float64 sums, fixed order) -> out = fp32 [2][Cin] (scale = gamma / sqrt(var + eps), shift = beta - mean * scale)
-       for FTC_OP_BNACT, and the running statistics aux = fp32 [2][Cin] (mean | var) updated in place:
+       (fp32 or 16-bit; float64 sums, fixed order) -> out = fp32 [4][Cin] (scale = gamma / sqrt(var + eps), shift = beta - mean * scale
+       for FTC_OP_BNACT; mean and 1 / sqrt(var + eps) for FTC_OP_BNBWD), and the running statistics aux = fp32 [2][Cin] (mean | var) updated in place:
        r = (1 - momentum) * r + momentum * batch value (the variance unbiased, as torch.nn.BatchNorm2d does).
        w = gamma, bias = beta (fp32 [Cin]); aux0 / aux1 = the bit patterns of the floats eps / momentum; in2 = scratch for the partial sums,
        float64 [chunks = min(512, ceil(B*H*W / 256))][2][Cin] (2 launches: partial sums, finalize) */
@@ -93,6 +96,57 @@ typedef enum ftc_op_kind {
        copy (w_dtype) when out is fp32; aux0 = row chunks per image (the launch is B x aux0 x Cin/64 workgroups); aux: optional
        fp32 [B][aux0][Cin] per-image partial channel sums of the result for the SE squeeze */
     FTC_OP_BNACT = 9,
+    /* ---- train step (BASELINE configs[4]; /root/reference/train1.py:125-131, 170-179): the backward kernels.  All tensors fp32 NHWC;
+       parameter gradients are ACCUMULATED (+=) into the FTC_BASE_GRADS buffer in the PyTorch parameter layout (conv OIHW), so that
+       `optimizer.zero_grad()` = one memset and gradient accumulation over micro-batches (train1.py:176-179) needs nothing extra. */
+    /* rows[i][0..Cin) = in[in2[i]][0..Cin), zero-padded to Cout_total columns, i < aux0 (`features[fmask]`, models/detector.py:265-266):
+       in = features [P][Cin] fp32, in2 = int32 [aux0] ascending pixel indices, out = fp32 [aux0][Cout_total] */
+    FTC_OP_GATHER_ROWS = 10,
+    /* loss_function (loss_func.py:94-177) as a plan step = ftc_losses: in = maps [B,H,W,9], in2 = labelmap [B,5,H,W], w = idmap int32
+       [B,2,H,W], w2 / bias / bias2 = decoder logits [aux0][1091 | 1093 | 1097], scale = int32 [aux0] selected pixels, out = fp32 [16],
+       aux = scratch (ftc_losses_scratch_bytes) */
+    FTC_OP_LOSSES = 11,
+    /* d(sum_i alpha_i * loss_i) * loss_scale / d(maps, decoder logits): operands as FTC_OP_LOSSES plus shift = alphas fp32 [9] in the
+       reference's key order (keymap, size, textline, separator, id, code1, code2, code4, code8: train1.py:107-114), aux = the fp32 [16]
+       vector FTC_OP_LOSSES wrote (out[12], out[13] = the clamped weight sums), out = d maps [B,H,W,9], out2 = d logits, three blocks
+       [aux0][aux1] (rows zero-padded to aux1 columns), Cout = the bit pattern of the float loss_scale (1 / iters_to_accumulate) */
+    FTC_OP_LOSS_BWD = 12,
+    /* out = zeros [B*H*W][Cout_total]; out[in2[i]][0..Cin_total) = in[i][0..Cin_total), i < aux0 (backward of GATHER_ROWS) */
+    FTC_OP_SCATTER_ROWS = 13,
+    /* Backward of BNSTAT + BNACT: incoming gradient g = in[r][cin_off + c] (row stride Cin_total, 0 = Cin) * bias[b][c] + bias2[b][c]
+       (both optional: the SE gate and the squeeze-mean gradient of an MBConv block), * w2[b] (optional StochasticDepth keep-scale);
+       t = z * scale + shift; dt = g * act'(t); out (+= with FTC_FLAG_ACCUM) = scale * (dt - mean(dt) - zhat * mean(dt * zhat));
+       w (gamma grad) += sum dt * zhat, shift (beta grad) += sum dt.  in2 = z [B*H*W][Cin], scale = the [4][Cin] block of BNSTAT,
+       aux = scratch float64 [chunks][2][Cin] + fp32 [2][Cin] (chunks as BNSTAT) */
+    FTC_OP_BNBWD = 14,
+    /* Weight gradient of a dense 1x1 / 3x3 convolution on MFMA: out[co][ci][r][s] += sum_p in2[p][cout_off + co] * in[p @ (r,s)][cin_off + ci]
+       (* scale[b][ci] with FTC_FLAG_SE_SCALE).  in = the layer input [B,H,W,Cin_total], in2 = d output [B,Ho,Wo,Cout_total], w_dtype = the
+       MFMA operand type (operands narrowed while they are staged), aux = fp32 partial sums [aux0 pixel splits][k*k][Cout][Cin], aux0 >= 1 */
+    FTC_OP_WGRAD = 15,
+    /* Depthwise 3x3 backward: in = layer input [B,H,W,Cin], in2 = d output [B,Ho,Wo,Cin], w = fp32 [9][Cin] -> out = d input,
+       out2 ([Cin][1][3][3], grads) += d weight; aux = float64 [chunks][9][Cin] (chunks as BNSTAT over B*Ho*Wo) */
+    FTC_OP_DWBWD = 16,
+    /* SqueezeExcitation backward: in = d(y * s) [B,H*W,Cin], in2 = y, scale = s [B][Cin], aux = the forward's partial channel sums
+       [B][aux1][Cin], w / w2 / bias / bias2 as FTC_OP_SE (aux0 = squeeze width S) -> out = fp32 scratch [4][B][Cin] + [2][B][S]:
+       block 3 = d mean / (H*W) (the `bias2` of the following FTC_OP_BNBWD, whose `bias` is s); out2 = grads of fc1.weight [S][Cin],
+       fc1.bias [S], fc2.weight [Cin][S], fc2.bias [Cin], consecutive, += */
+    FTC_OP_SEBWD = 17,
+    /* Backward of the upsampled part of UPCAT: out[b,y,x,0..aux0) = sum over the x2 bilinear (align_corners) footprint of
+       in[b,Y,X,0..aux0) (row stride Cin_total); in = d cat [B,Ho,Wo,Cin_total], out = [B,H,W,aux0] */
+    FTC_OP_UPCATBWD = 18,
+    /* out [B,Ho,Wo,Cin] = in [B,H,W,Cin] with a zero between the pixels (Ho = 2H, Wo = 2W): turns the data gradient of a stride-2
+       convolution into a stride-1 convolution with the flipped kernel */
+    FTC_OP_DILATE = 19,
+    /* Data gradient of a 3x3 convolution with very few output channels (the map heads' top_conv, 1 or 2): in = d maps [B,H,W,Cin_total]
+       (channels cin_off .. cin_off + Cin), w = [Cin][9][Cout] (w_dtype), out = [B,H,W,Cout] fp32 */
+    FTC_OP_TOPDGRAD = 20,
+    /* out[c] += sum_r in[r][cin_off + c], c < Cin (bias gradients); in = [B*H*W][Cin_total]; aux = float64 [chunks][Cin] */
+    FTC_OP_COLSUM = 21,
+    /* Weight gradient of the stem (3 -> Cout <= 32, stride 2, input x*2-1): in = image [B,H,W,3], in2 = d output [B,Ho,Wo,Cout],
+       out [Cout][3][3][3] +=; aux = float64 [chunks][27][Cout] */
+    FTC_OP_STEMWGRAD = 22,
+    /* out[0 .. B*H*W*Cin) fp32 = 0 */
+    FTC_OP_FILL = 23,
     FTC_OP_TAPSUM = 7          /* second half of a 3x3 convolution split as per-pixel taps + 9-point sum (FTC_FLAG_TOP_FUSE):
                                   out[b,y,x,ch_j] = bias[j] + sum_{r,s} in[g_j][b,y+r-1,x+s-1][(3r+s)*co_j + o_j] (zero outside),
                                   for the aux1 outputs j listed in `w` as int32 quadruples (g_j, o_j, co_j, ch_j);
@@ -132,6 +186,7 @@ enum {
                                   FRAGMENT-MAJOR -- [groups][6 row blocks of 32][9 taps][Cin/64][4 K groups of 16][64 lanes][8]: element e of
                                   lane L = W[32*rb + (L & 31)][tap][64*cb + 16*g + 8*(L >> 5) + e] -- so that a wave reads an MFMA A fragment
                                   as one coalesced 1 KiB load straight from global memory (the weights never touch LDS) */
+    FTC_FLAG_ACCUM = 0x800000, /* BNBWD / CONV-as-dgrad helpers: the data-gradient output is added to what `out` holds */
     FTC_FLAG_SE_FOLD = 32      /* SE: besides scale[b,c], write out2[b][n][c] = bf16(in[n][c] * scale[b,c]) for the
                                   bf16 matrix `in` [Cout_total][C] -- the following 1x1 convolution then runs with
                                   FTC_FLAG_W_PER_IMAGE on unscaled activations (both operands by DMA) */
@@ -364,7 +419,8 @@ int ftc_decoder_forward(ftc_model* model, const void* weights_dev, const void* r
 /* loss_function (loss_func.py:94-177, heatmap_loss :74-92).  heatmap = the NINE reference channels addressed through element strides
    (batch, channel, y, x) so that NHWC and NCHW memory are both accepted; labelmap [B,5,h,w] fp32 and idmap [B,2,h,w] int32 contiguous;
    dec0..2 [cap, 1091 | 1093 | 1097] fp32 decoder outputs of the pixels sel_index[0..count) (may all be NULL: id_loss = 0).
-   out[0..12) = loss, keymap, size, textline, separator, id, code1, code2, code4, code8, correct, total (fp32).
+   out[0..14) = loss, keymap, size, textline, separator, id, code1, code2, code4, code8, correct, total, max(1, sum weight1),
+   max(1, sum weight3) (fp32; the last two are the normalisers of size_loss / id_loss, consumed by FTC_OP_LOSS_BWD).
    scratch >= ftc_losses_scratch_bytes() bytes. */
 int64_t ftc_losses_scratch_bytes(void);
 int ftc_losses(const float* heatmap, const int64_t heat_strides[4], const float* labelmap, const int32_t* idmap, int B, int h, int w,
@@ -391,6 +447,22 @@ typedef struct ftc_mt_chunk {
 } ftc_mt_chunk;
 int ftc_adamw_schedulefree_step(const ftc_mt_chunk* chunks_dev, int n_chunks, float beta2, float one_minus_beta2, float bias_correction2,
                                 float eps, float weight_decay, float ckp1, float y_alpha, float lr, int write_grad, void* stream);
+
+/* Train step: one multi-tensor launch that re-packs the raw parameters an optimizer step changed into the layouts the kernels read
+ * (replaces ~1500 small permute / cast launches per step).  Every entry converts one fp32 OIHW convolution / Linear weight
+ * [Cout][Cin][k][k] into   fwd  = [Cout][k*k][cin_pad]            (K-major, `dtype`; columns >= Cin zero)   and, if dgrad != NULL,
+ *                          dgrad = [Cin][k*k flipped][cout_pad]    (the data-gradient convolution's weights; columns >= Cout zero).
+ * entries_dev: device array. */
+typedef struct ftc_pack_entry {
+    const void* src;           /* fp32 [Cout][Cin][k][k] */
+    void* fwd;                 /* may be NULL */
+    void* dgrad;               /* may be NULL */
+    int32_t Cout, Cin, kk, cin_pad, cout_pad, dtype, reserved0, reserved1;
+} ftc_pack_entry;
+int ftc_pack_train_weights(const ftc_pack_entry* entries_dev, int n_entries, int64_t max_elems, void* stream);
+
+/* Pixel splits FTC_OP_WGRAD should use for a layer (fills the GPU without oversizing the partial-sum scratch). */
+int ftc_wgrad_splits(int B, int Ho, int Wo, int Cout, int Cin, int ksize);
 
 #ifdef __cplusplus
 }

@@ -429,7 +429,94 @@ def gen_train_forward(model):
     save("g9_train_forward.npz", **out)
 
 
+def train_step_pick(names_shapes):
+    """The parameters whose FULL (or strided-subsampled) gradients are stored in g10: first / last conv of every stage, one
+    depthwise, SE fc1 / fc2 with biases, BatchNorm affines, head in_bn / upsamplers / top_conv, the decoder."""
+    want = [r"backbone\.features\.0\.0\.weight", r"backbone\.features\.0\.1\.(weight|bias)",
+            r"backbone\.features\.[1-7]\.0\.block\.0\.0\.weight", r"backbone\.features\.2\.7\.block\.1\.0\.weight",
+            r"backbone\.features\.3\.0\.block\.0\.1\.(weight|bias)",
+            r"backbone\.features\.4\.0\.block\.1\.0\.weight", r"backbone\.features\.5\.3\.block\.1\.0\.weight",
+            r"backbone\.features\.5\.3\.block\.1\.1\.(weight|bias)",
+            r"backbone\.features\.4\.0\.block\.2\.fc[12]\.(weight|bias)", r"backbone\.features\.6\.31\.block\.2\.fc[12]\.(weight|bias)",
+            r"backbone\.features\.6\.31\.block\.3\.0\.weight", r"backbone\.features\.7\.7\.block\.3\.1\.(weight|bias)",
+            r"backbone\.features\.8\.0\.weight", r"backbone\.features\.8\.1\.(weight|bias)",
+            r"detector\.keyheatmap\.in_bn\.[0-3]\.(weight|bias)", r"detector\.(keyheatmap|sizes|feature)\.upsamplers\.[0-3]\.0\.weight",
+            r"detector\.(keyheatmap|code8|feature)\.upsamplers\.3\.1\.(weight|bias)",
+            r"detector\.(keyheatmap|sizes|sepatator|feature)\.top_conv\.0\.(weight|bias)",
+            r"decoder\.blocks\.0\.0\.weight", r"decoder\.blocks\.1\.[14]\.(weight|bias)", r"decoder\.blocks\.1\.3\.weight",
+            r"decoder\.blocks\.2\.6\.(weight|bias)"]
+    import re as _re
+    return [n for n, _ in names_shapes if any(_re.search(w + "$", n) for w in want)]
+
+
+def gen_train_step(model):
+    """g10: the reference's TRAIN step (train1.py:125-131, 170-179) on CPU in fp32 (no autocast: the parity mode): model.train(),
+    fmask = model.get_fmask(labelmap) -> heatmap, decoder_outputs = model(image, fmask) -> loss_function -> CoVWeightingLoss
+    (first iteration: alphas = 1/9) -> loss.backward().  StochasticDepth uses a seeded draw stored with the outputs (as g9).
+    Stored: the raw losses, the weighted loss, the L2 norm of every parameter's gradient, and the gradients of a spread of
+    parameters (large ones as a strided subsample of the flattened OIHW tensor)."""
+    import loss_func as ref_loss  # noqa: E402  (reference code)
+    from oracle import tv_efficientnet as tv
+    B, H, W = 2, 256, 256
+    x = synth.page_images(1029, B, H, W)
+    label, idmap = synth.train_labels(1030, B, H // 4, W // 4)
+    rng = np.random.Generator(np.random.PCG64(1031))
+    sds = [(n, m) for n, m in model.named_modules() if isinstance(m, tv.StochasticDepth)]
+    keep = {}
+    for n, m in sds:
+        surv = 1.0 - m.p
+        keep[n[: -len(".stochastic_depth")]] = torch.from_numpy((rng.random(B) < surv).astype(np.float32) / np.float32(surv))
+    by_id = {id(m): keep[n[: -len(".stochastic_depth")]] for n, m in sds}
+    orig = tv.StochasticDepth.forward
+
+    def fwd(self, t):
+        if not self.training or self.p == 0.0:
+            return t
+        return t * by_id[id(self)].reshape(-1, 1, 1, 1)
+    tv.StochasticDepth.forward = fwd
+    keys = ["keymap_loss", "size_loss", "textline_loss", "separator_loss", "id_loss", "code1_loss", "code2_loss", "code4_loss", "code8_loss"]
+    try:
+        before = {k: v.clone() for k, v in model.state_dict().items()}
+        model.train()
+        model.zero_grad(set_to_none=True)
+        lab_t, id_t = torch.from_numpy(label), torch.from_numpy(idmap).to(torch.long)
+        fmask = model.get_fmask(lab_t, None)
+        heatmap, dec = model(torch.from_numpy(x).permute(0, 3, 1, 2), fmask)
+        raw = ref_loss.loss_function(fmask, lab_t, id_t, heatmap, dec)
+        cov = ref_loss.CoVWeightingLoss(losses=keys)
+        cov.train()
+        loss = cov(raw)
+        loss.backward()
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    finally:
+        tv.StochasticDepth.forward = orig
+        model.load_state_dict(before)
+        model.zero_grad(set_to_none=True)
+        model.eval()
+    names = sorted(keep)
+    out = {"keep_names": np.array(names), "keep": np.stack([keep[n].numpy() for n in names]), "n_mask": np.array(int(fmask.sum())),
+           "heatmap": heatmap.detach().numpy(), "loss": np.array(float(loss)), "alphas": cov.alphas.numpy(),
+           "grad_names": np.array(list(grads)), "grad_norms": np.array([float(g.double().norm()) for g in grads.values()]),
+           "grad_absmax": np.array([float(g.abs().max()) for g in grads.values()])}
+    for k in keys + ["loss"]:
+        out["raw_" + k] = np.array(float(raw[k]))
+    pick = train_step_pick([(n, tuple(g.shape)) for n, g in grads.items()])
+    out["pick_names"] = np.array(pick)
+    for i, n in enumerate(pick):
+        g = grads[n].numpy().reshape(-1)
+        stride = max(1, g.size // 40000)
+        out[f"pick{i}"] = g[::stride].copy()
+        out[f"pick{i}_stride"] = np.array(stride)
+    save("g10_train_step.npz", **out)
+
+
 def main():
+    if "--train-step-only" in sys.argv:
+        torch.manual_seed(0)
+        model = ref_detector.TextDetectorModel(pre_weights=False)
+        model.load_state_dict(deterministic_state_dict(SEED_W))
+        gen_train_step(model)
+        return
     if "--train-only" in sys.argv:
         torch.manual_seed(0)
         model = ref_detector.TextDetectorModel(pre_weights=False)
@@ -466,6 +553,7 @@ def main():
     gen_adamw()
     gen_validation_step(model)
     gen_train_forward(model)
+    gen_train_step(model)
     gen_small_models()
 
 

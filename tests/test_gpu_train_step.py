@@ -1,0 +1,142 @@
+"""-m gpu: the TRAIN step (BASELINE configs[4]; /root/reference/train1.py:125-131, 170-179) on MI355X -- train()-mode forward,
+loss_function, CoV weighting and the hand-written backward -- against
+
+* tests/golden/g10_train_step.npz, written by the reference's own modules + ``loss.backward()`` on CPU in fp32, and
+* the CPU oracle (oracle/train_oracle.py, pinned by the same fixture) on fresh seeded inputs with non-uniform loss weights.
+
+Tolerance (fp32 mode): every parameter gradient within 1e-3 of its largest reference entry (+ 1e-7 absolute: the gradients the
+reference itself only holds as rounding noise -- a BatchNorm bias in front of another batch-statistics BatchNorm is analytically
+zero and comes out as 1e-9 .. 1e-7 in the reference), L2 norms within 1e-3 relative.  16-bit modes: cosine similarity gates.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from findtextcenternet_amd import TextDetectorModel, deterministic_state_dict
+from findtextcenternet_amd.train_step import COV_KEYS, TrainStep
+from oracle import train_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g10(golden_dir):
+    return np.load(os.path.join(golden_dir, "g10_train_step.npz"))
+
+
+def _model(precision):
+    m = TextDetectorModel(pre_weights=False, precision=precision)
+    m.load_state_dict(deterministic_state_dict(0))
+    return m.to("cuda").train()
+
+
+def grad_report(ts, ref_grads, tol_rel=1e-3, tol_abs=1e-7):
+    """[(name, max abs error / max |ref|, ok)] in parameter order; ref_grads: name -> (flat numpy array, stride)."""
+    out = []
+    for n, p in ts.params:
+        if n not in ref_grads:
+            continue
+        ref, st = ref_grads[n]
+        mine = p.grad.detach().float().cpu().numpy().reshape(-1)[::st]
+        err = float(np.abs(mine - ref).max())
+        scale = float(np.abs(ref).max())
+        out.append((n, err / max(scale, 1e-30), err <= tol_rel * scale + tol_abs, err, scale))
+    return out
+
+
+def test_train_step_fp32_matches_reference_backward(g10):
+    B, H, W = 2, 256, 256
+    model = _model("fp32")
+    ts = TrainStep(model)
+    x = torch.from_numpy(synth.page_images(1029, B, H, W)).permute(0, 3, 1, 2).cuda()
+    label, idmap = synth.train_labels(1030, B, H // 4, W // 4)
+    keep = {str(n): torch.from_numpy(k) for n, k in zip(g10["keep_names"], g10["keep"])}
+    ts.zero_grad()
+    loss, raw = ts.forward_backward(x, torch.from_numpy(label).cuda(), torch.from_numpy(idmap).cuda(), keep=keep)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(g10["loss"])) < 2e-4 * abs(float(g10["loss"]))
+    for k in COV_KEYS + ["loss"]:
+        assert abs(float(raw[k]) - float(g10["raw_" + k])) < 2e-4 * max(1e-3, abs(float(g10["raw_" + k]))), k
+    maps = ts.maps(B, H, W).cpu().numpy()
+    assert np.abs(maps - g10["heatmap"]).max() < 1e-3
+    # every parameter: L2 norm of the gradient
+    names = [str(n) for n in g10["grad_names"]]
+    norms = dict(zip(names, g10["grad_norms"]))
+    amax = dict(zip(names, g10["grad_absmax"]))
+    bad = []
+    for n, p in ts.params:
+        mine = float(p.grad.double().norm())
+        tol = 1e-3 * norms[n] + 1e-7 * np.sqrt(p.numel())
+        if abs(mine - norms[n]) > tol:
+            bad.append((n, mine, norms[n]))
+    assert not bad, f"{len(bad)} gradient norms off, first: {bad[:8]}"
+    # the stored gradients entry by entry
+    ref = {str(n): (g10[f"pick{i}"], int(g10[f"pick{i}_stride"])) for i, n in enumerate(g10["pick_names"])}
+    rep = grad_report(ts, ref)
+    assert len(rep) == len(ref)
+    fails = [(n, f"{r:.2e}") for n, r, ok, _, _ in rep if not ok]
+    assert not fails, fails
+    # a block whose StochasticDepth draw dropped every image gets exactly zero gradients, as in the reference
+    zero = [n for n in names if amax[n] == 0.0]
+    assert zero and all(float(dict(ts.params)[n].grad.abs().max()) == 0.0 for n in zero)
+    # running statistics moved, counters incremented
+    assert int(dict(model.named_buffers())["detector.backbone.features.0.1.num_batches_tracked"]) == 1
+
+
+def test_train_step_accumulates_and_weights_like_the_oracle():
+    """Fresh inputs, non-uniform alphas, loss_scale 0.5, two micro-batches accumulated into .grad (train1.py:176-179)."""
+    B, H, W = 2, 128, 128
+    model = _model("fp32")
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ts = TrainStep(model)
+    alphas = torch.tensor([0.3, 0.05, 0.1, 0.02, 0.2, 0.08, 0.1, 0.1, 0.05])
+    ts.zero_grad()
+    want = None
+    sd = sd0
+    for it, seed in enumerate((41, 43)):
+        x = synth.page_images(seed, B, H, W)
+        label, idmap = synth.train_labels(seed + 1, B, H // 4, W // 4)
+        rng = np.random.Generator(np.random.PCG64(seed + 2))
+        probs = ts.stochastic_depth_probs()
+        keep = {n: torch.from_numpy((rng.random(B) < 1 - p).astype(np.float32) / np.float32(1 - p)) for n, p in probs.items()}
+        xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+        _, _, grads, _ = train_oracle.train_step(sd, xt, torch.from_numpy(label), torch.from_numpy(idmap).long(), keep, alphas.tolist(), 0.5)
+        want = grads if want is None else {k: want[k] + v for k, v in grads.items()}
+        ts.forward_backward(xt.cuda(), torch.from_numpy(label).cuda(), torch.from_numpy(idmap).cuda(), keep=keep, alphas=alphas, loss_scale=0.5)
+        # the oracle's second micro-batch must see the running statistics the first one moved (they do not enter the gradients, but
+        # the state dict the oracle reads is the module's)
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    torch.cuda.synchronize()
+    ref = {k: (v.numpy().reshape(-1), 1) for k, v in want.items()}
+    rep = grad_report(ts, ref)
+    fails = [(n, f"{r:.2e}") for n, r, ok, _, _ in rep if not ok]
+    assert len(rep) == len(ts.params) and not fails, (len(fails), fails[:10])
+
+
+@pytest.mark.parametrize("precision,cos_min", [("bf16", 0.98), ("fp16", 0.999)])
+def test_train_step_16bit_gradients_point_the_same_way(g10, precision, cos_min):
+    """bf16 / fp16 MFMA operands (the reference trains under bf16 autocast, train1.py:127): gradient direction per stored tensor."""
+    B, H, W = 2, 256, 256
+    model = _model(precision)
+    ts = TrainStep(model)
+    x = torch.from_numpy(synth.page_images(1029, B, H, W)).permute(0, 3, 1, 2).cuda()
+    label, idmap = synth.train_labels(1030, B, H // 4, W // 4)
+    keep = {str(n): torch.from_numpy(k) for n, k in zip(g10["keep_names"], g10["keep"])}
+    ts.zero_grad()
+    loss, _ = ts.forward_backward(x, torch.from_numpy(label).cuda(), torch.from_numpy(idmap).cuda(), keep=keep)
+    assert abs(float(loss) - float(g10["loss"])) < 0.05 * abs(float(g10["loss"]))
+    amax = dict(zip([str(n) for n in g10["grad_names"]], g10["grad_absmax"]))
+    worst = []
+    for i, n in enumerate(g10["pick_names"]):
+        n = str(n)
+        if amax[n] < 1e-6:
+            continue                                                   # analytically-zero gradients: noise in the reference too
+        ref, st = g10[f"pick{i}"], int(g10[f"pick{i}_stride"])
+        mine = dict(ts.params)[n].grad.detach().float().cpu().numpy().reshape(-1)[::st]
+        cos = float((mine * ref).sum() / (np.linalg.norm(mine) * np.linalg.norm(ref) + 1e-30))
+        worst.append((cos, n))
+    worst.sort()
+    assert worst[0][0] > cos_min, worst[:5]

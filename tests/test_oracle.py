@@ -219,3 +219,28 @@ def test_train_mode_oracle_matches_reference():
     for j in range(3):
         assert float((dec[j][torch.from_numpy(g["dec_rows"])] - torch.from_numpy(g[f"dec{j}_at"])).abs().max()) < 5e-3
         assert float((torch.logsumexp(dec[j], 1) - torch.from_numpy(g[f"dec{j}_lse"])).abs().max()) < 5e-3
+
+
+def test_train_step_oracle_matches_reference_backward():
+    """oracle/train_oracle.py vs g10 (the reference's own train step + loss.backward() in fp32): loss, maps, every gradient norm, and
+    the stored gradients entry by entry.  Gradients the reference holds only as rounding noise (|g| < 1e-7: a BatchNorm bias in front of
+    another batch-statistics BatchNorm) are compared absolutely."""
+    from oracle import train_oracle
+    g = np.load(os.path.join(G, "g10_train_step.npz"))
+    sd = deterministic_state_dict(0)
+    B, H, W = 2, 256, 256
+    x = torch.from_numpy(synth.page_images(1029, B, H, W)).permute(0, 3, 1, 2)
+    label, idmap = synth.train_labels(1030, B, H // 4, W // 4)
+    keep = {str(n): torch.from_numpy(k) for n, k in zip(g["keep_names"], g["keep"])}
+    loss, raw, grads, maps = train_oracle.train_step(sd, x, torch.from_numpy(label), torch.from_numpy(idmap).long(), keep)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    assert np.allclose(g["alphas"], 1.0 / 9)
+    assert np.abs(maps.numpy() - g["heatmap"]).max() < 1e-3
+    for n, nr in zip(g["grad_names"], g["grad_norms"]):
+        gr = grads[str(n)]
+        assert abs(float(gr.double().norm()) - nr) <= 1e-3 * nr + 1e-7 * np.sqrt(gr.numel()), n
+    for i, n in enumerate(g["pick_names"]):
+        st, ref = int(g[f"pick{i}_stride"]), g[f"pick{i}"]
+        mine = grads[str(n)].numpy().reshape(-1)[::st]
+        assert np.abs(mine - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-7, n
+    assert sum(1 for a in g["grad_absmax"] if a == 0.0) >= 13      # a block dropped for every image: exact zeros

@@ -175,6 +175,181 @@ def dry_run(args, rank, world):
         dist.barrier()
         dist.destroy_process_group()
 
+# ------------------------------------------------------------------------------------------------------------------
+# --train: BASELINE configs[4], "train1.py step: detector fwd+bwd with loss_func.py focal/L1 heads, batch=16, 2xMI355X DDP" = 8 tiles
+# per GPU.  A step = zero_grad + get_fmask + forward (train mode) + loss_function + CoV weighting + backward (+ bucketed RCCL
+# all-reduce of the 1.05 GB of gradients when N > 1) + the Schedule-Free AdamW update -- the body of the reference's loop,
+# /root/reference/train1.py:170-179.
+# ------------------------------------------------------------------------------------------------------------------
+TRAIN_METRIC = "768x768 images/s (train step: fwd+loss+bwd+optimizer)"
+
+
+def train_dry_run(args, rank, world):
+    """The N-rank control flow of the train bench on CPU tensors (gloo): bucketed all-reduce of a flat gradient buffer, the
+    max-over-ranks timing and the JSON line -- no HIP library."""
+    from findtextcenternet_amd.dist import BucketedAllReduce
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 3_000_003
+    g = torch.Generator().manual_seed(5 + rank)
+    flat = torch.randn(n, generator=g)
+    want = sum(torch.randn(n, generator=torch.Generator().manual_seed(5 + r)) for r in range(world))
+    red = BucketedAllReduce(flat, bucket_bytes=4 << 20)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(len(red.ranges)):
+        red.reduce_bucket(i, async_op=True)
+    red.wait()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ok = bool(torch.allclose(flat, want, rtol=1e-6, atol=1e-6))
+    if rank == 0:
+        print(json.dumps({"metric": TRAIN_METRIC, "value": round(world * args.batch / el, 2), "unit": "images/s", "n_gpus": world, "steps": 1,
+                          "warmup": 0, "ms_per_step": round(1000 * el, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "none", "data": "synthetic", "dry_run": True, "allreduce_ok": ok, "buckets": len(red.ranges),
+                          "config": {"workload": "DRY RUN (CPU tensors, gloo): gradient all-reduce control flow of the train bench only",
+                                     "global_batch": world * args.batch, "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def train_bench(args, rank, local_rank, world):
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from findtextcenternet_amd import AdamWScheduleFree, TextDetectorModel, TrainStep, deterministic_state_dict, synth
+    from findtextcenternet_amd import _lib as L
+    B, S = args.batch, 768
+    sd = deterministic_state_dict(0)
+    model = TextDetectorModel(pre_weights=False, precision=args.precision)
+    model.load_state_dict(sd)
+    model = model.to(dev).train()
+    ts = TrainStep(model)
+    if world > 1:
+        ts.enable_ddp()
+    opt = AdamWScheduleFree([p for p in model.parameters() if p.requires_grad], lr=1e-4)     # train1.py:103-104
+    opt.train()
+    x = torch.from_numpy(synth.noise_images(1234 + rank, B, S, S)).to(dev).permute(0, 3, 1, 2)
+    lab, idm = synth.train_labels(99 + rank, B, S // 4, S // 4)
+    lab, idm = torch.from_numpy(lab).to(dev), torch.from_numpy(idm).to(dev)
+    state = {"fmask": None, "loss": None}
+
+    def step():
+        ts.zero_grad()
+        state["fmask"] = model.get_fmask(lab, state["fmask"])
+        state["loss"], _ = ts.forward_backward(x, lab, idm, state["fmask"])
+        opt.step()
+
+    for _ in range(args.warmup):
+        step()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(args.steps):
+        step()
+        ev[i + 1].record()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    loss = float(state["loss"])
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    value = world * B * args.steps / el
+    plan = ts.plan_for(B, S, S, 1.0 / world)
+    result = {"metric": TRAIN_METRIC, "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": round(1000 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+              "dtype": args.precision, "data": "synthetic",
+              "config": {"workload": f"BASELINE configs[4]: train1.py step (train-mode detector + SimpleDecoder forward, loss_function, CoV weighting, "
+                                     f"backward, Schedule-Free AdamW), batch={B}/GPU synthetic 768x768x3 tiles + synthetic label maps"
+                                     + (", bucketed RCCL gradient all-reduce" if world > 1 else ""),
+                         "global_batch": world * B, "tile": "768x768x3", "weights": "deterministic seed 0 (random-init)", "parallelism": f"dp{world}",
+                         "fp32 master parameters, MFMA operands": args.precision},
+              "ms_per_step_median": round(statistics.median(step_ms), 3), "loss_last_step": round(loss, 5), "finite": bool(np.isfinite(loss)),
+              "plan_ops": plan["n_ops"], "forward_ops": plan["n_fwd"], "workspace_gb": round(plan["workspace_bytes"] / 2**30, 2),
+              "gradient_bytes": int(ts.grads.numel() * 4), "source_hash": source_hash(),
+              "train_gflop_per_image_dense": round(3 * GFLOP_PER_IMAGE, 1),
+              "path_tflops_per_gpu": round(value / world * 3 * GFLOP_PER_IMAGE / 1000, 2),
+              "path_frac_of_mfma_peak": round(value / world * 3 * GFLOP_PER_IMAGE / 1000 / PEAK[args.precision], 4)}
+    if not args.no_profile:
+        lib = L.load()
+        n_ops = plan["n_ops"]
+        ms = (C.c_float * n_ops)()
+        xn = x.permute(0, 2, 3, 1).contiguous()
+        bases = (C.c_void_p * L.NUM_BASES)(None, ts.workspace.data_ptr(), ts.blob.data_ptr(), xn.data_ptr(), None, None, ts.grads.data_ptr())
+        acc = np.zeros((3, n_ops))
+        for r in range(3):
+            L.check(lib.ftc_plan_profile(plan["handle"], bases, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), ms), "ftc_plan_profile")
+            acc[r] = np.frombuffer(ms, dtype=np.float32)
+        acc = np.median(acc, axis=0)
+        by = {}
+        buf = C.create_string_buffer(256)
+        for i in range(n_ops):
+            o = plan["ops"][i]
+            lib.ftc_op_kernel_label(C.byref(o), buf, 256)
+            k = buf.value.decode()
+            fl = by_ = 0.0
+            if o.kind == L.OP_CONV:
+                k = ("dgrad:" if plan["names"][i].startswith("dgrad:") else "fwd:") + k.split("<")[0]
+                fl = 2.0 * o.B * o.Ho * o.Wo * o.Cout * o.Cin * o.ksize * o.ksize
+            elif o.kind == L.OP_WGRAD:
+                fl = 2.0 * o.B * o.Ho * o.Wo * o.Cout * o.Cin * o.ksize * o.ksize
+            elif o.kind in (L.OP_BNBWD, L.OP_BNSTAT, L.OP_BNACT):
+                by_ = float(o.B) * o.H * o.W * o.Cin * 4 * {L.OP_BNBWD: 5, L.OP_BNSTAT: 1, L.OP_BNACT: 2}[o.kind]
+            d = by.setdefault(k, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
+            d["ms"] += float(acc[i]); d["flops"] += fl; d["bytes"] += by_; d["launches"] += 1
+        total = float(acc.sum())
+        name, d = max(by.items(), key=lambda kv: kv[1]["ms"])
+        if d["flops"] > 0:
+            roof = {"bound": "mfma", "achieved": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s"}
+        else:
+            roof = {"bound": "hbm", "achieved": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s"}
+        roof.update({"frac": round(roof["achieved"] / roof["peak"], 4), "traffic": None, "kernel": name, "launches_per_step": d["launches"],
+                     "share_of_step_time": round(d["ms"] / total, 3),
+                     "algorithmic_note": "MFMA kernels: 2 * pixels * Cout * Cin * k^2 per launch; BatchNorm passes: streams of 4-byte elements "
+                                         "(backward: dy and z twice + dz = 5, statistics 1, normalise 2)"})
+        result["roofline"] = roof
+        result["kernel_time_by_label_ms"] = {k: round(v["ms"], 2) for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+        result["forward_ms_sum_of_kernels"] = round(float(acc[:plan["n_fwd"]].sum()), 2)
+        result["backward_ms_sum_of_kernels"] = round(float(acc[plan["n_fwd"]:].sum()), 2)
+    if world == 1 and not args.no_cpu_baseline:
+        # the CPU oracle of the same step (torch autograd, fp32) on a bounded sample: batch 1, 384x384 (a quarter of a tile), once
+        from oracle import train_oracle
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        xs = torch.from_numpy(synth.noise_images(7, 1, 384, 384)).permute(0, 3, 1, 2)
+        l2, i2 = synth.train_labels(8, 1, 96, 96)
+        t0 = time.perf_counter()
+        train_oracle.train_step(sd, xs, torch.from_numpy(l2), torch.from_numpy(i2).long())
+        e = time.perf_counter() - t0
+        result["cpu_baseline"] = {"value": round(0.25 / e, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                                  "sample": f"one train step (forward + loss + backward, no optimizer) of the CPU oracle on 1 x 384x384 "
+                                            f"(= 1/4 of a 768x768 tile) in {e:.1f} s, scaled by pixel count"}
+    print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -190,6 +365,7 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode record")
     ap.add_argument("--dump-ops", default="", help="write per-op timings (JSON) to this path")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo walk through the N-rank control flow (no GPU work)")
+    ap.add_argument("--train", action="store_true", help="BASELINE configs[4]: the train step (fwd + loss + bwd + optimizer, DDP all-reduce when N > 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -198,7 +374,9 @@ def main():
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
     if args.dry_run:
-        return dry_run(args, rank, world)
+        return train_dry_run(args, rank, world) if args.train else dry_run(args, rank, world)
+    if args.train:
+        return train_bench(args, rank, local_rank, world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     if world > 1:

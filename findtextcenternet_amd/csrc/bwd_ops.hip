@@ -27,6 +27,9 @@ __device__ __forceinline__ float dact(float t, int act) {
 
 // ------------------------------------------------------------------------------------------------------------------------
 // FTC_OP_BNBWD: batch-statistics BatchNorm + activation backward (torch.nn.BatchNorm2d in train(), native_batch_norm_backward).
+// Both passes are HBM streams: a workgroup owns Q channel quads x (256 / Q) row lanes, every access is one 16-byte lane (Q is the
+// largest power of two dividing C / 4, so no channel guards), the per-(image, channel) operands of the MBConv blocks are reloaded only
+// when the row crosses into the next image.  FAST: the exp2 / rcp forms of the 16-bit modes; the fp32 parity mode keeps libm.
 // ------------------------------------------------------------------------------------------------------------------------
 struct BnBwdP {
     const float* gy; int gs, goff;      // incoming gradient, row stride / channel offset
@@ -35,154 +38,234 @@ struct BnBwdP {
     const float* keep;                  // [B] or null
     const float* ga;                    // [B][C] or null
     const float* gb;                    // [B][C] or null
-    int HW; long M; int C; int act;
+    int HW; int M; int C; int act;
 };
 
-__device__ __forceinline__ float bn_dt(const BnBwdP& p, long r, int c, int b, float zv, float sc, float sh) {
-    float g = p.gy[r * p.gs + p.goff + c];
-    if (p.ga) g *= p.ga[(long)b * p.C + c];
-    if (p.gb) g += p.gb[(long)b * p.C + c];
-    if (p.keep) g *= p.keep[b];
-    return g * dact(zv * sc + sh, p.act);
-}
-
-__global__ __launch_bounds__(256) void bnbwd_partial_kernel(BnBwdP p, double* __restrict__ part, int nchunk) {
-    __shared__ double red[2][4][64];
-    const int t = threadIdx.x, cl = t & 63, rl = t >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    const int chunk = blockIdx.y;
-    const long rows = (p.M + nchunk - 1) / nchunk;
-    const long r0 = (long)chunk * rows, r1 = r0 + rows < p.M ? r0 + rows : p.M;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < p.C) {
-        const float sc = p.ss[c], sh = p.ss[p.C + c], mean = p.ss[2 * p.C + c], istd = p.ss[3 * p.C + c];
-        for (long r = r0 + rl; r < r1; r += 4) {
-            const int b = (int)(r / p.HW);
-            const float zv = p.z[r * p.C + c];
-            const float dt = bn_dt(p, r, c, b, zv, sc, sh);
-            s1 += (double)dt;
-            s2 += (double)dt * (double)((zv - mean) * istd);
+template <bool FAST> __device__ __forceinline__ f32x4 dact4(f32x4 t, int act) {
+    f32x4 r;
+    if constexpr (FAST) {
+        if (act == FTC_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t[e]));
+                r[e] = s * (1.0f + t[e] * (1.0f - s));
+            }
+            return r;
+        }
+        if (act == FTC_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                      // Phi(t) + t phi(t); erf by Abramowitz-Stegun 7.1.26, sharing exp(-t^2/2) with phi
+                const float a = fabsf(t[e]), zz = a * 0.70710678118654752440f;
+                const float k = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * zz);
+                float poly = 1.061405429f;
+                poly = poly * k - 1.453152027f;
+                poly = poly * k + 1.421413741f;
+                poly = poly * k - 0.284496736f;
+                poly = poly * k + 0.254829592f;
+                const float ex = __builtin_amdgcn_exp2f(-0.72134752044448170368f * t[e] * t[e]);
+                const float erfa = 1.0f - poly * k * ex;
+                r[e] = 0.5f + copysignf(0.5f * erfa, t[e]) + t[e] * 0.39894228040143267794f * ex;
+            }
+            return r;
+        }
+    } else {
+        if (act != FTC_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = dact(t[e], act);
+            return r;
         }
     }
-    red[0][rl][cl] = s1;
-    red[1][rl][cl] = s2;
+    r = f32x4{1.f, 1.f, 1.f, 1.f};
+    return r;
+}
+
+template <int Q, bool FAST>
+__global__ __launch_bounds__(256) void bnbwd_partial_kernel(BnBwdP p, double* __restrict__ part, int nchunk) {
+    constexpr int RL = 256 / Q;
+    __shared__ double red[2][RL][Q * 4];
+    const int t = threadIdx.x, cq = t % Q, rl = t / Q;
+    const int c = (blockIdx.x * Q + cq) * 4;
+    const int chunk = blockIdx.y;
+    const int rows = (p.M + nchunk - 1) / nchunk;
+    const int r0 = chunk * rows, r1 = min(p.M, r0 + rows);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.ss + c), sh = *reinterpret_cast<const f32x4*>(p.ss + p.C + c);
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(p.ss + 2 * p.C + c), istd = *reinterpret_cast<const f32x4*>(p.ss + 3 * p.C + c);
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    int bcur = -1;
+    f32x4 ga = {1.f, 1.f, 1.f, 1.f}, gb = {0.f, 0.f, 0.f, 0.f};
+    float kp = 1.0f;
+    for (int r = r0 + rl; r < r1; r += RL) {
+        const int b = r / p.HW;
+        if (b != bcur) {
+            bcur = b;
+            if (p.ga) ga = *reinterpret_cast<const f32x4*>(p.ga + (long)b * p.C + c);
+            if (p.gb) gb = *reinterpret_cast<const f32x4*>(p.gb + (long)b * p.C + c);
+            if (p.keep) kp = p.keep[b];
+        }
+        const f32x4 g = (*reinterpret_cast<const f32x4*>(p.gy + (long)r * p.gs + p.goff + c) * ga + gb) * kp;
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(p.z + (long)r * p.C + c);
+        const f32x4 dt = g * dact4<FAST>(zv * sc + sh, p.act);
+        const f32x4 zh = (zv - mean) * istd;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s1[e] += (double)dt[e];
+            s2[e] += (double)dt[e] * (double)zh[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[0][rl][cq * 4 + e] = s1[e];
+        red[1][rl][cq * 4 + e] = s2[e];
+    }
     __syncthreads();
-    if (t < 64 && c < p.C) {
-        part[((long)chunk * 2 + 0) * p.C + c] = (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
-        part[((long)chunk * 2 + 1) * p.C + c] = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+    for (int i = t; i < 2 * Q * 4; i += 256) {
+        const int which = i / (Q * 4), l = i - which * (Q * 4);
+        double a = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < RL; ++k) a += red[which][k][l];
+        part[((long)chunk * 2 + which) * p.C + blockIdx.x * Q * 4 + l] = a;
     }
 }
 
 __global__ __launch_bounds__(256) void bnbwd_final_kernel(const double* __restrict__ part, float* __restrict__ ggamma, float* __restrict__ gbeta,
                                                           float* __restrict__ coef, long M, int C, int nchunk) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[2][4][64];                            // 64 channels x 4 chunk lanes (as bnstat_final_kernel)
+    const int t = threadIdx.x, cl = t & 63, kl = t >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-        s1 += part[((long)k * 2 + 0) * C + c];
-        s2 += part[((long)k * 2 + 1) * C + c];
-    }
+    if (c < C)
+        for (int k = kl; k < nchunk; k += 4) {
+            s1 += part[((long)k * 2 + 0) * C + c];
+            s2 += part[((long)k * 2 + 1) * C + c];
+        }
+    red[0][kl][cl] = s1;
+    red[1][kl][cl] = s2;
+    __syncthreads();
+    if (t >= 64 || c >= C) return;
+    s1 = (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
+    s2 = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
     if (gbeta) gbeta[c] += (float)s1;
     if (ggamma) ggamma[c] += (float)s2;
     coef[c] = (float)(s1 / (double)M);
     coef[C + c] = (float)(s2 / (double)M);
 }
 
-__global__ __launch_bounds__(256) void bnbwd_apply_kernel(BnBwdP p, const float* __restrict__ coef, float* __restrict__ out, int accum) {
-    const int Q = p.C >> 2;
-    const long total = p.M * Q;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long r = idx / Q;
-        const int c = (int)(idx - r * Q) * 4;
-        const int b = (int)(r / p.HW);
-        const f32x4 zv = *reinterpret_cast<const f32x4*>(p.z + r * p.C + c);
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float sc = p.ss[c + e], sh = p.ss[p.C + c + e], mean = p.ss[2 * p.C + c + e], istd = p.ss[3 * p.C + c + e];
-            const float dt = bn_dt(p, r, c + e, b, zv[e], sc, sh);
-            o[e] = sc * (dt - coef[c + e] - (zv[e] - mean) * istd * coef[p.C + c + e]);
+template <int Q, bool FAST>
+__global__ __launch_bounds__(256) void bnbwd_apply_kernel(BnBwdP p, const float* __restrict__ coef, float* __restrict__ out, int accum, int nchunk) {
+    constexpr int RL = 256 / Q;
+    const int t = threadIdx.x, cq = t % Q, rl = t / Q;
+    const int c = (blockIdx.x * Q + cq) * 4;
+    const int chunk = blockIdx.y;
+    const int rows = (p.M + nchunk - 1) / nchunk;
+    const int r0 = chunk * rows, r1 = min(p.M, r0 + rows);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(p.ss + c), sh = *reinterpret_cast<const f32x4*>(p.ss + p.C + c);
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(p.ss + 2 * p.C + c), istd = *reinterpret_cast<const f32x4*>(p.ss + 3 * p.C + c);
+    const f32x4 c1 = *reinterpret_cast<const f32x4*>(coef + c), c2 = *reinterpret_cast<const f32x4*>(coef + p.C + c);
+    int bcur = -1;
+    f32x4 ga = {1.f, 1.f, 1.f, 1.f}, gb = {0.f, 0.f, 0.f, 0.f};
+    float kp = 1.0f;
+    for (int r = r0 + rl; r < r1; r += RL) {
+        const int b = r / p.HW;
+        if (b != bcur) {
+            bcur = b;
+            if (p.ga) ga = *reinterpret_cast<const f32x4*>(p.ga + (long)b * p.C + c);
+            if (p.gb) gb = *reinterpret_cast<const f32x4*>(p.gb + (long)b * p.C + c);
+            if (p.keep) kp = p.keep[b];
         }
-        float* op = out + r * p.C + c;
+        const f32x4 g = (*reinterpret_cast<const f32x4*>(p.gy + (long)r * p.gs + p.goff + c) * ga + gb) * kp;
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(p.z + (long)r * p.C + c);
+        const f32x4 dt = g * dact4<FAST>(zv * sc + sh, p.act);
+        f32x4 o = sc * (dt - c1 - (zv - mean) * istd * c2);
+        float* op = out + (long)r * p.C + c;
         if (accum) o += *reinterpret_cast<const f32x4*>(op);
         *reinterpret_cast<f32x4*>(op) = o;
     }
 }
 
+inline int pick_quads(int C) {
+    const int q = C / 4;
+    for (int t : {64, 32, 16, 8, 4, 2}) if (q % t == 0) return t;
+    return 1;
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
-// FTC_OP_DWBWD: depthwise 3x3 (pad 1, stride 1|2) backward.
+// FTC_OP_DWBWD: depthwise 3x3 (pad 1, stride 1|2) backward.  32-bit index arithmetic throughout (validated: < 2^31 quads).
 // ------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dwbwd_data_kernel(const float* __restrict__ dz, const float* __restrict__ w, float* __restrict__ out, int B, int H,
                                                          int W, int Ho, int Wo, int C, int stride) {
-    const int Q = C >> 2;
-    const long total = (long)B * H * W * Q;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const long pix = idx / Q;
+    const unsigned Q = (unsigned)C >> 2;
+    const unsigned total = (unsigned)B * H * W * Q;
+    for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < total; idx += gridDim.x * 256u) {
+        const unsigned pix = idx / Q;
         const int c = (int)(idx - pix * Q) * 4;
-        const long row = pix / W;
+        const unsigned row = pix / (unsigned)W;
         const int ix = (int)(pix - row * W);
-        const int b = (int)(row / H);
-        const int iy = (int)(row - (long)b * H);
+        const int b = (int)(row / (unsigned)H);
+        const int iy = (int)(row - (unsigned)b * H);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int ty = iy + 1 - r;
-            if (ty < 0 || (ty % stride) != 0) continue;
-            const int oy = ty / stride;
+            if (ty < 0 || (stride == 2 && (ty & 1))) continue;
+            const int oy = stride == 2 ? ty >> 1 : ty;
             if (oy >= Ho) continue;
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
                 const int tx = ix + 1 - s;
-                if (tx < 0 || (tx % stride) != 0) continue;
-                const int ox = tx / stride;
+                if (tx < 0 || (stride == 2 && (tx & 1))) continue;
+                const int ox = stride == 2 ? tx >> 1 : tx;
                 if (ox >= Wo) continue;
                 const f32x4 g = *reinterpret_cast<const f32x4*>(dz + (((long)b * Ho + oy) * Wo + ox) * C + c);
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (r * 3 + s) * C + c);
                 acc += g * wv;
             }
         }
-        *reinterpret_cast<f32x4*>(out + pix * C + c) = acc;
+        *reinterpret_cast<f32x4*>(out + (long)pix * C + c) = acc;
     }
 }
 
+// Q channel quads x (256 / Q) pixel lanes; every lane keeps 9 taps x 4 channels of partial sums over its pixels of the chunk
+template <int Q>
 __global__ __launch_bounds__(256) void dwbwd_weight_partial_kernel(const float* __restrict__ x, const float* __restrict__ dz, double* __restrict__ part, int B,
                                                                    int H, int W, int Ho, int Wo, int C, int stride, int nchunk) {
-    __shared__ float red[4][9][64];
-    const int t = threadIdx.x, cl = t & 63, rl = t >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    constexpr int RL = 256 / Q;
+    __shared__ float red[RL][9][Q * 4];
+    const int t = threadIdx.x, cq = t % Q, rl = t / Q;
+    const int c = (blockIdx.x * Q + cq) * 4;
     const int chunk = blockIdx.y;
-    const long M = (long)B * Ho * Wo;
-    const long rows = (M + nchunk - 1) / nchunk;
-    const long r0 = (long)chunk * rows, r1 = r0 + rows < M ? r0 + rows : M;
-    float acc[9];
+    const int M = B * Ho * Wo;
+    const int rows = (M + nchunk - 1) / nchunk;
+    const int r0 = chunk * rows, r1 = min(M, r0 + rows);
+    f32x4 acc[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
-    if (c < C)
-        for (long p = r0 + rl; p < r1; p += 4) {
-            const long row = p / Wo;
-            const int ox = (int)(p - row * Wo);
-            const int b = (int)(row / Ho);
-            const int oy = (int)(row - (long)b * Ho);
-            const float g = dz[p * C + c];
+    for (int k = 0; k < 9; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = r0 + rl; p < r1; p += RL) {
+        const int row = p / Wo;
+        const int ox = p - row * Wo;
+        const int b = row / Ho;
+        const int oy = row - b * Ho;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dz + (long)p * C + c);
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int iy = oy * stride + r - 1;
-                if ((unsigned)iy >= (unsigned)H) continue;
+        for (int r = 0; r < 3; ++r) {
+            const int iy = oy * stride + r - 1;
+            if ((unsigned)iy >= (unsigned)H) continue;
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const int ix = ox * stride + s - 1;
-                    if ((unsigned)ix >= (unsigned)W) continue;
-                    acc[r * 3 + s] += g * x[(((long)b * H + iy) * W + ix) * C + c];
-                }
+            for (int s = 0; s < 3; ++s) {
+                const int ix = ox * stride + s - 1;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                acc[r * 3 + s] += g * *reinterpret_cast<const f32x4*>(x + (((long)b * H + iy) * W + ix) * C + c);
             }
         }
+    }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) red[rl][k][cl] = acc[k];
+    for (int k = 0; k < 9; ++k) *reinterpret_cast<f32x4*>(&red[rl][k][cq * 4]) = acc[k];
     __syncthreads();
-    for (int i = t; i < 9 * 64; i += 256) {
-        const int k = i >> 6, l = i & 63;
-        if (blockIdx.x * 64 + l < C)
-            part[((long)chunk * 9 + k) * C + blockIdx.x * 64 + l] = ((double)red[0][k][l] + (double)red[1][k][l]) + ((double)red[2][k][l] + (double)red[3][k][l]);
+    for (int i = t; i < 9 * Q * 4; i += 256) {
+        const int k = i / (Q * 4), l = i - k * (Q * 4);
+        double a = 0.0;
+#pragma unroll 4
+        for (int j = 0; j < RL; ++j) a += (double)red[j][k][l];
+        part[((long)chunk * 9 + k) * C + blockIdx.x * Q * 4 + l] = a;
     }
 }
 
@@ -197,76 +280,90 @@ __global__ __launch_bounds__(256) void dwbwd_weight_final_kernel(const double* _
 
 // ------------------------------------------------------------------------------------------------------------------------
 // FTC_OP_SEBWD: y*s with s = sigmoid(fc2(SiLU(fc1(mean_hw y)))).  Scratch layout (floats): ds [B][C] | du2 [B][C] | mean [B][C] |
-// dmean/HW [B][C] | da1 [B][S] | h [B][S].
+// dmean/HW [B][C] | da1 [B][S] | h [B][S] | ds partial sums [B][SE_PCH][C].
 // ------------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sebwd_ds_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ ds, int HW, int C) {
-    __shared__ double red[4][64];
-    const int t = threadIdx.x, cl = t & 63, rl = t >> 6;
-    const int c = blockIdx.x * 64 + cl, b = blockIdx.y;
-    double acc = 0.0;
-    if (c < C)
-        for (int r = rl; r < HW; r += 4) {
-            const long i = ((long)b * HW + r) * C + c;
-            acc += (double)(g[i] * y[i]);
-        }
-    red[rl][cl] = acc;
+constexpr int SE_PCH = 32;
+
+template <int Q>
+__global__ __launch_bounds__(256) void sebwd_ds_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ dsp, int HW, int C, int pch) {
+    constexpr int RL = 256 / Q;
+    __shared__ float red[RL][Q * 4];
+    const int t = threadIdx.x, cq = t % Q, rl = t / Q;
+    const int c = (blockIdx.x * Q + cq) * 4, chunk = blockIdx.y, b = blockIdx.z;
+    const int rows = (HW + pch - 1) / pch;
+    const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0 + rl; r < r1; r += RL) {
+        const long i = ((long)b * HW + r) * C + c;
+        acc += *reinterpret_cast<const f32x4*>(g + i) * *reinterpret_cast<const f32x4*>(y + i);
+    }
+    *reinterpret_cast<f32x4*>(&red[rl][cq * 4]) = acc;
     __syncthreads();
-    if (t < 64 && c < C) ds[(long)b * C + c] = (float)((red[0][t] + red[1][t]) + (red[2][t] + red[3][t]));
+    for (int l = t; l < Q * 4; l += 256) {
+        double a = 0.0;
+#pragma unroll 4
+        for (int j = 0; j < RL; ++j) a += (double)red[j][l];
+        dsp[((long)b * pch + chunk) * C + blockIdx.x * Q * 4 + l] = (float)a;
+    }
 }
 
-__global__ __launch_bounds__(512) void sebwd_mlp_kernel(const float* __restrict__ sums, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                        const float* __restrict__ w2t, const float* __restrict__ scale, float* __restrict__ scratch,
-                                                        int B, int C, int S, int P, float inv_hw) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];      // mean [C] | du2 [C] | a1 [S] | da1 [S]
-    float* mean = lds;
-    float* du2 = lds + C;
-    float* a1 = du2 + C;
-    float* da1 = a1 + S;
-    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+// (1) grid (ceil(C / 256), B): mean of y, total of the ds partial sums, d(pre-sigmoid)
+__global__ __launch_bounds__(256) void sebwd_prep_kernel(const float* __restrict__ sums, const float* __restrict__ scale, float* __restrict__ scratch, int B, int C,
+                                                         int S, int P, float inv_hw, int pch) {
+    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
     float* o_ds = scratch;
     float* o_du2 = scratch + (long)B * C;
     float* o_mean = scratch + (long)2 * B * C;
-    float* o_gb = scratch + (long)3 * B * C;
+    const float* dsp = scratch + (long)4 * B * C + (long)2 * B * S;
+    float m = 0.f;
+    for (int p = 0; p < P; ++p) m += sums[((long)b * P + p) * C + c];
+    o_mean[(long)b * C + c] = m * inv_hw;
+    double dsum = 0.0;
+    for (int p = 0; p < pch; ++p) dsum += (double)dsp[((long)b * pch + p) * C + c];
+    const float dsv = (float)dsum;
+    o_ds[(long)b * C + c] = dsv;
+    const float sv = scale[(long)b * C + c];
+    o_du2[(long)b * C + c] = dsv * sv * (1.0f - sv);
+}
+
+// (2) grid (ceil(S / 4), B), one wave per hidden unit j: a1 = fc1 . mean + b1, dh = fc2^T . du2 -> da1, h
+__global__ __launch_bounds__(256) void sebwd_hidden_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2t,
+                                                           float* __restrict__ scratch, int B, int C, int S) {
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (j >= S) return;
+    const float* du2 = scratch + (long)B * C + (long)b * C;
+    const float* mean = scratch + (long)2 * B * C + (long)b * C;
     float* o_da1 = scratch + (long)4 * B * C;
     float* o_h = o_da1 + (long)B * S;
-    for (int c = t; c < C; c += 512) {
-        float m = 0.f;
-        for (int p = 0; p < P; ++p) m += sums[((long)b * P + p) * C + c];
-        m *= inv_hw;
-        mean[c] = m;
-        o_mean[(long)b * C + c] = m;
-        const float sv = scale[(long)b * C + c];
-        const float d = o_ds[(long)b * C + c] * sv * (1.0f - sv);
-        du2[c] = d;
-        o_du2[(long)b * C + c] = d;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, dh = {0.f, 0.f, 0.f, 0.f};
+    for (int c = lane * 4; c < C; c += 256) {
+        acc += *reinterpret_cast<const f32x4*>(w1 + (long)j * C + c) * *reinterpret_cast<const f32x4*>(mean + c);
+        dh += *reinterpret_cast<const f32x4*>(w2t + (long)j * C + c) * *reinterpret_cast<const f32x4*>(du2 + c);
     }
-    __syncthreads();
-    for (int j = wave; j < S; j += 8) {
-        float acc = 0.f, dh = 0.f;
-        for (int c = lane; c < C; c += 64) {
-            acc += w1[(long)j * C + c] * mean[c];
-            dh += w2t[(long)j * C + c] * du2[c];
-        }
-        acc = wave_sum(acc);
-        dh = wave_sum(dh);
-        if (lane == 0) {
-            const float a = acc + b1[j];
-            a1[j] = a;
-            const float d = dh * dact(a, FTC_ACT_SILU);
-            da1[j] = d;
-            o_da1[(long)b * S + j] = d;
-            o_h[(long)b * S + j] = a / (1.0f + expf(-a));
-        }
-    }
-    __syncthreads();
-    for (int c = t; c < C; c += 512) {
-        float acc = 0.f;
-        for (int j = 0; j < S; ++j) acc += da1[j] * w1[(long)j * C + c];
-        o_gb[(long)b * C + c] = acc * inv_hw;
+    const float a = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3])) + b1[j];
+    const float d = wave_sum((dh[0] + dh[1]) + (dh[2] + dh[3])) * dact(a, FTC_ACT_SILU);
+    if (lane == 0) {
+        o_da1[(long)b * S + j] = d;
+        o_h[(long)b * S + j] = a / (1.0f + expf(-a));
     }
 }
 
-// grads: fc1.weight [S][C] | fc1.bias [S] | fc2.weight [C][S] | fc2.bias [C]
+// (3) grid (ceil(C / 256), B): d mean / HW = fc1^T . da1 / HW
+__global__ __launch_bounds__(256) void sebwd_dmean_kernel(const float* __restrict__ w1, float* __restrict__ scratch, int B, int C, int S, float inv_hw) {
+    extern __shared__ float da1[];
+    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    const float* o_da1 = scratch + (long)4 * B * C + (long)b * S;
+    for (int j = threadIdx.x; j < S; j += 256) da1[j] = o_da1[j];
+    __syncthreads();
+    if (c >= C) return;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < S; ++j) acc += da1[j] * w1[(long)j * C + c];
+    scratch[(long)3 * B * C + (long)b * C + c] = acc * inv_hw;
+}
+
+// grads: fc1.weight [S][C] | fc1.bias [S] | fc2.weight [C][S] | fc2.bias [C].  grid (ceil(C / 256), S): one (j, c) pair per thread
 __global__ __launch_bounds__(256) void sebwd_w_kernel(const float* __restrict__ scratch, float* __restrict__ grads, int B, int C, int S) {
     const float* du2 = scratch + (long)B * C;
     const float* mean = scratch + (long)2 * B * C;
@@ -276,26 +373,23 @@ __global__ __launch_bounds__(256) void sebwd_w_kernel(const float* __restrict__ 
     float* gb1 = gw1 + (long)S * C;
     float* gw2 = gb1 + S;
     float* gb2 = gw2 + (long)C * S;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x == 0)
-        for (int j = threadIdx.x; j < S; j += 256) {
-            float a = 0.f;
-            for (int b = 0; b < B; ++b) a += da1[(long)b * S + j];
-            gb1[j] += a;
-        }
-    if (c >= C) return;
-    float sb = 0.f;
-    for (int b = 0; b < B; ++b) sb += du2[(long)b * C + c];
-    gb2[c] += sb;
-    for (int j = 0; j < S; ++j) {
-        float a1 = 0.f, a2 = 0.f;
-        for (int b = 0; b < B; ++b) {
-            a1 += da1[(long)b * S + j] * mean[(long)b * C + c];
-            a2 += du2[(long)b * C + c] * h[(long)b * S + j];
-        }
-        gw1[(long)j * C + c] += a1;
-        gw2[(long)c * S + j] += a2;
+    const int c = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += da1[(long)b * S + j];
+        gb1[j] += a;
     }
+    if (c >= C) return;
+    float a1 = 0.f, a2 = 0.f, sb = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float d = du2[(long)b * C + c];
+        a1 += da1[(long)b * S + j] * mean[(long)b * C + c];
+        a2 += d * h[(long)b * S + j];
+        sb += d;
+    }
+    gw1[(long)j * C + c] += a1;
+    gw2[(long)c * S + j] += a2;
+    if (j == 0) gb2[c] += sb;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -595,24 +689,51 @@ hipError_t launch_pack_train(const ftc_pack_entry* entries, int n, long max_elem
     return hipGetLastError();
 }
 
+namespace {
+template <int Q, bool FAST>
+hipError_t bnbwd_run(const BnBwdP& p, double* part, float* coef, float* ggamma, float* gbeta, float* out, int accum, int nchunk, hipStream_t s) {
+    const dim3 grid(p.C / (4 * Q), nchunk);
+    hipLaunchKernelGGL((bnbwd_partial_kernel<Q, FAST>), grid, dim3(256), 0, s, p, part, nchunk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(bnbwd_final_kernel, dim3((p.C + 63) / 64), dim3(256), 0, s, part, ggamma, gbeta, coef, (long)p.M, p.C, nchunk);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // the apply pass streams: enough row chunks to fill the GPU (the partial pass is bound to the scratch layout's chunk count)
+    int ach = (int)((4096L * 4 * Q) / p.C);
+    ach = ach < 1 ? 1 : ach > p.M / 8 + 1 ? p.M / 8 + 1 : ach;
+    hipLaunchKernelGGL((bnbwd_apply_kernel<Q, FAST>), dim3(p.C / (4 * Q), ach), dim3(256), 0, s, p, coef, out, accum, ach);
+    return hipGetLastError();
+}
+template <bool FAST>
+hipError_t bnbwd_q(int q, const BnBwdP& p, double* part, float* coef, float* gg, float* gb, float* out, int accum, int nchunk, hipStream_t s) {
+    switch (q) {
+    case 64: return bnbwd_run<64, FAST>(p, part, coef, gg, gb, out, accum, nchunk, s);
+    case 32: return bnbwd_run<32, FAST>(p, part, coef, gg, gb, out, accum, nchunk, s);
+    case 16: return bnbwd_run<16, FAST>(p, part, coef, gg, gb, out, accum, nchunk, s);
+    case 8: return bnbwd_run<8, FAST>(p, part, coef, gg, gb, out, accum, nchunk, s);
+    case 4: return bnbwd_run<4, FAST>(p, part, coef, gg, gb, out, accum, nchunk, s);
+    case 2: return bnbwd_run<2, FAST>(p, part, coef, gg, gb, out, accum, nchunk, s);
+    default: return bnbwd_run<1, FAST>(p, part, coef, gg, gb, out, accum, nchunk, s);
+    }
+}
+}  // namespace
+
 hipError_t launch_bnbwd(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
     BnBwdP p;
     p.gy = (const float*)a.in; p.gs = o.Cin_total > 0 ? o.Cin_total : o.Cin; p.goff = o.cin_off;
     p.z = (const float*)a.in2; p.ss = a.scale; p.keep = (const float*)a.w2; p.ga = a.bias; p.gb = a.bias2;
-    p.HW = o.H * o.W; p.M = (long)o.B * o.H * o.W; p.C = o.Cin; p.act = o.act;
+    p.HW = o.H * o.W; p.M = o.B * o.H * o.W; p.C = o.Cin; p.act = o.act;
     const int nchunk = ftc_bnstat_chunks(p.M);
     double* part = reinterpret_cast<double*>(a.aux);
     float* coef = reinterpret_cast<float*>(part + (long)nchunk * 2 * p.C);
-    hipLaunchKernelGGL(bnbwd_partial_kernel, dim3((p.C + 63) / 64, nchunk), dim3(256), 0, s, p, part, nchunk);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bnbwd_final_kernel, dim3((p.C + 255) / 256), dim3(256), 0, s, part, (float*)const_cast<void*>(a.w), const_cast<float*>(a.shift), coef,
-                       p.M, p.C, nchunk);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bnbwd_apply_kernel, dim3(nblocks(p.M * (p.C / 4))), dim3(256), 0, s, p, coef, (float*)a.out, (o.flags & FTC_FLAG_ACCUM) ? 1 : 0);
-    return hipGetLastError();
+    const int q = pick_quads(p.C);
+    float* gg = (float*)const_cast<void*>(a.w);
+    float* gb = const_cast<float*>(a.shift);
+    const int accum = (o.flags & FTC_FLAG_ACCUM) ? 1 : 0;
+    if (o.w_dtype == FTC_F32) return bnbwd_q<false>(q, p, part, coef, gg, gb, (float*)a.out, accum, nchunk, s);
+    return bnbwd_q<true>(q, p, part, coef, gg, gb, (float*)a.out, accum, nchunk, s);
 }
 
 hipError_t launch_dwbwd(const OpArgs& a, hipStream_t s) {
@@ -624,8 +745,11 @@ hipError_t launch_dwbwd(const OpArgs& a, hipStream_t s) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     double* part = reinterpret_cast<double*>(a.aux);
-    hipLaunchKernelGGL(dwbwd_weight_partial_kernel, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, (const float*)a.in, (const float*)a.in2, part, o.B, o.H, o.W,
-                       o.Ho, o.Wo, C, o.stride, nchunk);
+    const int Q = pick_quads(C) > 16 ? 16 : pick_quads(C);        // 9 x 4 accumulators per lane: keep the LDS image at 36 KB
+#define DWW(QQ) hipLaunchKernelGGL(dwbwd_weight_partial_kernel<QQ>, dim3(C / (4 * QQ), nchunk), dim3(256), 0, s, (const float*)a.in, (const float*)a.in2, part, \
+                                   o.B, o.H, o.W, o.Ho, o.Wo, C, o.stride, nchunk)
+    switch (Q) { case 16: DWW(16); break; case 8: DWW(8); break; case 4: DWW(4); break; case 2: DWW(2); break; default: DWW(1); }
+#undef DWW
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(dwbwd_weight_final_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, s, part, (float*)a.out2, C, nchunk);
@@ -636,14 +760,28 @@ hipError_t launch_sebwd(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
     const int C = o.Cin, S = o.aux0, P = o.aux1, HW = o.H * o.W;
     float* scratch = (float*)a.out;
-    hipLaunchKernelGGL(sebwd_ds_kernel, dim3((C + 63) / 64, o.B), dim3(256), 0, s, (const float*)a.in, (const float*)a.in2, scratch, HW, C);
+    float* dsp = scratch + (long)4 * o.B * C + (long)2 * o.B * S;
+    const int Q = pick_quads(C);
+    int pch = 1024 / ((C / (4 * Q)) * o.B);
+    pch = pch < 1 ? 1 : pch > SE_PCH ? SE_PCH : pch;
+    if (pch > HW / 16) pch = HW / 16 > 0 ? HW / 16 : 1;
+#define SEDS(QQ) hipLaunchKernelGGL(sebwd_ds_kernel<QQ>, dim3(C / (4 * QQ), pch, o.B), dim3(256), 0, s, (const float*)a.in, (const float*)a.in2, dsp, HW, C, pch)
+    switch (Q) { case 64: SEDS(64); break; case 32: SEDS(32); break; case 16: SEDS(16); break; case 8: SEDS(8); break; case 4: SEDS(4); break;
+                 case 2: SEDS(2); break; default: SEDS(1); }
+#undef SEDS
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sebwd_mlp_kernel, dim3(o.B), dim3(512), (size_t)(2 * C + 2 * S) * sizeof(float), s, (const float*)a.aux, (const float*)a.w, a.bias,
-                       (const float*)a.w2, a.scale, scratch, o.B, C, S, P, 1.0f / (float)HW);
+    const float inv_hw = 1.0f / (float)HW;
+    hipLaunchKernelGGL(sebwd_prep_kernel, dim3((C + 255) / 256, o.B), dim3(256), 0, s, (const float*)a.aux, a.scale, scratch, o.B, C, S, P, inv_hw, pch);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sebwd_w_kernel, dim3((C + 255) / 256), dim3(256), 0, s, scratch, (float*)a.out2, o.B, C, S);
+    hipLaunchKernelGGL(sebwd_hidden_kernel, dim3((S + 3) / 4, o.B), dim3(256), 0, s, (const float*)a.w, a.bias, (const float*)a.w2, scratch, o.B, C, S);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sebwd_dmean_kernel, dim3((C + 255) / 256, o.B), dim3(256), (size_t)S * sizeof(float), s, (const float*)a.w, scratch, o.B, C, S, inv_hw);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sebwd_w_kernel, dim3((C + 255) / 256, S), dim3(256), 0, s, scratch, (float*)a.out2, o.B, C, S);
     return hipGetLastError();
 }
 

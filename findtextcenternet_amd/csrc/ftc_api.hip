@@ -244,11 +244,11 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
             !need(o.aux, true, "aux", (int64_t)ftc_bnstat_chunks(pout) * 9 * o.Cin * 8)) return why->c_str();
         return nullptr;
     case FTC_OP_SEBWD:
-        if (o.Cin <= 0 || o.aux0 <= 0 || o.aux1 <= 0) return "sebwd: C, S, P must be positive";
+        if (o.Cin <= 0 || (o.Cin & 3) || o.aux0 <= 0 || o.aux1 <= 0) return "sebwd: C (% 4 == 0), S, P must be positive";
         if ((size_t)(2 * o.Cin + 2 * o.aux0) * 4 > 64000) return "sebwd: C / S too large for LDS";
         if (!need(o.in, true, "in", pin * o.Cin * 4) || !need(o.in2, true, "in2", pin * o.Cin * 4) || !need(o.scale, true, "scale", (int64_t)o.B * o.Cin * 4) ||
             !need(o.aux, true, "aux", (int64_t)o.B * o.aux1 * o.Cin * 4) || !need(o.w, true, "w", (int64_t)o.aux0 * o.Cin * 4) || !need(o.w2, true, "w2", (int64_t)o.aux0 * o.Cin * 4) ||
-            !need(o.bias, true, "bias", (int64_t)o.aux0 * 4) || !need(o.out, true, "out", ((int64_t)4 * o.B * o.Cin + (int64_t)2 * o.B * o.aux0) * 4) ||
+            !need(o.bias, true, "bias", (int64_t)o.aux0 * 4) || !need(o.out, true, "out", ((int64_t)(4 + 32) * o.B * o.Cin + (int64_t)2 * o.B * o.aux0) * 4) ||
             !need(o.out2, true, "out2", ((int64_t)2 * o.aux0 * o.Cin + o.aux0 + o.Cin) * 4)) return why->c_str();
         return nullptr;
     case FTC_OP_UPCATBWD:

@@ -334,16 +334,62 @@ __global__ __launch_bounds__(256) void bnstat_partial_kernel(const T* __restrict
     }
 }
 
+// fp32 input with C % 4 == 0 (the train step): 16-byte lanes, Q channel quads x (256 / Q) row lanes per workgroup (Q = the largest
+// power of two dividing C / 4); same sums as above up to the association of the per-lane partial sums
+template <int Q>
+__global__ __launch_bounds__(256) void bnstat_partial_q_kernel(const float* __restrict__ x, double* __restrict__ part, int M, int C, int nchunk) {
+    constexpr int RL = 256 / Q;
+    __shared__ double red[2][RL][Q * 4];
+    const int t = threadIdx.x, cq = t % Q, rl = t / Q;
+    const int c = (blockIdx.x * Q + cq) * 4;
+    const int chunk = blockIdx.y;
+    const int rows = (M + nchunk - 1) / nchunk;
+    const int r0 = chunk * rows, r1 = min(M, r0 + rows);
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r = r0 + rl; r < r1; r += RL) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (long)r * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double d = (double)v[e];
+            s1[e] += d;
+            s2[e] += d * d;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[0][rl][cq * 4 + e] = s1[e];
+        red[1][rl][cq * 4 + e] = s2[e];
+    }
+    __syncthreads();
+    for (int i = t; i < 2 * Q * 4; i += 256) {
+        const int which = i / (Q * 4), l = i - which * (Q * 4);
+        double a = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < RL; ++k) a += red[which][k][l];
+        part[((long)chunk * 2 + which) * C + blockIdx.x * Q * 4 + l] = a;
+    }
+}
+
+// 64 channels x 4 chunk lanes per workgroup: lane k sums chunks k, k+4, ... (one thread per channel walking up to 512 chunks made this
+// kernel, not the streaming pass, the larger half of a BNSTAT op)
 __global__ __launch_bounds__(256) void bnstat_final_kernel(const double* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ running, float* __restrict__ out, long M, int C, int nchunk, float eps,
                                                            float momentum) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[2][4][64];
+    const int t = threadIdx.x, cl = t & 63, kl = t >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-        s1 += part[((long)k * 2 + 0) * C + c];
-        s2 += part[((long)k * 2 + 1) * C + c];
-    }
+    if (c < C)
+        for (int k = kl; k < nchunk; k += 4) {
+            s1 += part[((long)k * 2 + 0) * C + c];
+            s2 += part[((long)k * 2 + 1) * C + c];
+        }
+    red[0][kl][cl] = s1;
+    red[1][kl][cl] = s2;
+    __syncthreads();
+    if (t >= 64 || c >= C) return;
+    s1 = (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
+    s2 = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
     const double mean = s1 / (double)M;
     double var = s2 / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -401,12 +447,21 @@ hipError_t launch_bnstat(const OpArgs& a, hipStream_t s) {
     memcpy(&eps, &o.aux0, 4);
     memcpy(&mom, &o.aux1, 4);
     const dim3 grid((C + 63) / 64, nchunk);
-    if (o.in_dtype == FTC_F32) hipLaunchKernelGGL(bnstat_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)a.in, part, M, C, nchunk);
+    if (o.in_dtype == FTC_F32 && C % 4 == 0 && M < 0x7fffffffL) {
+        const int q = C / 4;
+        const int Q = q % 64 == 0 ? 64 : q % 32 == 0 ? 32 : q % 16 == 0 ? 16 : q % 8 == 0 ? 8 : q % 4 == 0 ? 4 : q % 2 == 0 ? 2 : 1;
+        const dim3 gq(C / (4 * Q), nchunk);
+#define BNSTAT_Q(QQ) hipLaunchKernelGGL(bnstat_partial_q_kernel<QQ>, gq, dim3(256), 0, s, (const float*)a.in, part, (int)M, C, nchunk)
+        switch (Q) { case 64: BNSTAT_Q(64); break; case 32: BNSTAT_Q(32); break; case 16: BNSTAT_Q(16); break; case 8: BNSTAT_Q(8); break;
+                     case 4: BNSTAT_Q(4); break; case 2: BNSTAT_Q(2); break; default: BNSTAT_Q(1); }
+#undef BNSTAT_Q
+    }
+    else if (o.in_dtype == FTC_F32) hipLaunchKernelGGL(bnstat_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)a.in, part, M, C, nchunk);
     else if (o.in_dtype == FTC_F16) hipLaunchKernelGGL(bnstat_partial_kernel<_Float16>, grid, dim3(256), 0, s, (const _Float16*)a.in, part, M, C, nchunk);
     else hipLaunchKernelGGL(bnstat_partial_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)a.in, part, M, C, nchunk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bnstat_final_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, (const float*)a.w, a.bias, a.aux, (float*)a.out, M, C, nchunk, eps, mom);
+    hipLaunchKernelGGL(bnstat_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, part, (const float*)a.w, a.bias, a.aux, (float*)a.out, M, C, nchunk, eps, mom);
     return hipGetLastError();
 }
 

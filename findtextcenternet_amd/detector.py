@@ -85,12 +85,13 @@ class _HipEngine:
         self.wdev: Optional[torch.Tensor] = None
         self.workspace: Optional[torch.Tensor] = None
         self.fingerprint = None
-        self._flat = None
 
     def invalidate(self) -> None:
+        """Forces a re-pack on the next forward.  Needed by hand only after writes the fingerprint cannot see: in-place edits through
+        ``p.data`` (``p.data.copy_()``, ``p.data.mul_()`` ...: ``.data`` carries its own version counter) or raw-pointer writes."""
         if self.model is not None:
             self.model.close()
-        self.model, self.wdev, self.fingerprint, self._flat = None, None, None, None
+        self.model, self.wdev, self.fingerprint = None, None, None
 
     def __del__(self):
         try:
@@ -100,12 +101,14 @@ class _HipEngine:
 
     def _fingerprint(self):
         module = self.module
-        # Parameters and buffers can change behind our back (optimizer.step(), p.data.copy_(), .half().float(), the
-        # schedule-free optimizer's train()/eval() swap ...): in-place writes bump Tensor._version, re-allocations move
-        # data_ptr.  ~1 ms of host time for the 2400 tensors, hidden behind the previous forward's GPU work.
-        if self._flat is None:
-            self._flat = list(module.parameters()) + list(module.buffers())
-        return (sum(t._version for t in self._flat), sum(t.data_ptr() for t in self._flat))
+        # Parameters and buffers can change behind our back: in-place writes on the tensor itself (p.add_(), optimizer.step() --
+        # findtextcenternet_amd's AdamWScheduleFree and TrainStep bump the counters of what their kernels wrote --, the schedule-free
+        # train()/eval() swap) bump Tensor._version; re-allocations (p.data = ..., .half().float()) move data_ptr; replaced Parameter
+        # objects (load_state_dict(assign=True), m.backbone = ..., parametrizations) change id().  The tensors are re-enumerated on
+        # every call (~2 ms of host time for the 2400 tensors, hidden behind the previous forward's GPU work).  NOT seen: in-place
+        # writes through `p.data` (its own version counter) -- call invalidate() after those.
+        ts = list(module.parameters()) + list(module.buffers())
+        return (sum(t._version for t in ts), sum(t.data_ptr() for t in ts), sum(id(t) for t in ts))
 
     def ensure_model(self, device) -> None:
         fp = self._fingerprint()
@@ -185,6 +188,11 @@ class CenterNetDetection(nn.Module):
     @property
     def precision(self) -> str:
         return self._engine.precision
+
+    def load_state_dict(self, *args, **kwargs):
+        r = super().load_state_dict(*args, **kwargs)
+        self._engine.invalidate()                        # a new checkpoint always re-packs (also with assign=True)
+        return r
 
     def set_precision(self, precision: str) -> None:
         if precision not in PRECISIONS:
@@ -266,6 +274,11 @@ class TextDetectorModel(nn.Module):
         object.__setattr__(self.detector, "_engine", eng)
         object.__setattr__(self, "_engine", eng)
         object.__setattr__(self.decoder, "_owner", self)
+
+    def load_state_dict(self, *args, **kwargs):
+        r = super().load_state_dict(*args, **kwargs)
+        self._engine.invalidate()                        # a new checkpoint always re-packs (also with assign=True)
+        return r
 
     def __getstate__(self):
         st = dict(self.__dict__)

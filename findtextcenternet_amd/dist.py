@@ -79,3 +79,58 @@ def all_gather_boxes(counts: torch.Tensor, records: torch.Tensor, group: Optiona
         keep = torch.cat([torch.arange(r * b_pad, r * b_pad + int(metas_h[r, 0])) for r in range(world)]).to(dev)
         out_c, out_r = out_c.index_select(0, keep), out_r.index_select(0, keep)
     return GatheredBoxes(out_c, out_r, feat0, rec.numel() * rec.element_size() + cnt.numel() * 4 + 8)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Train step (BASELINE configs[4]: "train1.py step ... 2xMI355X DDP"): data-parallel gradient all-reduce.  The reference has no
+# distributed training code; this is the build's own: one process per GPU, per-rank BatchNorm statistics (the
+# reference uses plain BatchNorm2d), gradients summed over ranks.  TrainStep keeps every gradient in ONE flat fp32 buffer in
+# parameter order; the backward pass completes it from the END (decoder, heads) towards the stem, so the buffer is cut into
+# buckets from the end and each bucket is all-reduced on a side stream as soon as the ops that write into it have run -- the
+# collective of bucket k overlaps the backward kernels of bucket k+1.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring
+# all-reduce of 1.05 GB of gradients is per-link bound (~2 * 1.05 GB * (N-1)/N / link rate), so FEW LARGE buckets (default
+# 256 MB) rather than DDP's 25 MB ones: the per-collective latency is paid 4-5 times per step instead of 40.
+# ----------------------------------------------------------------------------------------------------------------------
+class BucketedAllReduce:
+    """Sums a flat gradient buffer over the ranks of `group` in buckets cut from the END of the buffer.  Device-agnostic (RCCL on
+    GPU tensors, gloo on CPU tensors in the tests).  Averaging is the caller's business (TrainStep scales the loss by 1/world)."""
+
+    def __init__(self, flat: torch.Tensor, bucket_bytes: int = 256 << 20, group: Optional[dist.ProcessGroup] = None, align: int = 4):
+        if flat.dim() != 1 or not flat.is_contiguous():
+            raise ValueError("BucketedAllReduce needs a contiguous 1-d buffer")
+        self.flat, self.group = flat, group
+        n = flat.numel()
+        per = max(align, (bucket_bytes // flat.element_size()) // align * align)
+        self.ranges = []                       # [(lo, hi)] element ranges, LAST part of the buffer first
+        hi = n
+        while hi > 0:
+            lo = max(0, hi - per)
+            self.ranges.append((lo, hi))
+            hi = lo
+        self.handles = []
+
+    @property
+    def world(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def reduce_bucket(self, i: int, async_op: bool = True):
+        lo, hi = self.ranges[i]
+        if self.world == 1:
+            return None
+        h = dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        if async_op:
+            self.handles.append(h)
+        return h
+
+    def wait(self) -> None:
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+
+    def reduce_all(self) -> None:
+        for i in range(len(self.ranges)):
+            self.reduce_bucket(i, async_op=True)
+        self.wait()
+
+    def message_bytes(self) -> int:
+        return self.flat.numel() * self.flat.element_size()

@@ -18,6 +18,14 @@ from . import _lib as L
 CHUNK = 4096          # elements per workgroup of the update kernel
 
 
+def bump_versions(tensors) -> None:
+    """Marks tensors that a HIP kernel wrote through raw pointers as modified (Tensor._version + 1), as an in-place ATen op would:
+    the detector engine re-packs its weight blob when the counters of the module's parameters / buffers move."""
+    ts = list(tensors)
+    if ts:
+        torch._C._autograd._unsafe_set_version_counter(ts, [t._version + 1 for t in ts])
+
+
 def step_scalars(group: dict) -> Dict[str, float]:
     """The per-step scalars of one parameter group, in float64 exactly as the reference derives them
     (adamw_schedulefree.py:124-147), and the group's bookkeeping updated in place (scheduled_lr, lr_max, weight_sum)."""
@@ -120,5 +128,6 @@ class AdamWScheduleFree(torch.optim.Optimizer):
                     L.check(lib.ftc_adamw_schedulefree_step(table.data_ptr(), n, f(sc["beta2"]), f(sc["one_minus_beta2"]), f(sc["bias_correction2"]),
                                                             f(sc["eps"]), f(sc["weight_decay"]), f(sc["ckp1"]), f(sc["y_alpha"]), f(sc["lr"]), 1,
                                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "ftc_adamw_schedulefree_step")
+                bump_versions(active)                # the kernel wrote through raw pointers: tell whoever fingerprints the parameters
             group["k"] = group["k"] + 1
         return loss

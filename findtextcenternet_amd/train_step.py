@@ -136,6 +136,7 @@ class TrainStep:
         self.blob, self.flat, self.grads = blob, fl, grads
         self.params = params
         self.counters = [b for k, b in self.module.named_buffers() if k.endswith("num_batches_tracked")]
+        self.stat_buffers = [b for k, b in self.module.named_buffers() if k.endswith("running_mean") or k.endswith("running_var")]
         # pack-entry table on the device
         ents = (L.PackEntry * len(self.pack_specs))()
         base = blob.data_ptr()
@@ -241,7 +242,7 @@ class TrainStep:
             M = B * h * w
             nchunk = max(1, min(512, -(-M // 256)))
             dz = out if out is not None else self.buf(M * c * 4)
-            self.emit("bwd:" + bn_name, kind=L.OP_BNBWD, flags=L.FLAG_ACCUM if accum else 0, act=act, B=B, H=h, W=w, Cin=c, Cin_total=gy_total, cin_off=gy_off,
+            self.emit("bwd:" + bn_name, kind=L.OP_BNBWD, flags=L.FLAG_ACCUM if accum else 0, act=act, w_dtype=self.ts.cdt, B=B, H=h, W=w, Cin=c, Cin_total=gy_total, cin_off=gy_off,
                       in_=gy, in2=z, scale=ss, w2=keep, bias=ga, bias2=gb, out=dz, w=self.g(bn_name + ".weight"), shift=self.g(bn_name + ".bias"),
                       aux=self.buf(nchunk * 2 * c * 8 + 2 * c * 4))
             return dz
@@ -504,7 +505,7 @@ class TrainStep:
                 g.wgrad(rec["y1"], gz3, ho, wo, e, cout, 1, 1, b + ".3.0.weight", se=rec["sc"])
                 gys = g.dgrad(gz3, ho, wo, cout, b + ".3.0.weight", e, 1, 1, ho, wo)
                 s = rec["s"]
-                scr = g.buf((4 * B * e + 2 * B * s) * 4)
+                scr = g.buf((36 * B * e + 2 * B * s) * 4)
                 g.emit("sebwd:" + b, kind=L.OP_SEBWD, B=B, H=ho, W=wo, Cin=e, aux0=s, aux1=rec["pse"], in_=gys, in2=rec["y1"], scale=rec["sc"], aux=rec["sums"],
                        w=g.w(b + ".2.fc1.weight"), w2=g.w(b + ".2.fc2.weight#t"), bias=g.w(b + ".2.fc1.bias"), bias2=g.w(b + ".2.fc2.bias"), out=scr,
                        out2=g.g(b + ".2.fc1.weight"))
@@ -596,7 +597,7 @@ class TrainStep:
 
     def forward_backward(self, image: torch.Tensor, labelmap: torch.Tensor, idmap: torch.Tensor, fmask: Optional[torch.Tensor] = None,
                          keep: Optional[Dict[str, torch.Tensor]] = None, generator=None, loss_scale: float = 1.0, alphas: Optional[torch.Tensor] = None,
-                         backward: bool = True):
+                         backward: bool = True, sync_grads: bool = True):
         """image [B,3,H,W] fp32 0..1 (NHWC memory behind the NCHW view, or NCHW-contiguous); labelmap [B,5,h,w]; idmap [B,2,h,w]; fmask =
         ``model.get_fmask(labelmap, fmask)`` (computed here when None).  Runs the train()-mode forward, loss_function, the CoV weighting
         (``self.cov``; or explicit ``alphas`` [9]) and ADDS d(loss * loss_scale)/d(parameter) to every ``.grad``.
@@ -611,7 +612,9 @@ class TrainStep:
         if not xn.is_contiguous():
             xn = xn.contiguous()
         with torch.cuda.device(dev):
-            plan = self.plan_for(B, H, W, loss_scale)
+            ddp = getattr(self, "ddp", None)
+            world = ddp.world if ddp is not None else 1
+            plan = self.plan_for(B, H, W, loss_scale / world)
             if self.workspace is None or self.workspace.numel() < plan["workspace_bytes"]:
                 self.workspace = torch.empty(plan["workspace_bytes"], dtype=torch.uint8, device=dev)
             mh, mw, n_rows = plan["mh"], plan["mw"], plan["n_rows"]
@@ -654,10 +657,59 @@ class TrainStep:
                 loss = self.cov(raw)
                 a = self.cov.alphas
             self._view(plan["alphas"], (9,)).copy_(a)
-            if backward:
+            if backward and (ddp is None or world == 1 or not sync_grads):
                 L.check(lib.ftc_plan_run(plan["handle"], bases, stream, plan["n_fwd"], -1), "ftc_plan_run (train step, backward)")
+            elif backward:
+                key = (B, H, W, float(loss_scale / world))
+                if key not in self._segments:
+                    self._segments[key] = self._bucket_segments(plan)
+                cur = torch.cuda.current_stream(dev)
+                for first, last, bi in self._segments[key]:
+                    if first <= last:
+                        L.check(lib.ftc_plan_run(plan["handle"], bases, stream, first, last), "ftc_plan_run (train step, backward segment)")
+                    if bi is not None:
+                        self.comm_stream.wait_stream(cur)                 # the bucket is complete once everything enqueued so far has run
+                        with torch.cuda.stream(self.comm_stream):
+                            ddp.reduce_bucket(bi, async_op=True)
+                ddp.wait()
+                cur.wait_stream(self.comm_stream)
             torch._foreach_add_(self.counters, 1)
+            from .optim import bump_versions
+            bump_versions(self.stat_buffers)           # the kernels moved the running statistics in place
         return loss, {k: v.clone() for k, v in raw.items()}
+
+    # ---- data-parallel gradients ----------------------------------------------------------------------------------------------
+    def enable_ddp(self, group=None, bucket_bytes: int = 256 << 20) -> None:
+        """One process per GPU, every rank a full replica: from now on forward_backward(sync_grads=True) all-reduces the flat gradient
+        buffer over `group` in buckets, each bucket on a side stream as soon as the backward ops writing into it have been enqueued
+        (findtextcenternet_amd.dist.BucketedAllReduce), and scales the loss by 1 / world so that the SUM is the average DDP gives."""
+        from .dist import BucketedAllReduce
+        self.ddp = BucketedAllReduce(self.grads, bucket_bytes, group)
+        self.comm_stream = torch.cuda.Stream(device=self.dev) if self.grads.is_cuda else None
+        self._segments: Dict[tuple, list] = {}
+
+    def _bucket_segments(self, plan: dict) -> list:
+        """[(first_op, last_op, bucket index)]: the backward ops in order, cut after the last op that writes into each bucket."""
+        ops, n_fwd, n = plan["ops"], plan["n_fwd"], plan["n_ops"]
+        last_writer = [n_fwd - 1] * len(self.ddp.ranges)
+        for i in range(n_fwd, n):
+            for f in ("out", "out2", "w", "shift"):
+                r = getattr(ops[i], f)
+                if r.base == L.BASE_GRADS:
+                    e = r.offset // 4
+                    for bi, (lo, hi) in enumerate(self.ddp.ranges):
+                        if lo <= e < hi:
+                            last_writer[bi] = max(last_writer[bi], i)
+        # FTC_OP_SEBWD writes four consecutive parameters from one operand: they never straddle a bucket start by more than their size;
+        # buckets complete in the order of `ranges` only if last_writer is monotone -- enforce it
+        segs, start, done = [], n_fwd, n_fwd - 1
+        for bi in range(len(self.ddp.ranges)):
+            done = max(done, last_writer[bi])
+            segs.append((start, done, bi))
+            start = done + 1
+        if start <= n - 1:
+            segs.append((start, n - 1, None))
+        return segs
 
     def maps(self, B: int, H: int, W: int, loss_scale: float = 1.0) -> torch.Tensor:
         """The [B,9,h,w] heat-map block of the last forward (a copy)."""

@@ -127,7 +127,7 @@ typedef enum ftc_op_kind {
        out2 ([Cin][1][3][3], grads) += d weight; aux = float64 [chunks][9][Cin] (chunks as BNSTAT over B*Ho*Wo) */
     FTC_OP_DWBWD = 16,
     /* SqueezeExcitation backward: in = d(y * s) [B,H*W,Cin], in2 = y, scale = s [B][Cin], aux = the forward's partial channel sums
-       [B][aux1][Cin], w / w2 / bias / bias2 as FTC_OP_SE (aux0 = squeeze width S) -> out = fp32 scratch [4][B][Cin] + [2][B][S]:
+       [B][aux1][Cin], w / w2 / bias / bias2 as FTC_OP_SE (aux0 = squeeze width S) -> out = fp32 scratch [4][B][Cin] + [2][B][S] + [32][B][Cin]:
        block 3 = d mean / (H*W) (the `bias2` of the following FTC_OP_BNBWD, whose `bias` is s); out2 = grads of fc1.weight [S][Cin],
        fc1.bias [S], fc2.weight [Cin][S], fc2.bias [Cin], consecutive, += */
     FTC_OP_SEBWD = 17,

@@ -34,3 +34,20 @@ def test_bench_single_rank_dry_run():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert j["n_gpus"] == 1 and j["gather_ok"] is True
+
+
+def test_train_bench_two_ranks_dry_run():
+    """bench.py --train --dry-run with 2 ranks under gloo: the bucketed gradient all-reduce (findtextcenternet_amd.dist.BucketedAllReduce),
+    max-over-ranks timing and the JSON line of the train bench."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--train", "--dry-run", "--batch", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["allreduce_ok"] is True and j["buckets"] == 3 and j["config"]["global_batch"] == 16

@@ -88,3 +88,38 @@ def test_single_process_passthrough():
     rec = torch.randn(2, 4, W)
     out = all_gather_boxes(counts, rec)
     assert torch.equal(out.counts, counts) and torch.equal(out.records, rec[:, :2]) and out.message_bytes_per_rank == 0
+
+
+def test_bucketed_allreduce_ranges_cover_the_buffer_from_the_end():
+    from findtextcenternet_amd.dist import BucketedAllReduce
+    flat = torch.arange(1003, dtype=torch.float32)
+    red = BucketedAllReduce(flat, bucket_bytes=400 * 4)
+    assert red.ranges[0] == (603, 1003) and red.ranges[-1][0] == 0
+    assert sorted(i for lo, hi in red.ranges for i in range(lo, hi)) == list(range(1003))
+    red.reduce_all()                                            # single process: nothing to do, nothing changes
+    assert torch.equal(flat, torch.arange(1003, dtype=torch.float32))
+
+
+def test_train_plan_bucket_segments_follow_the_backward_order():
+    """The train plan built on CPU (ftc_plan_create validates every operand without a GPU): every gradient-writing backward op lies in
+    a segment that ends before its bucket is handed to the all-reduce, segments tile the backward ops in order."""
+    from findtextcenternet_amd import TextDetectorModel, TrainStep
+    from findtextcenternet_amd import _lib as L
+    ts = TrainStep(TextDetectorModel(pre_weights=False, precision="bf16").train())
+    plan = ts.plan_for(2, 128, 128)
+    assert plan["n_ops"] > 2 * plan["n_fwd"] * 0.9 and plan["n_rows"] == 2048
+    ts.enable_ddp(bucket_bytes=256 << 20)
+    assert len(ts.ddp.ranges) == 4                               # 1.05 GB of gradients in 256 MB buckets
+    segs = ts._bucket_segments(plan)
+    assert segs[0][0] == plan["n_fwd"] and segs[-1][1] == plan["n_ops"] - 1
+    for (a0, a1, _), (b0, b1, _) in zip(segs, segs[1:]):
+        assert b0 == a1 + 1
+    end_of = {bi: last for _, last, bi in segs if bi is not None}
+    for i in range(plan["n_fwd"], plan["n_ops"]):
+        for f in ("out", "out2", "w", "shift"):
+            r = getattr(plan["ops"][i], f)
+            if r.base == L.BASE_GRADS:
+                bi = next(k for k, (lo, hi) in enumerate(ts.ddp.ranges) if lo <= r.offset // 4 < hi)
+                assert i <= end_of[bi]
+    # the last bucket (stem side) can only be complete at the very end, the first (decoder, heads) long before
+    assert end_of[0] < plan["n_fwd"] + (plan["n_ops"] - plan["n_fwd"]) * 0.6

@@ -325,8 +325,9 @@ def test_bench_plans_b8_b32_bf16_match_their_b1_results_and_the_golden(det_bf16,
 
 
 def test_parameter_edits_are_noticed(sd):
-    """The packed weight blob must follow the module: in-place edits (optimizer.step(), p.data.copy_()), dtype round trips and
-    load_state_dict all change the next forward; a deep copy gets its own engine."""
+    """The packed weight blob must follow the module: in-place edits on the parameter (p.add_(), optimizer.step() incl. this repo's
+    raw-pointer AdamWScheduleFree), re-allocations, load_state_dict (also assign=True) all change the next forward; a deep copy gets
+    its own engine.  Writes through `p.data` are not detectable (separate version counter): they need engine.invalidate()."""
     import copy
     m = TextDetectorModel(pre_weights=False, precision="bf16")
     m.load_state_dict(sd)
@@ -345,6 +346,26 @@ def test_parameter_edits_are_noticed(sd):
         assert d2.detector._engine is not d.detector._engine and d2.detector._engine.model is None
         h3, _ = d2(x)
         assert torch.equal(h3, h2)
+        # in-place writes through `.data` carry their own version counter: NOT seen, documented -> invalidate() by hand
+        p.data.add_(1.0)
+        m.detector._engine.invalidate()
+        h4, _ = d(x)
+        assert float((h4[:, 0] - h0[:, 0] - 1.0).abs().max()) < 1e-5
+        # load_state_dict(assign=True) replaces the Parameter objects: the post-hook re-packs
+        m.load_state_dict(sd, assign=True)
+        h5, _ = d(x)
+        assert torch.equal(h5[:, 0], h0[:, 0])
+        # this repo's optimizer writes parameters through raw device pointers and bumps their version counters
+        from findtextcenternet_amd import AdamWScheduleFree
+        m.to("cuda")
+        q = m.detector.keyheatmap.top_conv._modules["0"].bias
+        opt = AdamWScheduleFree([q], lr=0.5)
+        opt.train()
+        h6, _ = d(x)
+        q.grad = torch.ones_like(q)
+        opt.step()
+        h7, _ = d(x)
+        assert float((h7[:, 0] - h6[:, 0]).abs().max()) > 1e-3
 
 
 def test_fp16_mode_same_plan_much_closer_to_the_reference(sd, golden_dir):

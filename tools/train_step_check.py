@@ -45,7 +45,8 @@ for n, p in reversed(ts.params):
         st, r = int(g[f"pick{i}_stride"]), g[f"pick{i}"]
         mv = p.grad.detach().float().cpu().numpy().reshape(-1)[::st]
         e = np.abs(mv - r).max()
-        line += f" | entry err {e:.2e} of {np.abs(r).max():.2e}"
+        cos = float((mv * r).sum() / (np.linalg.norm(mv) * np.linalg.norm(r) + 1e-30))
+        line += f" | entry err {e:.2e} of {np.abs(r).max():.2e} cos {cos:.4f}"
         ok = ok and e <= 1e-3 * np.abs(r).max() + 1e-7
     if not ok:
         nbad += 1

@@ -90,14 +90,16 @@ class Decoded:
 
 class DecodeWorkspace:
     """Output block + scratch of ``decode_peaks`` for a fixed (B, h, w, C, max_boxes), allocated once and reused:
-    nothing is allocated or cleared per call, so rows at and beyond ``counts[b]`` keep whatever an earlier call left there."""
+    nothing is allocated or cleared per call, so rows at and beyond ``counts[b]`` keep whatever an earlier call left there --
+    consumers of a REUSED workspace must slice by ``counts`` (``page_merge_gpu`` and the box gather treat rows with p < cut_off as
+    inert padding, which only holds for the zero-initialised block of a fresh workspace: ``PageDetector`` uses a fresh one per batch)."""
 
     def __init__(self, B: int, h: int, w: int, C_: int, max_boxes: int, device):
-        if C_ + REC_FEAT0 > REC_W and C_ != feature_dim:
-            raise ValueError("record layout is sized for the 100-d feature rows")
+        if C_ + REC_FEAT0 > REC_W:
+            raise ValueError("record layout is sized for feature rows of at most 100 floats")
         lib = L.load()
         self.key = (B, h, w, C_, max_boxes)
-        self.rec_w = REC_W if C_ + REC_FEAT0 <= REC_W else (C_ + REC_FEAT0 + 3) // 4 * 4
+        self.rec_w = REC_W
         self.records = torch.zeros((B, max_boxes, self.rec_w), dtype=torch.float32, device=device)
         self.index = torch.full((B, max_boxes), -1, dtype=torch.int32, device=device)
         self.counts = torch.zeros((B,), dtype=torch.int32, device=device)

@@ -35,6 +35,7 @@ class GatheredBoxes:
     records: torch.Tensor     # [n_tiles, n_max, W] fp32 record rows (W = 112: box 0..8, feature row 12..111)
     feat0: int = 12
     message_bytes_per_rank: int = 0
+    overflow: Optional[torch.Tensor] = None      # all_gather_boxes_static: device flag, a tile had more peaks than rows were sent
 
     def tile(self, i: int):
         n = min(int(self.counts[i]), self.records.shape[1])
@@ -79,6 +80,47 @@ def all_gather_boxes(counts: torch.Tensor, records: torch.Tensor, group: Optiona
         keep = torch.cat([torch.arange(r * b_pad, r * b_pad + int(metas_h[r, 0])) for r in range(world)]).to(dev)
         out_c, out_r = out_c.index_select(0, keep), out_r.index_select(0, keep)
     return GatheredBoxes(out_c, out_r, feat0, rec.numel() * rec.element_size() + cnt.numel() * 4 + 8)
+
+
+STATIC_GATHER_BYTES = 8 << 20      # per-rank message up to which the whole fixed-capacity record block is sent as it is
+
+
+def all_gather_boxes_static(counts: torch.Tensor, records: torch.Tensor, n_tiles: int, group: Optional[dist.ProcessGroup] = None,
+                            feat0: int = 12, rows: Optional[int] = None) -> GatheredBoxes:
+    """The steady-state form of ``all_gather_boxes``: NO host synchronisation, ONE collective, no copy of the record block.
+
+    The counts-first protocol above needs two host round trips per step (``.item()`` for the row count, ``.cpu()`` for the other
+    ranks' batch sizes), which serialise the host enqueue behind the GPU every step.  Here everything the host needs is static:
+    ``n_tiles`` (the global tile count; ``shard_range`` gives every rank's share, so the padding to the largest shard is known
+    without asking), and the row count -- the whole decode capacity when the block is small (8 tiles x 2048 rows x 448 B = 7.3 MB:
+    latency-bound on xGMI either way), else the caller's ``rows`` (e.g. last step's maximum, rounded up), with ``overflow`` (a device
+    flag) telling afterwards whether a tile had more peaks than were sent.  The per-tile counts travel INSIDE the block, in the first
+    padding word (column 9) of every tile's row 0 -- the box occupies columns 0..8, the feature row starts at ``feat0`` = 12."""
+    cap = records.shape[1]
+    n_rows = cap if rows is None else max(1, min(cap, int(rows)))
+    records[:, 0, 9] = counts.view(torch.float32)                  # int32 bit patterns in a padding word (in place: rows are the caller's scratch)
+    block = records if n_rows == cap else records[:, :n_rows].contiguous()
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        g = GatheredBoxes(counts, block, feat0, 0)
+        g.overflow = (counts > n_rows).any()
+        return g
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    shares = [shard_range(n_tiles, r, world) for r in range(world)]
+    b_pad = max(hi - lo for lo, hi in shares)
+    B = counts.shape[0]
+    if B != shares[rank][1] - shares[rank][0]:
+        raise ValueError("all_gather_boxes_static: the local batch is not this rank's shard_range share of n_tiles")
+    if B < b_pad:                                                   # short shard: count-0 tiles (zeros: column 9 of row 0 reads as count 0)
+        block = torch.cat([block, torch.zeros((b_pad - B,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)])
+    out = torch.empty((world * b_pad,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+    dist.all_gather_into_tensor(out.view(-1), block.view(-1), group=group)
+    if any(hi - lo != b_pad for lo, hi in shares):                  # static index list: no device data needed
+        keep = torch.tensor([r * b_pad + i for r, (lo, hi) in enumerate(shares) for i in range(hi - lo)], device=out.device)
+        out = out.index_select(0, keep)
+    cnt = out[:, 0, 9].contiguous().view(torch.int32)
+    g = GatheredBoxes(cnt, out, feat0, block.numel() * block.element_size())
+    g.overflow = (cnt > n_rows).any()
+    return g
 
 
 # ----------------------------------------------------------------------------------------------------------------------

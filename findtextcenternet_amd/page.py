@@ -91,12 +91,16 @@ class PageDetector:
     """``run_detector`` / tiling of ``OCR_Processer`` on top of a HIP ``CenterNetDetector``."""
 
     def __init__(self, detector, step_ratio: float = 0.6, cut_off: float = 0.4, batch: int = 8, max_boxes: int = 4096,
-                 device: str = "cuda"):
+                 device: str = "cuda", group=None, shard: bool = True):
         self.device = torch.device(device)
         detector.to(device=self.device)
         detector.eval()
         self.detector = detector
         self.step_ratio, self.cut_off, self.batch, self.max_boxes = step_ratio, cut_off, batch, max_boxes
+        # With torch.distributed initialised the tiles OF ONE PAGE are split over the ranks (dist.shard_range: contiguous blocks), the
+        # record rows are gathered (one collective, no host sync) and the page canvases merged with an all-reduce(MAX): every rank
+        # ends up with the whole page's boxes.  shard=False: every rank runs the whole page (replicas).
+        self.group, self.shard = group, shard
         self.stepx, self.stepy = int(width * step_ratio), int(height * step_ratio)      # process_ocr_base.py:43-45
 
     # -- reference signature -----------------------------------------------------------------
@@ -134,9 +138,13 @@ class PageDetector:
         mh, mw = page_h // scale, page_w // scale
         canv = torch.zeros((7, mh, mw), dtype=torch.float32, device=self.device)
         parts = []
+        import torch.distributed as tdist
+        from .dist import all_gather_boxes_static, shard_range
+        world = tdist.get_world_size(self.group) if (self.shard and tdist.is_available() and tdist.is_initialized()) else 1
+        first, last = shard_range(len(origins), tdist.get_rank(self.group), world) if world > 1 else (0, len(origins))
         with torch.cuda.device(self.device), torch.no_grad():
-            for lo in range(0, len(origins), self.batch):
-                hi = min(len(origins), lo + self.batch)
+            for lo in range(first, last, self.batch):
+                hi = min(last, lo + self.batch)
                 x = get_tiles(lo, hi).permute(0, 3, 1, 2)
                 heat, feat = self.detector.forward_nhwc(x)
                 geoms = [TileGeom(ox, oy, page_w, page_h, tile_keep_rect(ox, oy, page_w, page_h, self.step_ratio)) for (oy, ox) in origins[lo:hi]]
@@ -145,11 +153,21 @@ class PageDetector:
                 L.check(lib.ftc_paste_maps(heat.data_ptr(), tl.data_ptr(), hi - lo, heat.shape[1], heat.shape[2], scale, canv.data_ptr(),
                                            mh, mw, C.c_void_p(stream)), "ftc_paste_maps")
                 dec = decode_peaks(heat, feat, tl, cut_off=self.cut_off, max_boxes=self.max_boxes)
-                parts.append((dec.counts, dec.boxes, dec.feats))
+                parts.append((dec.counts, dec.boxes, dec.feats, dec.records))
             # every tile's rows in tile order; rows past a tile's count are zeros (p = 0 < cut_off): inert padding
-            counts = torch.cat([c for c, _, _ in parts])
-            boxes = torch.cat([b.reshape(-1, 9) for _, b, _ in parts])
-            fts = torch.cat([f.reshape(-1, f.shape[-1]) for _, _, f in parts])
+            if world > 1:
+                n_feat = parts[0][2].shape[-1] if parts else 100
+                cnt_l = torch.cat([c for c, _, _, _ in parts]) if parts else torch.zeros(0, dtype=torch.int32, device=self.device)
+                rec_l = torch.cat([r for _, _, _, r in parts]) if parts else torch.zeros((0, self.max_boxes, 112), dtype=torch.float32, device=self.device)
+                g = all_gather_boxes_static(cnt_l, rec_l, len(origins), group=self.group)
+                tdist.all_reduce(canv, op=tdist.ReduceOp.MAX, group=self.group)
+                counts = g.counts
+                boxes = g.records[:, :, :9].reshape(-1, 9)
+                fts = g.records[:, :, g.feat0:g.feat0 + n_feat].reshape(-1, n_feat)
+            else:
+                counts = torch.cat([c for c, _, _, _ in parts])
+                boxes = torch.cat([b.reshape(-1, 9) for _, b, _, _ in parts])
+                fts = torch.cat([f.reshape(-1, f.shape[-1]) for _, _, f, _ in parts])
             page_dev = torch.from_numpy(np.ascontiguousarray(org_img, dtype=np.float32)).to(self.device)
             loc_d, glyph_d = page_merge_gpu(boxes, fts, page_dev, canv, self.cut_off)
             if int(counts.max().item()) > self.max_boxes:

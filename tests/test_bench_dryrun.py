@@ -26,6 +26,8 @@ def test_bench_two_ranks_dry_run():
     assert j["gather_ok"] is True and j["config"]["global_batch"] == 6 and j["value"] > 0
     # counts first, then only the rows any rank filled: far below the 512-row capacity of the decode block
     assert 0 < j["gather_message_bytes_per_rank"] <= 3 * 400 * 112 * 4 + 3 * 4 + 8
+    # the steady-state form: the whole capacity block in ONE collective (tests/test_dist.py asserts it contains no host synchronisation)
+    assert j["static_gather_ok"] is True and j["static_gather_message_bytes_per_rank"] == 3 * 512 * 112 * 4
 
 
 def test_bench_single_rank_dry_run():

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from findtextcenternet_amd.dist import all_gather_boxes, shard_range
+from findtextcenternet_amd.dist import all_gather_boxes, all_gather_boxes_static, shard_range
 
 
 def test_shard_range_partitions_everything():
@@ -123,3 +123,84 @@ def test_train_plan_bucket_segments_follow_the_backward_order():
                 assert i <= end_of[bi]
     # the last bucket (stem side) can only be complete at the very end, the first (decoder, heads) long before
     assert end_of[0] < plan["n_fwd"] + (plan["n_ops"] - plan["n_fwd"]) * 0.6
+
+
+class _NoHostSync:
+    """Inside this context every host read of tensor DATA raises: the steady-state gather must not contain one."""
+
+    def __enter__(self):
+        self.saved = {n: getattr(torch.Tensor, n) for n in ("item", "cpu", "tolist", "numpy", "__bool__", "__int__", "__float__")}
+
+        def boom(*a, **k):
+            raise AssertionError("host synchronisation inside the steady-state gather")
+        for n in self.saved:
+            setattr(torch.Tensor, n, boom)
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self.saved.items():
+            setattr(torch.Tensor, n, f)
+
+
+def _worker_static(rank, world, port, q, n_tiles, rows):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cap = 16
+    shards = [shard_range(n_tiles, r, world) for r in range(world)]
+    Bs = [hi - lo for lo, hi in shards]
+    counts, rec = _rank_data(rank, Bs[rank], cap)
+    rec = rec.clone()
+    with _NoHostSync():
+        out = all_gather_boxes_static(counts, rec, n_tiles, rows=rows)
+    n_rows = cap if rows is None else rows
+    ok = out.counts.shape == (n_tiles,) and out.records.shape == (n_tiles, n_rows, W) and out.counts.dtype == torch.int32
+    over = False
+    for r in range(world):
+        c, rc = _rank_data(r, Bs[r], cap)
+        lo, hi = shards[r]
+        ok &= torch.equal(out.counts[lo:hi], c)
+        got = out.records[lo:hi].clone()
+        want = rc[:, :n_rows].clone()
+        got[:, 0, 9] = 0                                       # the count word
+        want[:, 0, 9] = 0
+        ok &= torch.equal(got, want)
+        over |= bool((c > n_rows).any())
+    ok &= bool(out.overflow) == over
+    ok &= out.message_bytes_per_rank == max(Bs) * n_rows * W * 4
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_static(n_tiles, rows):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_static, args=(r, 2, port, q, n_tiles, rows)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+def test_static_gather_world2_one_collective_no_host_sync():
+    _run_static(6, None)                                       # whole capacity block, even shards
+
+
+def test_static_gather_uneven_shards_and_row_hint_with_overflow_flag():
+    _run_static(5, 8)                                          # shards of 3 and 2; 8 of 16 rows sent: some tiles overflow -> flag
+
+
+def test_static_gather_single_process_is_sync_free():
+    counts = torch.tensor([2, 0, 5], dtype=torch.int32)
+    rec = torch.randn(3, 4, W)
+    with _NoHostSync():
+        out = all_gather_boxes_static(counts, rec, 3)
+    assert torch.equal(out.counts, counts) and out.records.shape == (3, 4, W) and bool(out.overflow) is True

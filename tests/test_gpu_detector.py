@@ -21,8 +21,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-3
 # peak-set agreement of the bf16 speed mode with the fp32 reference golden; the reference itself under CPU bf16 autocast reaches
 # 0.85 Jaccard / 0.93 recall against its own fp32 run (1590 common of 1702 vs 1765)
-BF16_JACCARD_GATE = 0.88
-BF16_RECALL_GATE = 0.93
+# Gates = just below what is MEASURED on the 768x768 page fixture (gpurun_out/test_detector.log over rounds 2-3: Jaccard 0.893 - 0.898,
+# recall 0.950 - 0.959), so that a regression of the bf16 kernels fails instead of hiding in the slack.
+BF16_JACCARD_GATE = 0.885
+BF16_RECALL_GATE = 0.945
+# fp16 (the recommended 16-bit mode, same speed): measured Jaccard 0.997 / recall 0.999 on the same fixture
+FP16_JACCARD_GATE = 0.985
+FP16_RECALL_GATE = 0.99
 
 
 def _log(msg):
@@ -50,6 +55,16 @@ def det_fp32(sd):
 @pytest.fixture(scope="module")
 def det_bf16(sd):
     m = TextDetectorModel(pre_weights=False, precision="bf16")
+    m.load_state_dict(sd)
+    d = CenterNetDetector(m.detector)
+    d.to(device="cuda")
+    d.eval()
+    return d
+
+
+@pytest.fixture(scope="module")
+def det_fp16(sd):
+    m = TextDetectorModel(pre_weights=False, precision="fp16")
     m.load_state_dict(sd)
     d = CenterNetDetector(m.detector)
     d.to(device="cuda")
@@ -270,12 +285,15 @@ def _peak_sets(hm):
     return [set(decode_oracle.decode_tile(hm[b:b + 1], z, 0, 0, 768, 768, 0.4, rect)[2].tolist()) for b in range(hm.shape[0])]
 
 
-@pytest.mark.parametrize("B", [8, 32])
-def test_bench_plans_b8_b32_bf16_match_their_b1_results_and_the_golden(det_bf16, golden_dir, B):
+@pytest.mark.parametrize("prec,B", [("bf16", 8), ("bf16", 32), ("fp16", 8), ("fp16", 32)])
+def test_bench_plans_b8_b32_16bit_match_their_b1_results_and_the_golden(det_bf16, det_fp16, golden_dir, prec, B):
     """BASELINE configs[1] (batch 8, what bench.py times) and configs[3] (batch 32, forward + NMS + decode + gather): the plan is
     built per batch size and the measured kernel table is keyed by it, so the big-batch plans get their own check -- every image
     against the SAME image run alone (tiles are independent units), image 0 against the reference golden, and the GPU decode of
     the whole batch against the oracle decode of the same maps."""
+    det_bf16 = det_bf16 if prec == "bf16" else det_fp16            # (the body below is written for "the 16-bit detector under test")
+    # plan-vs-plan and plan-vs-golden gates, just below the measurements (bf16: B-vs-1 Jaccard 0.880 - 0.883, golden 0.897 / 0.950)
+    jmin_gate, lin_gate, jac_gate, rec_gate = (0.87, 0.02, BF16_JACCARD_GATE, BF16_RECALL_GATE) if prec == "bf16" else (0.97, 0.004, FP16_JACCARD_GATE, FP16_RECALL_GATE)
     g = np.load(os.path.join(golden_dir, "g2_fwd768_page.npz"))
     imgs = np.concatenate([synth.page_images(4242, 1, 768, 768)] + [synth.noise_images(900 + i, 1, 768, 768) if i % 2 else
                                                                      synth.page_images(900 + i, 1, 768, 768) for i in range(1, B)])
@@ -302,10 +320,10 @@ def test_bench_plans_b8_b32_bf16_match_their_b1_results_and_the_golden(det_bf16,
     # Same network and the same bf16 rounding POINTS in both plans, but the batch-N plan picks other tile shapes / split-K variants
     # (measured per shape): their fp32 sums associate differently, which moves a fraction of the bf16 roundings of the activations
     # by one ulp.  Two bf16 plans therefore agree to bf16 noise (as bf16 vs fp32 does), not to fp32 noise.
-    _log(f"bf16 B={B} vs B=1 plans: heatmap Linf {100 * worst:.2f}% of range, features {100 * worst_f:.2f}%, NMS flips {flips} of {npx}, "
+    _log(f"{prec} B={B} vs B=1 plans: heatmap Linf {100 * worst:.2f}% of range, features {100 * worst_f:.2f}%, NMS flips {flips} of {npx}, "
          f"min peak jaccard {jmin:.3f}")
     # (two independently rounded bf16 results differ from each other by ~sqrt(2) x what each differs from fp32)
-    assert worst < 0.02 and worst_f < 0.02 and flips < 0.02 * npx and jmin >= 0.80
+    assert worst < lin_gate and worst_f < lin_gate and flips < lin_gate * npx and jmin >= jmin_gate
     gh = g["heatmap"]
     both = np.isfinite(hm[:1]) & np.isfinite(gh)
     rng = float(gh[np.isfinite(gh)].max() - gh[np.isfinite(gh)].min())
@@ -313,8 +331,8 @@ def test_bench_plans_b8_b32_bf16_match_their_b1_results_and_the_golden(det_bf16,
     ref, got = _peak_sets(gh)[0], sets_b[0]
     jac = len(ref & got) / max(1, len(ref | got))
     recall = len(ref & got) / max(1, len(ref))
-    _log(f"bf16 B={B} image 0 vs reference golden: heatmap Linf {e:.3e} ({100 * e / rng:.2f}% of range), peak jaccard {jac:.3f} recall {recall:.3f}")
-    assert e / rng < 0.03 and jac >= BF16_JACCARD_GATE and recall >= BF16_RECALL_GATE
+    _log(f"{prec} B={B} image 0 vs reference golden: heatmap Linf {e:.3e} ({100 * e / rng:.2f}% of range), peak jaccard {jac:.3f} recall {recall:.3f}")
+    assert e / rng < (0.03 if prec == "bf16" else 0.0015) and jac >= jac_gate and recall >= rec_gate
     # GPU decode + gather of the whole batch == oracle decode of the same maps (bit-exact index sets, copied feature rows)
     for b in range(B):
         n = int(dec.counts[b])
@@ -390,7 +408,7 @@ def test_fp16_mode_same_plan_much_closer_to_the_reference(sd, golden_dir):
     jac, recall = len(ref & got) / max(1, len(ref | got)), len(ref & got) / max(1, len(ref))
     _log(f"fp16 768 page: heatmap Linf {e:.3e} ({100 * e / rng:.3f}% of range)  features Linf {e_ft:.3e} ({100 * e_ft / frng:.3f}%)  "
          f"peaks ref {len(ref)} fp16 {len(got)} jaccard {jac:.3f} recall {recall:.3f}")
-    assert e / rng < 0.0015 and e_ft / frng < 0.0015 and jac >= 0.97 and recall >= 0.98
+    assert e / rng < 0.0015 and e_ft / frng < 0.0015 and jac >= FP16_JACCARD_GATE and recall >= FP16_RECALL_GATE
     # other geometries / batch sizes run the same code paths as bf16 (shared tuning table): quick agreement check with fp32
     x2 = torch.from_numpy(synth.page_images(778, 3, 256, 192)).permute(0, 3, 1, 2).to("cuda")
     m32 = TextDetectorModel(pre_weights=False, precision="fp32")

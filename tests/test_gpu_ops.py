@@ -622,7 +622,7 @@ def test_training_mode_batchnorm_ops(shape, cfg):
     ar = Arena()
     o_x, o_g, o_b, o_res, o_keep = ar.put(to_dev_bytes(x, idt)), ar.put(gamma), ar.put(beta), ar.put(res), ar.put(keep)
     o_run = ar.put(torch.stack([rm, rv]))
-    o_ss, o_part = ar.reserve(2 * C * 4), ar.reserve(nchunk * 2 * C * 8)
+    o_ss, o_part = ar.reserve(4 * C * 4), ar.reserve(nchunk * 2 * C * 8)      # scale | shift | mean | 1/std
     o_out = ar.reserve(M * C * (4 if odt == L.F32 else 2))
     o_out2 = ar.reserve(M * C * 2) if odt == L.F32 else None
     o_sums = ar.reserve(B * P * C * 4)

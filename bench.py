@@ -39,7 +39,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+# dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md; fp16x3 = three fp16 MFMAs per product: a third of the 16-bit peak
+PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "fp16x3": 833.3}
 GFLOP_PER_IMAGE = 865.0006                 # SURVEY.md 8(d); reproduced by the library's own op list (tests/test_abi_and_plan.py)
 
 
@@ -83,32 +84,30 @@ def cpu_baseline(sd, budget_s: float):
         return time.perf_counter() - t0
 
     fwd(x1)                                                    # warm-up (thread pools, allocations, oneDNN primitives)
-    sweep = {}
+    # ONE measurement decides the thread count and is the reported batch-1 rate: per candidate, one warm-up at that thread count, then
+    # the median of 3 (round 2 took min-of-2 in the sweep and a separate median-of-5 afterwards, and the two disagreed by 1.8x)
+    sweep, runs = {}, {}
     for n in [t for t in (8, 16, 32, 64, 128, 256) if t <= ncpu] or [ncpu]:
         torch.set_num_threads(n)
         fwd(x1)
-        sweep[n] = min(fwd(x1)[0] for _ in range(2))
+        runs[n] = [fwd(x1)[0] for _ in range(3)]
+        sweep[n] = statistics.median(runs[n])
         # past the knee more threads only get slower (256 threads: 200 s per image on the 256-thread host): stop climbing there
-        if time.perf_counter() - t_start > 0.5 * budget_s or sweep[n] > 1.3 * min(sweep.values()):
+        if time.perf_counter() - t_start > 0.6 * budget_s or sweep[n] > 1.3 * min(sweep.values()):
             break
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
-    t1, d1 = [], []
-    hm0 = ft0 = None
-    for _ in range(5):
-        t, hm, ft = fwd(x1)
-        t1.append(t)
-        d1.append(dec(hm, ft))
-        hm0, ft0 = hm, ft
-        if time.perf_counter() - t_start > 0.8 * budget_s and len(t1) >= 3:
-            break
+    t1 = runs[best]
+    _, hm0, ft0 = fwd(x1)
+    d1 = [dec(hm0, ft0) for _ in range(3)]
     t8, hm8, ft8 = fwd(x8)
     d8 = dec(hm8, ft8)
     torch.set_num_threads(nthr0)
     m1, md1 = statistics.median(t1), statistics.median(d1)
     rec = {"value": round(1.0 / (m1 + md1), 4), "unit": "images/s", "cores": best, "kind": "port",
            "sample": (f"CPU oracle (torch fp32 forward+NMS, numpy decode), 768x768 noise tiles, {best} of {ncpu} host threads chosen by "
-                      f"sweep; batch 1: median of {len(t1)} after warm-up; batch 8: 1 pass; {time.perf_counter() - t_start:.0f} s total"),
+                      f"sweep (per thread count: 1 warm-up, median of 3 -- the winner's median IS the batch-1 figure); batch 8: 1 pass; "
+                      f"{time.perf_counter() - t_start:.0f} s total"),
            "threads_sweep_images_per_s_b1_fwd_nms": {str(k): round(1.0 / v, 4) for k, v in sweep.items()},
            "b1_fwd_nms_images_per_s": round(1.0 / m1, 4), "b1_fwd_nms_decode_images_per_s": round(1.0 / (m1 + md1), 4),
            "b8_fwd_nms_images_per_s": round(8.0 / t8, 4), "b8_fwd_nms_decode_images_per_s": round(8.0 / (t8 + d8), 4)}
@@ -361,7 +360,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="tiles per GPU per step")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp16"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp16", "fp16x3"])
     ap.add_argument("--max-boxes", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (and with it the parity records)")
     ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of CPU-oracle time to aim for")
@@ -369,6 +368,7 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode record")
     ap.add_argument("--dump-ops", default="", help="write per-op timings (JSON) to this path")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo walk through the N-rank control flow (no GPU work)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 300-step / >= 4 s sustained-rate record")
     ap.add_argument("--train", action="store_true", help="BASELINE configs[4]: the train step (fwd + loss + bwd + optimizer, DDP all-reduce when N > 1)")
     args = ap.parse_args()
 
@@ -450,6 +450,26 @@ def main():
         el = float(t.item())
     peaks = float(out.counts.float().mean().item())
 
+    # ---- sustained rate: >= 300 steps and >= 4 s (the 20-step burst above lasts 0.3 s; the part's clock settles over seconds) ----
+    sus_steps = max(300, int(4.0 / max(1e-4, el / args.steps)) + 1) if not args.no_sustained else 0
+    sus = None
+    if sus_steps:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0s = time.perf_counter()
+        for _ in range(sus_steps):
+            out = step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        els = time.perf_counter() - t0s
+        if world > 1:
+            t = torch.tensor([els], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            els = float(t.item())
+        sus = {"steps": sus_steps, "seconds": round(els, 3), "value": round(world * B * sus_steps / els, 2), "ms_per_step": round(1000 * els / sus_steps, 3)}
+
     result = None
     if rank == 0:
         value = world * B * args.steps / el
@@ -468,6 +488,8 @@ def main():
                       "ms_per_step_median from per-step HIP events on the launch stream (rank 0)",
             "source_hash": source_hash(),
         }
+        if sus is not None:
+            result["sustained"] = sus
         if world > 1:
             result["gather_message_bytes_per_rank"] = out.message_bytes_per_rank
         result["host_enqueue_ms_first_step"] = round(1000 * el_enqueue, 3)
@@ -541,7 +563,7 @@ def main():
 
     # ---- the other numeric mode, parity of both against the CPU oracle, CPU baseline (rank 0, N = 1) -------------
     if rank == 0 and world == 1:
-        others = [] if args.no_fp32 else [p_ for p_ in ("fp32", "fp16", "bf16") if p_ != args.precision]
+        others = [] if args.no_fp32 else [p_ for p_ in ("fp32", "fp16x3", "fp16", "bf16") if p_ != args.precision]
         recs, maps = {}, {}
         for other in others:
             model2, det2 = make(other)
@@ -552,7 +574,7 @@ def main():
                 with torch.no_grad():
                     det2.forward_nhwc(x, out=(heat2, feat2))
                 return decode_peaks(heat2, feat2, tiles, cut_off=0.4, max_boxes=args.max_boxes, logit_cut=lcut, workspace=dws2)
-            k2 = max(3, args.steps // 4) if other == "fp32" else args.steps
+            k2 = max(3, args.steps // 4) if other == "fp32" else max(3, args.steps // 2) if other == "fp16x3" else args.steps
             step2()
             step2()
             torch.cuda.synchronize()
@@ -566,6 +588,28 @@ def main():
             maps[other] = (heat2[:1].clone(), feat2[:1].clone())
             del model2, det2, heat2, feat2, dws2
             torch.cuda.empty_cache()
+        # ---- seam 2 exactly as the reference calls it (process_ocr_torch.py:43-49): call_detector(np [1,768,768,3] 0..255) ->
+        # numpy heatmap + features, batch 1, host buffers in and out (H2D 7 MB, D2H 16 MB per tile) -- latency, not the headline
+        from findtextcenternet_amd import HipDetectorBackend
+        seam = {}
+        tile_np = (synth.noise_images(4321, 1, 768, 768) * 255.0).astype(np.float32)
+        for prec in ([args.precision] + ([] if args.no_fp32 else [p_ for p_ in ("fp32",) if p_ != args.precision])):
+            mdl, dd = (model, det) if prec == args.precision else make(prec)
+            be = HipDetectorBackend(dd, device=dev)
+            for _ in range(3):
+                be.call_detector(tile_np)
+            ts_ = []
+            for _ in range(20):
+                t0c = time.perf_counter()
+                be.call_detector(tile_np)
+                ts_.append(time.perf_counter() - t0c)
+            seam[prec] = {"ms_per_call_median": round(1000 * statistics.median(ts_), 3), "images_per_s": round(1.0 / statistics.median(ts_), 2)}
+            if prec != args.precision:
+                del mdl, dd, be
+                torch.cuda.empty_cache()
+        seam["note"] = ("HipDetectorBackend.call_detector: host float32 tile in (7.1 MB), numpy heatmap [1,10,192,192] + features [1,100,192,192] out "
+                        "(16.2 MB), batch 1, synchronous -- the reference's own calling convention; compare cpu_baseline.b1_fwd_nms_images_per_s")
+        result["seam2_call_detector_b1"] = seam
         if not args.no_cpu_baseline:
             cpu, o_hm, o_ft = cpu_baseline({k: v for k, v in sd.items()}, args.cpu_budget)
             result["cpu_baseline"] = cpu
@@ -573,7 +617,7 @@ def main():
                                 args.precision: parity_record(heat, feat, o_hm, o_ft)}
             for other in others:
                 result["parity"][other] = parity_record(maps[other][0], maps[other][1], o_hm, o_ft)
-        names = {"fp32": "fp32_parity_mode", "fp16": "fp16_mode", "bf16": "bf16_speed_mode"}
+        names = {"fp32": "fp32_parity_mode", "fp16x3": "fp16x3_parity_mode", "fp16": "fp16_mode", "bf16": "bf16_speed_mode"}
         for other in others:
             result[names[other]] = recs[other]
             if "parity" in result:

@@ -104,6 +104,27 @@ template <> struct Frag<_Float16> { using type = f16x8; };
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
+// FTC_FLAG_SPLIT16 ("fp16x3": fp32 tensors, weights and accumulation; the products on the 16-bit matrix pipe).  Two fp32 fragments of
+// four K values (two K groups of the fp32 kernels: the lower half-wave holds k = 0..3 | 8..11, the upper 4..7 | 12..15 -- the same
+// permutation on both operands) become the hi / lo halves of ONE 32x32x16 operand: hi = fp16(x) (clamped to the format's range),
+// lo = fp16(x - hi): 22 significand bits.  A.B ~= Ahi.Blo + Alo.Bhi + Ahi.Bhi (the dropped lo.lo term is 2^-24 relative): 3 MFMAs of
+// 32 cycles for 16 K values instead of 8 fp32 MFMAs of 64 cycles.
+__device__ __forceinline__ void split16(const f32x4& a0, const f32x4& a1, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 h0 = (_Float16)f16_sat(a0[e]), h1 = (_Float16)f16_sat(a1[e]);
+        hi[e] = h0;
+        hi[4 + e] = h1;
+        lo[e] = (_Float16)(a0[e] - (float)h0);
+        lo[4 + e] = (_Float16)(a1[e] - (float)h1);
+    }
+}
+__device__ __forceinline__ f32x16 mfma_split(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+}
+
 constexpr int OOB = 0x7ffffff0;      // byte offset beyond any buffer: the load returns zeros
 
 __device__ __forceinline__ u32x4 bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
@@ -519,6 +540,7 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(const ConvP p_laun
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rse = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.se), 0, p.se_bytes, 0x00020000);
     constexpr bool use_se = SE;
+    const bool split16_on = sizeof(WT) == 4 && (p.flags & FTC_FLAG_SPLIT16) != 0;      // wave-uniform (launch-wide)
 
     const int kc = t % CPR;                      // this thread's 16-byte chunk inside a K row
     const int row0 = t / CPR;
@@ -614,6 +636,24 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(const ConvP p_laun
         const WT* A = fA + buf * BUF;
         const WT* Bm = fB + buf * BUF;
         if constexpr (sizeof(WT) == 4) {
+            if (split16_on) {
+                static_assert((BK / 8) % 2 == 0, "fp16x3 pairs the K groups of the fp32 kernel");
+#pragma unroll
+                for (int g = 0; g < BK / 8; g += 2) {
+                    f16x8 ah[SN], al[SN], bh[SM], bl[SM];
+#pragma unroll
+                    for (int i = 0; i < SN; ++i)
+                        split16(*reinterpret_cast<const FragT*>(A + i * 32 * ROW + g * 8), *reinterpret_cast<const FragT*>(A + i * 32 * ROW + g * 8 + 8), ah[i], al[i]);
+#pragma unroll
+                    for (int j = 0; j < SM; ++j)
+                        split16(*reinterpret_cast<const FragT*>(Bm + j * 32 * ROW + g * 8), *reinterpret_cast<const FragT*>(Bm + j * 32 * ROW + g * 8 + 8), bh[j], bl[j]);
+#pragma unroll
+                    for (int i = 0; i < SN; ++i)
+#pragma unroll
+                        for (int j = 0; j < SM; ++j) acc[i][j] = mfma_split(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+                }
+                return;
+            }
             // 8 k per group: lanes 0-31 hold k = 0..3, lanes 32-63 hold k = 4..7 of the group;
             // step tt feeds A[:,k=tt | 4+tt], B likewise -- same permutation on both operands.
 #pragma unroll
@@ -835,8 +875,29 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p_laun
         offA[g] = (wn * SN * 32 + l31) * ROWB + sl;
         offB[g] = (TN + wm * SM * 32 + l31) * ROWB + sl;
     }
+    const bool split16_on = sizeof(WT) == 4 && (p.flags & FTC_FLAG_SPLIT16) != 0;
     auto compute = [&](int bufoff) {
         const unsigned char* base = smem_raw + bufoff;
+        if constexpr (sizeof(WT) == 4) {
+            if (split16_on) {
+                static_assert(sizeof(WT) != 4 || G % 2 == 0, "fp16x3 pairs the K groups of the fp32 kernel");
+#pragma unroll
+                for (int g = 0; g < G; g += 2) {
+                    f16x8 ah[SN], al[SN], bh[SM], bl[SM];
+#pragma unroll
+                    for (int i = 0; i < SN; ++i)
+                        split16(*reinterpret_cast<const f32x4*>(base + offA[g] + i * 32 * ROWB), *reinterpret_cast<const f32x4*>(base + offA[g + 1] + i * 32 * ROWB), ah[i], al[i]);
+#pragma unroll
+                    for (int j = 0; j < SM; ++j)
+                        split16(*reinterpret_cast<const f32x4*>(base + offB[g] + j * 32 * ROWB), *reinterpret_cast<const f32x4*>(base + offB[g + 1] + j * 32 * ROWB), bh[j], bl[j]);
+#pragma unroll
+                    for (int i = 0; i < SN; ++i)
+#pragma unroll
+                        for (int j = 0; j < SM; ++j) acc[i][j] = mfma_split(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             FragT af[SN], bf[SM];
@@ -1064,6 +1125,7 @@ __global__ __launch_bounds__(128 * WMQ, (WMQ == 2) ? 2 : (CPR == 4 && !UPIN && !
 #pragma unroll
     for (int j = 0; j < SM; ++j) hr0[j] = (wm * 4 + j * 2 + (lpix >> 4)) * HW + (lpix & 15);
 
+    const bool split16_on = sizeof(WT) == 4 && (p.flags & FTC_FLAG_SPLIT16) != 0;      // fp16x3 (see split16)
     auto compute = [&](int k) {
         const int cb = k / 9, tap = k - cb * 9;
         const int d = (tap / 3) * HW + (tap % 3);
@@ -1084,6 +1146,26 @@ __global__ __launch_bounds__(128 * WMQ, (WMQ == 2) ? 2 : (CPR == 4 && !UPIN && !
 #pragma unroll
             for (int j = 0; j < SM; ++j) bf[s][j] = *reinterpret_cast<const FragT*>(hb + rowB[j] + ((((g * 2 + half) << 4)) ^ f4[j]));
         };
+        if constexpr (sizeof(WT) == 4) {
+            if (split16_on) {
+                static_assert(sizeof(WT) != 4 || G % 2 == 0, "fp16x3 pairs the K groups of the fp32 kernel");
+#pragma unroll
+                for (int g = 0; g < G; g += 2) {
+                    ldfrag(g, 0);
+                    ldfrag(g + 1, 1);
+                    f16x8 ah[SN], al[SN], bh[SM], bl[SM];
+#pragma unroll
+                    for (int i = 0; i < SN; ++i) split16(af[0][i], af[1][i], ah[i], al[i]);
+#pragma unroll
+                    for (int j = 0; j < SM; ++j) split16(bf[0][j], bf[1][j], bh[j], bl[j]);
+#pragma unroll
+                    for (int i = 0; i < SN; ++i)
+#pragma unroll
+                        for (int j = 0; j < SM; ++j) acc[i][j] = mfma_split(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+                }
+                return;
+            }
+        }
         ldfrag(0, 0);
 #pragma unroll
         for (int g = 0; g < G; ++g) {

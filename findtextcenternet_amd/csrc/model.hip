@@ -250,7 +250,8 @@ struct ModelPlan {
 
 struct ftc_model {
     std::string size;
-    int precision;                          // FTC_F32 | FTC_BF16
+    int precision;                          // FTC_F32 | FTC_BF16 | FTC_F16
+    int split16 = 0;                        // FTC_PRECISION_F16X3: the fp32 plan with FTC_FLAG_SPLIT16 on every convolution
     Blob blob;
     bool has_decoder = false;               // the checkpoint carried the "decoder.*" tensors (SimpleDecoder)
     std::mutex mu;
@@ -523,7 +524,7 @@ std::string conv_signature(const ftc_op& o) {
     // fp16 operands run the same kernels at the same rate as bf16: they share the measured table (dtype 2 looks up as 1)
     auto d = [](int dt) { return dt == FTC_F16 ? (int)FTC_BF16 : dt; };
     int n = std::snprintf(buf, sizeof buf, "w%di%do%d_B%d_%dx%d_c%dof%d_n%dof%d_k%ds%d_f%d_a%d", d(o.w_dtype), d(o.in_dtype), d(o.out_dtype), o.B, o.H, o.W,
-                          o.Cin, o.Cin_total, o.Cout, o.Cout_total, o.ksize, o.stride, o.flags, o.act);
+                          o.Cin, o.Cin_total, o.Cout, o.Cout_total, o.ksize, o.stride, o.flags & ~FTC_FLAG_SPLIT16, o.act);     // (fp16x3 shares the fp32 table)
     if (o.groups > 1) std::snprintf(buf + n, sizeof buf - n, "_g%d", o.groups);
     return buf;
 }
@@ -599,7 +600,7 @@ private:
     void conv(const std::string& name, R x, int xdt, int h, int w, int cin, int cin_total, int cin_off, const std::string& wname, int cout, int k,
               int stride, int act, R out, int odt, const ConvOpt& c = ConvOpt()) {
         const int Ho = (h - 1) / stride + 1, Wo = (w - 1) / stride + 1;
-        int flags = (c.residual ? FTC_FLAG_RESIDUAL : 0) | (c.se ? FTC_FLAG_SE_SCALE : 0) | c.extra_flags;
+        int flags = (c.residual ? FTC_FLAG_RESIDUAL : 0) | (c.se ? FTC_FLAG_SE_SCALE : 0) | c.extra_flags | (m_->split16 && cdt_ == FTC_F32 ? FTC_FLAG_SPLIT16 : 0);
         const double macs = (double)c.groups * B * Ho * Wo * cout * cin * k * k;
         double byt = (double)c.groups * ((double)B * h * w * cin * esize(xdt) + (double)B * Ho * Wo * cout * esize(odt) + (double)cout * cin * k * k * esize(cdt_));
         if (c.residual) byt += (double)B * Ho * Wo * cout * esize(c.res_dt);
@@ -782,7 +783,7 @@ int Builder::build(ModelPlan* out) {
             s.out = outr;
             s.w = wref(wname + ".w", (int64_t)g0 * wsz);
             s.bias = wref(wname + ".b", (int64_t)g0 * brows * FPN_DIM * 4);
-            int flags = 0;
+            int flags = (m_->split16 && cdt_ == FTC_F32) ? FTC_FLAG_SPLIT16 : 0;
             // weights-through-L1 kernel for the fused last level (fragment-major copy of the folded weights); FTC_NO_WL1=1: the LDS-ring halo kernel
             const bool wl1 = bn_fold && has_w(lf + ".wfrag") && !env_on("FTC_NO_WL1");
             if (bn_fold) {
@@ -975,7 +976,10 @@ int ftc_create(const ftc_tensor* tensors, int n_tensors, const char* model_size,
     if (!tensors || n_tensors <= 0 || !out) return ftc_set_error(FTC_ERR_INVALID, "ftc_create: null/empty arguments");
     const std::string size = model_size && *model_size ? model_size : "xl";
     if (stage_rows(size).empty()) return ftc_set_error(FTC_ERR_INVALID, "ftc_create: model_size must be one of xl, l, m, s");
-    if (precision != FTC_F32 && precision != FTC_BF16 && precision != FTC_F16) return ftc_set_error(FTC_ERR_INVALID, "ftc_create: precision must be FTC_F32, FTC_BF16 or FTC_F16");
+    if (precision != FTC_F32 && precision != FTC_BF16 && precision != FTC_F16 && precision != FTC_PRECISION_F16X3)
+        return ftc_set_error(FTC_ERR_INVALID, "ftc_create: precision must be FTC_F32, FTC_BF16, FTC_F16 or FTC_PRECISION_F16X3");
+    const int split16 = precision == FTC_PRECISION_F16X3 ? 1 : 0;
+    if (split16) precision = FTC_F32;
     Weights w;
     for (int i = 0; i < n_tensors; ++i) {
         const ftc_tensor& t = tensors[i];
@@ -993,6 +997,7 @@ int ftc_create(const ftc_tensor* tensors, int n_tensors, const char* model_size,
     if (!m) return ftc_set_error(FTC_ERR_NOMEM, "ftc_create: out of host memory");
     m->size = size;
     m->precision = precision;
+    m->split16 = split16;
     const int rc = pack_weights(m, w);
     if (rc != FTC_OK) { delete m; return rc; }
     *out = m;

@@ -179,7 +179,7 @@ class CenterNetDetection(nn.Module):
         _populate(self, detector_schema(model_size))
         prec = precision or os.environ.get("FTC_PRECISION", "fp32")
         if prec not in PRECISIONS:
-            raise ValueError("precision must be 'fp32', 'bf16' or 'fp16'")
+            raise ValueError("precision must be 'fp32', 'fp16x3', 'bf16' or 'fp16'")
         object.__setattr__(self, "_engine", _HipEngine(prec, model_size, self))
         # pre_weights: the reference looks for efficientnetv2-xl-21k.npz next to detector.py and
         # silently continues when it is missing (models/detector.py:34-36, :129-130); use
@@ -196,7 +196,7 @@ class CenterNetDetection(nn.Module):
 
     def set_precision(self, precision: str) -> None:
         if precision not in PRECISIONS:
-            raise ValueError("precision must be 'fp32', 'bf16' or 'fp16'")
+            raise ValueError("precision must be 'fp32', 'fp16x3', 'bf16' or 'fp16'")
         if precision != self._engine.precision:
             self._engine.invalidate()
             self._engine.precision = precision
@@ -355,8 +355,8 @@ class TextDetectorModel(nn.Module):
         rows = torch.empty((max(n, 1), 128), dtype=cdt, device=dev)
         with torch.cuda.device(dev):
             L.check(lib.ftc_gather_rows(feat.data_ptr(), sel.data_ptr(), cnt.data_ptr(), max(n, 1), feature_dim, 128, rows.data_ptr(),
-                                        PRECISIONS[self.detector.precision], C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
-                    "ftc_gather_rows")
+                                        min(PRECISIONS[self.detector.precision], 2) if cdt != torch.float32 else L.F32,
+                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "ftc_gather_rows")
         idx = torch.tensor([0, 2, 3, 4, 5, 6, 7, 8, 9], device=dev)
         heatmap = heat.index_select(3, idx).permute(0, 3, 1, 2)
         if n == 0:

@@ -18,8 +18,10 @@ from . import _lib as L
 
 # numeric modes: fp32 = parity mode (exact-f32 MFMA); bf16 = speed mode (BASELINE config 2); fp16 = the speed-mode plan with IEEE-half
 # operands (same MFMA rate, 3 more mantissa bits: ~8x closer to the fp32 result, activations saturate at +-65504)
-PRECISIONS = {"fp32": L.F32, "bf16": L.BF16, "fp16": L.F16}
-TORCH_DTYPE = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+# "fp16x3": the fp32 plan (fp32 tensors, weights, epilogues, accumulation) with every product on the 16-bit matrix pipe as three
+# fp16 MFMAs of hi / lo split operands (FTC_FLAG_SPLIT16, include/ftc.h): the reference's fp32 tolerance at about twice the fp32 speed
+PRECISIONS = {"fp32": L.F32, "bf16": L.BF16, "fp16": L.F16, "fp16x3": 3}
+TORCH_DTYPE = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16, "fp16x3": torch.float32}
 
 
 @dataclass
@@ -58,7 +60,7 @@ class FtcModel:
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], precision: str = "fp32", model_size: str = "xl"):
         if precision not in PRECISIONS:
-            raise ValueError("precision must be 'fp32', 'bf16' or 'fp16'")
+            raise ValueError("precision must be 'fp32', 'fp16x3', 'bf16' or 'fp16'")
         lib = L.load()
         keep = []
         arr = (L.Tensor * len(state_dict))()

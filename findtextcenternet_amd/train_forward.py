@@ -46,7 +46,7 @@ class TrainForward:
 
     def __init__(self, module, precision: str):
         self.module, self.precision = module, precision
-        self.cdt = PRECISIONS[precision]
+        self.cdt = PRECISIONS["fp32" if precision == "fp16x3" else precision]      # (fp16x3 is an inference mode: the BN-refresh pass runs fp32)
         self.fingerprint = None
         self.wdev: Optional[torch.Tensor] = None
         self.table: Dict[str, int] = {}
@@ -65,7 +65,7 @@ class TrainForward:
             return
         sd = {k: v.detach() for k, v in self.module.state_dict().items()}
         self.sd_shapes = {k: tuple(v.shape) for k, v in sd.items()}
-        tdt = TORCH_DTYPE[self.precision]
+        tdt = TORCH_DTYPE[self.precision]                                           # (fp16x3 -> float32)
         items: List[Tuple[str, torch.Tensor]] = []
         cmax = 0
         for k, v in sd.items():

@@ -43,6 +43,8 @@ class TrainStep:
     def __init__(self, module, precision: Optional[str] = None, cov=None):
         self.module = module
         self.precision = precision or module.detector.precision
+        if self.precision == "fp16x3":
+            raise ValueError("TrainStep: 'fp16x3' is an inference mode; train in 'bf16' (what the reference's autocast does), 'fp16' or 'fp32'")
         self.cdt = PRECISIONS[self.precision]
         self.esz = 4 if self.cdt == L.F32 else 2
         self.cov = cov

@@ -45,6 +45,8 @@ typedef enum ftc_status {
 } ftc_status;
 
 typedef enum ftc_dtype { FTC_F32 = 0, FTC_BF16 = 1, FTC_F16 = 2 } ftc_dtype;     /* FTC_F16: IEEE half (same MFMA rate as bf16, 3 more mantissa bits) */
+/* ftc_create precision only: the fp32 plan (fp32 tensors and weights) with FTC_FLAG_SPLIT16 on every convolution */
+#define FTC_PRECISION_F16X3 3
 
 /* Address bases an op operand can be relative to; resolved at ftc_plan_run time. */
 typedef enum ftc_base {
@@ -186,6 +188,10 @@ enum {
                                   FRAGMENT-MAJOR -- [groups][6 row blocks of 32][9 taps][Cin/64][4 K groups of 16][64 lanes][8]: element e of
                                   lane L = W[32*rb + (L & 31)][tap][64*cb + 16*g + 8*(L >> 5) + e] -- so that a wave reads an MFMA A fragment
                                   as one coalesced 1 KiB load straight from global memory (the weights never touch LDS) */
+    FTC_FLAG_SPLIT16 = 0x2000000, /* CONV with fp32 operands (w_dtype = in_dtype = out_dtype = FTC_F32): "fp16x3" arithmetic -- every fp32 operand is
+                                  split into hi + lo IEEE halves while the MFMA fragments are read from LDS and a product becomes three
+                                  v_mfma_f32_32x32x16_f16 (hi.lo + lo.hi + hi.hi, fp32 accumulation) instead of eight v_mfma_f32_32x32x2_f32:
+                                  22-bit operands at up to 5.3x the fp32 matrix rate.  Tensors, weights, epilogues: those of the fp32 mode */
     FTC_FLAG_ACCUM = 0x800000, /* BNBWD / CONV-as-dgrad helpers: the data-gradient output is added to what `out` holds */
     FTC_FLAG_SE_FOLD = 32      /* SE: besides scale[b,c], write out2[b][n][c] = bf16(in[n][c] * scale[b,c]) for the
                                   bf16 matrix `in` [Cout_total][C] -- the following 1x1 convolution then runs with
@@ -294,6 +300,7 @@ typedef struct ftc_model ftc_model;
    matrix rate, 11-bit significands: ~8x closer to the fp32 result than bf16; activations saturate at +-65504).  Fails with FTC_ERR_INVALID naming the first missing
    or mis-shaped tensor.  The tensors may be freed after the call. */
 int ftc_create(const ftc_tensor* tensors, int n_tensors, const char* model_size, int precision, ftc_model** out);
+/* precision may also be FTC_PRECISION_F16X3: the parity-grade fast mode (fp32 everywhere except the multiplier: see FTC_FLAG_SPLIT16) */
 void ftc_destroy(ftc_model* model);
 /* The packed weight blob: the caller copies ftc_weights_bytes() bytes from ftc_weights_host() into device memory
    (256-byte aligned) once and passes that address to every ftc_forward. */

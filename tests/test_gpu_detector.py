@@ -42,9 +42,12 @@ def sd():
     return deterministic_state_dict(0)
 
 
-@pytest.fixture(scope="module")
-def det_fp32(sd):
-    m = TextDetectorModel(pre_weights=False, precision="fp32")
+# Every test written for the fp32 parity mode also runs on "fp16x3" (fp32 tensors / weights / accumulation, each product as three
+# fp16 MFMAs of hi / lo split operands): ONE program that has to meet the reference's 1e-3 tolerance, the exact NMS mask and the
+# exact peak set AND run above 125 images/s per GPU (the fp32-MFMA mode: 117).
+@pytest.fixture(scope="module", params=["fp32", "fp16x3"])
+def det_fp32(sd, request):
+    m = TextDetectorModel(pre_weights=False, precision=request.param)
     m.load_state_dict(sd)
     d = CenterNetDetector(m.detector)
     d.to(device="cuda")

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--nbuf", type=int, default=0, help="tuning hints (ftc_op.aux0): 4 = no direct-to-LDS, 8 = 3-deep DMA ring, 16 = force direct-to-LDS")
     ap.add_argument("--no-se", action="store_true", help="drop the SE-scale flag (what-if: scale folded into per-image weights)")
     ap.add_argument("--wl1", action="store_true", help="3x3 192-channel layers: the weights-through-L1 kernel (FTC_FLAG_W_FRAG; weight values are random anyway)")
+    ap.add_argument("--split16", action="store_true", help="fp32 mode: FTC_FLAG_SPLIT16 (fp16x3 arithmetic)")
     ap.add_argument("--sweep", action="store_true", help="try every tuner candidate for the layer and print the five fastest")
     a = ap.parse_args()
     lib = L.load()
@@ -84,7 +85,7 @@ def main():
             ws[off["w"]:off["w"] + sizes["w"]].view(torch.bfloat16).normal_(0, 0.05)
         op = (L.Op * 1)()
         o = op[0]
-        o.kind, o.flags, o.act = L.OP_CONV, (L.FLAG_RESIDUAL if res else 0) | (L.FLAG_SE_SCALE if se else 0) | (a.ablate << 8) | (0x1000 if a.timeline else 0), act
+        o.kind, o.flags, o.act = L.OP_CONV, (L.FLAG_RESIDUAL if res else 0) | (L.FLAG_SE_SCALE if se else 0) | (a.ablate << 8) | (0x1000 if a.timeline else 0) | (L.FLAG_SPLIT16 if a.split16 else 0), act
         o.in_dtype, o.out_dtype, o.w_dtype, o.res_dtype = idt, odt, cdt, L.F32
         o.B, o.H, o.W, o.Ho, o.Wo = B, H, W, Ho, Wo
         o.Cin = o.Cin_total = Cin

@@ -7,6 +7,7 @@
 using namespace convimpl;
 
 hipError_t launch_conv_f32(const ConvP& p, const ftc_op& o, hipStream_t s);
+hipError_t launch_conv_x3(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_bf16_bb(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_bf16_fb(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_bf16_bf(const ConvP& p, const ftc_op& o, hipStream_t s);
@@ -30,7 +31,7 @@ void conv_kernel_label(const ftc_op& op, char* buf, int len) {
         return;
     }
     const bool dma = uses_glds(op);
-    snprintf(buf, len, "conv_igemm%s<%s,in=%s,out=%s,tile=%s,bk=%d,nbuf=%d>", dma ? "_glds" : "", dt[op.w_dtype & 3], dt[op.in_dtype & 3],
+    snprintf(buf, len, "conv_igemm%s<%s,in=%s,out=%s,tile=%s,bk=%d,nbuf=%d>", dma ? "_glds" : "", (op.flags & FTC_FLAG_SPLIT16) ? "f16x3" : dt[op.w_dtype & 3], dt[op.in_dtype & 3],
              dt[op.out_dtype & 3], kCfgName[select_cfg(op)], select_bk(op), dma ? glds_ring(op) : 1);
     if (!dma && hint_splitk(op) > 1) snprintf(buf + strlen(buf) - 1, len - strlen(buf) + 1, ",splitk=%d>", hint_splitk(op));
     if (op.groups > 1) snprintf(buf + strlen(buf) - 1, len - strlen(buf) + 1, ",groups=%d>", op.groups);
@@ -57,6 +58,7 @@ const char* conv_validate(const ftc_op& op) {
     if (op.Ho != (op.H + 2 * pad - op.ksize) / op.stride + 1 || op.Wo != (op.W + 2 * pad - op.ksize) / op.stride + 1)
         return "conv: Ho/Wo inconsistent with H/W/ksize/stride";
     if ((op.flags & FTC_FLAG_SE_SCALE) && op.ksize != 1) return "conv: SE scale only on 1x1";
+    if ((op.flags & FTC_FLAG_SPLIT16) && op.w_dtype != FTC_F32) return "conv: SPLIT16 (fp16x3) applies to fp32 operands";
     if ((op.flags & FTC_FLAG_BORDER_BIAS) && (op.ksize != 3 || op.stride != 1)) return "conv: border-bias table only for 3x3 stride 1";
     if ((long)op.B * op.Ho * op.Wo > 0x7fffffffL / 4) return "conv: too many output pixels";
     // buffer addressing is 32-bit: keep every operand below 2 GiB
@@ -147,7 +149,7 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
         p.out_gs = (long)o.B * o.Ho * o.Wo * o.aux1 * 4;       // `out` holds T [G][B,Ho,Wo][aux1] fp32
         p.out2 = nullptr;
     }
-    if (o.w_dtype == FTC_F32) return launch_conv_f32(p, o, s);
+    if (o.w_dtype == FTC_F32) return (o.flags & FTC_FLAG_SPLIT16) ? launch_conv_x3(p, o, s) : launch_conv_f32(p, o, s);
     if (o.w_dtype == FTC_F16) {
         if (o.in_dtype == FTC_F16 && o.out_dtype == FTC_F16) return launch_conv_f16_hh(p, o, s);
         if (o.in_dtype == FTC_F32 && o.out_dtype == FTC_F16) return launch_conv_f16_fh(p, o, s);

@@ -95,8 +95,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const ConvP& p, in
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(w), 0, p.w_bytes, 0x00020000);
 }
 
+// Compute-type tag of the fp16x3 mode (FTC_FLAG_SPLIT16): staged, stored and addressed exactly like fp32 (4-byte elements), multiplied
+// as hi / lo IEEE halves.  Its own tag = its own kernel instantiations: the exact-fp32 kernels keep their register budget.
+struct x3f32 { float v; };
+template <typename WT> constexpr bool is_x3 = std::is_same<WT, x3f32>::value;
+
 template <typename WT> struct Frag;
 template <> struct Frag<float> { using type = f32x4; };
+template <> struct Frag<x3f32> { using type = f32x4; };
 template <> struct Frag<__bf16> { using type = bf16x8; };
 template <> struct Frag<_Float16> { using type = f16x8; };
 
@@ -540,8 +546,6 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(const ConvP p_laun
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rse = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.se), 0, p.se_bytes, 0x00020000);
     constexpr bool use_se = SE;
-    const bool split16_on = sizeof(WT) == 4 && (p.flags & FTC_FLAG_SPLIT16) != 0;      // wave-uniform (launch-wide)
-
     const int kc = t % CPR;                      // this thread's 16-byte chunk inside a K row
     const int row0 = t / CPR;
     const int HoWo = p.Ho * p.Wo;
@@ -636,21 +640,21 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(const ConvP p_laun
         const WT* A = fA + buf * BUF;
         const WT* Bm = fB + buf * BUF;
         if constexpr (sizeof(WT) == 4) {
-            if (split16_on) {
+            if constexpr (is_x3<WT>) {
                 static_assert((BK / 8) % 2 == 0, "fp16x3 pairs the K groups of the fp32 kernel");
 #pragma unroll
                 for (int g = 0; g < BK / 8; g += 2) {
-                    f16x8 ah[SN], al[SN], bh[SM], bl[SM];
+                    f16x8 ah[SN], al[SN];
 #pragma unroll
                     for (int i = 0; i < SN; ++i)
                         split16(*reinterpret_cast<const FragT*>(A + i * 32 * ROW + g * 8), *reinterpret_cast<const FragT*>(A + i * 32 * ROW + g * 8 + 8), ah[i], al[i]);
 #pragma unroll
-                    for (int j = 0; j < SM; ++j)
-                        split16(*reinterpret_cast<const FragT*>(Bm + j * 32 * ROW + g * 8), *reinterpret_cast<const FragT*>(Bm + j * 32 * ROW + g * 8 + 8), bh[j], bl[j]);
+                    for (int j = 0; j < SM; ++j) {
+                        f16x8 bh, bl;
+                        split16(*reinterpret_cast<const FragT*>(Bm + j * 32 * ROW + g * 8), *reinterpret_cast<const FragT*>(Bm + j * 32 * ROW + g * 8 + 8), bh, bl);
 #pragma unroll
-                    for (int i = 0; i < SN; ++i)
-#pragma unroll
-                        for (int j = 0; j < SM; ++j) acc[i][j] = mfma_split(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+                        for (int i = 0; i < SN; ++i) acc[i][j] = mfma_split(ah[i], al[i], bh, bl, acc[i][j]);
+                    }
                 }
                 return;
             }
@@ -875,28 +879,25 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p_laun
         offA[g] = (wn * SN * 32 + l31) * ROWB + sl;
         offB[g] = (TN + wm * SM * 32 + l31) * ROWB + sl;
     }
-    const bool split16_on = sizeof(WT) == 4 && (p.flags & FTC_FLAG_SPLIT16) != 0;
     auto compute = [&](int bufoff) {
         const unsigned char* base = smem_raw + bufoff;
-        if constexpr (sizeof(WT) == 4) {
-            if (split16_on) {
-                static_assert(sizeof(WT) != 4 || G % 2 == 0, "fp16x3 pairs the K groups of the fp32 kernel");
+        if constexpr (is_x3<WT>) {
+            static_assert(!is_x3<WT> || G % 2 == 0, "fp16x3 pairs the K groups of the fp32 kernel");
 #pragma unroll
-                for (int g = 0; g < G; g += 2) {
-                    f16x8 ah[SN], al[SN], bh[SM], bl[SM];
+            for (int g = 0; g < G; g += 2) {
+                f16x8 ah[SN], al[SN];
 #pragma unroll
-                    for (int i = 0; i < SN; ++i)
-                        split16(*reinterpret_cast<const f32x4*>(base + offA[g] + i * 32 * ROWB), *reinterpret_cast<const f32x4*>(base + offA[g + 1] + i * 32 * ROWB), ah[i], al[i]);
+                for (int i = 0; i < SN; ++i)
+                    split16(*reinterpret_cast<const f32x4*>(base + offA[g] + i * 32 * ROWB), *reinterpret_cast<const f32x4*>(base + offA[g + 1] + i * 32 * ROWB), ah[i], al[i]);
 #pragma unroll
-                    for (int j = 0; j < SM; ++j)
-                        split16(*reinterpret_cast<const f32x4*>(base + offB[g] + j * 32 * ROWB), *reinterpret_cast<const f32x4*>(base + offB[g + 1] + j * 32 * ROWB), bh[j], bl[j]);
+                for (int j = 0; j < SM; ++j) {
+                    f16x8 bh, bl;
+                    split16(*reinterpret_cast<const f32x4*>(base + offB[g] + j * 32 * ROWB), *reinterpret_cast<const f32x4*>(base + offB[g + 1] + j * 32 * ROWB), bh, bl);
 #pragma unroll
-                    for (int i = 0; i < SN; ++i)
-#pragma unroll
-                        for (int j = 0; j < SM; ++j) acc[i][j] = mfma_split(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+                    for (int i = 0; i < SN; ++i) acc[i][j] = mfma_split(ah[i], al[i], bh, bl, acc[i][j]);
                 }
-                return;
             }
+            return;
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -1125,7 +1126,6 @@ __global__ __launch_bounds__(128 * WMQ, (WMQ == 2) ? 2 : (CPR == 4 && !UPIN && !
 #pragma unroll
     for (int j = 0; j < SM; ++j) hr0[j] = (wm * 4 + j * 2 + (lpix >> 4)) * HW + (lpix & 15);
 
-    const bool split16_on = sizeof(WT) == 4 && (p.flags & FTC_FLAG_SPLIT16) != 0;      // fp16x3 (see split16)
     auto compute = [&](int k) {
         const int cb = k / 9, tap = k - cb * 9;
         const int d = (tap / 3) * HW + (tap % 3);
@@ -1146,25 +1146,24 @@ __global__ __launch_bounds__(128 * WMQ, (WMQ == 2) ? 2 : (CPR == 4 && !UPIN && !
 #pragma unroll
             for (int j = 0; j < SM; ++j) bf[s][j] = *reinterpret_cast<const FragT*>(hb + rowB[j] + ((((g * 2 + half) << 4)) ^ f4[j]));
         };
-        if constexpr (sizeof(WT) == 4) {
-            if (split16_on) {
-                static_assert(sizeof(WT) != 4 || G % 2 == 0, "fp16x3 pairs the K groups of the fp32 kernel");
+        if constexpr (is_x3<WT>) {
+            static_assert(!is_x3<WT> || G % 2 == 0, "fp16x3 pairs the K groups of the fp32 kernel");
 #pragma unroll
-                for (int g = 0; g < G; g += 2) {
-                    ldfrag(g, 0);
-                    ldfrag(g + 1, 1);
-                    f16x8 ah[SN], al[SN], bh[SM], bl[SM];
+            for (int g = 0; g < G; g += 2) {
+                f16x8 ah[SN], al[SN];
 #pragma unroll
-                    for (int i = 0; i < SN; ++i) split16(af[0][i], af[1][i], ah[i], al[i]);
+                for (int i = 0; i < SN; ++i)
+                    split16(*reinterpret_cast<const FragT*>(wa + offA[g] + i * 32 * ROWB), *reinterpret_cast<const FragT*>(wa + offA[g + 1] + i * 32 * ROWB), ah[i], al[i]);
 #pragma unroll
-                    for (int j = 0; j < SM; ++j) split16(bf[0][j], bf[1][j], bh[j], bl[j]);
+                for (int j = 0; j < SM; ++j) {
+                    f16x8 bh, bl;
+                    split16(*reinterpret_cast<const FragT*>(hb + rowB[j] + ((((g * 2 + half) << 4)) ^ f4[j])),
+                            *reinterpret_cast<const FragT*>(hb + rowB[j] + (((((g + 1) * 2 + half) << 4)) ^ f4[j])), bh, bl);
 #pragma unroll
-                    for (int i = 0; i < SN; ++i)
-#pragma unroll
-                        for (int j = 0; j < SM; ++j) acc[i][j] = mfma_split(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+                    for (int i = 0; i < SN; ++i) acc[i][j] = mfma_split(ah[i], al[i], bh, bl, acc[i][j]);
                 }
-                return;
             }
+            return;
         }
         ldfrag(0, 0);
 #pragma unroll

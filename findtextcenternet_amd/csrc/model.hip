@@ -519,12 +519,12 @@ const TuneEntry kTuning[] = {
 #include "tuning_table.inc"
     {nullptr, 0}};
 
-std::string conv_signature(const ftc_op& o) {
+std::string conv_signature(const ftc_op& o, bool strip_split = false) {
     char buf[192];
     // fp16 operands run the same kernels at the same rate as bf16: they share the measured table (dtype 2 looks up as 1)
     auto d = [](int dt) { return dt == FTC_F16 ? (int)FTC_BF16 : dt; };
     int n = std::snprintf(buf, sizeof buf, "w%di%do%d_B%d_%dx%d_c%dof%d_n%dof%d_k%ds%d_f%d_a%d", d(o.w_dtype), d(o.in_dtype), d(o.out_dtype), o.B, o.H, o.W,
-                          o.Cin, o.Cin_total, o.Cout, o.Cout_total, o.ksize, o.stride, o.flags & ~FTC_FLAG_SPLIT16, o.act);     // (fp16x3 shares the fp32 table)
+                          o.Cin, o.Cin_total, o.Cout, o.Cout_total, o.ksize, o.stride, strip_split ? (o.flags & ~FTC_FLAG_SPLIT16) : o.flags, o.act);
     if (o.groups > 1) std::snprintf(buf + n, sizeof buf - n, "_g%d", o.groups);
     return buf;
 }
@@ -537,6 +537,7 @@ void apply_tuning(std::vector<ftc_op>& ops) {
     for (ftc_op& o : ops) {
         if (o.kind != FTC_OP_CONV) continue;
         auto it = table.find(conv_signature(o));
+        if (it == table.end() && (o.flags & FTC_FLAG_SPLIT16)) it = table.find(conv_signature(o, true));     // fp16x3 without its own measurement: the fp32 choice
         if (it != table.end() && it->second) o.aux0 = it->second;
     }
 }

@@ -368,6 +368,7 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode record")
     ap.add_argument("--dump-ops", default="", help="write per-op timings (JSON) to this path")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo walk through the N-rank control flow (no GPU work)")
+    ap.add_argument("--no-seam2", action="store_true", help="skip the batch-1 host-in / host-out call_detector latency record")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 300-step / >= 4 s sustained-rate record")
     ap.add_argument("--train", action="store_true", help="BASELINE configs[4]: the train step (fwd + loss + bwd + optimizer, DDP all-reduce when N > 1)")
     args = ap.parse_args()
@@ -593,7 +594,7 @@ def main():
         from findtextcenternet_amd import HipDetectorBackend
         seam = {}
         tile_np = (synth.noise_images(4321, 1, 768, 768) * 255.0).astype(np.float32)
-        for prec in ([args.precision] + ([] if args.no_fp32 else [p_ for p_ in ("fp32",) if p_ != args.precision])):
+        for prec in ([] if args.no_seam2 else [args.precision] + ([] if args.no_fp32 else [p_ for p_ in ("fp32",) if p_ != args.precision])):
             mdl, dd = (model, det) if prec == args.precision else make(prec)
             be = HipDetectorBackend(dd, device=dev)
             for _ in range(3):
@@ -609,7 +610,8 @@ def main():
                 torch.cuda.empty_cache()
         seam["note"] = ("HipDetectorBackend.call_detector: host float32 tile in (7.1 MB), numpy heatmap [1,10,192,192] + features [1,100,192,192] out "
                         "(16.2 MB), batch 1, synchronous -- the reference's own calling convention; compare cpu_baseline.b1_fwd_nms_images_per_s")
-        result["seam2_call_detector_b1"] = seam
+        if not args.no_seam2:
+            result["seam2_call_detector_b1"] = seam
         if not args.no_cpu_baseline:
             cpu, o_hm, o_ft = cpu_baseline({k: v for k, v in sd.items()}, args.cpu_budget)
             result["cpu_baseline"] = cpu

@@ -9,11 +9,26 @@ ROOT="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="$ROOT/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
-CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-fp32 --no-profile"
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32 --dump-ops "$OUT/ops.json" > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
+CMD="python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-fp32 --no-profile --no-sustained --no-seam2"
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32 --no-sustained --no-seam2 --dump-ops "$OUT/ops.json" > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
 rocprofv3 --kernel-trace --stats -d "$OUT" -o trace -- $CMD > "$OUT/trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT" -o write -- $CMD > "$OUT/write.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d "$OUT" -o sq1 -- $CMD > "$OUT/sq1.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "$OUT" -o sq2 -- $CMD > "$OUT/sq2.log" 2>&1
+# round 3: the train step (BASELINE configs[4]) and the fp16x3 parity mode, kernel durations only
+rocprofv3 --kernel-trace --stats -d "$OUT" -o train -- python bench.py --train --steps 3 --warmup 1 --no-profile --no-cpu-baseline > "$OUT/train.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT" -o x3 -- python bench.py --precision fp16x3 --steps 3 --warmup 2 --no-cpu-baseline --no-fp32 --no-profile --no-sustained --no-seam2 > "$OUT/x3.log" 2>&1
 ls -la "$OUT" | head -40
+# summaries are made ON the box (gpurun copies back at most 64 MiB of gpurun_out/): the raw counter CSVs stay behind
+mkdir -p "$ROOT/gpurun_out/summ_$TAG"
+python profiles/pmc_kernels.py "$OUT" --tag "$TAG" > "$ROOT/gpurun_out/summ_$TAG/pmc_kernels.log" 2>&1
+python profiles/summarize_rocpd.py "$OUT/trace_results.db" "profiles/${TAG}_bf16_b8_kernel_stats.txt"
+python profiles/summarize_rocpd.py "$OUT/train_results.db" "profiles/${TAG}_train_bf16_b8_kernel_stats.txt"
+python profiles/summarize_rocpd.py "$OUT/x3_results.db" "profiles/${TAG}_fp16x3_b8_kernel_stats.txt"
+cp profiles/${TAG}_* "$ROOT/gpurun_out/summ_$TAG/"
+cp "$OUT/bench_unprofiled.json" "$ROOT/gpurun_out/summ_$TAG/${TAG}_bf16_b8_bench.json"
+cp "$OUT/ops.json" "$ROOT/gpurun_out/summ_$TAG/ops.json"
+tail -2 "$OUT/train.log" > "$ROOT/gpurun_out/summ_$TAG/train_bench_line.txt"
+tail -2 "$OUT/x3.log" > "$ROOT/gpurun_out/summ_$TAG/x3_bench_line.txt"
+rm -rf "$OUT"

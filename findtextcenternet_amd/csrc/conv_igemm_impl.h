@@ -125,6 +125,27 @@ __device__ __forceinline__ void split16(const f32x4& a0, const f32x4& a1, f16x8&
         lo[4 + e] = (_Float16)(a1[e] - (float)h1);
     }
 }
+// One 16-byte chunk of four fp32 values <-> the same 16 bytes as [hi x4 | lo x4] IEEE halves ("pre-split" chunk).  The WEIGHTS of an
+// fp16x3 convolution are stored pre-split (model.hip packs them so; the K order is untouched), activations are converted where they pass
+// through registers anyway (register-staged kernel) or once per LDS-resident halo (3x3 halo kernel); only the DMA-staged activation
+// tiles of conv_igemm_glds_kernel are still split per fragment read.
+__device__ __forceinline__ u32x4 chunk_hl(const f32x4& v) {
+    f16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 hh = (_Float16)f16_sat(v[e]);
+        h[e] = hh;
+        l[e] = (_Float16)(v[e] - (float)hh);
+    }
+    const u32x2 hu = __builtin_bit_cast(u32x2, h), lu = __builtin_bit_cast(u32x2, l);
+    return u32x4{hu[0], hu[1], lu[0], lu[1]};
+}
+// two pre-split chunks (K groups g, g+1 of the fp32 kernels) -> the hi / lo operands of one 32x32x16 MFMA: register renaming only
+__device__ __forceinline__ void frag_hl(const f32x4& c0, const f32x4& c1, f16x8& hi, f16x8& lo) {
+    const u32x4 a = __builtin_bit_cast(u32x4, c0), b = __builtin_bit_cast(u32x4, c1);
+    hi = __builtin_bit_cast(f16x8, u32x4{a[0], a[1], b[0], b[1]});
+    lo = __builtin_bit_cast(f16x8, u32x4{a[2], a[3], b[2], b[3]});
+}
 __device__ __forceinline__ f32x16 mfma_split(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x16 c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
@@ -147,6 +168,7 @@ __device__ __forceinline__ u32x4 load_act(__amdgpu_buffer_rsrc_t rin, int voff, 
             f32x4 v = __builtin_bit_cast(f32x4, raw) * __builtin_bit_cast(f32x4, bload(rse, seoff, 0));
             raw = __builtin_bit_cast(u32x4, v);
         }
+        if constexpr (is_x3<WT>) raw = chunk_hl(__builtin_bit_cast(f32x4, raw));      // fp16x3: split once, on the way to LDS
         return raw;
     } else {
         using FragW = typename Frag<WT>::type;
@@ -647,11 +669,11 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(const ConvP p_laun
                     f16x8 ah[SN], al[SN];
 #pragma unroll
                     for (int i = 0; i < SN; ++i)
-                        split16(*reinterpret_cast<const FragT*>(A + i * 32 * ROW + g * 8), *reinterpret_cast<const FragT*>(A + i * 32 * ROW + g * 8 + 8), ah[i], al[i]);
+                        frag_hl(*reinterpret_cast<const FragT*>(A + i * 32 * ROW + g * 8), *reinterpret_cast<const FragT*>(A + i * 32 * ROW + g * 8 + 8), ah[i], al[i]);
 #pragma unroll
                     for (int j = 0; j < SM; ++j) {
                         f16x8 bh, bl;
-                        split16(*reinterpret_cast<const FragT*>(Bm + j * 32 * ROW + g * 8), *reinterpret_cast<const FragT*>(Bm + j * 32 * ROW + g * 8 + 8), bh, bl);
+                        frag_hl(*reinterpret_cast<const FragT*>(Bm + j * 32 * ROW + g * 8), *reinterpret_cast<const FragT*>(Bm + j * 32 * ROW + g * 8 + 8), bh, bl);
 #pragma unroll
                         for (int i = 0; i < SN; ++i) acc[i][j] = mfma_split(ah[i], al[i], bh, bl, acc[i][j]);
                     }
@@ -888,7 +910,7 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p_laun
                 f16x8 ah[SN], al[SN];
 #pragma unroll
                 for (int i = 0; i < SN; ++i)
-                    split16(*reinterpret_cast<const f32x4*>(base + offA[g] + i * 32 * ROWB), *reinterpret_cast<const f32x4*>(base + offA[g + 1] + i * 32 * ROWB), ah[i], al[i]);
+                    frag_hl(*reinterpret_cast<const f32x4*>(base + offA[g] + i * 32 * ROWB), *reinterpret_cast<const f32x4*>(base + offA[g + 1] + i * 32 * ROWB), ah[i], al[i]);
 #pragma unroll
                 for (int j = 0; j < SM; ++j) {
                     f16x8 bh, bl;
@@ -1153,11 +1175,11 @@ __global__ __launch_bounds__(128 * WMQ, (WMQ == 2) ? 2 : (CPR == 4 && !UPIN && !
                 f16x8 ah[SN], al[SN];
 #pragma unroll
                 for (int i = 0; i < SN; ++i)
-                    split16(*reinterpret_cast<const FragT*>(wa + offA[g] + i * 32 * ROWB), *reinterpret_cast<const FragT*>(wa + offA[g + 1] + i * 32 * ROWB), ah[i], al[i]);
+                    frag_hl(*reinterpret_cast<const FragT*>(wa + offA[g] + i * 32 * ROWB), *reinterpret_cast<const FragT*>(wa + offA[g + 1] + i * 32 * ROWB), ah[i], al[i]);
 #pragma unroll
                 for (int j = 0; j < SM; ++j) {
-                    f16x8 bh, bl;
-                    split16(*reinterpret_cast<const FragT*>(hb + rowB[j] + ((((g * 2 + half) << 4)) ^ f4[j])),
+                    f16x8 bh, bl;                                    // the halo image was split in place (halo_split below)
+                    frag_hl(*reinterpret_cast<const FragT*>(hb + rowB[j] + ((((g * 2 + half) << 4)) ^ f4[j])),
                             *reinterpret_cast<const FragT*>(hb + rowB[j] + (((((g + 1) * 2 + half) << 4)) ^ f4[j])), bh, bl);
 #pragma unroll
                     for (int i = 0; i < SN; ++i) acc[i][j] = mfma_split(ah[i], al[i], bh, bl, acc[i][j]);
@@ -1251,9 +1273,27 @@ __global__ __launch_bounds__(128 * WMQ, (WMQ == 2) ? 2 : (CPR == 4 && !UPIN && !
     const bool tl_on = (p.flags & 0x1000) && blockIdx.x < 512 && t == 0;
     unsigned long long* tl = reinterpret_cast<unsigned long long*>(const_cast<void*>(p.res)) + (size_t)blockIdx.x * 64;
     if (tl_on) tl[0] = __builtin_amdgcn_s_memtime();
+    // fp16x3: the fp32 halo image is split IN PLACE into [hi x4 | lo x4] chunks, once per channel block, by the thread that DMA'd the
+    // chunk (its own vmcnt wait is all the ordering that needs; the next workgroup barrier publishes the result) -- instead of once per
+    // fragment read, which repeated the conversion for every tap and every channel-block wave (18x).  Pass i of block nxt runs in tap
+    // 2 + i of the block before it: the DMA issued in tap 0 is complete by the wait at the top of tap 2.
+    static_assert(!is_x3<WT> || NLH <= 7, "one in-place split pass per tap 2..8");
+    auto halo_split = [&](int pass, int bufidx) {
+#pragma unroll
+        for (int i = 0; i < NLH; ++i)
+            if (i == pass && i * NT + t < HCH) {
+                f32x4* q = reinterpret_cast<f32x4*>(hbase + bufidx * HBUF + (i * NT + t) * 16);
+                *reinterpret_cast<u32x4*>(q) = chunk_hl(*q);
+            }
+    };
     issue_h(0);
     issue_w(0);
     if (nk > 1) issue_w(1);
+    if constexpr (is_x3<WT>) {
+        wait_vmcnt<0>();                                                 // (prologue only) own halo chunks of block 0 have landed
+#pragma unroll
+        for (int i = 0; i < NLH; ++i) halo_split(i, 0);
+    }
     if (tl_on) tl[1] = __builtin_amdgcn_s_memtime();
     for (int k = 0; k < nk; ++k) {
         if (tl_on && k < 40) tl[2 + k] = __builtin_amdgcn_s_memtime();
@@ -1274,6 +1314,9 @@ __global__ __launch_bounds__(128 * WMQ, (WMQ == 2) ? 2 : (CPR == 4 && !UPIN && !
                 }
             }
             if (k + 2 < nk) issue_w(k + 2);                              // slot (k+2)%3 was read in step k-1
+            if constexpr (is_x3<WT>) {
+                if (tapj >= 2 && tapj - 2 < NLH && nxt < p.ncb) halo_split(tapj - 2, nxt & 1);
+            }
         };
         // Round-2 timeline of this loop (tools/conv_bench.py --timeline --ablate N, s_memtime per K step, last FPN level, 1536 = the
         // MFMA-bound step): MFMA + LDS reads alone 1510-1565 | + barrier 2064 | DMA + barrier alone 1229 | everything 2697.  The

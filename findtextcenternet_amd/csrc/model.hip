@@ -131,6 +131,12 @@ inline uint16_t f32_to_bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
+inline float f16_to_f32(uint16_t u) {
+    _Float16 h;
+    std::memcpy(&h, &u, 2);
+    return (float)h;
+}
+
 inline uint16_t f32_to_f16_rne(float f) {           // IEEE half, round-to-nearest-even, saturating like the device stores
     if (f > 65504.0f) f = 65504.0f;
     if (f < -65504.0f) f = -65504.0f;
@@ -157,6 +163,18 @@ struct Blob {
     // MFMA compute type: fp32, or bf16 / fp16 (double -> float -> 16 bit, both steps round-to-nearest-even)
     void add_compute(const std::string& name, const double* v, int64_t n, int dt) {
         if (dt == FTC_F32) { add_f32(name, v, n); return; }
+        if (dt == FTC_PRECISION_F16X3) {                    // fp16x3: every 16-byte chunk of four fp32 weights becomes [hi x4 | lo x4] IEEE halves
+            uint16_t* d = reinterpret_cast<uint16_t*>(add(name, n * 4));
+            for (int64_t i = 0; i + 3 < n; i += 4)
+                for (int e = 0; e < 4; ++e) {
+                    float x = (float)v[i + e];
+                    const float xs = x > 65504.0f ? 65504.0f : x < -65504.0f ? -65504.0f : x;
+                    const uint16_t h = f32_to_f16_rne(xs);
+                    d[2 * i + e] = h;
+                    d[2 * i + 4 + e] = f32_to_f16_rne(x - f16_to_f32(h));
+                }
+            return;
+        }
         uint16_t* d = reinterpret_cast<uint16_t*>(add(name, n * 2));
         if (dt == FTC_BF16) for (int64_t i = 0; i < n; ++i) d[i] = f32_to_bf16_rne((float)v[i]);
         else for (int64_t i = 0; i < n; ++i) d[i] = f32_to_f16_rne((float)v[i]);
@@ -266,7 +284,7 @@ bool env_on(const char* k) { const char* v = std::getenv(k); return v && *v && s
 // ---- weight packing (once per checkpoint) -------------------------------------------------------
 int pack_weights(ftc_model* m, Weights& w) {
     const bool bf = m->precision != FTC_F32;      // a 16-bit speed mode (bf16 or fp16 operands): the fused / folded head variants exist
-    const int cdt = m->precision;                 // dtype of the MFMA operands
+    const int cdt = m->split16 ? FTC_PRECISION_F16X3 : m->precision;      // storage of the MFMA weight operands (fp16x3: pre-split fp32 chunks)
     Blob& bl = m->blob;
     bool ok = true;
     std::vector<double> wf, b;

@@ -88,3 +88,12 @@ def run_op(fields: Dict, arena: Arena) -> None:
 
 def tdtype(d: int) -> torch.dtype:
     return torch.float32 if d == L.F32 else torch.bfloat16 if d == L.BF16 else torch.float16
+
+
+def presplit_f16x3(w: torch.Tensor) -> torch.Tensor:
+    """fp32 K-major weights -> the storage FTC_FLAG_SPLIT16 expects: every 16-byte chunk of four fp32 values becomes
+    [hi x4 | lo x4] IEEE halves (hi = fp16(x), lo = fp16(x - hi)); same byte size, returned as a flat uint8 tensor."""
+    f = w.contiguous().float().reshape(-1, 4)
+    hi = f.clamp(-65504.0, 65504.0).to(torch.float16)
+    lo = (f - hi.float()).to(torch.float16)
+    return torch.cat([hi, lo], dim=1).contiguous().view(torch.uint8).reshape(-1)

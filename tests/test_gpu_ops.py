@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from findtextcenternet_amd import _lib as L
-from gpu_harness import round16, Arena, bf16_round, run_op, tdtype, to_dev_bytes
+from gpu_harness import round16, Arena, bf16_round, presplit_f16x3, run_op, tdtype, to_dev_bytes
 
 pytestmark = pytest.mark.gpu
 
@@ -130,7 +130,8 @@ def _run_conv_case(case, mode, aux0):
         ref = ref + res
     ar = Arena()
     o_in = ar.put(to_dev_bytes(x_full, idt))
-    o_w = ar.put(to_dev_bytes(w.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin), wdt))
+    wk = w.permute(0, 2, 3, 1).reshape(Cout, k * k, Cin)
+    o_w = ar.put(presplit_f16x3(wk) if mname == "f32x3" else to_dev_bytes(wk, wdt))      # fp16x3: the weights come pre-split
     o_b = ar.put(bias)
     o_res = ar.put(res) if residual else None
     o_sc = ar.put(sc) if se else None

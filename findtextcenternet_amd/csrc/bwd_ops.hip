@@ -150,8 +150,12 @@ __global__ __launch_bounds__(256) void bnbwd_final_kernel(const double* __restri
     coef[C + c] = (float)(s2 / (double)M);
 }
 
-template <int Q, bool FAST>
-__global__ __launch_bounds__(256) void bnbwd_apply_kernel(BnBwdP p, const float* __restrict__ coef, float* __restrict__ out, int accum, int nchunk) {
+// out (fp32, optional) and / or out2 (16-bit copy in the plan's compute type, optional): the gradient of a convolution's output is only
+// ever read by that convolution's data- and weight-gradient GEMMs, which narrow it anyway -- writing it once in 16 bits halves their
+// operand streams and lets them run on the DMA-staged kernels
+template <int Q, bool FAST, typename TC>
+__global__ __launch_bounds__(256) void bnbwd_apply_kernel(BnBwdP p, const float* __restrict__ coef, float* __restrict__ out, TC* __restrict__ out2, int accum,
+                                                          int nchunk) {
     constexpr int RL = 256 / Q;
     const int t = threadIdx.x, cq = t % Q, rl = t / Q;
     const int c = (blockIdx.x * Q + cq) * 4;
@@ -176,9 +180,14 @@ __global__ __launch_bounds__(256) void bnbwd_apply_kernel(BnBwdP p, const float*
         const f32x4 zv = *reinterpret_cast<const f32x4*>(p.z + (long)r * p.C + c);
         const f32x4 dt = g * dact4<FAST>(zv * sc + sh, p.act);
         f32x4 o = sc * (dt - c1 - (zv - mean) * istd * c2);
-        float* op = out + (long)r * p.C + c;
-        if (accum) o += *reinterpret_cast<const f32x4*>(op);
-        *reinterpret_cast<f32x4*>(op) = o;
+        if (out) {
+            float* op = out + (long)r * p.C + c;
+            if (accum) o += *reinterpret_cast<const f32x4*>(op);
+            *reinterpret_cast<f32x4*>(op) = o;
+        }
+        if constexpr (sizeof(TC) == 2) {
+            if (out2) store4<TC>(out2 + (long)r * p.C + c, o);
+        }
     }
 }
 
@@ -690,8 +699,8 @@ hipError_t launch_pack_train(const ftc_pack_entry* entries, int n, long max_elem
 }
 
 namespace {
-template <int Q, bool FAST>
-hipError_t bnbwd_run(const BnBwdP& p, double* part, float* coef, float* ggamma, float* gbeta, float* out, int accum, int nchunk, hipStream_t s) {
+template <int Q, bool FAST, typename TC>
+hipError_t bnbwd_run(const BnBwdP& p, double* part, float* coef, float* ggamma, float* gbeta, float* out, TC* out2, int accum, int nchunk, hipStream_t s) {
     const dim3 grid(p.C / (4 * Q), nchunk);
     hipLaunchKernelGGL((bnbwd_partial_kernel<Q, FAST>), grid, dim3(256), 0, s, p, part, nchunk);
     hipError_t e = hipGetLastError();
@@ -702,19 +711,19 @@ hipError_t bnbwd_run(const BnBwdP& p, double* part, float* coef, float* ggamma, 
     // the apply pass streams: enough row chunks to fill the GPU (the partial pass is bound to the scratch layout's chunk count)
     int ach = (int)((4096L * 4 * Q) / p.C);
     ach = ach < 1 ? 1 : ach > p.M / 8 + 1 ? p.M / 8 + 1 : ach;
-    hipLaunchKernelGGL((bnbwd_apply_kernel<Q, FAST>), dim3(p.C / (4 * Q), ach), dim3(256), 0, s, p, coef, out, accum, ach);
+    hipLaunchKernelGGL((bnbwd_apply_kernel<Q, FAST, TC>), dim3(p.C / (4 * Q), ach), dim3(256), 0, s, p, coef, out, out2, accum, ach);
     return hipGetLastError();
 }
-template <bool FAST>
-hipError_t bnbwd_q(int q, const BnBwdP& p, double* part, float* coef, float* gg, float* gb, float* out, int accum, int nchunk, hipStream_t s) {
+template <bool FAST, typename TC>
+hipError_t bnbwd_q(int q, const BnBwdP& p, double* part, float* coef, float* gg, float* gb, float* out, TC* out2, int accum, int nchunk, hipStream_t s) {
     switch (q) {
-    case 64: return bnbwd_run<64, FAST>(p, part, coef, gg, gb, out, accum, nchunk, s);
-    case 32: return bnbwd_run<32, FAST>(p, part, coef, gg, gb, out, accum, nchunk, s);
-    case 16: return bnbwd_run<16, FAST>(p, part, coef, gg, gb, out, accum, nchunk, s);
-    case 8: return bnbwd_run<8, FAST>(p, part, coef, gg, gb, out, accum, nchunk, s);
-    case 4: return bnbwd_run<4, FAST>(p, part, coef, gg, gb, out, accum, nchunk, s);
-    case 2: return bnbwd_run<2, FAST>(p, part, coef, gg, gb, out, accum, nchunk, s);
-    default: return bnbwd_run<1, FAST>(p, part, coef, gg, gb, out, accum, nchunk, s);
+    case 64: return bnbwd_run<64, FAST, TC>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
+    case 32: return bnbwd_run<32, FAST, TC>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
+    case 16: return bnbwd_run<16, FAST, TC>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
+    case 8: return bnbwd_run<8, FAST, TC>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
+    case 4: return bnbwd_run<4, FAST, TC>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
+    case 2: return bnbwd_run<2, FAST, TC>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
+    default: return bnbwd_run<1, FAST, TC>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
     }
 }
 }  // namespace
@@ -732,8 +741,9 @@ hipError_t launch_bnbwd(const OpArgs& a, hipStream_t s) {
     float* gg = (float*)const_cast<void*>(a.w);
     float* gb = const_cast<float*>(a.shift);
     const int accum = (o.flags & FTC_FLAG_ACCUM) ? 1 : 0;
-    if (o.w_dtype == FTC_F32) return bnbwd_q<false>(q, p, part, coef, gg, gb, (float*)a.out, accum, nchunk, s);
-    return bnbwd_q<true>(q, p, part, coef, gg, gb, (float*)a.out, accum, nchunk, s);
+    if (o.w_dtype == FTC_F32) return bnbwd_q<false, float>(q, p, part, coef, gg, gb, (float*)a.out, (float*)nullptr, accum, nchunk, s);
+    if (o.w_dtype == FTC_F16) return bnbwd_q<true, _Float16>(q, p, part, coef, gg, gb, (float*)a.out, (_Float16*)a.out2, accum, nchunk, s);
+    return bnbwd_q<true, __bf16>(q, p, part, coef, gg, gb, (float*)a.out, (__bf16*)a.out2, accum, nchunk, s);
 }
 
 hipError_t launch_dwbwd(const OpArgs& a, hipStream_t s) {
@@ -849,7 +859,7 @@ hipError_t launch_fill(const OpArgs& a, hipStream_t s) {
 
 hipError_t launch_gather_rows_op(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
-    return launch_gather_rows((const float*)a.in, (const int32_t*)a.in2, nullptr, o.aux0, o.Cin, o.Cout_total, a.out, FTC_F32, s);
+    return launch_gather_rows((const float*)a.in, (const int32_t*)a.in2, nullptr, o.aux0, o.Cin, o.Cout_total, a.out, o.out_dtype, s);
 }
 
 hipError_t launch_scatter_rows(const OpArgs& a, hipStream_t s) {

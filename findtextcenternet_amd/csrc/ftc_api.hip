@@ -192,7 +192,8 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         return nullptr;
     case FTC_OP_GATHER_ROWS:
         if (o.aux0 <= 0 || o.Cin <= 0 || (o.Cin & 3) || o.Cout_total < o.Cin || (o.Cout_total & 7)) return "gather_rows: need aux0 > 0, Cin % 4 == 0, Cout_total >= Cin, Cout_total % 8 == 0";
-        if (!need(o.in, true, "in", pin * o.Cin * 4) || !need(o.in2, true, "in2", (int64_t)o.aux0 * 4) || !need(o.out, true, "out", (int64_t)o.aux0 * o.Cout_total * 4)) return why->c_str();
+        if (o.out_dtype != FTC_F32 && !ftc_is16(o.out_dtype)) return "gather_rows: unknown out_dtype";
+        if (!need(o.in, true, "in", pin * o.Cin * 4) || !need(o.in2, true, "in2", (int64_t)o.aux0 * 4) || !need(o.out, true, "out", (int64_t)o.aux0 * o.Cout_total * es(o.out_dtype))) return why->c_str();
         return nullptr;
     case FTC_OP_LOSSES:
     case FTC_OP_LOSS_BWD: {
@@ -218,8 +219,10 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         const int64_t gs = o.Cin_total > 0 ? o.Cin_total : o.Cin;
         if ((gs & 3) || (o.cin_off & 3) || o.cin_off + o.Cin > gs) return "bnbwd: bad channel slice of the incoming gradient";
         if (o.act != FTC_ACT_NONE && o.act != FTC_ACT_SILU && o.act != FTC_ACT_GELU) return "bnbwd: unknown activation";
+        if (o.out.base == FTC_BASE_NULL && o.out2.base == FTC_BASE_NULL) return "bnbwd: needs out (fp32) and / or out2 (16-bit copy)";
+        if (o.out2.base != FTC_BASE_NULL && !ftc_is16(o.w_dtype)) return "bnbwd: out2 is a 16-bit copy in the plan's compute type (w_dtype)";
         if (!need(o.in, true, "in", pin * gs * 4) || !need(o.in2, true, "in2", pin * o.Cin * 4) || !need(o.scale, true, "scale", (int64_t)4 * o.Cin * 4) ||
-            !need(o.out, true, "out", pin * o.Cin * 4) || !need(o.w, false, "w", (int64_t)o.Cin * 4) || !need(o.shift, false, "shift", (int64_t)o.Cin * 4) ||
+            !need(o.out, false, "out", pin * o.Cin * 4) || !need(o.out2, false, "out2", pin * o.Cin * 2) || !need(o.w, false, "w", (int64_t)o.Cin * 4) || !need(o.shift, false, "shift", (int64_t)o.Cin * 4) ||
             !need(o.w2, false, "w2", (int64_t)o.B * 4) || !need(o.bias, false, "bias", (int64_t)o.B * o.Cin * 4) || !need(o.bias2, false, "bias2", (int64_t)o.B * o.Cin * 4) ||
             !need(o.aux, true, "aux", (int64_t)ftc_bnstat_chunks(pin) * 2 * o.Cin * 8 + (int64_t)2 * o.Cin * 4)) return why->c_str();
         return nullptr;
@@ -227,12 +230,14 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
     case FTC_OP_WGRAD: {
         if (o.Cin <= 0 || o.Cout <= 0 || o.Ho <= 0 || o.Wo <= 0 || (o.ksize != 1 && o.ksize != 3) || (o.stride != 1 && o.stride != 2)) return "wgrad: bad sizes";
         if (o.w_dtype != FTC_F32 && !ftc_is16(o.w_dtype)) return "wgrad: unknown compute type";
+        if ((o.in_dtype != FTC_F32 && o.in_dtype != o.w_dtype) || (o.res_dtype != FTC_F32 && o.res_dtype != o.w_dtype))
+            return "wgrad: operands are fp32 or 16-bit copies in the compute type (in_dtype: layer input, res_dtype: output gradient)";
         const int pad = (o.ksize - 1) / 2;
         if (o.Ho != (o.H + 2 * pad - o.ksize) / o.stride + 1 || o.Wo != (o.W + 2 * pad - o.ksize) / o.stride + 1) return "wgrad: Ho/Wo inconsistent";
         const int64_t cit = o.Cin_total > 0 ? o.Cin_total : o.Cin, cot = o.Cout_total > 0 ? o.Cout_total : o.Cout;
         if (o.cin_off + o.Cin > cit || o.cout_off + o.Cout > cot || o.aux0 < 1 || o.aux0 > 4096) return "wgrad: channel slices / splits out of range";
         const int64_t kk = (int64_t)o.ksize * o.ksize;
-        if (!need(o.in, true, "in", pin * cit * 4) || !need(o.in2, true, "in2", pout * cot * 4) || !need(o.out, true, "out", kk * o.Cout * o.Cin * 4) ||
+        if (!need(o.in, true, "in", pin * cit * es(o.in_dtype)) || !need(o.in2, true, "in2", pout * cot * es(o.res_dtype)) || !need(o.out, true, "out", kk * o.Cout * o.Cin * 4) ||
             !need(o.aux, true, "aux", (int64_t)o.aux0 * kk * o.Cout * o.Cin * 4) || !need(o.scale, (o.flags & FTC_FLAG_SE_SCALE) != 0, "scale", (int64_t)o.B * o.Cin * 4)) return why->c_str();
         return nullptr;
     }

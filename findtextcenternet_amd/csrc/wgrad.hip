@@ -19,7 +19,7 @@ template <> struct WFrag<__bf16> { using type = bf16x8; };
 template <> struct WFrag<_Float16> { using type = f16x8; };
 
 struct WgradP {
-    const float* x; const float* dz; const float* se; float* part;
+    const void* x; const void* dz; const float* se; float* part;
     int B, H, W, Ho, Wo, Cin, CinT, cin_off, Cout, CoutT, cout_off, KS, stride, pad;
     long P;          // B * Ho * Wo
     long chunk;      // pixels per split (multiple of BK)
@@ -30,14 +30,15 @@ template <> __device__ __forceinline__ float narrow<float>(float v) { return v; 
 template <> __device__ __forceinline__ __bf16 narrow<__bf16>(float v) { return (__bf16)v; }
 template <> __device__ __forceinline__ _Float16 narrow<_Float16>(float v) { return (_Float16)f16_sat(v); }
 
-// 4 consecutive channels c..c+3 of row `row` (channel stride CT, offset off), zero beyond C
-__device__ __forceinline__ f32x4 load_ch4(const float* base, long row, int CT, int off, int c, int C, bool vec_ok) {
-    const float* q = base + row * CT + off + c;
-    if (vec_ok && c + 3 < C) return *reinterpret_cast<const f32x4*>(q);
+// 4 consecutive channels c..c+3 of row `row` (channel stride CT, offset off), zero beyond C; T = fp32 or a 16-bit copy
+template <typename T>
+__device__ __forceinline__ f32x4 load_ch4(const T* base, long row, int CT, int off, int c, int C, bool vec_ok) {
+    const T* q = base + row * CT + off + c;
+    if (vec_ok && c + 3 < C) return load4<T>(q);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-        if (c + e < C) v[e] = q[e];
+        if (c + e < C) v[e] = to_f32<T>(q[e]);
     return v;
 }
 
@@ -59,12 +60,83 @@ __device__ __forceinline__ void put8(_Float16* dst, const f32x4 (&r)[8], int j) 
     *reinterpret_cast<f16x8*>(dst) = v;
 }
 
-template <typename WT, int TM, int TN, int WM, int WN>
+// One staging task of an operand stored as T: CH consecutive channels (one 16-byte access: 4 fp32 | 8 halves) of 8 consecutive pixels,
+// transposed in registers into CH pixel-contiguous 16-byte LDS rows.  16-bit copies (T == WT) move without a conversion.
+template <typename WT, typename T>
+struct Stager {
+    static constexpr int CH = sizeof(T) == 2 ? 8 : 4;
+    u32x4 r[8];
+    __device__ __forceinline__ void zero(int i) { r[i] = u32x4{0u, 0u, 0u, 0u}; }
+    __device__ __forceinline__ void load(int i, const T* base, long row, int CT, int off, int c, int C, bool vec_ok) {
+        const T* q = base + row * CT + off + c;
+        if (vec_ok && c + CH - 1 < C) { r[i] = *reinterpret_cast<const u32x4*>(q); return; }
+        if constexpr (sizeof(T) == 4) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < C) v[e] = q[e];
+            r[i] = __builtin_bit_cast(u32x4, v);
+        } else {
+            typedef __attribute__((ext_vector_type(8))) T t8;
+            t8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = c + e < C ? q[e] : (T)0.0f;
+            r[i] = __builtin_bit_cast(u32x4, v);
+        }
+    }
+    // r[i][e] *= se[e] (fp32 gate per channel, zero beyond C)
+    __device__ __forceinline__ void scale(int i, const float* se, int c, int C) {
+        if constexpr (sizeof(T) == 4) {
+            f32x4 v = __builtin_bit_cast(f32x4, r[i]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= c + e < C ? se[e] : 0.f;
+            r[i] = __builtin_bit_cast(u32x4, v);
+        } else {
+            typedef __attribute__((ext_vector_type(8))) T t8;
+            t8 v = __builtin_bit_cast(t8, r[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = from_f32<T>((float)v[e] * (c + e < C ? se[e] : 0.f));
+            r[i] = __builtin_bit_cast(u32x4, v);
+        }
+    }
+    // channel j of the 8 staged pixels -> 8 consecutive K elements of one LDS row
+    __device__ __forceinline__ void put(WT* dst, int j) const {
+        if constexpr (sizeof(T) == 4) {
+            typedef __attribute__((ext_vector_type(8))) WT w8;
+            if constexpr (sizeof(WT) == 4) {
+                *reinterpret_cast<f32x4*>(dst) = f32x4{__uint_as_float(r[0][j]), __uint_as_float(r[1][j]), __uint_as_float(r[2][j]), __uint_as_float(r[3][j])};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{__uint_as_float(r[4][j]), __uint_as_float(r[5][j]), __uint_as_float(r[6][j]), __uint_as_float(r[7][j])};
+            } else {
+                w8 v;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = narrow<WT>(__uint_as_float(r[i][j]));
+                *reinterpret_cast<w8*>(dst) = v;
+            }
+        } else {
+            static_assert(sizeof(T) != 2 || sizeof(WT) == 2, "16-bit copies come in the compute type");
+            u32x4 o;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const uint32_t lo = (j & 1) ? (r[2 * w][j >> 1] >> 16) : (r[2 * w][j >> 1] & 0xffffu);
+                const uint32_t hi = (j & 1) ? (r[2 * w + 1][j >> 1] & 0xffff0000u) : (r[2 * w + 1][j >> 1] << 16);
+                o[w] = lo | hi;
+            }
+            *reinterpret_cast<u32x4*>(dst) = o;
+        }
+    }
+};
+
+// XT / DT: storage types of the layer input and of the output gradient (fp32, or the 16-bit copies the BatchNorm passes write)
+template <typename WT, typename XT, typename DT, int TM, int TN, int WM, int WN>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
     constexpr int BK = sizeof(WT) == 4 ? 32 : 64;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int LD = BK + 16 / (int)sizeof(WT);             // row stride in elements: 144 bytes -> conflict-free ds_read_b128 fragments
     constexpr int OCT = BK / 8;                                // pixel octets per K step
+    using SA = Stager<WT, DT>;
+    using SB = Stager<WT, XT>;
+    constexpr int CHA = SA::CH, CHB = SB::CH;
+    constexpr int NTA = (BM / CHA) * OCT, NTB = (BN / CHB) * OCT;       // staging tasks per operand (<= 256 each)
     __shared__ __attribute__((aligned(16))) WT As[BM * LD];
     __shared__ __attribute__((aligned(16))) WT Bs[BN * LD];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -73,30 +145,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
     const int mt = blockIdx.x, nt = blockIdx.y / KK, tap = blockIdx.y - nt * KK, split = blockIdx.z;
     const int tr = tap / p.KS, ts = tap - tr * p.KS;
     const long k0 = (long)split * p.chunk, k1 = k0 + p.chunk < p.P ? k0 + p.chunk : p.P;
-    const bool a_vec = (p.CoutT % 4 == 0) && (p.cout_off % 4 == 0);
-    const bool b_vec = (p.CinT % 4 == 0) && (p.cin_off % 4 == 0);
+    const bool a_vec = (p.CoutT % CHA == 0) && (p.cout_off % CHA == 0);
+    const bool b_vec = (p.CinT % CHB == 0) && (p.cin_off % CHB == 0);
     const bool plain = p.KS == 1 && p.stride == 1;
     const int HoWo = p.Ho * p.Wo;
-    // staging tasks: (channel quad, pixel octet); one per thread at most (BM, BN <= 128)
-    const bool a_on = t < (BM / 4) * OCT, b_on = t < (BN / 4) * OCT;
-    const int a_cq = t % (BM / 4), a_po = t / (BM / 4);
-    const int b_cq = t % (BN / 4), b_po = t / (BN / 4);
-    const int m0 = mt * BM + a_cq * 4, n0 = nt * BN + b_cq * 4;
-    f32x4 ra[8], rb[8];
+    // staging tasks: (channel group, pixel octet); the output-gradient tasks fill the threads from 0 up, the input tasks from 128 up, so that
+    // with 16-bit copies (128 tasks each at 128 x 128) every thread has exactly one
+    const int tb = (t + 128) & 255;
+    const bool a_on = t < NTA, b_on = tb < NTB;
+    const int a_cq = t % (BM / CHA), a_po = t / (BM / CHA);
+    const int b_cq = tb % (BN / CHB), b_po = tb / (BN / CHB);
+    const int m0 = mt * BM + a_cq * CHA, n0 = nt * BN + b_cq * CHB;
+    SA sa;
+    SB sb;
 
     auto fetch = [&](long kb) {
         if (a_on) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const long pix = kb + a_po * 8 + i;
-                ra[i] = (pix < k1 && m0 < p.Cout) ? load_ch4(p.dz, pix, p.CoutT, p.cout_off, m0, p.Cout, a_vec) : f32x4{0.f, 0.f, 0.f, 0.f};
+                if (pix < k1 && m0 < p.Cout) sa.load(i, static_cast<const DT*>(p.dz), pix, p.CoutT, p.cout_off, m0, p.Cout, a_vec);
+                else sa.zero(i);
             }
         }
         if (b_on) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const long pix = kb + b_po * 8 + i;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                sb.zero(i);
                 if (pix < k1 && n0 < p.Cin) {
                     long row;
                     int b;
@@ -113,22 +189,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
                         row = ((long)b * p.H + iy) * p.W + ix;
                     }
                     if (ok) {
-                        v = load_ch4(p.x, row, p.CinT, p.cin_off, n0, p.Cin, b_vec);
-                        if (p.se) v *= load_ch4(p.se, b, p.Cin, 0, n0, p.Cin, (p.Cin & 3) == 0);
+                        sb.load(i, static_cast<const XT*>(p.x), row, p.CinT, p.cin_off, n0, p.Cin, b_vec);
+                        if (p.se) sb.scale(i, p.se + (long)b * p.Cin + n0, n0, p.Cin);
                     }
                 }
-                rb[i] = v;
             }
         }
     };
     auto stage = [&]() {
         if (a_on) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) put8(As + (a_cq * 4 + j) * LD + a_po * 8, ra, j);
+            for (int j = 0; j < CHA; ++j) sa.put(As + (a_cq * CHA + j) * LD + a_po * 8, j);
         }
         if (b_on) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) put8(Bs + (b_cq * 4 + j) * LD + b_po * 8, rb, j);
+            for (int j = 0; j < CHB; ++j) sb.put(Bs + (b_cq * CHB + j) * LD + b_po * 8, j);
         }
     };
 
@@ -222,11 +297,19 @@ inline WgCfg wgrad_cfg(int Cout, int Cin) {
     return {2, 128, 128};
 }
 
-template <typename WT>
+template <typename WT, typename XT, typename DT>
 void launch_cfg(const WgradP& p, int cfg, dim3 grid, hipStream_t s) {
-    if (cfg == 0) hipLaunchKernelGGL((wgrad_kernel<WT, 1, 1, 1, 4>), grid, dim3(256), 0, s, p);
-    else if (cfg == 1) hipLaunchKernelGGL((wgrad_kernel<WT, 1, 1, 2, 2>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((wgrad_kernel<WT, 2, 2, 2, 2>), grid, dim3(256), 0, s, p);
+    if (cfg == 0) hipLaunchKernelGGL((wgrad_kernel<WT, XT, DT, 1, 1, 1, 4>), grid, dim3(256), 0, s, p);
+    else if (cfg == 1) hipLaunchKernelGGL((wgrad_kernel<WT, XT, DT, 1, 1, 2, 2>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_kernel<WT, XT, DT, 2, 2, 2, 2>), grid, dim3(256), 0, s, p);
+}
+// 16-bit compute type: every combination of fp32 / 16-bit storage of the two operands
+template <typename WT>
+void launch_io(const WgradP& p, int cfg, dim3 grid, bool x16, bool d16, hipStream_t s) {
+    if (x16 && d16) launch_cfg<WT, WT, WT>(p, cfg, grid, s);
+    else if (x16) launch_cfg<WT, WT, float>(p, cfg, grid, s);
+    else if (d16) launch_cfg<WT, float, WT>(p, cfg, grid, s);
+    else launch_cfg<WT, float, float>(p, cfg, grid, s);
 }
 
 }  // namespace
@@ -246,7 +329,7 @@ int ftc_wgrad_splits_impl(int B, int Ho, int Wo, int Cout, int Cin, int ksize) {
 hipError_t launch_wgrad(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
     WgradP p;
-    p.x = (const float*)a.in; p.dz = (const float*)a.in2; p.se = (o.flags & FTC_FLAG_SE_SCALE) ? a.scale : nullptr; p.part = a.aux;
+    p.x = a.in; p.dz = a.in2; p.se = (o.flags & FTC_FLAG_SE_SCALE) ? a.scale : nullptr; p.part = a.aux;
     p.B = o.B; p.H = o.H; p.W = o.W; p.Ho = o.Ho; p.Wo = o.Wo;
     p.Cin = o.Cin; p.CinT = o.Cin_total > 0 ? o.Cin_total : o.Cin; p.cin_off = o.cin_off;
     p.Cout = o.Cout; p.CoutT = o.Cout_total > 0 ? o.Cout_total : o.Cout; p.cout_off = o.cout_off;
@@ -258,9 +341,10 @@ hipError_t launch_wgrad(const OpArgs& a, hipStream_t s) {
     const WgCfg c = wgrad_cfg(o.Cout, o.Cin);
     const int KK = o.ksize * o.ksize;
     const dim3 grid((o.Cout + c.BM - 1) / c.BM, ((o.Cin + c.BN - 1) / c.BN) * KK, S);
-    if (o.w_dtype == FTC_F32) launch_cfg<float>(p, c.id, grid, s);
-    else if (o.w_dtype == FTC_F16) launch_cfg<_Float16>(p, c.id, grid, s);
-    else launch_cfg<__bf16>(p, c.id, grid, s);
+    // in_dtype / res_dtype: storage of the layer input / of the output gradient (fp32, or a 16-bit copy in the compute type)
+    if (o.w_dtype == FTC_F32) launch_cfg<float, float, float>(p, c.id, grid, s);
+    else if (o.w_dtype == FTC_F16) launch_io<_Float16>(p, c.id, grid, o.in_dtype == FTC_F16, o.res_dtype == FTC_F16, s);
+    else launch_io<__bf16>(p, c.id, grid, o.in_dtype == FTC_BF16, o.res_dtype == FTC_BF16, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const long per = (long)KK * o.Cout * o.Cin;

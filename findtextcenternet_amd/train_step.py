@@ -182,9 +182,16 @@ class TrainStep:
 
     # ---- op-list builder -------------------------------------------------------------------------------------------------------
     class _G:
+        """Op-list builder.  An activation is a pair (fp32 tensor | None, 16-bit copy | None): in the 16-bit modes the BatchNorm passes
+        write a copy in the compute type next to (or instead of) the fp32 tensor, the GEMMs (forward conv, data gradient, weight gradient)
+        read the copies -- half the operand bytes, DMA-staged kernels -- and fp32 stays where something other than a GEMM reads it
+        (residual trunk, FPN taps, depthwise input, SE)."""
+
         def __init__(self, ts: "TrainStep", B: int):
             self.ts, self.B, self.ops, self.bufs, self.names = ts, B, [], [], []
             self.lib = L.load()
+            self.h16 = ts.cdt != L.F32
+            self.cdt = ts.cdt
 
         def buf(self, nbytes: int) -> tuple:
             b = _Buf(nbytes)
@@ -208,14 +215,19 @@ class TrainStep:
         def pin(self, ref) -> None:
             ref[1].first, ref[1].last = 0, 1 << 29
 
+        def pick(self, act):
+            """(operand, dtype) a GEMM reads for activation `act` = (fp32, copy16)."""
+            return (act[1], self.cdt) if act[1] is not None else (act[0], L.F32)
+
         # ---- forward pieces
         def conv(self, x, h, w, cin, wname, cout, k, stride=1, se=None, bias=None, out=None, cout_total=None, cout_off=0, cin_total=None, B=None):
             B = B or self.B
             ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
             z = out if out is not None else self.buf(B * ho * wo * cout * 4)
-            self.emit(wname, kind=L.OP_CONV, flags=L.FLAG_SE_SCALE if se is not None else 0, act=L.ACT_NONE, in_dtype=L.F32, out_dtype=L.F32,
-                      w_dtype=self.ts.cdt, B=B, H=h, W=w, Ho=ho, Wo=wo, Cin=cin, Cin_total=cin_total or cin, Cout=cout, Cout_total=cout_total or cout,
-                      cout_off=cout_off, ksize=k, stride=stride, res_dtype=L.F32, in_=x, out=z, w=self.w(wname + "#f"), bias=bias or self.w("zeros"), scale=se)
+            xin, xdt = self.pick(x)
+            self.emit(wname, kind=L.OP_CONV, flags=L.FLAG_SE_SCALE if se is not None else 0, act=L.ACT_NONE, in_dtype=xdt, out_dtype=L.F32,
+                      w_dtype=self.cdt, B=B, H=h, W=w, Ho=ho, Wo=wo, Cin=cin, Cin_total=cin_total or cin, Cout=cout, Cout_total=cout_total or cout,
+                      cout_off=cout_off, ksize=k, stride=stride, res_dtype=L.F32, in_=xin, out=z, w=self.w(wname + "#f"), bias=bias or self.w("zeros"), scale=se)
             return z, ho, wo
 
         def bnstat(self, z, h, w, c, bn_name, eps, B=None):
@@ -227,47 +239,61 @@ class TrainStep:
                       bias=self.w(bn_name + ".bias"), aux=self.w(bn_name + ".running"), out=ss, in2=self.buf(nchunk * 2 * c * 8))
             return ss
 
-        def bn(self, z, h, w, c, bn_name, eps, act, residual=None, keep=None, sums_p=0, B=None):
+        def bn(self, z, h, w, c, bn_name, eps, act, residual=None, keep=None, sums_p=0, B=None, want32=True, want16=True):
+            """-> ((y fp32 | None, y 16-bit | None), SE partial sums, statistics block)"""
             B = B or self.B
             ss = self.bnstat(z, h, w, c, bn_name, eps, B)
-            y = self.buf(B * h * w * c * 4)
+            want16 = want16 and self.h16
+            want32 = want32 or not want16
+            M = B * h * w
+            y32 = self.buf(M * c * 4) if want32 else None
+            y16 = self.buf(M * c * 2) if want16 else None
             sums = self.buf(B * sums_p * c * 4) if sums_p else None
             rows_p = sums_p if sums_p else max(1, min(2048, (h * w) // 64))
-            self.emit(bn_name, kind=L.OP_BNACT, flags=L.FLAG_RESIDUAL if residual is not None else 0, act=act, in_dtype=L.F32, out_dtype=L.F32,
-                      w_dtype=L.F16 if self.ts.cdt == L.F16 else L.BF16, res_dtype=L.F32, B=B, H=h, W=w, Cin=c, aux0=rows_p, in_=z, scale=ss,
-                      shift=("ws", ss[1], c * 4), in2=residual, w2=keep, out=y, aux=sums)
-            return y, sums, ss
+            self.emit(bn_name, kind=L.OP_BNACT, flags=L.FLAG_RESIDUAL if residual is not None else 0, act=act, in_dtype=L.F32,
+                      out_dtype=L.F32 if want32 else self.cdt, w_dtype=L.F16 if self.cdt == L.F16 else L.BF16, res_dtype=L.F32, B=B, H=h, W=w, Cin=c,
+                      aux0=rows_p, in_=z, scale=ss, shift=("ws", ss[1], c * 4), in2=residual, w2=keep, out=y32 if want32 else y16,
+                      out2=y16 if (want32 and want16) else None, aux=sums)
+            return (y32, y16), sums, ss
 
         # ---- backward pieces
-        def bn_bwd(self, gy, z, ss, h, w, c, bn_name, act, keep=None, ga=None, gb=None, gy_total=0, gy_off=0, out=None, accum=False, B=None):
+        def bn_bwd(self, gy, z, ss, h, w, c, bn_name, act, keep=None, ga=None, gb=None, gy_total=0, gy_off=0, out=None, accum=False, B=None,
+                   want32=False, want16=True):
+            """-> (dz fp32 | None, dz 16-bit | None): dz of a convolution's BatchNorm is read by that convolution's two GEMMs only."""
             B = B or self.B
             M = B * h * w
             nchunk = max(1, min(512, -(-M // 256)))
-            dz = out if out is not None else self.buf(M * c * 4)
-            self.emit("bwd:" + bn_name, kind=L.OP_BNBWD, flags=L.FLAG_ACCUM if accum else 0, act=act, w_dtype=self.ts.cdt, B=B, H=h, W=w, Cin=c, Cin_total=gy_total, cin_off=gy_off,
-                      in_=gy, in2=z, scale=ss, w2=keep, bias=ga, bias2=gb, out=dz, w=self.g(bn_name + ".weight"), shift=self.g(bn_name + ".bias"),
-                      aux=self.buf(nchunk * 2 * c * 8 + 2 * c * 4))
-            return dz
+            want16 = want16 and self.h16 and out is None
+            want32 = want32 or not want16 or out is not None
+            d32 = out if out is not None else (self.buf(M * c * 4) if want32 else None)
+            d16 = self.buf(M * c * 2) if want16 else None
+            self.emit("bwd:" + bn_name, kind=L.OP_BNBWD, flags=L.FLAG_ACCUM if accum else 0, act=act, w_dtype=self.cdt, B=B, H=h, W=w, Cin=c,
+                      Cin_total=gy_total, cin_off=gy_off, in_=gy, in2=z, scale=ss, w2=keep, bias=ga, bias2=gb, out=d32, out2=d16,
+                      w=self.g(bn_name + ".weight"), shift=self.g(bn_name + ".bias"), aux=self.buf(nchunk * 2 * c * 8 + 2 * c * 4))
+            return (d32, d16)
 
         def wgrad(self, x, dz, h, w, cin, cout, k, stride, wname, se=None, cin_total=0, cin_off=0, cout_total=0, cout_off=0, B=None):
             B = B or self.B
             ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
             S = int(self.lib.ftc_wgrad_splits(B, ho, wo, cout, cin, k))
-            self.emit("wgrad:" + wname, kind=L.OP_WGRAD, flags=L.FLAG_SE_SCALE if se is not None else 0, w_dtype=self.ts.cdt, B=B, H=h, W=w, Ho=ho, Wo=wo,
-                      Cin=cin, Cin_total=cin_total, cin_off=cin_off, Cout=cout, Cout_total=cout_total, cout_off=cout_off, ksize=k, stride=stride, aux0=S,
-                      in_=x, in2=dz, scale=se, out=self.g(wname), aux=self.buf(S * k * k * cout * cin * 4))
+            xin, xdt = self.pick(x)
+            din, ddt = self.pick(dz)
+            self.emit("wgrad:" + wname, kind=L.OP_WGRAD, flags=L.FLAG_SE_SCALE if se is not None else 0, w_dtype=self.cdt, in_dtype=xdt, res_dtype=ddt, B=B, H=h,
+                      W=w, Ho=ho, Wo=wo, Cin=cin, Cin_total=cin_total, cin_off=cin_off, Cout=cout, Cout_total=cout_total, cout_off=cout_off, ksize=k,
+                      stride=stride, aux0=S, in_=xin, in2=din, scale=se, out=self.g(wname), aux=self.buf(S * k * k * cout * cin * 4))
 
         def dgrad(self, dz, ho, wo, cout, wname, cin, k, stride, h, w, add=None, cout_pad=None, B=None):
-            """d input [B,h,w,cin] of a convolution whose d output is dz [B,ho,wo,cout] (+ add)."""
+            """d input fp32 [B,h,w,cin] of a convolution whose d output is dz = (fp32, 16-bit) [B,ho,wo,cout] (+ add)."""
             B = B or self.B
-            src = dz
-            if stride == 2:
-                src = self.buf(B * h * w * cout * 4)
-                self.emit("dilate:" + wname, kind=L.OP_DILATE, B=B, H=ho, W=wo, Ho=h, Wo=w, Cin=cout, in_=dz, out=src)
+            src, sdt = self.pick(dz)
+            if stride == 2:                                            # (the two stride-2 dense convs: fp32 through the dilation)
+                assert dz[0] is not None
+                src, sdt = self.buf(B * h * w * cout * 4), L.F32
+                self.emit("dilate:" + wname, kind=L.OP_DILATE, B=B, H=ho, W=wo, Ho=h, Wo=w, Cin=cout, in_=dz[0], out=src)
             dx = self.buf(B * h * w * cin * 4)
             cp = cout_pad or cout
-            self.emit("dgrad:" + wname, kind=L.OP_CONV, flags=L.FLAG_RESIDUAL if add is not None else 0, act=L.ACT_NONE, in_dtype=L.F32, out_dtype=L.F32,
-                      w_dtype=self.ts.cdt, B=B, H=h, W=w, Ho=h, Wo=w, Cin=cp, Cin_total=cp, Cout=cin, Cout_total=cin, ksize=k, stride=1, res_dtype=L.F32,
+            self.emit("dgrad:" + wname, kind=L.OP_CONV, flags=L.FLAG_RESIDUAL if add is not None else 0, act=L.ACT_NONE, in_dtype=sdt, out_dtype=L.F32,
+                      w_dtype=self.cdt, B=B, H=h, W=w, Ho=h, Wo=w, Cin=cp, Cin_total=cp, Cout=cin, Cout_total=cin, ksize=k, stride=1, res_dtype=L.F32,
                       in_=src, out=dx, w=self.w(wname + "#d"), bias=self.w("zeros"), in2=add)
             return dx
 
@@ -277,6 +303,8 @@ class TrainStep:
         pre = "detector."
         P = pre + "backbone.features"
         n_rows = min(1024 * B, B * (H // 4) * (W // 4))
+        F32ONLY = dict(want32=True, want16=False)
+        GEMM_ONLY = dict(want32=False, want16=True)          # read by convolutions only: the 16-bit copy suffices (fp32 mode: fp32)
         # ---------------- forward ----------------
         res_names: List[str] = []
         keep_buf = g.buf(4096 * 4)
@@ -302,7 +330,7 @@ class TrainStep:
                 fused4 = (not mb) and f"{b}.1.0.weight" in sh
                 last = ".3" if mb else (".1" if fused4 else ".0")
                 cout = sh[b + last + ".0.weight"][0]
-                residual = x if (stride == 1 and c == cout) else None
+                residual = x[0] if (stride == 1 and c == cout) else None
                 keep = None
                 if residual is not None:
                     keep = ("ws", keep_buf[1], len(res_names) * _align(B, 4) * 4)
@@ -313,15 +341,15 @@ class TrainStep:
                 if mb:
                     e = sh[b + ".0.0.weight"][0]
                     z0, _, _ = g.conv(x, h, w, c, b + ".0.0.weight", e, 1)
-                    y0, _, ss0 = g.bn(z0, h, w, e, b + ".0.1", BACKBONE_EPS, L.ACT_SILU)
+                    y0, _, ss0 = g.bn(z0, h, w, e, b + ".0.1", BACKBONE_EPS, L.ACT_SILU, **F32ONLY)       # read by the fp32 depthwise kernels
                     ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
                     th = 8 if stride == 1 else 4
                     pdw = -(-ho // th) * -(-wo // 8)
                     zd = g.buf(B * ho * wo * e * 4)
                     g.emit(b + ".1.0", kind=L.OP_DWCONV, act=L.ACT_NONE, in_dtype=L.F32, out_dtype=L.F32, B=B, H=h, W=w, Ho=ho, Wo=wo, Cin=e, Cout=e, ksize=3,
-                           stride=stride, aux0=pdw, in_=y0, out=zd, w=g.w(b + ".1.0.weight#dw"), bias=g.w("zeros"), aux=g.buf(B * pdw * e * 4))
+                           stride=stride, aux0=pdw, in_=y0[0], out=zd, w=g.w(b + ".1.0.weight#dw"), bias=g.w("zeros"), aux=g.buf(B * pdw * e * 4))
                     pse = max(1, min(16, (ho * wo) // 64))
-                    y1, sums, ss1 = g.bn(zd, ho, wo, e, b + ".1.1", BACKBONE_EPS, L.ACT_SILU, sums_p=pse)
+                    y1, sums, ss1 = g.bn(zd, ho, wo, e, b + ".1.1", BACKBONE_EPS, L.ACT_SILU, sums_p=pse)                 # fp32 for the SE backward + copy
                     s = sh[b + ".2.fc1.weight"][0]
                     sc = g.buf(B * e * 4)
                     g.emit(b + ".2", kind=L.OP_SE, B=B, H=ho, W=wo, Cin=e, Cout=e, aux0=s, aux1=pse, aux=sums, out=sc, in2=g.buf(B * s * 4),
@@ -333,7 +361,7 @@ class TrainStep:
                 elif fused4:
                     e = sh[b + ".0.0.weight"][0]
                     z0, ho, wo = g.conv(x, h, w, c, b + ".0.0.weight", e, 3, stride)
-                    y0, _, ss0 = g.bn(z0, ho, wo, e, b + ".0.1", BACKBONE_EPS, L.ACT_SILU)
+                    y0, _, ss0 = g.bn(z0, ho, wo, e, b + ".0.1", BACKBONE_EPS, L.ACT_SILU, **GEMM_ONLY)
                     z1, _, _ = g.conv(y0, ho, wo, e, b + ".1.0.weight", cout, 1)
                     x, _, ss1 = g.bn(z1, ho, wo, cout, b + ".1.1", BACKBONE_EPS, L.ACT_NONE, residual=residual, keep=keep)
                     rec.update(kind="f4", e=e, z0=z0, y0=y0, ss0=ss0, z1=z1, ss1=ss1, ho=ho, wo=wo)
@@ -348,17 +376,17 @@ class TrainStep:
                 c = cout
                 j += 1
             if i in (2, 3, 5):
-                taps.append((x, c, h, w))
+                taps.append((x[0], c, h, w))
                 pending_tap = len(taps) - 1
             i += 1
         cl = sh[f"{P}.{i}.0.weight"][0]
         zl, _, _ = g.conv(x, h, w, c, f"{P}.{i}.0.weight", cl, 1)
-        xl, _, ssl = g.bn(zl, h, w, cl, f"{P}.{i}.1", BACKBONE_EPS, L.ACT_SILU)
+        xl, _, ssl = g.bn(zl, h, w, cl, f"{P}.{i}.1", BACKBONE_EPS, L.ACT_SILU, **F32ONLY)               # the last tap: read by the heads' fp32 tap path only
         hc = dict(kind="headconv", name=f"{P}.{i}", xin=x, z=zl, ss=ssl, h=h, w=w, c=c, cout=cl, out=xl, tap=len(taps))
         if pending_tap is not None:
             hc["xin_tap"], pending_tap = pending_tap, None
         tape.append(hc)
-        taps.append((xl, cl, h, w))
+        taps.append((xl[0], cl, h, w))
         mh, mw = taps[0][2], taps[0][3]
         maps = g.buf(B * mh * mw * 9 * 4)
         feats = g.buf(B * mh * mw * 100 * 4)
@@ -366,6 +394,8 @@ class TrainStep:
         ch = 0
         n = len(taps)
         heads = []
+        adt = g.cdt if g.h16 else L.F32                              # dtype of the FPN level tensors (read by convolutions / the upsampler only)
+        aes = 2 if g.h16 else 4
         for name in HEAD_NAMES + ["feature"]:
             hp = pre + name
             y, cy, yh, yw = None, 0, 0, 0
@@ -373,13 +403,14 @@ class TrainStep:
             for lvl, (tx, tc, th_, tw_) in enumerate(reversed(taps)):
                 ti = n - 1 - lvl
                 ssi = g.bnstat(tx, th_, tw_, tc, f"{hp}.in_bn.{ti}", HEAD_EPS)
-                cat = g.buf(B * th_ * tw_ * (cy + tc) * 4)
-                g.emit(f"{hp}.upcat.{lvl}", kind=L.OP_UPCAT, in_dtype=L.F32, out_dtype=L.F32, res_dtype=L.F32, B=B, H=yh if y is not None else th_,
-                       W=yw if y is not None else tw_, Ho=th_, Wo=tw_, Cin=cy + tc, Cout=cy + tc, aux0=cy, aux1=tc, in_=y, in2=tx, out=cat, scale=ssi,
-                       shift=("ws", ssi[1], tc * 4))
+                catb = g.buf(B * th_ * tw_ * (cy + tc) * aes)
+                cat = (None, catb) if g.h16 else (catb, None)
+                g.emit(f"{hp}.upcat.{lvl}", kind=L.OP_UPCAT, in_dtype=adt, out_dtype=adt, res_dtype=L.F32, B=B, H=yh if y is not None else th_,
+                       W=yw if y is not None else tw_, Ho=th_, Wo=tw_, Cin=cy + tc, Cout=cy + tc, aux0=cy, aux1=tc, in_=g.pick(y)[0] if y is not None else None,
+                       in2=tx, out=catb, scale=ssi, shift=("ws", ssi[1], tc * 4))
                 cm = sh[f"{hp}.upsamplers.{lvl}.0.weight"][0]
                 zc, _, _ = g.conv(cat, th_, tw_, cy + tc, f"{hp}.upsamplers.{lvl}.0.weight", cm, 3)
-                yn, _, ssc = g.bn(zc, th_, tw_, cm, f"{hp}.upsamplers.{lvl}.1", HEAD_EPS, L.ACT_GELU)
+                yn, _, ssc = g.bn(zc, th_, tw_, cm, f"{hp}.upsamplers.{lvl}.1", HEAD_EPS, L.ACT_GELU, **GEMM_ONLY)
                 levels.append(dict(lvl=lvl, ti=ti, tx=tx, tc=tc, h=th_, w=tw_, cy=cy, yh=yh, yw=yw, ssi=ssi, cat=cat, cm=cm, z=zc, ss=ssc, y=yn))
                 y, cy, yh, yw = yn, cm, th_, tw_
             co = sh[f"{hp}.top_conv.0.weight"][0]
@@ -398,8 +429,9 @@ class TrainStep:
         alphas = g.buf(64)
         for r in (sel, lab, idm, lossv, alphas):
             g.pin(r)
-        rows = g.buf(n_rows * 128 * 4)
-        g.emit("gather_rows", kind=L.OP_GATHER_ROWS, B=B, H=mh, W=mw, Cin=100, Cout_total=128, aux0=n_rows, in_=feats, in2=sel, out=rows)
+        rowsb = g.buf(n_rows * 128 * aes)
+        rows = (None, rowsb) if g.h16 else (rowsb, None)
+        g.emit("gather_rows", kind=L.OP_GATHER_ROWS, out_dtype=adt, B=B, H=mh, W=mw, Cin=100, Cout_total=128, aux0=n_rows, in_=feats, in2=sel, out=rowsb)
         dec = []
         jb = 0
         while f"decoder.blocks.{jb}.0.weight" in sh:
@@ -409,7 +441,7 @@ class TrainStep:
             for li, bi in ((0, 1), (3, 4)):
                 coq = sh[f"{bq}.{li}.weight"][0]
                 zq, _, _ = g.conv(yq, n_rows, 1, cq, f"{bq}.{li}.weight", coq, 1, B=1)
-                yn, _, ssq = g.bn(zq, n_rows, 1, coq, f"{bq}.{bi}", HEAD_EPS, L.ACT_GELU, B=1)
+                yn, _, ssq = g.bn(zq, n_rows, 1, coq, f"{bq}.{bi}", HEAD_EPS, L.ACT_GELU, B=1, **GEMM_ONLY)
                 lay.append(dict(x=yq, cin=cq, z=zq, ss=ssq, y=yn, cout=coq, wname=f"{bq}.{li}.weight", bn=f"{bq}.{bi}"))
                 yq, cq = yn, coq
             coq = sh[f"{bq}.6.weight"][0]
@@ -437,8 +469,8 @@ class TrainStep:
                 go = ("ws", gdec[1], jb * n_rows * DEC_PAD * 4)
                 g.emit("bwd:" + d["b"] + ".6.bias", kind=L.OP_COLSUM, B=1, H=n_rows, W=1, Cin=d["cout"], Cin_total=DEC_PAD, in_=go, out=g.g(d["b"] + ".6.bias"),
                        aux=g.buf(max(1, min(512, -(-n_rows // 256))) * d["cout"] * 8))
-                g.wgrad(d["x"], go, n_rows, 1, d["cin"], d["cout"], 1, 1, d["b"] + ".6.weight", cout_total=DEC_PAD, B=1)
-                gy = g.dgrad(go, n_rows, 1, d["cout"], d["b"] + ".6.weight", d["cin"], 1, 1, n_rows, 1, cout_pad=DEC_PAD, B=1)
+                g.wgrad(d["x"], (go, None), n_rows, 1, d["cin"], d["cout"], 1, 1, d["b"] + ".6.weight", cout_total=DEC_PAD, B=1)
+                gy = g.dgrad((go, None), n_rows, 1, d["cout"], d["b"] + ".6.weight", d["cin"], 1, 1, n_rows, 1, cout_pad=DEC_PAD, B=1)
                 for li in (1, 0):
                     ly = d["lay"][li]
                     gz = g.bn_bwd(gy, ly["z"], ly["ss"], n_rows, 1, ly["cout"], ly["bn"], L.ACT_GELU, B=1)
@@ -461,12 +493,12 @@ class TrainStep:
             if hd["ch"] is None:
                 g.emit("bwd:" + hp + ".top.bias", kind=L.OP_COLSUM, B=B, H=mh, W=mw, Cin=co, Cin_total=128, in_=gfeat, out=g.g(f"{hp}.top_conv.0.bias"),
                        aux=g.buf(nchunk_m * co * 8))
-                g.wgrad(hd["y"], gfeat, mh, mw, cy, co, 3, 1, wn, cout_total=128)
-                gy = g.dgrad(gfeat, mh, mw, co, wn, cy, 3, 1, mh, mw, cout_pad=128)        # (_flatten pads the 100 feature channels to 128)
+                g.wgrad(hd["y"], (gfeat, None), mh, mw, cy, co, 3, 1, wn, cout_total=128)
+                gy = g.dgrad((gfeat, None), mh, mw, co, wn, cy, 3, 1, mh, mw, cout_pad=128)        # (_flatten pads the 100 feature channels to 128)
             else:
                 g.emit("bwd:" + hp + ".top.bias", kind=L.OP_COLSUM, B=B, H=mh, W=mw, Cin=co, Cin_total=9, cin_off=hd["ch"], in_=gmaps,
                        out=g.g(f"{hp}.top_conv.0.bias"), aux=g.buf(nchunk_m * co * 8))
-                g.wgrad(hd["y"], gmaps, mh, mw, cy, co, 3, 1, wn, cout_total=9, cout_off=hd["ch"])
+                g.wgrad(hd["y"], (gmaps, None), mh, mw, cy, co, 3, 1, wn, cout_total=9, cout_off=hd["ch"])
                 gy = g.buf(B * mh * mw * cy * 4)
                 g.emit("topdgrad:" + hp, kind=L.OP_TOPDGRAD, w_dtype=self.cdt, B=B, H=mh, W=mw, Cin=co, Cin_total=9, cin_off=hd["ch"], Cout=cy, in_=gmaps,
                        w=g.w(wn + "#f"), out=gy)
@@ -493,14 +525,15 @@ class TrainStep:
                 gx = g.dgrad(gz, rec["h"], rec["w"], rec["cout"], rec["name"] + ".0.weight", rec["c"], 1, 1, rec["h"], rec["w"], add=tap_add)
                 continue
             if kind == "stem":
-                gz = g.bn_bwd(gx, rec["z"], rec["ss"], rec["h"], rec["w"], rec["c"], P + ".0.1", L.ACT_SILU)
-                g.emit("stemwgrad", kind=L.OP_STEMWGRAD, B=B, H=H, W=W, Ho=rec["h"], Wo=rec["w"], Cout=rec["c"], in_=("in",), in2=gz, out=g.g(P + ".0.0.weight"),
+                gz = g.bn_bwd(gx, rec["z"], rec["ss"], rec["h"], rec["w"], rec["c"], P + ".0.1", L.ACT_SILU, want32=True, want16=False)
+                g.emit("stemwgrad", kind=L.OP_STEMWGRAD, B=B, H=H, W=W, Ho=rec["h"], Wo=rec["w"], Cout=rec["c"], in_=("in",), in2=gz[0], out=g.g(P + ".0.0.weight"),
                        aux=g.buf(max(1, min(2048, -(-(B * rec["h"] * rec["w"]) // 256))) * 27 * rec["c"] * 8))
                 continue
             gout = gx
             b, h_, w_, c_, cout, stride, ho, wo = rec["b"], rec["h"], rec["w"], rec["c"], rec["cout"], rec["stride"], rec["ho"], rec["wo"]
             assert not (rec["residual"] and tap_add is not None)
             skip = gout if rec["residual"] else tap_add
+            s2 = dict(want32=True) if stride == 2 else {}                # a stride-2 data gradient goes through the fp32 dilation
             if kind == "mb":
                 e = rec["e"]
                 gz3 = g.bn_bwd(gout, rec["z3"], rec["ss3"], ho, wo, cout, b + ".3.1", L.ACT_NONE, keep=rec["keep"])
@@ -508,12 +541,12 @@ class TrainStep:
                 gys = g.dgrad(gz3, ho, wo, cout, b + ".3.0.weight", e, 1, 1, ho, wo)
                 s = rec["s"]
                 scr = g.buf((36 * B * e + 2 * B * s) * 4)
-                g.emit("sebwd:" + b, kind=L.OP_SEBWD, B=B, H=ho, W=wo, Cin=e, aux0=s, aux1=rec["pse"], in_=gys, in2=rec["y1"], scale=rec["sc"], aux=rec["sums"],
+                g.emit("sebwd:" + b, kind=L.OP_SEBWD, B=B, H=ho, W=wo, Cin=e, aux0=s, aux1=rec["pse"], in_=gys, in2=rec["y1"][0], scale=rec["sc"], aux=rec["sums"],
                        w=g.w(b + ".2.fc1.weight"), w2=g.w(b + ".2.fc2.weight#t"), bias=g.w(b + ".2.fc1.bias"), bias2=g.w(b + ".2.fc2.bias"), out=scr,
                        out2=g.g(b + ".2.fc1.weight"))
-                gzd = g.bn_bwd(gys, rec["zd"], rec["ss1"], ho, wo, e, b + ".1.1", L.ACT_SILU, ga=rec["sc"], gb=("ws", scr[1], 3 * B * e * 4))
+                gzd = g.bn_bwd(gys, rec["zd"], rec["ss1"], ho, wo, e, b + ".1.1", L.ACT_SILU, ga=rec["sc"], gb=("ws", scr[1], 3 * B * e * 4), want32=True, want16=False)
                 gy0 = g.buf(B * h_ * w_ * e * 4)
-                g.emit("dwbwd:" + b, kind=L.OP_DWBWD, B=B, H=h_, W=w_, Ho=ho, Wo=wo, Cin=e, stride=stride, in_=rec["y0"], in2=gzd, w=g.w(b + ".1.0.weight#dw"),
+                g.emit("dwbwd:" + b, kind=L.OP_DWBWD, B=B, H=h_, W=w_, Ho=ho, Wo=wo, Cin=e, stride=stride, in_=rec["y0"][0], in2=gzd[0], w=g.w(b + ".1.0.weight#dw"),
                        out=gy0, out2=g.g(b + ".1.0.weight"), aux=g.buf(max(1, min(512, -(-(B * ho * wo) // 256))) * 9 * e * 8))
                 gz0 = g.bn_bwd(gy0, rec["z0"], rec["ss0"], h_, w_, e, b + ".0.1", L.ACT_SILU)
                 g.wgrad(rec["xin"], gz0, h_, w_, c_, e, 1, 1, b + ".0.0.weight")
@@ -523,11 +556,11 @@ class TrainStep:
                 gz1 = g.bn_bwd(gout, rec["z1"], rec["ss1"], ho, wo, cout, b + ".1.1", L.ACT_NONE, keep=rec["keep"])
                 g.wgrad(rec["y0"], gz1, ho, wo, e, cout, 1, 1, b + ".1.0.weight")
                 gy0 = g.dgrad(gz1, ho, wo, cout, b + ".1.0.weight", e, 1, 1, ho, wo)
-                gz0 = g.bn_bwd(gy0, rec["z0"], rec["ss0"], ho, wo, e, b + ".0.1", L.ACT_SILU)
+                gz0 = g.bn_bwd(gy0, rec["z0"], rec["ss0"], ho, wo, e, b + ".0.1", L.ACT_SILU, **s2)
                 g.wgrad(rec["xin"], gz0, h_, w_, c_, e, 3, stride, b + ".0.0.weight")
                 gx = g.dgrad(gz0, ho, wo, e, b + ".0.0.weight", c_, 3, stride, h_, w_, add=skip)
             else:
-                gz0 = g.bn_bwd(gout, rec["z0"], rec["ss0"], ho, wo, cout, b + ".0.1", L.ACT_SILU, keep=rec["keep"])
+                gz0 = g.bn_bwd(gout, rec["z0"], rec["ss0"], ho, wo, cout, b + ".0.1", L.ACT_SILU, keep=rec["keep"], **s2)
                 g.wgrad(rec["xin"], gz0, h_, w_, c_, cout, 3, stride, b + ".0.0.weight")
                 gx = g.dgrad(gz0, ho, wo, cout, b + ".0.0.weight", c_, 3, stride, h_, w_, add=skip)
         plan = self._finish(g)

@@ -100,10 +100,15 @@ WG_CASES = [  # name, B,H,W, Cin,CinT,cin_off, Cout,CoutT,cout_off, k, stride, s
 ]
 
 
-@pytest.mark.parametrize("wd", [L.F32, L.BF16, L.F16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("wd,io", [(L.F32, "f32"), (L.BF16, "f32"), (L.F16, "f32"), (L.BF16, "x16"), (L.BF16, "x16d16"), (L.F16, "x16d16"), (L.F16, "d16")],
+                         ids=["f32", "bf16", "f16", "bf16_x16", "bf16_x16d16", "f16_x16d16", "f16_d16"])
 @pytest.mark.parametrize("case", WG_CASES, ids=[c[0] for c in WG_CASES])
-def test_wgrad(case, wd):
-    """FTC_OP_WGRAD vs autograd of F.conv2d with respect to the weight, accumulated into a pre-loaded OIHW gradient."""
+def test_wgrad(case, wd, io):
+    """FTC_OP_WGRAD vs autograd of F.conv2d with respect to the weight, accumulated into a pre-loaded OIHW gradient; operands stored
+    fp32 or as the 16-bit copies the BatchNorm passes of the train step write (in_dtype: layer input, res_dtype: output gradient)."""
+    from gpu_harness import to_dev_bytes
+    xdt = wd if "x16" in io else L.F32
+    ddt = wd if "d16" in io else L.F32
     _, B, H, W, Cin, CinT, cio, Cout, CoutT, coo, k, stride, se = case
     g = torch.Generator().manual_seed(Cin + Cout)
     pad = (k - 1) // 2
@@ -113,6 +118,8 @@ def test_wgrad(case, wd):
     sc = torch.rand(B, Cin, generator=g) + 0.25 if se else None
     x = x_full[..., cio:cio + Cin]
     dz = dz_full[..., coo:coo + Cout]
+    if xdt != L.F32:
+        x = round16(x, xdt)
     xe = x * sc[:, None, None, :] if se else x
     w = torch.zeros(Cout, Cin, k, k, requires_grad=True)
     F.conv2d(round16(xe, wd).permute(0, 3, 1, 2), w, None, stride, pad).backward(round16(dz, wd).permute(0, 3, 1, 2))
@@ -120,11 +127,11 @@ def test_wgrad(case, wd):
     S = int(lib.ftc_wgrad_splits(B, Ho, Wo, Cout, Cin, k))
     pre = torch.randn(Cout, Cin, k, k, generator=g)
     ar = Arena()
-    o_x, o_dz, o_out = ar.put(x_full), ar.put(dz_full), ar.put(pre)
+    o_x, o_dz, o_out = ar.put(to_dev_bytes(x_full, xdt)), ar.put(to_dev_bytes(dz_full, ddt)), ar.put(pre)
     o_sc = ar.put(sc) if se else None
     o_aux = ar.reserve(S * k * k * Cout * Cin * 4)
     ar.materialize()
-    run_op(dict(kind=L.OP_WGRAD, flags=L.FLAG_SE_SCALE if se else 0, w_dtype=wd, B=B, H=H, W=W, Ho=Ho, Wo=Wo, Cin=Cin, Cin_total=CinT, cin_off=cio,
+    run_op(dict(kind=L.OP_WGRAD, flags=L.FLAG_SE_SCALE if se else 0, w_dtype=wd, in_dtype=xdt, res_dtype=ddt, B=B, H=H, W=W, Ho=Ho, Wo=Wo, Cin=Cin, Cin_total=CinT, cin_off=cio,
                 Cout=Cout, Cout_total=CoutT, cout_off=coo, ksize=k, stride=stride, aux0=S, in_=o_x, in2=o_dz, scale=o_sc, out=o_out, aux=o_aux), ar)
     got = ar.read(o_out, (Cout, Cin, k, k), torch.float32) - pre
     # (with SE the kernel rounds x * s, the reference rounds the same product)

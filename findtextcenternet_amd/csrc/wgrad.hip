@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
     using SA = Stager<WT, DT>;
     using SB = Stager<WT, XT>;
     constexpr int CHA = SA::CH, CHB = SB::CH;
-    constexpr int NTA = (BM / CHA) * OCT, NTB = (BN / CHB) * OCT;       // staging tasks per operand (<= 256 each)
+    constexpr int NTA = (BM / CHA) * OCT, NTB = (BN / CHB) * OCT;       // staging tasks per operand (<= 256 each: launch_wgrad picks the tile accordingly)
     __shared__ __attribute__((aligned(16))) WT As[BM * LD];
     __shared__ __attribute__((aligned(16))) WT Bs[BN * LD];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -291,9 +291,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 struct WgCfg { int id, BM, BN; };
-inline WgCfg wgrad_cfg(int Cout, int Cin) {
+inline WgCfg wgrad_cfg(int Cout, int Cin, int ksize) {
     if (Cout <= 32) return {0, 32, 128};
     if (Cout <= 64 || Cin <= 64) return {1, 64, 64};
+    // every (Cout tile, Cin tile, tap) workgroup re-reads its two operand streams: the kernel is bound by those re-reads (last FPN level:
+    // 4.7 GB per launch at 128 x 128), so wide layers take the 192 x 256 tile (12 accumulators per wave, one workgroup per CU)
+    if (ksize == 3 && Cout >= 192 && Cin >= 256) return {3, 192, 256};        // (1x1 layers: measured slower, 25.5 -> 29.6 ms per step)
     return {2, 128, 128};
 }
 
@@ -301,6 +304,7 @@ template <typename WT, typename XT, typename DT>
 void launch_cfg(const WgradP& p, int cfg, dim3 grid, hipStream_t s) {
     if (cfg == 0) hipLaunchKernelGGL((wgrad_kernel<WT, XT, DT, 1, 1, 1, 4>), grid, dim3(256), 0, s, p);
     else if (cfg == 1) hipLaunchKernelGGL((wgrad_kernel<WT, XT, DT, 1, 1, 2, 2>), grid, dim3(256), 0, s, p);
+    else if (cfg == 3) hipLaunchKernelGGL((wgrad_kernel<WT, XT, DT, 3, 4, 2, 2>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((wgrad_kernel<WT, XT, DT, 2, 2, 2, 2>), grid, dim3(256), 0, s, p);
 }
 // 16-bit compute type: every combination of fp32 / 16-bit storage of the two operands
@@ -315,7 +319,7 @@ void launch_io(const WgradP& p, int cfg, dim3 grid, bool x16, bool d16, hipStrea
 }  // namespace
 
 int ftc_wgrad_splits_impl(int B, int Ho, int Wo, int Cout, int Cin, int ksize) {
-    const WgCfg c = wgrad_cfg(Cout, Cin);
+    const WgCfg c = wgrad_cfg(Cout, Cin, ksize);
     const long tiles = (long)((Cout + c.BM - 1) / c.BM) * ((Cin + c.BN - 1) / c.BN) * ksize * ksize;
     const long P = (long)B * Ho * Wo;
     long S = (1536 + tiles - 1) / tiles;                          // ~6 workgroups per CU in flight
@@ -338,7 +342,9 @@ hipError_t launch_wgrad(const OpArgs& a, hipStream_t s) {
     const int S = o.aux0 > 0 ? o.aux0 : 1;
     const int BK = o.w_dtype == FTC_F32 ? 32 : 64;
     p.chunk = ((p.P + S - 1) / S + BK - 1) / BK * BK;
-    const WgCfg c = wgrad_cfg(o.Cout, o.Cin);
+    WgCfg c = wgrad_cfg(o.Cout, o.Cin, o.ksize);
+    // the 192 x 256 tile has one staging task per thread only with 16-byte accesses of 8 channels (16-bit copies) or the fp32 K step of 32
+    if (c.id == 3 && ftc_is16(o.w_dtype) && !(o.in_dtype == o.w_dtype && o.res_dtype == o.w_dtype)) c = WgCfg{2, 128, 128};
     const int KK = o.ksize * o.ksize;
     const dim3 grid((o.Cout + c.BM - 1) / c.BM, ((o.Cin + c.BN - 1) / c.BN) * KK, S);
     // in_dtype / res_dtype: storage of the layer input / of the output gradient (fp32, or a 16-bit copy in the compute type)

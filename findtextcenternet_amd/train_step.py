@@ -601,6 +601,8 @@ class TrainStep:
                         r.base, r.offset = L.BASE_INPUT, 0
                 else:
                     setattr(ops[i], k, int(v))
+        from . import tuning
+        tuning.apply(ops)                                   # measured kernel choice per conv signature (tuning_gfx950.json; FTC_NO_TUNING=1: heuristics)
         h = C.c_void_p()
         L.check(L.load().ftc_plan_create(ops, n_ops, top + 256, self.blob.numel(), C.byref(h)), "ftc_plan_create (train step)")
         return {"handle": h, "workspace_bytes": top + 256, "n_ops": n_ops, "ops": ops}

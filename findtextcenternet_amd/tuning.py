@@ -26,8 +26,10 @@ CFG_NAMES = ["192x128", "128x128", "96x128", "64x128", "128x64", "32x256", "64x6
 _table: Optional[Dict[str, int]] = None
 
 
-def signature(o) -> str:
-    return (f"w{o.w_dtype}i{o.in_dtype}o{o.out_dtype}_B{o.B}_{o.H}x{o.W}_c{o.Cin}of{o.Cin_total}_n{o.Cout}of{o.Cout_total}"
+def signature(o, merge16: bool = False) -> str:
+    """merge16: fp16 operands look up their bf16 twins (same kernels, same rate), as csrc/model.hip does."""
+    d = (lambda t: L.BF16 if t == L.F16 else t) if merge16 else (lambda t: t)
+    return (f"w{d(o.w_dtype)}i{d(o.in_dtype)}o{d(o.out_dtype)}_B{o.B}_{o.H}x{o.W}_c{o.Cin}of{o.Cin_total}_n{o.Cout}of{o.Cout_total}"
             f"_k{o.ksize}s{o.stride}_f{o.flags}_a{o.act}" + (f"_g{o.groups}" if o.groups > 1 else ""))
 
 
@@ -61,11 +63,61 @@ def apply(ops, table: Optional[Dict[str, int]] = None) -> int:
     n = 0
     for o in ops:
         if o.kind == L.OP_CONV:
-            v = table.get(signature(o))
+            v = table.get(signature(o)) or table.get(signature(o, merge16=True))
             if v:
                 o.aux0 = v
                 n += 1
     return n
+
+
+def tune_train_step(ts, B: int, H: int, W: int, reps: int = 5, verbose: bool = False) -> Dict[str, int]:
+    """The convolutions of the TRAIN plan (forward with raw weights, data gradients): findtextcenternet_amd.train_step.TrainStep `ts`
+    after one forward_backward at this shape (buffers filled), plan built with FTC_NO_TUNING=1."""
+    import numpy as np
+    import torch
+    lib = L.load()
+    plan = ts.plan_for(B, H, W)
+    dev = ts.dev
+    x = torch.rand((B, H, W, 3), dtype=torch.float32, device=dev)
+    bases = (C.c_void_p * L.NUM_BASES)(None, ts.workspace.data_ptr(), ts.blob.data_ptr(), x.data_ptr(), None, None, ts.grads.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    choices: Dict[str, int] = {}
+    ms = (C.c_float * 1)()
+    for i in range(plan["n_ops"]):
+        o = plan["ops"][i]
+        if o.kind != L.OP_CONV:
+            continue
+        key = signature(o, merge16=True)
+        if key in choices:
+            continue
+        best, best_t, base_t = 0, 1e30, None
+        one = (L.Op * 1)()
+        for aux in [0] + candidates(o):
+            C.memmove(C.byref(one[0]), C.byref(o), C.sizeof(L.Op))
+            one[0].aux0 = aux
+            h = C.c_void_p()
+            if lib.ftc_plan_create(one, 1, plan["workspace_bytes"], ts.blob.numel(), C.byref(h)) != 0:
+                continue
+            ts_ = []
+            ok = lib.ftc_plan_run(h, bases, stream, 0, -1) == 0
+            for _ in range(reps if ok else 0):
+                if lib.ftc_plan_profile(h, bases, stream, ms) != 0:
+                    ok = False
+                    break
+                ts_.append(ms[0])
+            lib.ftc_plan_destroy(h)
+            if not ok:
+                continue
+            t = float(np.median(ts_))
+            if aux == 0:
+                base_t = t
+            if t < best_t * 0.98:
+                best, best_t = aux, t
+        choices[key] = best
+        if verbose:
+            base = f"{base_t * 1e3:8.1f}" if base_t is not None else " illegal"
+            print(f"{key:74s} default {base} us -> {best_t * 1e3:8.1f} us  {describe(best)}", flush=True)
+    return choices
 
 
 def candidates(o) -> List[int]:
@@ -163,12 +215,34 @@ def main():
     ap.add_argument("--out", default=TABLE_PATH)
     ap.add_argument("--merge", action="store_true", help="keep existing entries of --out")
     ap.add_argument("--filter", default="", help="only re-measure conv signatures matching this regular expression (e.g. _k1s1_)")
+    ap.add_argument("--train", action="store_true", help="tune the convolutions of the TRAIN plan (TrainStep) instead of the inference plan")
     a = ap.parse_args()
     os.environ["FTC_NO_TUNING"] = "1"
     allc: Dict[str, int] = {}
     if a.merge and os.path.exists(a.out):
         allc = {k: int(v) for k, v in json.load(open(a.out)).get("choices", {}).items()}
     sd = deterministic_state_dict(0)
+    if a.train:
+        from findtextcenternet_amd import TrainStep, synth
+        for prec in a.precision:
+            model = TextDetectorModel(pre_weights=False, precision=prec)
+            model.load_state_dict(sd)
+            model = model.to("cuda").train()
+            ts = TrainStep(model)
+            for B in a.batch:
+                x = torch.rand((B, a.size, a.size, 3), device="cuda").permute(0, 3, 1, 2)
+                lab, idm = synth.train_labels(1, B, a.size // 4, a.size // 4)
+                ts.zero_grad()
+                ts.forward_backward(x, torch.from_numpy(lab).cuda(), torch.from_numpy(idm).cuda())
+                torch.cuda.synchronize()
+                allc.update(tune_train_step(ts, B, a.size, a.size, verbose=True))
+            del ts, model
+            torch.cuda.empty_cache()
+        with open(a.out, "w") as f:
+            json.dump({"device": "MI355X gfx950", "note": "aux0 per conv signature, measured by findtextcenternet_amd.tuning",
+                       "choices": dict(sorted(allc.items()))}, f, indent=0)
+        print("wrote", a.out, len(allc), "entries")
+        return
     for prec in a.precision:
         model = TextDetectorModel(pre_weights=False, precision=prec)
         model.load_state_dict(sd)

@@ -323,7 +323,9 @@ int ftc_wgrad_splits_impl(int B, int Ho, int Wo, int Cout, int Cin, int ksize) {
     const long tiles = (long)((Cout + c.BM - 1) / c.BM) * ((Cin + c.BN - 1) / c.BN) * ksize * ksize;
     const long P = (long)B * Ho * Wo;
     long S = (1536 + tiles - 1) / tiles;                          // ~6 workgroups per CU in flight
-    const long smax = (P + 255) / 256;                            // at least 256 pixels per split
+    // ... but every split writes (and the reduction re-reads) a full fp32 copy of the gradient: on the deep stages (4608 pixels, 1.5 M
+    // weights) 16 splits moved 200 MB of partial sums around 33 MB of operands.  At least 1024 pixels (16 K steps) per split.
+    const long smax = (P + 1023) / 1024;
     if (S > smax) S = smax;
     if (S < 1) S = 1;
     if (S > 4096) S = 4096;

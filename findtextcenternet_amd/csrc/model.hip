@@ -274,7 +274,12 @@ struct ftc_model {
     bool has_decoder = false;               // the checkpoint carried the "decoder.*" tensors (SimpleDecoder)
     std::mutex mu;
     std::map<std::tuple<int, int, int, int>, std::unique_ptr<ModelPlan>> plans;
-    std::map<int, std::unique_ptr<ModelPlan>> decoder_plans;     // by number of rows
+    // by number of rows.  The row count follows the data (peaks per page), so this cache is bounded: at most kMaxDecoderPlans entries,
+    // the least recently used one is dropped (shared_ptr: a caller that is still running the evicted plan keeps it alive)
+    std::map<int, std::shared_ptr<ModelPlan>> decoder_plans;
+    std::map<int, uint64_t> decoder_plan_use;
+    uint64_t decoder_clock = 0;
+    static constexpr size_t kMaxDecoderPlans = 16;
 };
 
 namespace {
@@ -1052,15 +1057,22 @@ int ftc_forward(ftc_model* model, const void* weights_dev, const void* image, in
     return ftc_plan_run(&mp->plan, bases, stream, 0, with_nms ? n - 1 : n - 2);
 }
 
-static int get_decoder_plan(ftc_model* m, int n_rows, ModelPlan** out) {
+static int get_decoder_plan(ftc_model* m, int n_rows, std::shared_ptr<ModelPlan>* out) {
     if (!m) return ftc_set_error(FTC_ERR_INVALID, "ftc decoder: null model");
     if (!m->has_decoder) return ftc_set_error(FTC_ERR_INVALID, "ftc decoder: the model was created from a checkpoint without decoder.* tensors");
     if (n_rows <= 0) return ftc_set_error(FTC_ERR_INVALID, "ftc decoder: n_rows must be positive");
     std::lock_guard<std::mutex> lk(m->mu);
     auto it = m->decoder_plans.find(n_rows);
     if (it == m->decoder_plans.end()) {
-        std::unique_ptr<ModelPlan> mp(new (std::nothrow) ModelPlan());
+        std::shared_ptr<ModelPlan> mp(new (std::nothrow) ModelPlan());
         if (!mp) return ftc_set_error(FTC_ERR_NOMEM, "ftc decoder: out of host memory");
+        if (m->decoder_plans.size() >= ftc_model::kMaxDecoderPlans) {
+            auto lru = m->decoder_plan_use.begin();
+            for (auto u = m->decoder_plan_use.begin(); u != m->decoder_plan_use.end(); ++u)
+                if (u->second < lru->second) lru = u;
+            m->decoder_plans.erase(lru->first);
+            m->decoder_plan_use.erase(lru);
+        }
         Builder b(m, 1, n_rows, 1, false);
         int rc = b.build_decoder(mp.get());
         if (rc != FTC_OK) return rc;
@@ -1070,12 +1082,13 @@ static int get_decoder_plan(ftc_model* m, int n_rows, ModelPlan** out) {
         ftc_plan_destroy(checked);
         it = m->decoder_plans.emplace(n_rows, std::move(mp)).first;
     }
-    *out = it->second.get();
+    m->decoder_plan_use[n_rows] = ++m->decoder_clock;
+    *out = it->second;
     return FTC_OK;
 }
 
 int64_t ftc_decoder_workspace_bytes(ftc_model* model, int n_rows) {
-    ModelPlan* mp = nullptr;
+    std::shared_ptr<ModelPlan> mp;
     if (get_decoder_plan(model, n_rows, &mp) != FTC_OK) return -1;
     return mp->plan.workspace_bytes;
 }
@@ -1083,7 +1096,7 @@ int64_t ftc_decoder_workspace_bytes(ftc_model* model, int n_rows) {
 int ftc_decoder_forward(ftc_model* model, const void* weights_dev, const void* rows, int n_rows, float* out0, float* out1, float* out2,
                         void* workspace, void* stream) {
     if (!weights_dev || !rows || !out0 || !out1 || !out2 || !workspace) return ftc_set_error(FTC_ERR_INVALID, "ftc_decoder_forward: null pointer argument");
-    ModelPlan* mp = nullptr;
+    std::shared_ptr<ModelPlan> mp;
     int rc = get_decoder_plan(model, n_rows, &mp);
     if (rc != FTC_OK) return rc;
     float* outs[3] = {out0, out1, out2};

@@ -104,8 +104,23 @@ class TrainForward:
             raw = t.view(torch.int16).view(torch.uint8).reshape(-1) if t.dtype in (torch.bfloat16, torch.float16) else t.view(torch.uint8).reshape(-1)
             blob[table[k]: table[k] + raw.numel()] = raw
         self.wdev, self.table, self.fingerprint = blob, table, fp
-        self.plans.clear()
-        self.dec_plans.clear()
+        self._drop_plans()
+
+    def _drop_plans(self) -> None:
+        """The plans hold native memory (ftc_plan_create): destroy the handles, do not just forget them."""
+        lib = L.load()
+        for d in (self.plans, self.dec_plans):
+            for pl in d.values():
+                if pl.get("handle") is not None:
+                    lib.ftc_plan_destroy(pl["handle"])
+                    pl["handle"] = None
+            d.clear()
+
+    def __del__(self):
+        try:
+            self._drop_plans()
+        except Exception:
+            pass
 
     def _unpack_running_stats(self) -> None:
         """The kernels moved the running statistics inside the packed blob: copy them back into the module's buffers."""

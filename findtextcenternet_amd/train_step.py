@@ -157,6 +157,16 @@ class TrainStep:
         self._stem_src = pmap["detector.backbone.features.0.0.weight"]
         self._param_ptrs = [p.data_ptr() for _, p in params]
 
+    def __del__(self):
+        try:
+            lib = L.load()
+            for pl in self.plans.values():
+                if pl.get("handle") is not None:
+                    lib.ftc_plan_destroy(pl["handle"])
+                    pl["handle"] = None
+        except Exception:
+            pass
+
     def check_views(self) -> None:
         """The parameters must still live in the flat buffer (``module.to()`` / ``load_state_dict(assign=True)`` would move them)."""
         for (n, p), ptr in zip(self.params, self._param_ptrs):

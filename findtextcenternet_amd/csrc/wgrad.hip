@@ -278,6 +278,138 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 weight gradient with the NINE TAPS IN ONE WORKGROUP (16-bit copies of both operands, Wo % 32 == 0).
+// The generic kernel above gives every (Cout tile, Cin tile, tap) its own workgroup, so both operand streams are re-read per tap and per
+// tile of the other operand: the last FPN level moved 4.7 GB per launch and ran at the speed of those re-reads.  Here a workgroup owns a
+// 64 x 64 (Cout x Cin) tile for all nine taps: a K step is 32 consecutive output pixels of one image row; the output-gradient tile is
+// staged ONCE and its fragments feed nine MFMAs each, the activation rows y-1, y, y+1 are staged as nine pre-shifted 64 x 32 tiles (one
+// per tap: a shift by one pixel is 2 bytes, which a 16-byte fragment read cannot absorb; the shifted loads of a step hit L1).
+// Each wave keeps the nine taps' accumulators of its 32 x 32 sub-tile (144 registers).  Same partial-sum layout and reduction.
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename WT>
+__global__ __launch_bounds__(256) void wgrad3_kernel(WgradP p, int nseg, long steps_per_split) {
+    constexpr int LD = 40;                                    // 32 pixels + 8: 80-byte rows, conflict-free ds_read_b128 fragments
+    using ST = Stager<WT, WT>;
+    // tile 0 = output gradient; tiles 1 + 3 * slot + sx = activation row `slot` (a ring of three input rows) shifted by sx - 1 pixels
+    __shared__ __attribute__((aligned(16))) WT Ls[10 * 64 * LD];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int mt = blockIdx.x, nt = blockIdx.y, split = blockIdx.z;
+    // K steps walk DOWN an image column segment (step = (image, x segment) * Ho + y): consecutive steps share two of their three input
+    // rows, which stay in the LDS ring -- only row y + 1 is staged per step (3 shifted tiles + the gradient tile = 128 tasks instead of 320)
+    const long total = (long)p.B * nseg * p.Ho;
+    const long s0 = (long)split * steps_per_split, s1 = s0 + steps_per_split < total ? s0 + steps_per_split : total;
+    const bool a_vec = (p.CoutT % 8 == 0) && (p.cout_off % 8 == 0), b_vec = (p.CinT % 8 == 0) && (p.cin_off % 8 == 0);
+    ST st[2];
+    auto decode = [&](long step, int& b, int& x0, int& y) {
+        const long col = step / p.Ho;
+        y = (int)(step - col * p.Ho);
+        const int seg = (int)(col % nseg);
+        b = (int)(col / nseg);
+        x0 = seg * 32;
+    };
+    // task q of a step: q < 32 the gradient tile; then activation tiles -- all nine (full: first step of a split or of a column) or the three of row y + 1
+    auto task = [&](int q, bool full, int y, int& tile, int& iy, int& sx) {
+        if (q < 32) { tile = 0; iy = 0; sx = 0; return; }
+        const int k = (q - 32) >> 5;
+        const int r = full ? k / 3 : 2;
+        sx = full ? k - r * 3 : k;
+        iy = y + r - 1;
+        tile = 1 + ((iy + 3) % 3) * 3 + sx;
+    };
+    auto fetch = [&](long step, bool full) {
+        int b, x0, y;
+        decode(step, b, x0, y);
+        const int ntask = full ? 320 : 128;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = t + 256 * u;
+            if (q >= ntask) break;
+            int tile, iy, sx;
+            task(q, full, y, tile, iy, sx);
+            const int w = q & 31, cq = w & 7, po = w >> 3;
+            if (tile == 0) {
+                const int m0 = mt * 64 + cq * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const long row = ((long)b * p.Ho + y) * p.Wo + x0 + po * 8 + i;
+                    if (m0 < p.Cout) st[u].load(i, static_cast<const WT*>(p.dz), row, p.CoutT, p.cout_off, m0, p.Cout, a_vec);
+                    else st[u].zero(i);
+                }
+            } else {
+                const int n0 = nt * 64 + cq * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int ix = x0 + po * 8 + i + sx - 1;
+                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && n0 < p.Cin)
+                        st[u].load(i, static_cast<const WT*>(p.x), ((long)b * p.H + iy) * p.W + ix, p.CinT, p.cin_off, n0, p.Cin, b_vec);
+                    else st[u].zero(i);
+                }
+            }
+        }
+    };
+    auto stage = [&](long step, bool full) {
+        int b, x0, y;
+        decode(step, b, x0, y);
+        const int ntask = full ? 320 : 128;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = t + 256 * u;
+            if (q >= ntask) break;
+            int tile, iy, sx;
+            task(q, full, y, tile, iy, sx);
+            const int w = q & 31, cq = w & 7, po = w >> 3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) st[u].put(Ls + (tile * 64 + cq * 8 + j) * LD + po * 8, j);
+        }
+    };
+    auto is_full = [&](long step) { return step == s0 || (step % p.Ho) == 0; };
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+    using F = typename WFrag<WT>::type;
+    const int fr = lane & 31, fk = (lane >> 5) * 8;
+    if (s0 < s1) fetch(s0, true);
+    for (long step = s0; step < s1; ++step) {
+        stage(step, is_full(step));
+        __syncthreads();
+        if (step + 1 < s1) fetch(step + 1, is_full(step + 1));  // in flight behind the 18 MFMAs of this step
+        const int y = (int)(step % p.Ho);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const F af = *reinterpret_cast<const F*>(Ls + (wm * 32 + fr) * LD + kk * 16 + fk);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int slot = (y + r + 2) % 3;                   // row y + r - 1
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    const F bf = *reinterpret_cast<const F*>(Ls + ((1 + slot * 3 + sx) * 64 + wn * 32 + fr) * LD + kk * 16 + fk);
+                    if constexpr (__is_same(WT, __bf16)) acc[r * 3 + sx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[r * 3 + sx], 0, 0, 0);
+                    else acc[r * 3 + sx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[r * 3 + sx], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int n = nt * 64 + wn * 32 + (lane & 31);
+    if (n >= p.Cin) return;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        float* pp = p.part + ((long)split * 9 + k) * p.Cout * p.Cin;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = mt * 64 + wm * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+            if (m < p.Cout) pp[(long)m * p.Cin + n] = acc[k][e];
+        }
+    }
+}
+
+inline bool wgrad3_shape(int Wo, int Cout, int Cin, int ksize) { return ksize == 3 && Wo % 32 == 0 && Cout >= 32 && Cin >= 32; }
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int S, int KK, int Cout, int Cin) {
     const long per = (long)KK * Cout * Cin;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long)gridDim.x * 256) {
@@ -320,7 +452,8 @@ void launch_io(const WgradP& p, int cfg, dim3 grid, bool x16, bool d16, hipStrea
 
 int ftc_wgrad_splits_impl(int B, int Ho, int Wo, int Cout, int Cin, int ksize) {
     const WgCfg c = wgrad_cfg(Cout, Cin, ksize);
-    const long tiles = (long)((Cout + c.BM - 1) / c.BM) * ((Cin + c.BN - 1) / c.BN) * ksize * ksize;
+    long tiles = (long)((Cout + c.BM - 1) / c.BM) * ((Cin + c.BN - 1) / c.BN) * ksize * ksize;
+    if (wgrad3_shape(Wo, Cout, Cin, ksize)) tiles = (long)((Cout + 63) / 64) * ((Cin + 63) / 64);      // the nine-tap kernel: 64 x 64 tiles, taps inside
     const long P = (long)B * Ho * Wo;
     long S = (1536 + tiles - 1) / tiles;                          // ~6 workgroups per CU in flight
     // ... but every split writes (and the reduction re-reads) a full fp32 copy of the gradient: on the deep stages (4608 pixels, 1.5 M
@@ -344,10 +477,25 @@ hipError_t launch_wgrad(const OpArgs& a, hipStream_t s) {
     const int S = o.aux0 > 0 ? o.aux0 : 1;
     const int BK = o.w_dtype == FTC_F32 ? 32 : 64;
     p.chunk = ((p.P + S - 1) / S + BK - 1) / BK * BK;
+    const int KK = o.ksize * o.ksize;
+    if (wgrad3_shape(o.Wo, o.Cout, o.Cin, o.ksize) && o.stride == 1 && ftc_is16(o.w_dtype) && o.in_dtype == o.w_dtype && o.res_dtype == o.w_dtype && !p.se &&
+        !(o.flags & 0x100)) {                                    // (0x100: the generic kernel, for A/B measurements)
+        const int nseg = o.Wo / 32;
+        const long total = (long)o.B * nseg * o.Ho;
+        const long sps = (total + S - 1) / S;
+        const dim3 g3((o.Cout + 63) / 64, (o.Cin + 63) / 64, S);
+        if (o.w_dtype == FTC_F16) hipLaunchKernelGGL(wgrad3_kernel<_Float16>, g3, dim3(256), 0, s, p, nseg, sps);
+        else hipLaunchKernelGGL(wgrad3_kernel<__bf16>, g3, dim3(256), 0, s, p, nseg, sps);
+        hipError_t e3 = hipGetLastError();
+        if (e3 != hipSuccess) return e3;
+        const long per3 = (long)KK * o.Cout * o.Cin;
+        const long nb3 = (per3 + 255) / 256;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb3 > 8192 ? 8192 : nb3)), dim3(256), 0, s, a.aux, (float*)a.out, S, KK, o.Cout, o.Cin);
+        return hipGetLastError();
+    }
     WgCfg c = wgrad_cfg(o.Cout, o.Cin, o.ksize);
     // the 192 x 256 tile has one staging task per thread only with 16-byte accesses of 8 channels (16-bit copies) or the fp32 K step of 32
     if (c.id == 3 && ftc_is16(o.w_dtype) && !(o.in_dtype == o.w_dtype && o.res_dtype == o.w_dtype)) c = WgCfg{2, 128, 128};
-    const int KK = o.ksize * o.ksize;
     const dim3 grid((o.Cout + c.BM - 1) / c.BM, ((o.Cin + c.BN - 1) / c.BN) * KK, S);
     // in_dtype / res_dtype: storage of the layer input / of the output gradient (fp32, or a 16-bit copy in the compute type)
     if (o.w_dtype == FTC_F32) launch_cfg<float, float, float>(p, c.id, grid, s);

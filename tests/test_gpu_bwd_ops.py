@@ -97,6 +97,11 @@ WG_CASES = [  # name, B,H,W, Cin,CinT,cin_off, Cout,CoutT,cout_off, k, stride, s
     ("linear_100_of_128", 1, 700, 1, 100, 128, 0, 2048, 2048, 0, 1, 1, False),
     ("linear_logits", 1, 300, 1, 256, 256, 0, 1091, 1104, 0, 1, 1, False),
     ("odd_hw", 1, 15, 17, 24, 24, 0, 48, 48, 0, 3, 1, False),
+    # Wo % 32 == 0: with 16-bit copies of both operands these run on the nine-taps-in-one-workgroup kernel (wgrad3_kernel)
+    ("c3n_64_256_w64", 2, 6, 64, 64, 64, 0, 256, 256, 0, 3, 1, False),
+    ("c3n_288_192_w32", 1, 5, 32, 288, 288, 0, 192, 192, 0, 3, 1, False),
+    ("c3n_slices_w96", 1, 4, 96, 40, 72, 32, 100, 128, 8, 3, 1, False),
+    ("c3n_many_rows", 3, 33, 32, 32, 32, 0, 64, 64, 0, 3, 1, False),
 ]
 
 

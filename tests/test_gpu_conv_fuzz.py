@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 from findtextcenternet_amd import _lib as L
 from findtextcenternet_amd import tuning as T
-from gpu_harness import Arena, bf16_round, run_op, tdtype, to_dev_bytes
+from gpu_harness import Arena, bf16_round, presplit_f16x3, run_op, tdtype, to_dev_bytes
 
 pytestmark = pytest.mark.gpu
 ACT = {L.ACT_NONE: lambda v: v, L.ACT_SILU: F.silu, L.ACT_GELU: F.gelu}
@@ -48,9 +48,27 @@ def _case(seed):
                 act=act, residual=residual, se=se, idt=idt, odt=odt, wdt=wdt)
 
 
+def _case_f32(seed):
+    for i in range(64):
+        c = _case(seed + 1000 * i)
+        if c["wdt"] == L.F32:
+            return c
+    raise AssertionError("no fp32 case found")
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_every_legal_kernel_variant_of_a_random_conv_fp16x3(seed):
+    """The same fuzz for the fp16x3 arithmetic (FTC_FLAG_SPLIT16: fp32 tensors, pre-split weights, three fp16 MFMAs per product) on the
+    fp32 cases, held to 2e-5 (the exact-fp32 kernels: 2e-4 budget, 1e-6 measured)."""
+    _run_fuzz_case(_case_f32(7000 + seed), x3=True)
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_every_legal_kernel_variant_of_a_random_conv(seed):
-    c = _case(9000 + seed)
+    _run_fuzz_case(_case(9000 + seed), x3=False)
+
+
+def _run_fuzz_case(c, x3):
     B, H, W, Cin, k, stride = c["B"], c["H"], c["W"], c["Cin"], c["k"], c["stride"]
     g = torch.Generator().manual_seed(zlib.crc32(str(c).encode()) % 100000)
     pad = (k - 1) // 2
@@ -73,21 +91,22 @@ def test_every_legal_kernel_variant_of_a_random_conv(seed):
         ref = ref + res
     ar = Arena()
     o_in = ar.put(to_dev_bytes(x_full, c["idt"]))
-    o_w = ar.put(to_dev_bytes(w.permute(0, 2, 3, 1).reshape(c["Cout"], k * k, Cin), c["wdt"]))
+    wk = w.permute(0, 2, 3, 1).reshape(c["Cout"], k * k, Cin)
+    o_w = ar.put(presplit_f16x3(wk) if x3 else to_dev_bytes(wk, c["wdt"]))
     o_b = ar.put(bias)
     o_res = ar.put(res) if c["residual"] else None
     o_sc = ar.put(sc) if c["se"] else None
     esz = 4 if c["odt"] == L.F32 else 2
     o_out = ar.reserve(B * Ho * Wo * c["CoutT"] * esz)
     ar.materialize()
-    fields = dict(kind=L.OP_CONV, flags=(L.FLAG_RESIDUAL if c["residual"] else 0) | (L.FLAG_SE_SCALE if c["se"] else 0), act=c["act"],
+    fields = dict(kind=L.OP_CONV, flags=(L.FLAG_RESIDUAL if c["residual"] else 0) | (L.FLAG_SE_SCALE if c["se"] else 0) | (L.FLAG_SPLIT16 if x3 else 0), act=c["act"],
                   in_dtype=c["idt"], out_dtype=c["odt"], w_dtype=c["wdt"], B=B, H=H, W=W, Ho=Ho, Wo=Wo, Cin=Cin, Cin_total=c["CinT"],
                   cin_off=c["cin_off"], Cout=c["Cout"], Cout_total=c["CoutT"], cout_off=c["cout_off"], ksize=k, stride=stride,
                   res_dtype=L.F32, in_=o_in, in2=o_res, out=o_out, w=o_w, bias=o_b, scale=o_sc)
     probe = L.Op()
     for name in ("w_dtype", "in_dtype", "out_dtype", "Cin", "Cout", "ksize", "stride", "groups"):
         setattr(probe, name, fields.get(name, 0))
-    tol = 2e-4 if c["wdt"] == L.F32 else 1.5e-2
+    tol = 2e-5 if x3 else 2e-4 if c["wdt"] == L.F32 else 1.5e-2
     ran = 0
     for aux0 in [0] + T.candidates(probe):
         try:

@@ -594,7 +594,7 @@ def main():
         from findtextcenternet_amd import HipDetectorBackend
         seam = {}
         tile_np = (synth.noise_images(4321, 1, 768, 768) * 255.0).astype(np.float32)
-        for prec in ([] if args.no_seam2 else [args.precision] + ([] if args.no_fp32 else [p_ for p_ in ("fp32",) if p_ != args.precision])):
+        for prec in ([] if args.no_seam2 else [args.precision] + ([] if args.no_fp32 else [p_ for p_ in ("fp32", "fp16x3") if p_ != args.precision])):
             mdl, dd = (model, det) if prec == args.precision else make(prec)
             be = HipDetectorBackend(dd, device=dev)
             for _ in range(3):

@@ -368,6 +368,7 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 parity-mode record")
     ap.add_argument("--dump-ops", default="", help="write per-op timings (JSON) to this path")
     ap.add_argument("--dry-run", action="store_true", help="CPU/gloo walk through the N-rank control flow (no GPU work)")
+    ap.add_argument("--lanes", type=int, default=2, help="successive batches alternate over this many HIP streams (1 = one stream)")
     ap.add_argument("--no-seam2", action="store_true", help="skip the batch-1 host-in / host-out call_detector latency record")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 300-step / >= 4 s sustained-rate record")
     ap.add_argument("--train", action="store_true", help="BASELINE configs[4]: the train step (fwd + loss + bwd + optimizer, DDP all-reduce when N > 1)")
@@ -426,6 +427,30 @@ def main():
             return all_gather_boxes(dec.counts, dec.records)
         return dec
 
+    # The timed step: successive batches alternate over `--lanes` HIP streams (findtextcenternet_amd.lanes.DetectorLanes): batch k+1's
+    # latency-bound backbone stages run under batch k's matrix-bound FPN heads.  Every lane has its own arena, outputs and decode block;
+    # a step still is one full pass (forward + NMS + decode [+ gather]) over one batch, and all K steps complete inside the timed region.
+    # The single-stream figure (the step above, on the current stream) is measured beside it.
+    single_step = step
+    lanes = None
+    if args.lanes > 1:
+        from findtextcenternet_amd import DetectorLanes
+        lanes = DetectorLanes(det, B, 768, 768, lanes=args.lanes, max_boxes=args.max_boxes, device=dev)
+
+        def gather(dec):
+            if world > 1:
+                if dec.records.numel() * 4 <= STATIC_GATHER_BYTES:
+                    return all_gather_boxes_static(dec.counts, dec.records, world * B)
+                return all_gather_boxes(dec.counts, dec.records)
+            return dec
+
+        def step():                                            # noqa: F811
+            return lanes.submit(x, tiles, cut_off=0.4, logit_cut=lcut, then=gather)[1]
+
+    def drain():
+        if lanes is not None:
+            lanes.wait()
+
     for _ in range(args.warmup):
         out = step()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # the kernels run on torch's current stream
@@ -437,14 +462,37 @@ def main():
     el_enqueue = 0.0
     for i in range(args.steps):
         out = step()
-        ev[i + 1].record()
+        ev[i + 1].record(lanes.streams[(lanes.k - 1) % lanes.n] if lanes is not None else None)
         if i == 0:
             el_enqueue = time.perf_counter() - t0  # host side of ONE step (later steps can block on a full hardware queue)
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
+    # per-step HIP events: with lanes, event i+1 is recorded on the lane that ran step i, so consecutive events of ONE lane are `lanes` steps apart
+    nl = lanes.n if lanes is not None else 1
+    step_ms = [ev[i].elapsed_time(ev[i + nl]) / nl for i in range(1 if nl > 1 else 0, args.steps + 1 - nl)] or [1000 * el / args.steps]
+    # the same K steps on ONE stream (no overlap between batches): reported beside the headline
+    single = None
+    if lanes is not None:
+        for _ in range(2):
+            single_step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            single_step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([e1], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e1 = float(t.item())
+        single = {"value": round(world * B * args.steps / e1, 2), "ms_per_step": round(1000 * e1 / args.steps, 3)}
     if world > 1:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -461,6 +509,7 @@ def main():
         t0s = time.perf_counter()
         for _ in range(sus_steps):
             out = step()
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -489,6 +538,11 @@ def main():
                       "ms_per_step_median from per-step HIP events on the launch stream (rank 0)",
             "source_hash": source_hash(),
         }
+        result["lanes"] = nl
+        if single is not None:
+            result["single_stream"] = single
+            result["config"]["pipelining"] = (f"successive batches alternate over {nl} HIP streams (own arena / outputs / decode block per lane): batch k+1's "
+                                              "backbone overlaps batch k's FPN heads; single_stream = the same steps on one stream")
         if sus is not None:
             result["sustained"] = sus
         if world > 1:

@@ -8,9 +8,10 @@ from .weights import deterministic_state_dict, load_tf_efficientnetv2_npz  # noq
 from .page import PageDetector, linedetect_parse, linedetect_request, page_merge_gpu   # noqa: F401
 from .optim import AdamWScheduleFree   # noqa: F401
 from .train_step import TrainStep   # noqa: F401
+from .lanes import DetectorLanes   # noqa: F401
 from . import synth   # noqa: F401
 
 __all__ = ["TextDetectorModel", "CenterNetDetection", "CenterNetDetector", "SimpleDecoder", "HipDetectorBackend",
            "TileGeom", "Decoded", "decode_peaks", "tiles_to_device", "exact_logit_cut", "tile_keep_rect", "deterministic_state_dict", "load_tf_efficientnetv2_npz", "PageDetector", "page_merge_gpu", "linedetect_request",
-           "linedetect_parse", "AdamWScheduleFree", "TrainStep",
+           "linedetect_parse", "AdamWScheduleFree", "TrainStep", "DetectorLanes",
            "width", "height", "scale", "feature_dim", "modulo_list"]

@@ -132,7 +132,9 @@ class _HipEngine:
             self.workspace = None
             self.workspace = torch.empty(need, dtype=torch.uint8, device=device)
 
-    def run(self, x: torch.Tensor, with_nms: bool = True, out=None):
+    def run(self, x: torch.Tensor, with_nms: bool = True, out=None, workspace: Optional[torch.Tensor] = None):
+        """workspace: a caller-owned activation arena (>= model.workspace_bytes(B, H, W) bytes) instead of the engine's own -- what lets
+        several batches be in flight on several streams at once (findtextcenternet_amd.lanes.DetectorLanes)."""
         if not x.is_cuda:
             raise RuntimeError("findtextcenternet_amd: the detector runs on MI355X (gfx950) only -- move the module and "
                                "the input to 'cuda' (there is no CPU fallback)")
@@ -153,7 +155,11 @@ class _HipEngine:
         dev = x.device
         with torch.cuda.device(dev):
             self.ensure_model(dev)
-            self.ensure_workspace(B, H, W, dev)
+            if workspace is None:
+                self.ensure_workspace(B, H, W, dev)
+                workspace = self.workspace
+            elif workspace.device != dev or workspace.numel() * workspace.element_size() < self.model.workspace_bytes(B, H, W):
+                raise ValueError("workspace= is smaller than model.workspace_bytes(B, H, W) or on another device")
             h, w = H // 4, W // 4
             if out is None:
                 heat = torch.empty((B, h, w, 10), dtype=torch.float32, device=dev)
@@ -165,7 +171,7 @@ class _HipEngine:
                     raise ValueError("out=(heat [B,h,w,10], feat [B,h,w,100]) must be contiguous fp32 tensors on the input's device")
             stream = torch.cuda.current_stream(dev).cuda_stream
             L.check(lib.ftc_forward(self.handle, self.wdev.data_ptr(), x.data_ptr(), B, H, W, 1 if nchw else 0, 1 if with_nms else 0,
-                                    heat.data_ptr(), feat.data_ptr(), self.workspace.data_ptr(), C.c_void_p(stream)), "ftc_forward")
+                                    heat.data_ptr(), feat.data_ptr(), workspace.data_ptr(), C.c_void_p(stream)), "ftc_forward")
         # x stays alive until the work is enqueued on the same stream (stream-ordered allocator)
         return heat, feat
 
@@ -222,12 +228,12 @@ class CenterNetDetection(nn.Module):
         object.__setattr__(new, "_engine", _HipEngine(self._engine.precision, self.model_size, new))
         return new
 
-    def forward_nhwc(self, x, with_nms: bool, out=None):
+    def forward_nhwc(self, x, with_nms: bool, out=None, workspace=None):
         """(heat[B,h,w,10] fp32, feat[B,h,w,100] fp32) in NHWC memory; channel 1 is the NMS slot.  ``out=(heat, feat)``
-        writes into caller-owned tensors instead of allocating."""
+        writes into caller-owned tensors instead of allocating; ``workspace`` = a caller-owned activation arena."""
         if self.training:
             raise NotImplementedError("findtextcenternet_amd implements the inference path (eval mode) only; call .eval()")
-        return self._engine.run(x, with_nms, out)
+        return self._engine.run(x, with_nms, out, workspace)
 
     def forward(self, x):
         heat, feat = self.forward_nhwc(x, with_nms=False)
@@ -391,8 +397,8 @@ class CenterNetDetector(nn.Module):
         self.detector = detector
         self.minval = torch.tensor(float("-inf"))
 
-    def forward_nhwc(self, x, out=None):
-        return self.detector.forward_nhwc(x, with_nms=True, out=out)
+    def forward_nhwc(self, x, out=None, workspace=None):
+        return self.detector.forward_nhwc(x, with_nms=True, out=out, workspace=workspace)
 
     def forward(self, x):
         heat, feat = self.detector.forward_nhwc(x, with_nms=True)

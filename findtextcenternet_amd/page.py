@@ -91,7 +91,7 @@ class PageDetector:
     """``run_detector`` / tiling of ``OCR_Processer`` on top of a HIP ``CenterNetDetector``."""
 
     def __init__(self, detector, step_ratio: float = 0.6, cut_off: float = 0.4, batch: int = 8, max_boxes: int = 4096,
-                 device: str = "cuda", group=None, shard: bool = True):
+                 device: str = "cuda", group=None, shard: bool = True, lanes: int = 2):
         self.device = torch.device(device)
         detector.to(device=self.device)
         detector.eval()
@@ -101,6 +101,11 @@ class PageDetector:
         # record rows are gathered (one collective, no host sync) and the page canvases merged with an all-reduce(MAX): every rank
         # ends up with the whole page's boxes.  shard=False: every rank runs the whole page (replicas).
         self.group, self.shard = group, shard
+        # The batches OF ONE PAGE alternate over `lanes` HIP streams (see lanes.py: batch k+1's backbone under batch k's FPN heads), each
+        # with its own activation arena; the page canvas is shared (ftc_paste_maps merges with atomicMax: order-independent).  Results do
+        # not depend on `lanes`.
+        self.lanes = max(1, int(lanes))
+        self._lane_streams, self._lane_ws = None, {}
         self.stepx, self.stepy = int(width * step_ratio), int(height * step_ratio)      # process_ocr_base.py:43-45
 
     # -- reference signature -----------------------------------------------------------------
@@ -142,18 +147,40 @@ class PageDetector:
         from .dist import all_gather_boxes_static, shard_range
         world = tdist.get_world_size(self.group) if (self.shard and tdist.is_available() and tdist.is_initialized()) else 1
         first, last = shard_range(len(origins), tdist.get_rank(self.group), world) if world > 1 else (0, len(origins))
+        n_batches = (last - first + self.batch - 1) // self.batch if last > first else 0
+        n_lanes = min(self.lanes, max(1, n_batches))
         with torch.cuda.device(self.device), torch.no_grad():
-            for lo in range(first, last, self.batch):
+            main = torch.cuda.current_stream(self.device)
+            if n_lanes > 1:
+                if self._lane_streams is None or len(self._lane_streams) < n_lanes:
+                    self._lane_streams = [torch.cuda.Stream(device=self.device) for _ in range(n_lanes)]
+                streams = self._lane_streams[:n_lanes]
+                eng = self.detector.detector._engine
+                eng.ensure_model(self.device)
+                need = eng.model.workspace_bytes(self.batch, height, width)
+                for i in range(n_lanes):
+                    if i not in self._lane_ws or self._lane_ws[i].numel() < need:
+                        self._lane_ws[i] = torch.empty(need, dtype=torch.uint8, device=self.device)
+                for s_ in streams:
+                    s_.wait_stream(main)
+            else:
+                streams = [main]
+            for k, lo in enumerate(range(first, last, self.batch)):
                 hi = min(last, lo + self.batch)
-                x = get_tiles(lo, hi).permute(0, 3, 1, 2)
-                heat, feat = self.detector.forward_nhwc(x)
-                geoms = [TileGeom(ox, oy, page_w, page_h, tile_keep_rect(ox, oy, page_w, page_h, self.step_ratio)) for (oy, ox) in origins[lo:hi]]
-                tl = tiles_to_device(geoms, self.device, heat.shape[1], heat.shape[2])
-                stream = torch.cuda.current_stream(self.device).cuda_stream
-                L.check(lib.ftc_paste_maps(heat.data_ptr(), tl.data_ptr(), hi - lo, heat.shape[1], heat.shape[2], scale, canv.data_ptr(),
-                                           mh, mw, C.c_void_p(stream)), "ftc_paste_maps")
-                dec = decode_peaks(heat, feat, tl, cut_off=self.cut_off, max_boxes=self.max_boxes)
-                parts.append((dec.counts, dec.boxes, dec.feats, dec.records))
+                lane = k % n_lanes
+                with torch.cuda.stream(streams[lane]):
+                    x = get_tiles(lo, hi).permute(0, 3, 1, 2)
+                    heat, feat = self.detector.forward_nhwc(x, workspace=self._lane_ws[lane] if n_lanes > 1 else None)
+                    geoms = [TileGeom(ox, oy, page_w, page_h, tile_keep_rect(ox, oy, page_w, page_h, self.step_ratio)) for (oy, ox) in origins[lo:hi]]
+                    tl = tiles_to_device(geoms, self.device, heat.shape[1], heat.shape[2])
+                    stream = torch.cuda.current_stream(self.device).cuda_stream
+                    L.check(lib.ftc_paste_maps(heat.data_ptr(), tl.data_ptr(), hi - lo, heat.shape[1], heat.shape[2], scale, canv.data_ptr(),
+                                               mh, mw, C.c_void_p(stream)), "ftc_paste_maps")
+                    dec = decode_peaks(heat, feat, tl, cut_off=self.cut_off, max_boxes=self.max_boxes)
+                    parts.append((dec.counts, dec.boxes, dec.feats, dec.records))
+            if n_lanes > 1:
+                for s_ in streams:
+                    main.wait_stream(s_)
             # every tile's rows in tile order; rows past a tile's count are zeros (p = 0 < cut_off): inert padding
             if world > 1:
                 n_feat = parts[0][2].shape[-1] if parts else 100

@@ -145,3 +145,14 @@ def test_run_detector_two_tiles_vs_oracle(detector):
     # tiling front-end from the uint8 page gives the same result as the reference-style ds list
     loc2, gf2, lines2, seps2 = pd.detect_page(img_u8)
     assert np.array_equal(loc2, loc) and np.array_equal(gf2, gf) and np.array_equal(lines2, lines)
+
+
+def test_page_lanes_give_the_same_page(detector):
+    """A page whose tile batches alternate over several HIP streams = the same page on one stream, byte for byte."""
+    img_u8 = synth.page_uint8(77, 1500, 1300)
+    one = page.PageDetector(detector, step_ratio=0.6, cut_off=0.4, batch=2, lanes=1).detect_page(img_u8)
+    for lanes in (2, 3):
+        got = page.PageDetector(detector, step_ratio=0.6, cut_off=0.4, batch=2, lanes=lanes).detect_page(img_u8)
+        assert len(one[0]) > 50
+        for a, b in zip(one, got):
+            assert np.array_equal(a, b)

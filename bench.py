@@ -227,8 +227,12 @@ def train_dry_run(args, rank, world):
 def train_bench(args, rank, local_rank, world):
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    # FTC_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, box gather under the lane streams, barriers) with one rank --
+    # the only way to exercise it on a 1-GPU box
+    dist_on = world > 1 or os.environ.get("FTC_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from findtextcenternet_amd import AdamWScheduleFree, TextDetectorModel, TrainStep, deterministic_state_dict, synth
     from findtextcenternet_amd import _lib as L
@@ -238,7 +242,7 @@ def train_bench(args, rank, local_rank, world):
     model.load_state_dict(sd)
     model = model.to(dev).train()
     ts = TrainStep(model)
-    if world > 1:
+    if dist_on:
         ts.enable_ddp()
     opt = AdamWScheduleFree([p for p in model.parameters() if p.requires_grad], lr=1e-4)     # train1.py:103-104
     opt.train()
@@ -256,7 +260,7 @@ def train_bench(args, rank, local_rank, world):
     for _ in range(args.warmup):
         step()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -264,18 +268,18 @@ def train_bench(args, rank, local_rank, world):
     for i in range(args.steps):
         step()
         ev[i + 1].record()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     step_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
-    if world > 1:
+    if dist_on:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     loss = float(state["loss"])
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -349,7 +353,7 @@ def train_bench(args, rank, local_rank, world):
                                   "sample": f"one train step (forward + loss + backward, no optimizer) of the CPU oracle on 1 x 384x384 "
                                             f"(= 1/4 of a 768x768 tile) in {e:.1f} s, scaled by pixel count"}
     print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -385,8 +389,10 @@ def main():
         return train_bench(args, rank, local_rank, world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    dist_on = world > 1 or os.environ.get("FTC_BENCH_FORCE_DIST") == "1"      # (see train_bench)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from findtextcenternet_amd import (CenterNetDetector, TextDetectorModel, TileGeom, decode_peaks, deterministic_state_dict,
@@ -420,7 +426,7 @@ def main():
         with torch.no_grad():
             det.forward_nhwc(x, out=(heat, feat))
         dec = decode_peaks(heat, feat, tiles, cut_off=0.4, max_boxes=args.max_boxes, logit_cut=lcut, workspace=dws)
-        if world > 1:
+        if dist_on:
             # one collective and no host round trip when the fixed-capacity block is small (8 tiles x 2048 rows = 7.3 MB), else counts first
             if dec.records.numel() * 4 <= STATIC_GATHER_BYTES:
                 return all_gather_boxes_static(dec.counts, dec.records, world * B)
@@ -438,7 +444,7 @@ def main():
         lanes = DetectorLanes(det, B, 768, 768, lanes=args.lanes, max_boxes=args.max_boxes, device=dev)
 
         def gather(dec):
-            if world > 1:
+            if dist_on:
                 if dec.records.numel() * 4 <= STATIC_GATHER_BYTES:
                     return all_gather_boxes_static(dec.counts, dec.records, world * B)
                 return all_gather_boxes(dec.counts, dec.records)
@@ -454,7 +460,7 @@ def main():
     for _ in range(args.warmup):
         out = step()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # the kernels run on torch's current stream
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -466,7 +472,7 @@ def main():
         if i == 0:
             el_enqueue = time.perf_counter() - t0  # host side of ONE step (later steps can block on a full hardware queue)
     drain()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
@@ -478,22 +484,22 @@ def main():
     if lanes is not None:
         for _ in range(2):
             single_step()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):
             single_step()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         e1 = time.perf_counter() - t1
-        if world > 1:
+        if dist_on:
             t = torch.tensor([e1], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             e1 = float(t.item())
         single = {"value": round(world * B * args.steps / e1, 2), "ms_per_step": round(1000 * e1 / args.steps, 3)}
-    if world > 1:
+    if dist_on:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -503,18 +509,18 @@ def main():
     sus_steps = max(300, int(4.0 / max(1e-4, el / args.steps)) + 1) if not args.no_sustained else 0
     sus = None
     if sus_steps:
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0s = time.perf_counter()
         for _ in range(sus_steps):
             out = step()
         drain()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         els = time.perf_counter() - t0s
-        if world > 1:
+        if dist_on:
             t = torch.tensor([els], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             els = float(t.item())
@@ -529,7 +535,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: batch={B}/GPU synthetic 768x768x3 uniform-noise tiles, full "
                                    f"EfficientNetV2-XL detector forward + NMS + GPU peak decode/100-d gather"
-                                   + (" + RCCL all-gather of boxes" if world > 1 else ""),
+                                   + (" + RCCL all-gather of boxes" if dist_on else ""),
                        "global_batch": world * B, "tile": "768x768x3", "weights": "deterministic seed 0 (random-init)",
                        "parallelism": f"dp{world}", "mean_peaks_per_tile": round(peaks, 1)},
             "ms_per_step_median": round(statistics.median(step_ms), 3),
@@ -545,7 +551,7 @@ def main():
                                               "backbone overlaps batch k's FPN heads; single_stream = the same steps on one stream")
         if sus is not None:
             result["sustained"] = sus
-        if world > 1:
+        if dist_on:
             result["gather_message_bytes_per_rank"] = out.message_bytes_per_rank
         result["host_enqueue_ms_first_step"] = round(1000 * el_enqueue, 3)
         result["path_tflops_per_gpu"] = round(value / world * GFLOP_PER_IMAGE / 1000, 2)
@@ -680,7 +686,7 @@ def main():
                 result[names[other]].update({k: result["parity"][other][k] for k in ("heatmap_linf", "features_linf", "peak_set_identical", "peak_jaccard")})
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -92,6 +92,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, c
                                                                          // widening it to fp32 at staging measured slower)
     __shared__ __attribute__((aligned(16))) float red[SLOTS * 64];
 
+    // Element index of halo pixel i.  16-bit, stride 2: a 16-lane group of a tap read covers two output pixels whose input pixels are
+    // 2 apart = 256 B = the same 32 banks twice (SQ_LDS_BANK_CONFLICT 32.5 %, profiles/r03b); swapping the two 128-byte halves of
+    // every second pixel PAIR puts them on the other 32 banks.
+    auto swz = [](int i) { return (STRIDE == 2 && sizeof(T) == 2) ? (i * 64) ^ (((i >> 1) & 1) << 6) : i * 64; };
     const int t = threadIdx.x;
     const int cq = t % LPP;         // channel group inside the 64-channel slab
     const int pt = t / LPP;         // pixel slot
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, c
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int i = pt + j * SLOTS;
-            if (i < NPX) *reinterpret_cast<u32x4*>(&tile[buf][i * 64 + cq * V]) = stage[j];
+            if (i < NPX) *reinterpret_cast<u32x4*>(&tile[buf][swz(i) + cq * V]) = stage[j];
         }
     };
 
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ in, c
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
                     float x[V];
-                    load16<T>(&tile[buf][((ly * STRIDE + r) * IW + lx * STRIDE + s) * 64 + cq * V], x);
+                    load16<T>(&tile[buf][swz((ly * STRIDE + r) * IW + lx * STRIDE + s) + cq * V], x);
 #pragma unroll
                     for (int e = 0; e < V; ++e) acc[e] = fmaf(wv[r * 3 + s][e], x[e], acc[e]);
                 }

@@ -99,7 +99,10 @@ __global__ __launch_bounds__(256) void nms_kernel(float* __restrict__ heat, int 
 // coalesced 16-byte loads (T is read once, sequentially), then lane = pixel adds the nine taps of the head's outputs.
 __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ T, const int* __restrict__ map, const float* __restrict__ bias,
                                                      float* __restrict__ out, int H, int W, int Tw, int nout, int CH, long gs, int G) {
-    extern __shared__ __attribute__((aligned(16))) float rows[];          // [18*18][Tw]
+    // [18*18][Tw + 1]: with the natural pitch (Tw = 20 floats) every address of a wave's tap read is a multiple of 4 floats, i.e. the 64
+    // lanes share 16 of the 64 banks (SQ_LDS_BANK_CONFLICT 45.7 % of the LDS cycles, profiles/r03b); an odd pitch spreads the 64
+    // pixels of a wave over 64 banks (pixel index * 21 mod 64 is a permutation; six lanes of the fourth row wrap -> 2-way).
+    extern __shared__ __attribute__((aligned(16))) float rows[];
     const int t = threadIdx.x;
     const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
     int bid = blockIdx.x;
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ T
     const bool inside = y < H && x < W;
     const long pix = ((long)b * H + y) * W + x;
     const int Q = Tw >> 2;                                                // float4 per pixel row
+    const int TP = Tw + 1;
     for (int g = 0; g < G; ++g) {
         __syncthreads();                                                  // previous head's rows are consumed
         const f32x4* Tg = reinterpret_cast<const f32x4*>(T + g * gs + (long)b * H * W * Tw);
@@ -119,7 +123,8 @@ __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ T
             const int yy = y0 - 1 + hp / 18, xx = x0 - 1 + hp % 18;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};                               // zero padding of the top convolution
             if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = Tg[((long)yy * W + xx) * Q + q];
-            reinterpret_cast<f32x4*>(rows)[c] = v;
+            float* dst = rows + hp * TP + 4 * q;
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
         }
         __syncthreads();
         if (!inside) continue;
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ T
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int s2 = 0; s2 < 3; ++s2) acc += rows[((ly + r) * 18 + lx + s2) * Tw + (r * 3 + s2) * co + o];
+                for (int s2 = 0; s2 < 3; ++s2) acc += rows[((ly + r) * 18 + lx + s2) * TP + (r * 3 + s2) * co + o];
             out[pix * CH + ch] = acc;
         }
     }
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ T
 hipError_t launch_tapsum(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
     const int nb = o.B * ((o.H + 15) / 16) * ((o.W + 15) / 16);
-    hipLaunchKernelGGL(tapsum_kernel, dim3(nb), dim3(256), (size_t)324 * o.aux0 * sizeof(float), s, (const float*)a.in, (const int*)a.w, a.bias,
+    hipLaunchKernelGGL(tapsum_kernel, dim3(nb), dim3(256), (size_t)324 * (o.aux0 + 1) * sizeof(float), s, (const float*)a.in, (const int*)a.w, a.bias,
                        (float*)a.out, o.H, o.W, o.aux0, o.aux1, o.Cout_total, (long)o.B * o.H * o.W * o.aux0, o.groups > 1 ? o.groups : 1);
     return hipGetLastError();
 }

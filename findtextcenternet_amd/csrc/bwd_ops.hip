@@ -94,22 +94,36 @@ __global__ __launch_bounds__(256) void bnbwd_partial_kernel(BnBwdP p, double* __
     int bcur = -1;
     f32x4 ga = {1.f, 1.f, 1.f, 1.f}, gb = {0.f, 0.f, 0.f, 0.f};
     float kp = 1.0f;
-    for (int r = r0 + rl; r < r1; r += RL) {
-        const int b = r / p.HW;
-        if (b != bcur) {
-            bcur = b;
-            if (p.ga) ga = *reinterpret_cast<const f32x4*>(p.ga + (long)b * p.C + c);
-            if (p.gb) gb = *reinterpret_cast<const f32x4*>(p.gb + (long)b * p.C + c);
-            if (p.keep) kp = p.keep[b];
-        }
-        const f32x4 g = (*reinterpret_cast<const f32x4*>(p.gy + (long)r * p.gs + p.goff + c) * ga + gb) * kp;
-        const f32x4 zv = *reinterpret_cast<const f32x4*>(p.z + (long)r * p.C + c);
-        const f32x4 dt = g * dact4<FAST>(zv * sc + sh, p.act);
-        const f32x4 zh = (zv - mean) * istd;
+    // four rows' loads (gradient + pre-activation) in flight before the first is consumed; same row order of the sums
+    constexpr int U = 4;
+    for (int r = r0 + rl; r < r1; r += RL * U) {
+        f32x4 gv[U], zv[U];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            s1[e] += (double)dt[e];
-            s2[e] += (double)dt[e] * (double)zh[e];
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * RL;
+            const bool ok = rr < r1;
+            gv[u] = ok ? *reinterpret_cast<const f32x4*>(p.gy + (long)rr * p.gs + p.goff + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            zv[u] = ok ? *reinterpret_cast<const f32x4*>(p.z + (long)rr * p.C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * RL;
+            if (rr >= r1) break;
+            const int b = rr / p.HW;
+            if (b != bcur) {
+                bcur = b;
+                if (p.ga) ga = *reinterpret_cast<const f32x4*>(p.ga + (long)b * p.C + c);
+                if (p.gb) gb = *reinterpret_cast<const f32x4*>(p.gb + (long)b * p.C + c);
+                if (p.keep) kp = p.keep[b];
+            }
+            const f32x4 g = (gv[u] * ga + gb) * kp;
+            const f32x4 dt = g * dact4<FAST>(zv[u] * sc + sh, p.act);
+            const f32x4 zh = (zv[u] - mean) * istd;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[e] += (double)dt[e];
+                s2[e] += (double)dt[e] * (double)zh[e];
+            }
         }
     }
 #pragma unroll
@@ -129,21 +143,26 @@ __global__ __launch_bounds__(256) void bnbwd_partial_kernel(BnBwdP p, double* __
 
 __global__ __launch_bounds__(256) void bnbwd_final_kernel(const double* __restrict__ part, float* __restrict__ ggamma, float* __restrict__ gbeta,
                                                           float* __restrict__ coef, long M, int C, int nchunk) {
-    __shared__ double red[2][4][64];                            // 64 channels x 4 chunk lanes (as bnstat_final_kernel)
-    const int t = threadIdx.x, cl = t & 63, kl = t >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double red[2][16][16];                           // 16 channels x 16 chunk lanes (as bnstat_final_kernel)
+    const int t = threadIdx.x, cl = t & 15, kl = t >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int k = kl; k < nchunk; k += 4) {
+        for (int k = kl; k < nchunk; k += 16) {
             s1 += part[((long)k * 2 + 0) * C + c];
             s2 += part[((long)k * 2 + 1) * C + c];
         }
     red[0][kl][cl] = s1;
     red[1][kl][cl] = s2;
     __syncthreads();
-    if (t >= 64 || c >= C) return;
-    s1 = (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
-    s2 = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+    if (t >= 16 || c >= C) return;
+    s1 = 0.0;
+    s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        s1 += red[0][k][t];
+        s2 += red[1][k][t];
+    }
     if (gbeta) gbeta[c] += (float)s1;
     if (ggamma) ggamma[c] += (float)s2;
     coef[c] = (float)(s1 / (double)M);
@@ -705,7 +724,7 @@ hipError_t bnbwd_run(const BnBwdP& p, double* part, float* coef, float* ggamma, 
     hipLaunchKernelGGL((bnbwd_partial_kernel<Q, FAST>), grid, dim3(256), 0, s, p, part, nchunk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bnbwd_final_kernel, dim3((p.C + 63) / 64), dim3(256), 0, s, part, ggamma, gbeta, coef, (long)p.M, p.C, nchunk);
+    hipLaunchKernelGGL(bnbwd_final_kernel, dim3((p.C + 15) / 16), dim3(256), 0, s, part, ggamma, gbeta, coef, (long)p.M, p.C, nchunk);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // the apply pass streams: enough row chunks to fill the GPU (the partial pass is bound to the scratch layout's chunk count)
@@ -749,7 +768,7 @@ hipError_t launch_bnbwd(const OpArgs& a, hipStream_t s) {
 hipError_t launch_dwbwd(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
     const long M = (long)o.B * o.Ho * o.Wo;
-    const int nchunk = ftc_bnstat_chunks(M), C = o.Cin;
+    const int nchunk = ftc_chunks256(M), C = o.Cin;
     hipLaunchKernelGGL(dwbwd_data_kernel, dim3(nblocks((long)o.B * o.H * o.W * (C / 4))), dim3(256), 0, s, (const float*)a.in2, (const float*)a.w, (float*)a.out,
                        o.B, o.H, o.W, o.Ho, o.Wo, C, o.stride);
     hipError_t e = hipGetLastError();
@@ -829,7 +848,7 @@ hipError_t launch_topdgrad(const OpArgs& a, hipStream_t s) {
 hipError_t launch_colsum(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
     const long M = (long)o.B * o.H * o.W;
-    const int nchunk = ftc_bnstat_chunks(M), C = o.Cin;
+    const int nchunk = ftc_chunks256(M), C = o.Cin;
     double* part = reinterpret_cast<double*>(a.aux);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, (const float*)a.in, part, M, C, o.Cin_total > 0 ? o.Cin_total : C, o.cin_off,
                        nchunk);

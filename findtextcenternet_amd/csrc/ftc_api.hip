@@ -246,7 +246,7 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if (o.Ho != (o.H - 1) / o.stride + 1 || o.Wo != (o.W - 1) / o.stride + 1) return "dwbwd: Ho/Wo inconsistent";
         if (!need(o.in, true, "in", pin * o.Cin * 4) || !need(o.in2, true, "in2", pout * o.Cin * 4) || !need(o.w, true, "w", (int64_t)9 * o.Cin * 4) ||
             !need(o.out, true, "out", pin * o.Cin * 4) || !need(o.out2, true, "out2", (int64_t)9 * o.Cin * 4) ||
-            !need(o.aux, true, "aux", (int64_t)ftc_bnstat_chunks(pout) * 9 * o.Cin * 8)) return why->c_str();
+            !need(o.aux, true, "aux", (int64_t)ftc_chunks256(pout) * 9 * o.Cin * 8)) return why->c_str();
         return nullptr;
     case FTC_OP_SEBWD:
         if (o.Cin <= 0 || (o.Cin & 3) || o.aux0 <= 0 || o.aux1 <= 0) return "sebwd: C (% 4 == 0), S, P must be positive";
@@ -271,7 +271,7 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
     case FTC_OP_COLSUM: {
         const int64_t ct = o.Cin_total > 0 ? o.Cin_total : o.Cin;
         if (o.Cin <= 0 || o.cin_off + o.Cin > ct) return "colsum: bad column slice";
-        if (!need(o.in, true, "in", pin * ct * 4) || !need(o.out, true, "out", (int64_t)o.Cin * 4) || !need(o.aux, true, "aux", (int64_t)ftc_bnstat_chunks(pin) * o.Cin * 8)) return why->c_str();
+        if (!need(o.in, true, "in", pin * ct * 4) || !need(o.out, true, "out", (int64_t)o.Cin * 4) || !need(o.aux, true, "aux", (int64_t)ftc_chunks256(pin) * o.Cin * 8)) return why->c_str();
         return nullptr;
     }
     case FTC_OP_STEMWGRAD:

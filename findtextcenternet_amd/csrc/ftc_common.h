@@ -212,7 +212,11 @@ hipError_t launch_dwconv(const OpArgs& a, hipStream_t s);
 hipError_t launch_bnstat(const OpArgs& a, hipStream_t s);
 hipError_t launch_bnact(const OpArgs& a, hipStream_t s);
 // FTC_OP_BNSTAT: number of row chunks the partial sums are split into
-inline int ftc_bnstat_chunks(long M) { const long n = (M + 255) / 256; return (int)(n < 1 ? 1 : n > 512 ? 512 : n); }
+// (64 rows per chunk up to 512 chunks: a 24x24-map layer has 4608 rows -- with 256-row chunks its partial pass was 200 workgroups of 64
+//  serial loads each, slower than the streaming it does)
+inline int ftc_bnstat_chunks(long M) { const long n = (M + 63) / 64; return (int)(n < 1 ? 1 : n > 512 ? 512 : n); }
+// row chunks of the depthwise weight-gradient and column-sum partial passes (256 rows each)
+inline int ftc_chunks256(long M) { const long n = (M + 255) / 256; return (int)(n < 1 ? 1 : n > 512 ? 512 : n); }
 inline int ftc_stemwgrad_chunks(long M) { const long n = (M + 255) / 256; return (int)(n < 1 ? 1 : n > 2048 ? 2048 : n); }
 // train step (bwd_ops.hip, wgrad.hip)
 hipError_t launch_bnbwd(const OpArgs& a, hipStream_t s);

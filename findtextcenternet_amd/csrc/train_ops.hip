@@ -346,14 +346,24 @@ __global__ __launch_bounds__(256) void bnstat_partial_q_kernel(const float* __re
     const int rows = (M + nchunk - 1) / nchunk;
     const int r0 = chunk * rows, r1 = min(M, r0 + rows);
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int r = r0 + rl; r < r1; r += RL) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (long)r * C + c);
+    // eight rows' loads in flight before the first is consumed (the plain loop issued one 16-byte load per trip and waited for it);
+    // the sums are taken in the same row order
+    constexpr int U = 8;
+    for (int r = r0 + rl; r < r1; r += RL * U) {
+        f32x4 v[U];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const double d = (double)v[e];
-            s1[e] += d;
-            s2[e] += d * d;
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * RL;
+            v[u] = rr < r1 ? *reinterpret_cast<const f32x4*>(x + (long)rr * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double d = (double)v[u][e];
+                s1[e] += d;
+                s2[e] += d * d;
+            }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -370,26 +380,31 @@ __global__ __launch_bounds__(256) void bnstat_partial_q_kernel(const float* __re
     }
 }
 
-// 64 channels x 4 chunk lanes per workgroup: lane k sums chunks k, k+4, ... (one thread per channel walking up to 512 chunks made this
-// kernel, not the streaming pass, the larger half of a BNSTAT op)
+// 16 channels x 16 chunk lanes per workgroup: lane k sums chunks k, k+16, ... in a fixed order (one thread per channel walking up to
+// 512 chunks made this kernel, not the streaming pass, the larger half of a BNSTAT op)
 __global__ __launch_bounds__(256) void bnstat_final_kernel(const double* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ running, float* __restrict__ out, long M, int C, int nchunk, float eps,
                                                            float momentum) {
-    __shared__ double red[2][4][64];
-    const int t = threadIdx.x, cl = t & 63, kl = t >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double red[2][16][16];
+    const int t = threadIdx.x, cl = t & 15, kl = t >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C)
-        for (int k = kl; k < nchunk; k += 4) {
+        for (int k = kl; k < nchunk; k += 16) {
             s1 += part[((long)k * 2 + 0) * C + c];
             s2 += part[((long)k * 2 + 1) * C + c];
         }
     red[0][kl][cl] = s1;
     red[1][kl][cl] = s2;
     __syncthreads();
-    if (t >= 64 || c >= C) return;
-    s1 = (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]);
-    s2 = (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]);
+    if (t >= 16 || c >= C) return;
+    s1 = 0.0;
+    s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        s1 += red[0][k][t];
+        s2 += red[1][k][t];
+    }
     const double mean = s1 / (double)M;
     double var = s2 / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -461,7 +476,7 @@ hipError_t launch_bnstat(const OpArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL(bnstat_partial_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)a.in, part, M, C, nchunk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(bnstat_final_kernel, dim3((C + 63) / 64), dim3(256), 0, s, part, (const float*)a.w, a.bias, a.aux, (float*)a.out, M, C, nchunk, eps, mom);
+    hipLaunchKernelGGL(bnstat_final_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, (const float*)a.w, a.bias, a.aux, (float*)a.out, M, C, nchunk, eps, mom);
     return hipGetLastError();
 }
 

@@ -18,6 +18,40 @@ template <typename WT> struct WFrag;
 template <> struct WFrag<__bf16> { using type = bf16x8; };
 template <> struct WFrag<_Float16> { using type = f16x8; };
 
+// gfx950 LDS transpose read: inside every 16-lane group, lane 4*j + q supplies the address of 4 consecutive 16-bit elements = columns
+// 4q..4q+3 of row j of a 4 x 16 block, and lane i receives column i of the four rows (measured: tools/ubench/tr16_probe.hip).  With it an
+// MFMA fragment along the PIXEL axis comes straight out of the [pixel][channel] image the operands have in memory: no register transpose.
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
+template <typename WT>
+__device__ __forceinline__ typename WFrag<WT>::type tr_frag(const WT* lo_rows, int hi_off) {
+    typedef short v8i16 __attribute__((ext_vector_type(8)));
+    const v4i16 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)lo_rows);
+    const v4i16 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(lo_rows + hi_off));
+    const v8i16 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(typename WFrag<WT>::type, v);
+}
+// 16-byte chunk swizzle of row `row` of a [pixel][channel] image with `pitch_bytes` per row: the four rows a 16-lane group reads land in
+// four different 64-byte bank quadrants
+__device__ __forceinline__ int tr_swz(int row, int pitch_bytes) {
+    return pitch_bytes % 256 == 0 ? (row & 3) << 2 : pitch_bytes % 128 == 0 ? ((row >> 1) & 1) << 2 : 0;
+}
+
+// Workgroup -> (x, y, z) of the launch grid such that the pixel split z is the SLOWEST index of what one XCD runs: the hardware hands
+// consecutive workgroups to the 8 XCDs round-robin, so with the plain blockIdx decode every XCD saw every pixel split and each operand
+// slice crossed HBM once per tile of the OTHER operand (stage-6 expand: 226 MB for 33 MB of operands).  Here XCD k owns the k-th
+// eighth of the split-major order: a split's slices of both operands (a few MB) are fetched into that XCD's L2 once and re-read there.
+__device__ __forceinline__ void xcd_major_block(int& bx, int& by, int& bz) {
+    const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * (int)gridDim.z;
+    const int L = (int)blockIdx.x + gx * ((int)blockIdx.y + gy * (int)blockIdx.z);
+    const int q = total >> 3, r = total & 7, xcd = L & 7, k = L >> 3;
+    const int Lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    bz = Lp / (gx * gy);
+    const int rem = Lp - bz * gx * gy;
+    by = rem / gx;
+    bx = rem - by * gx;
+}
+
 struct WgradP {
     const void* x; const void* dz; const float* se; float* part;
     int B, H, W, Ho, Wo, Cin, CinT, cin_off, Cout, CoutT, cout_off, KS, stride, pad;
@@ -136,13 +170,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
     using SA = Stager<WT, DT>;
     using SB = Stager<WT, XT>;
     constexpr int CHA = SA::CH, CHB = SB::CH;
+    // Both operands are 16-bit copies in the compute type: the LDS images stay [pixel][channel] (a staging task = eight plain 16-byte
+    // stores, no v_perm transposes -- they cost as many VALU cycles as the step's MFMAs), and the fragments are transpose reads.
+    constexpr bool TR = sizeof(WT) == 2 && sizeof(XT) == 2 && sizeof(DT) == 2;
     constexpr int NTA = (BM / CHA) * OCT, NTB = (BN / CHB) * OCT;       // staging tasks per operand (<= 256 each: launch_wgrad picks the tile accordingly)
     __shared__ __attribute__((aligned(16))) WT As[BM * LD];
     __shared__ __attribute__((aligned(16))) WT Bs[BN * LD];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int KK = p.KS * p.KS;
-    const int mt = blockIdx.x, nt = blockIdx.y / KK, tap = blockIdx.y - nt * KK, split = blockIdx.z;
+    int bx, by, split;
+    xcd_major_block(bx, by, split);
+    const int mt = bx, nt = by / KK, tap = by - nt * KK;
     const int tr = tap / p.KS, ts = tap - tr * p.KS;
     const long k0 = (long)split * p.chunk, k1 = k0 + p.chunk < p.P ? k0 + p.chunk : p.P;
     const bool a_vec = (p.CoutT % CHA == 0) && (p.cout_off % CHA == 0);
@@ -197,6 +236,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
         }
     };
     auto stage = [&]() {
+        if constexpr (TR) {
+            if (a_on) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = a_po * 8 + i;
+                    *reinterpret_cast<u32x4*>(As + row * BM + ((a_cq ^ tr_swz(row, BM * 2)) << 3)) = sa.r[i];
+                }
+            }
+            if (b_on) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = b_po * 8 + i;
+                    *reinterpret_cast<u32x4*>(Bs + row * BN + ((b_cq ^ tr_swz(row, BN * 2)) << 3)) = sb.r[i];
+                }
+            }
+            return;
+        }
         if (a_on) {
 #pragma unroll
             for (int j = 0; j < CHA; ++j) sa.put(As + (a_cq * CHA + j) * LD + a_po * 8, j);
@@ -216,6 +272,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int fr = lane & 31, fk = (lane >> 5) * 8;
+    // transpose-read addresses (elements): lane = 16 * g + 4 * j + q reads row (g >> 1) * 8 + j (+ 4 for the upper half of the fragment),
+    // columns (g & 1) * 16 + 4 * q .. + 3 of its 32-channel block
+    int tra[TM], trb[TN];
+    if constexpr (TR) {
+        const int g = lane >> 4, rowl = (g >> 1) * 8 + ((lane >> 2) & 3), coll = (g & 1) * 16 + (lane & 3) * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int col = (wm * TM + i) * 32 + coll;
+            tra[i] = rowl * BM + (((col >> 3) ^ tr_swz(rowl, BM * 2)) << 3) + (col & 7);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = (wn * TN + j) * 32 + coll;
+            trb[j] = rowl * BN + (((col >> 3) ^ tr_swz(rowl, BN * 2)) << 3) + (col & 7);
+        }
+    }
     if (k0 < k1) fetch(k0);
     for (long kb = k0; kb < k1; kb += BK) {
         stage();
@@ -247,10 +319,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
             } else {
                 using F = typename WFrag<WT>::type;
                 F af[TM], bf[TN];
+                if constexpr (TR) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const F*>(As + ((wm * TM + i) * 32 + fr) * LD + kk * 16 + fk);
+                    for (int i = 0; i < TM; ++i) af[i] = tr_frag<WT>(As + tra[i] + kk * 16 * BM, 4 * BM);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const F*>(Bs + ((wn * TN + j) * 32 + fr) * LD + kk * 16 + fk);
+                    for (int j = 0; j < TN; ++j) bf[j] = tr_frag<WT>(Bs + trb[j] + kk * 16 * BN, 4 * BN);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const F*>(As + ((wm * TM + i) * 32 + fr) * LD + kk * 16 + fk);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const F*>(Bs + ((wn * TN + j) * 32 + fr) * LD + kk * 16 + fk);
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -296,7 +375,8 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(WgradP p, int nseg, long st
     __shared__ __attribute__((aligned(16))) WT Ls[10 * 64 * LD];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int mt = blockIdx.x, nt = blockIdx.y, split = blockIdx.z;
+    int mt, nt, split;
+    xcd_major_block(mt, nt, split);
     // K steps walk DOWN an image column segment (step = (image, x segment) * Ho + y): consecutive steps share two of their three input
     // rows, which stay in the LDS ring -- only row y + 1 is staged per step (3 shifted tiles + the gradient tile = 128 tasks instead of 320)
     const long total = (long)p.B * nseg * p.Ho;

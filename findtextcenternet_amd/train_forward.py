@@ -171,7 +171,7 @@ class TrainForward:
         # BatchNorm with batch statistics (+ activation, keep-scale * branch + residual, SE sums) on z [B,h,w,c] fp32
         def bn(self, z, h, w, c, bn_name, eps, act, residual=None, keep=None, sums_p=0):
             M = self.B * h * w
-            nchunk = max(1, min(512, -(-M // 256)))
+            nchunk = max(1, min(512, -(-M // 64)))
             ss = ("ws", self.buf(4 * c * 4), 0)                 # scale | shift | mean | 1/std (FTC_OP_BNSTAT)
             part = ("ws", self.buf(nchunk * 2 * c * 8), 0)
             self.emit(kind=L.OP_BNSTAT, in_dtype=L.F32, B=self.B, H=h, W=w, Cin=c, aux0=_fbits(eps), aux1=_fbits(0.1), in_=z, w=self.w(bn_name + ".weight"),
@@ -265,7 +265,7 @@ class TrainForward:
                 ti = n - 1 - lvl
                 # the head's input BatchNorm of the tap: statistics here, the affine applied by the upsample+concat kernel
                 M = B * th_ * tw_
-                nchunk = max(1, min(512, -(-M // 256)))
+                nchunk = max(1, min(512, -(-M // 64)))
                 ss = ("ws", g.buf(4 * tc * 4), 0)
                 g.emit(kind=L.OP_BNSTAT, in_dtype=L.F32, B=B, H=th_, W=tw_, Cin=tc, aux0=_fbits(HEAD_EPS), aux1=_fbits(0.1), in_=tx,
                        w=g.w(f"{hp}.in_bn.{ti}.weight"), bias=g.w(f"{hp}.in_bn.{ti}.bias"), aux=g.w(f"{hp}.in_bn.{ti}.running"), out=ss,

@@ -243,7 +243,7 @@ class TrainStep:
         def bnstat(self, z, h, w, c, bn_name, eps, B=None):
             B = B or self.B
             M = B * h * w
-            nchunk = max(1, min(512, -(-M // 256)))
+            nchunk = max(1, min(512, -(-M // 64)))
             ss = self.buf(4 * c * 4)
             self.emit(bn_name, kind=L.OP_BNSTAT, in_dtype=L.F32, B=B, H=h, W=w, Cin=c, aux0=_fbits(eps), aux1=_fbits(0.1), in_=z, w=self.w(bn_name + ".weight"),
                       bias=self.w(bn_name + ".bias"), aux=self.w(bn_name + ".running"), out=ss, in2=self.buf(nchunk * 2 * c * 8))
@@ -272,7 +272,7 @@ class TrainStep:
             """-> (dz fp32 | None, dz 16-bit | None): dz of a convolution's BatchNorm is read by that convolution's two GEMMs only."""
             B = B or self.B
             M = B * h * w
-            nchunk = max(1, min(512, -(-M // 256)))
+            nchunk = max(1, min(512, -(-M // 64)))
             want16 = want16 and self.h16 and out is None
             want32 = want32 or not want16 or out is not None
             d32 = out if out is not None else (self.buf(M * c * 4) if want32 else None)

@@ -31,7 +31,7 @@ def _fbits(v):
 
 
 def _chunks(M, cap=512):
-    return max(1, min(cap, -(-M // 256)))
+    return max(1, min(cap, -(-M // 64)))
 
 
 @pytest.mark.parametrize("act", [L.ACT_NONE, L.ACT_SILU, L.ACT_GELU], ids=["none", "silu", "gelu"])

@@ -623,7 +623,7 @@ def test_training_mode_batchnorm_ops(shape, cfg):
     y = F.batch_norm(x.permute(0, 3, 1, 2), rm_ref, rv_ref, gamma, beta, True, mom, eps)
     ref = F.silu(y).permute(0, 2, 3, 1) * keep[:, None, None, None] + res
     M = B * H * W
-    nchunk = max(1, min(512, -(-M // 256)))
+    nchunk = max(1, min(512, -(-M // 64)))
     P = 3
     ar = Arena()
     o_x, o_g, o_b, o_res, o_keep = ar.put(to_dev_bytes(x, idt)), ar.put(gamma), ar.put(beta), ar.put(res), ar.put(keep)

@@ -58,3 +58,17 @@ for lab, (t, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
 slow = sorted(((float(v), i) for i, v in enumerate(a)), reverse=True)[:25]
 for v, i in slow:
     print(f"  op {i:5d} {v:7.3f} ms  {plan['names'][i]}")
+# weight-gradient ops by shape: time and TFLOP/s
+wg = collections.defaultdict(lambda: [0.0, 0, 0.0])
+for i in range(plan["n_ops"]):
+    o = plan["ops"][i]
+    if o.kind != L.OP_WGRAD:
+        continue
+    P = o.B * o.Ho * o.Wo
+    key = (o.Cout, o.Cin, o.ksize, o.stride, P, o.aux0, o.in_dtype, o.res_dtype, bool(o.flags & L.FLAG_SE_SCALE))
+    wg[key][0] += float(a[i])
+    wg[key][1] += 1
+    wg[key][2] += 2.0 * P * o.Cout * o.Cin * o.ksize * o.ksize
+print("wgrad by shape (Cout, Cin, k, stride, pixels, splits, x dtype, dz dtype, se): ms total, n, TFLOP/s")
+for key, (t, n, fl) in sorted(wg.items(), key=lambda kv: -kv[1][0]):
+    print(f"  {t:7.2f} ms {n:3d}  {fl / (t * 1e-3) / 1e12:7.1f} TF  {key}")

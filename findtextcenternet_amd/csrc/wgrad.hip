@@ -57,6 +57,7 @@ struct WgradP {
     int B, H, W, Ho, Wo, Cin, CinT, cin_off, Cout, CoutT, cout_off, KS, stride, pad;
     long P;          // B * Ho * Wo
     long chunk;      // pixels per split (multiple of BK)
+    int se_epi;      // the SE gate multiplies the partial tile's columns (every split lies inside one image) instead of every staged element
 };
 
 template <typename WT> __device__ __forceinline__ WT narrow(float v);
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
                     }
                     if (ok) {
                         sb.load(i, static_cast<const XT*>(p.x), row, p.CinT, p.cin_off, n0, p.Cin, b_vec);
-                        if (p.se) sb.scale(i, p.se + (long)b * p.Cin + n0, n0, p.Cin);
+                        if (p.se && !p.se_epi) sb.scale(i, p.se + (long)b * p.Cin + n0, n0, p.Cin);
                     }
                 }
             }
@@ -349,10 +350,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
         for (int j = 0; j < TN; ++j) {
             const int n = nt * BN + (wn * TN + j) * 32 + (lane & 31);
             if (n >= p.Cin) continue;
+            // sum_p dz[p][m] * (x[p][n] * g[b][n]) = g[b][n] * sum_p dz[p][m] * x[p][n] when all of this split's pixels are in image b
+            const float gate = p.se_epi ? p.se[(k0 / HoWo) * p.Cin + n] : 1.0f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = mt * BM + (wm * TM + i) * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
-                if (m < p.Cout) pp[(long)m * p.Cin + n] = acc[i][j][e];
+                if (m < p.Cout) pp[(long)m * p.Cin + n] = acc[i][j][e] * gate;
             }
         }
 }
@@ -557,6 +560,8 @@ hipError_t launch_wgrad(const OpArgs& a, hipStream_t s) {
     const int S = o.aux0 > 0 ? o.aux0 : 1;
     const int BK = o.w_dtype == FTC_F32 ? 32 : 64;
     p.chunk = ((p.P + S - 1) / S + BK - 1) / BK * BK;
+    const long HoWo = (long)o.Ho * o.Wo;
+    p.se_epi = (p.se && o.ksize == 1 && o.stride == 1 && HoWo % p.chunk == 0) ? 1 : 0;
     const int KK = o.ksize * o.ksize;
     if (wgrad3_shape(o.Wo, o.Cout, o.Cin, o.ksize) && o.stride == 1 && ftc_is16(o.w_dtype) && o.in_dtype == o.w_dtype && o.res_dtype == o.w_dtype && !p.se &&
         !(o.flags & 0x100)) {                                    // (0x100: the generic kernel, for A/B measurements)

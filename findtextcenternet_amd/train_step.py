@@ -286,6 +286,14 @@ class TrainStep:
             B = B or self.B
             ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
             S = int(self.lib.ftc_wgrad_splits(B, ho, wo, cout, cin, k))
+            if se is not None and k == 1 and stride == 1:
+                # SE-gated input (the project convolution): splits that each lie inside ONE image let the kernel apply the gate to the
+                # columns of the partial tile instead of to every staged element (FTC_OP_WGRAD does so when Ho*Wo % chunk == 0)
+                kk = max(1, round(S / B))
+                while kk > 1 and (ho * wo) % (kk * 64):
+                    kk -= 1
+                if (ho * wo) % (kk * 64) == 0:
+                    S = B * kk
             xin, xdt = self.pick(x)
             din, ddt = self.pick(dz)
             self.emit("wgrad:" + wname, kind=L.OP_WGRAD, flags=L.FLAG_SE_SCALE if se is not None else 0, w_dtype=self.cdt, in_dtype=xdt, res_dtype=ddt, B=B, H=h,

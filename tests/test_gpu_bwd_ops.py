@@ -102,6 +102,9 @@ WG_CASES = [  # name, B,H,W, Cin,CinT,cin_off, Cout,CoutT,cout_off, k, stride, s
     ("c3n_288_192_w32", 1, 5, 32, 288, 288, 0, 192, 192, 0, 3, 1, False),
     ("c3n_slices_w96", 1, 4, 96, 40, 72, 32, 100, 128, 8, 3, 1, False),
     ("c3n_many_rows", 3, 33, 32, 32, 32, 0, 64, 64, 0, 3, 1, False),
+    # SE-gated input with one or two splits per image: the gate multiplies the partial tile's columns instead of the staged elements
+    ("se_image_splits", 4, 16, 16, 96, 96, 0, 40, 40, 0, 1, 1, True),
+    ("se_image_splits_slices", 3, 16, 8, 72, 80, 8, 136, 136, 0, 1, 1, True),
 ]
 
 
@@ -130,6 +133,9 @@ def test_wgrad(case, wd, io):
     F.conv2d(round16(xe, wd).permute(0, 3, 1, 2), w, None, stride, pad).backward(round16(dz, wd).permute(0, 3, 1, 2))
     lib = L.load()
     S = int(lib.ftc_wgrad_splits(B, Ho, Wo, Cout, Cin, k))
+    if case[0].startswith("se_image_splits"):                  # (what TrainStep._G.wgrad asks for when the input is gated)
+        S = B * (2 if (Ho * Wo) % 128 == 0 and case[0].endswith("slices") is False else 1)
+        assert (Ho * Wo) % (S // B * 64) == 0
     pre = torch.randn(Cout, Cin, k, k, generator=g)
     ar = Arena()
     o_x, o_dz, o_out = ar.put(to_dev_bytes(x_full, xdt)), ar.put(to_dev_bytes(dz_full, ddt)), ar.put(pre)

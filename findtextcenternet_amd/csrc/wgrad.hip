@@ -491,6 +491,79 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(WgradP p, int nseg, long st
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// THIN weight gradient: a 3x3 (or 1x1) stride-1 convolution with ONE or TWO output channels (the map heads' top convolutions: 192 -> 1 | 2).
+// On the matrix cores 31 of a tile's 32 rows were padding and each of the nine taps re-read the activation: 550 us per head at 1.8 TFLOP/s
+// for what is a weighted column sum.  Here every INPUT pixel q is read once: lane = (pixel slot, CH-channel group) keeps
+// acc[co][tap][CH] += dz[q - tap offset][co] * x[q][ch] in registers (the nine dz values of a pixel are broadcast loads), the slots of a
+// workgroup meet in LDS in a fixed order, and the workgroup writes one partial block in the layout wgrad_reduce_kernel sums.
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename XT, int CO, int KS>
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(WgradP p) {
+    constexpr int CH = 16 / (int)sizeof(XT);
+    __shared__ float red[256 * CH];
+    const int t = threadIdx.x;
+    const int NQ = p.Cin / CH;                                 // lanes per pixel (Cin % CH == 0, NQ <= 256: launch_wgrad checks)
+    const int slots = 256 / NQ;
+    const int slot = t / NQ, cq = t - slot * NQ;
+    constexpr int KK = KS * KS, pad = (KS - 1) / 2;
+    const long k0 = (long)blockIdx.x * p.chunk, k1 = k0 + p.chunk < p.P ? k0 + p.chunk : p.P;      // (P = B*H*W: stride 1, same padding)
+    float acc[CO][KK][CH];
+#pragma unroll
+    for (int c = 0; c < CO; ++c)
+#pragma unroll
+        for (int k = 0; k < KK; ++k)
+#pragma unroll
+            for (int e = 0; e < CH; ++e) acc[c][k][e] = 0.f;
+    const XT* xb = static_cast<const XT*>(p.x);
+    const float* dzb = static_cast<const float*>(p.dz);
+    if (slot < slots) {
+        for (long q = k0 + slot; q < k1; q += slots) {
+            const int b = (int)(q / ((long)p.H * p.W));
+            const int rem = (int)(q - (long)b * p.H * p.W);
+            const int iy = rem / p.W, ix = rem - iy * p.W;
+            float xv[CH];
+            load16<XT>(xb + q * p.CinT + p.cin_off + cq * CH, xv);
+#pragma unroll
+            for (int k = 0; k < KK; ++k) {
+                const int r = k / KS, s2 = k - r * KS;
+                const int oy = iy - r + pad, ox = ix - s2 + pad;                 // the output pixel whose tap (r, s2) lands on q
+                if ((unsigned)oy >= (unsigned)p.Ho || (unsigned)ox >= (unsigned)p.Wo) continue;
+                const float* dq = dzb + (((long)b * p.Ho + oy) * p.Wo + ox) * p.CoutT + p.cout_off;
+#pragma unroll
+                for (int c = 0; c < CO; ++c) {
+                    const float d = c < p.Cout ? dq[c] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) acc[c][k][e] = fmaf(d, xv[e], acc[c][k][e]);
+                }
+            }
+        }
+    }
+    float* pp = p.part + (long)blockIdx.x * KK * p.Cout * p.Cin;
+#pragma unroll
+    for (int c = 0; c < CO; ++c)
+        for (int k = 0; k < KK; ++k) {
+            if (c >= p.Cout) break;
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                float v = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk)
+                    if (kk == k) v = acc[c][kk][e];
+                red[t * CH + e] = slot < slots ? v : 0.f;
+            }
+            __syncthreads();
+            for (int n = t; n < p.Cin; n += 256) {
+                float v = 0.f;
+                for (int sl = 0; sl < slots; ++sl) v += red[(sl * NQ + n / CH) * CH + n % CH];
+                pp[((long)k * p.Cout + c) * p.Cin + n] = v;
+            }
+        }
+}
+
+inline bool wgrad_thin_shape(int Cout, int Cin, int ksize, int stride) { return Cout <= 2 && stride == 1 && (ksize == 3 || ksize == 1) && Cin % 8 == 0 && Cin <= 1024; }
+
 inline bool wgrad3_shape(int Wo, int Cout, int Cin, int ksize) { return ksize == 3 && Wo % 32 == 0 && Cout >= 32 && Cin >= 32; }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int S, int KK, int Cout, int Cin) {
@@ -538,6 +611,10 @@ int ftc_wgrad_splits_impl(int B, int Ho, int Wo, int Cout, int Cin, int ksize) {
     long tiles = (long)((Cout + c.BM - 1) / c.BM) * ((Cin + c.BN - 1) / c.BN) * ksize * ksize;
     if (wgrad3_shape(Wo, Cout, Cin, ksize)) tiles = (long)((Cout + 63) / 64) * ((Cin + 63) / 64);      // the nine-tap kernel: 64 x 64 tiles, taps inside
     const long P = (long)B * Ho * Wo;
+    if (wgrad_thin_shape(Cout, Cin, ksize, 1)) {                  // (the thin kernel: one workgroup per ~1024 pixels, at most 512)
+        const long st = (P + 1023) / 1024;
+        return (int)(st < 1 ? 1 : st > 512 ? 512 : st);
+    }
     long S = (1536 + tiles - 1) / tiles;                          // ~6 workgroups per CU in flight
     // ... but every split writes (and the reduction re-reads) a full fp32 copy of the gradient: on the deep stages (4608 pixels, 1.5 M
     // weights) 16 splits moved 200 MB of partial sums around 33 MB of operands.  At least 1024 pixels (16 K steps) per split.
@@ -563,6 +640,21 @@ hipError_t launch_wgrad(const OpArgs& a, hipStream_t s) {
     const long HoWo = (long)o.Ho * o.Wo;
     p.se_epi = (p.se && o.ksize == 1 && o.stride == 1 && HoWo % p.chunk == 0) ? 1 : 0;
     const int KK = o.ksize * o.ksize;
+    if (wgrad_thin_shape(o.Cout, o.Cin, o.ksize, o.stride) && o.res_dtype == FTC_F32 && !p.se && o.H == o.Ho && o.W == o.Wo && !(o.flags & 0x100) &&
+        p.CinT % 8 == 0 && p.cin_off % 8 == 0) {
+        p.chunk = (p.P + S - 1) / S;
+#define THIN(XT) do { if (o.ksize == 3) { if (o.Cout == 1) hipLaunchKernelGGL((wgrad_thin_kernel<XT, 1, 3>), dim3(S), dim3(256), 0, s, p); \
+                                           else hipLaunchKernelGGL((wgrad_thin_kernel<XT, 2, 3>), dim3(S), dim3(256), 0, s, p); } \
+                      else { if (o.Cout == 1) hipLaunchKernelGGL((wgrad_thin_kernel<XT, 1, 1>), dim3(S), dim3(256), 0, s, p); \
+                             else hipLaunchKernelGGL((wgrad_thin_kernel<XT, 2, 1>), dim3(S), dim3(256), 0, s, p); } } while (0)
+        if (o.in_dtype == FTC_F32) THIN(float); else if (o.in_dtype == FTC_F16) THIN(_Float16); else THIN(__bf16);
+#undef THIN
+        hipError_t et = hipGetLastError();
+        if (et != hipSuccess) return et;
+        const long pert = (long)KK * o.Cout * o.Cin;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((pert + 255) / 256)), dim3(256), 0, s, a.aux, (float*)a.out, S, KK, o.Cout, o.Cin);
+        return hipGetLastError();
+    }
     if (wgrad3_shape(o.Wo, o.Cout, o.Cin, o.ksize) && o.stride == 1 && ftc_is16(o.w_dtype) && o.in_dtype == o.w_dtype && o.res_dtype == o.w_dtype && !p.se &&
         !(o.flags & 0x100)) {                                    // (0x100: the generic kernel, for A/B measurements)
         const int nseg = o.Wo / 32;

@@ -102,6 +102,10 @@ WG_CASES = [  # name, B,H,W, Cin,CinT,cin_off, Cout,CoutT,cout_off, k, stride, s
     ("c3n_288_192_w32", 1, 5, 32, 288, 288, 0, 192, 192, 0, 3, 1, False),
     ("c3n_slices_w96", 1, 4, 96, 40, 72, 32, 100, 128, 8, 3, 1, False),
     ("c3n_many_rows", 3, 33, 32, 32, 32, 0, 64, 64, 0, 3, 1, False),
+    # one or two output channels: the thin (column-sum) kernel when the output gradient is fp32
+    ("thin_1_of_9", 2, 12, 16, 192, 192, 0, 1, 9, 3, 3, 1, False),
+    ("thin_2_of_9", 3, 9, 11, 64, 72, 8, 2, 9, 5, 3, 1, False),
+    ("thin_1x1", 2, 40, 40, 96, 96, 0, 2, 2, 0, 1, 1, False),
     # SE-gated input with one or two splits per image: the gate multiplies the partial tile's columns instead of the staged elements
     ("se_image_splits", 4, 16, 16, 96, 96, 0, 40, 40, 0, 1, 1, True),
     ("se_image_splits_slices", 3, 16, 8, 72, 80, 8, 136, 136, 0, 1, 1, True),

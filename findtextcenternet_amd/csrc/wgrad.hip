@@ -289,6 +289,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradP p) {
             trb[j] = rowl * BN + (((col >> 3) ^ tr_swz(rowl, BN * 2)) << 3) + (col & 7);
         }
     }
+    // (a second staging set so that the loads run two K steps ahead was measured: 242 + 64 registers = one wave per SIMD instead of two,
+    //  1x1 layers 15.1 -> 22.9 ms per step)
     if (k0 < k1) fetch(k0);
     for (long kb = k0; kb < k1; kb += BK) {
         stage();
@@ -492,6 +494,245 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(WgradP p, int nseg, long st
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// The nine-tap kernel on TRANSPOSE READS (everything 8-channel aligned): the LDS images are [pixel][64 channels] exactly as in memory,
+// so (1) a tap's one-pixel shift is a ROW offset of the fragment read -- no pre-shifted copies: a step stages ONE activation row of 34
+// pixels and one gradient row of 32 (528 plain 16-byte stores per workgroup instead of 128 tasks of 8 loads + 64 v_perm + 8 stores),
+// (2) the staging registers of a step are two or three 16-byte values per thread, so the loads run TWO steps ahead of their use.
+// Ring of four activation rows (three live, one being filled) and two gradient rows: one barrier per step.
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename WT>
+__global__ __launch_bounds__(256) void wgrad3t_kernel(WgradP p, int nseg, long steps_per_split) {
+    constexpr int XROW = 34 * 64, DROW = 32 * 64;              // elements per ring row
+    __shared__ __attribute__((aligned(16))) WT XR[4 * XROW];
+    __shared__ __attribute__((aligned(16))) WT DR[2 * DROW];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int mt, nt, split;
+    xcd_major_block(mt, nt, split);
+    const long total = (long)p.B * nseg * p.Ho;
+    const long s0 = (long)split * steps_per_split, s1 = s0 + steps_per_split < total ? s0 + steps_per_split : total;
+    auto decode = [&](long step, int& b, int& x0, int& y) {
+        const long col = step / p.Ho;
+        y = (int)(step - col * p.Ho);
+        const int seg = (int)(col % nseg);
+        b = (int)(col / nseg);
+        x0 = seg * 32;
+    };
+    // item i of a row set: i < 272 activation (pixel i / 8 of 34, 16-byte chunk i % 8), then 256 of the gradient row
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    auto load_x = [&](int b, int iy, int x0, int i) -> u32x4 {
+        const int px = i >> 3, ch = (i & 7) * 8, ix = x0 - 1 + px, n = nt * 64 + ch;
+        if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W || n >= p.Cin) return zero4;
+        return *reinterpret_cast<const u32x4*>(static_cast<const WT*>(p.x) + (((long)b * p.H + iy) * p.W + ix) * p.CinT + p.cin_off + n);
+    };
+    auto load_d = [&](int b, int y, int x0, int i) -> u32x4 {
+        const int px = i >> 3, ch = (i & 7) * 8, m = mt * 64 + ch;
+        if (m >= p.Cout) return zero4;
+        return *reinterpret_cast<const u32x4*>(static_cast<const WT*>(p.dz) + (((long)b * p.Ho + y) * p.Wo + x0 + px) * p.CoutT + p.cout_off + m);
+    };
+    auto put = [&](WT* row, int i, u32x4 v) {                   // item i -> pixel i / 8, chunk (i % 8) ^ swizzle(pixel)
+        const int px = i >> 3;
+        *reinterpret_cast<u32x4*>(row + px * 64 + (((i & 7) ^ tr_swz(px, 128)) << 3)) = v;
+    };
+    // the row set of step s = activation row y + 1 and gradient row y of its column
+    struct Set { u32x4 v[3]; };
+    auto fetch = [&](long step, Set& st) {
+        int b, x0, y;
+        decode(step, b, x0, y);
+        st.v[0] = load_x(b, y + 1, x0, t);
+        st.v[1] = t < 16 ? load_x(b, y + 1, x0, 256 + t) : load_d(b, y, x0, t - 16);
+        st.v[2] = t < 16 ? load_d(b, y, x0, 240 + t) : zero4;
+    };
+    auto store = [&](long step, const Set& st) {
+        const int y = (int)(step % p.Ho);
+        WT* xr = XR + ((y + 1) & 3) * XROW;
+        WT* dr = DR + (y & 1) * DROW;
+        put(xr, t, st.v[0]);
+        if (t < 16) { put(xr, 256 + t, st.v[1]); put(dr, 240 + t, st.v[2]); }
+        else put(dr, t - 16, st.v[1]);
+    };
+    // first step of a split or of a column: rows y - 1 and y are not in the ring yet
+    auto fill = [&](long step) {
+        int b, x0, y;
+        decode(step, b, x0, y);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int iy = y - 1 + r;
+            WT* xr = XR + (iy & 3) * XROW;
+            put(xr, t, load_x(b, iy, x0, t));
+            if (t < 16) put(xr, 256 + t, load_x(b, iy, x0, 256 + t));
+        }
+    };
+    auto is_full = [&](long step) { return step == s0 || (step % p.Ho) == 0; };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[k][e] = 0.f;
+    // transpose-read addresses: lane = 16 g + 4 j + q reads pixel row (g >> 1) * 8 + j (+ 4: upper half), channels (g & 1) * 16 + 4 q .. + 3 of
+    // its 32-channel block; the activation fragment of tap column sx starts sx pixel rows lower, which moves the row's swizzle with it
+    const int g = lane >> 4, rowl = (g >> 1) * 8 + ((lane >> 2) & 3), coll = (g & 1) * 16 + (lane & 3) * 4;
+    const int cola = wm * 32 + coll, colb = wn * 32 + coll;
+    const int tra = rowl * 64 + (((cola >> 3) ^ tr_swz(rowl, 128)) << 3) + (cola & 7);
+    int trb[3];
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx) trb[sx] = (rowl + sx) * 64 + (((colb >> 3) ^ tr_swz(rowl + sx, 128)) << 3) + (colb & 7);
+
+    Set sa, sb;                                                  // sets of steps s and s + 1
+    if (s0 < s1) fetch(s0, sa);
+    if (s0 + 1 < s1) fetch(s0 + 1, sb);
+    for (long step = s0; step < s1; ++step) {
+        if (is_full(step)) {
+            __syncthreads();                                     // (the previous column's last step is still being read)
+            fill(step);
+        }
+        store(step, sa);
+        __syncthreads();
+        sa = sb;
+        if (step + 2 < s1) fetch(step + 2, sb);                  // two steps (36 MFMAs per wave) ahead of its use
+        const int y = (int)(step % p.Ho);
+        const WT* dr = DR + (y & 1) * DROW;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const auto af = tr_frag<WT>(dr + tra + kk * 16 * 64, 4 * 64);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const WT* xr = XR + ((y + r - 1) & 3) * XROW;
+#pragma unroll
+                for (int sx = 0; sx < 3; ++sx) {
+                    const auto bf = tr_frag<WT>(xr + trb[sx] + kk * 16 * 64, 4 * 64);
+                    if constexpr (__is_same(WT, __bf16)) acc[r * 3 + sx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[r * 3 + sx], 0, 0, 0);
+                    else acc[r * 3 + sx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[r * 3 + sx], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const int n = nt * 64 + wn * 32 + (lane & 31);
+    if (n >= p.Cin) return;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        float* pp = p.part + ((long)split * 9 + k) * p.Cout * p.Cin;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = mt * 64 + wm * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+            if (m < p.Cout) pp[(long)m * p.Cin + n] = acc[k][e];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// 1x1 stride-1 weight gradient, both operands 16-bit and 8-channel aligned (every MBConv expand / project convolution): DMA ring.
+// The generic kernel spends ~4.5 us per K step of 64 pixels on 0.3 us of MFMAs: its operands travel through 208 staging / address
+// registers (two waves per SIMD) one step ahead.  With transpose reads the LDS image IS the memory layout, so the tiles go
+// HBM -> LDS by buffer_load ... lds: no staging registers, three stages of 32 pixels in flight per workgroup, a 128 x 128 tile
+// (Cout x Cin), four waves of 64 x 64.  LDS slot (row, c') of a stage holds global chunk c' ^ swizzle(row) (the DMA writes lanes
+// linearly, so the bank swizzle is applied on the source side).  The SE gate, if any, multiplies the partial tile's columns (se_epi).
+// ------------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_w;
+template <int N> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename WT>
+__global__ __launch_bounds__(256, 2) void wgrad1t_kernel(WgradP p) {
+    constexpr int BK = 32, BM = 128, BN = 128, NST = 4, D = NST - 1;
+    constexpr int STAGE = BK * (BM + BN);                       // elements per stage: [32][128] gradient rows, then [32][128] activation rows
+    constexpr int OOBW = 0x7ffffff0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_smem[];
+    WT* const ring = reinterpret_cast<WT*>(wg_smem);
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int mt, nt, split;
+    xcd_major_block(mt, nt, split);
+    const long k0 = (long)split * p.chunk, k1 = k0 + p.chunk < p.P ? k0 + p.chunk : p.P;
+    const int nk = k1 > k0 ? (int)((k1 - k0 + BK - 1) / BK) : 0;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dz), 0, (unsigned)(p.P * p.CoutT * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, (unsigned)(p.P * p.CinT * 2), 0x00020000);
+    // DMA d (0, 1) of an operand: this wave's 64 lanes fill rows (d * 4 + wave) * 4 .. + 3, 16 chunks each
+    int rowd[2], offa[2], offb[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int row = (d * 4 + wave) * 4 + (lane >> 4), c = (lane & 15) ^ tr_swz(row, 256);
+        rowd[d] = row;
+        const int m = mt * BM + c * 8, n = nt * BN + c * 8;
+        offa[d] = m < p.Cout ? (p.cout_off + m) * 2 : OOBW;      // (+ pixel * CoutT * 2 per stage)
+        offb[d] = n < p.Cin ? (p.cin_off + n) * 2 : OOBW;
+    }
+    int ld = 0;
+    auto issue = [&](int slot) {
+        const long pix0 = k0 + (long)ld * BK;
+        WT* st = ring + slot * STAGE;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const long pix = pix0 + rowd[d];
+            const bool ok = pix < k1;
+            const int va = (ok && offa[d] != OOBW) ? (int)(pix * p.CoutT * 2) + offa[d] : OOBW;
+            const int vb = (ok && offb[d] != OOBW) ? (int)(pix * p.CinT * 2) + offb[d] : OOBW;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_void_w*)(st + (d * 4 + wave) * 4 * BM), 16, va, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_w*)(st + BK * BM + (d * 4 + wave) * 4 * BN), 16, vb, 0, 0, 0);
+        }
+        ++ld;
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int g = lane >> 4, rowl = (g >> 1) * 8 + ((lane >> 2) & 3), coll = (g & 1) * 16 + (lane & 3) * 4;
+    int tra[2], trb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ca = (wm * 2 + i) * 32 + coll, cb = (wn * 2 + i) * 32 + coll;
+        tra[i] = rowl * BM + (((ca >> 3) ^ tr_swz(rowl, 256)) << 3) + (ca & 7);
+        trb[i] = BK * BM + rowl * BN + (((cb >> 3) ^ tr_swz(rowl, 256)) << 3) + (cb & 7);
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j)
+        if (j < nk) issue(j);
+    int cur = 0, nxt = D;
+    for (int it = 0; it < nk; ++it) {
+        const int later = nk - 1 - it < D - 1 ? nk - 1 - it : D - 1;     // stages requested after this one: 4 DMAs each
+        if (later == 0) wg_wait_vmcnt<0>(); else if (later == 1) wg_wait_vmcnt<4>(); else wg_wait_vmcnt<8>();
+        __builtin_amdgcn_s_barrier();                                    // everyone's pieces of stage `it` are in; slot `nxt` was read in step it - 1
+        if (it + D < nk) issue(nxt);
+        nxt = nxt + 1 == NST ? 0 : nxt + 1;
+        const WT* st = ring + cur * STAGE;
+        cur = cur + 1 == NST ? 0 : cur + 1;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            typename WFrag<WT>::type af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = tr_frag<WT>(st + tra[i] + kk * 16 * BM, 4 * BM);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = tr_frag<WT>(st + trb[j] + kk * 16 * BN, 4 * BN);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (__is_same(WT, __bf16)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    float* pp = p.part + (long)split * p.Cout * p.Cin;
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = nt * BN + (wn * 2 + j) * 32 + (lane & 31);
+            if (n >= p.Cin) continue;
+            const float gate = p.se_epi ? p.se[(k0 / HoWo) * p.Cin + n] : 1.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mt * BM + (wm * 2 + i) * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+                if (m < p.Cout) pp[(long)m * p.Cin + n] = acc[i][j][e] * gate;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // THIN weight gradient: a 3x3 (or 1x1) stride-1 convolution with ONE or TWO output channels (the map heads' top convolutions: 192 -> 1 | 2).
 // On the matrix cores 31 of a tile's 32 rows were padding and each of the nine taps re-read the activation: 550 us per head at 1.8 TFLOP/s
 // for what is a weighted column sum.  Here every INPUT pixel q is read once: lane = (pixel slot, CH-channel group) keeps
@@ -518,25 +759,38 @@ __global__ __launch_bounds__(256) void wgrad_thin_kernel(WgradP p) {
     const XT* xb = static_cast<const XT*>(p.x);
     const float* dzb = static_cast<const float*>(p.dz);
     if (slot < slots) {
-        for (long q = k0 + slot; q < k1; q += slots) {
-            const int b = (int)(q / ((long)p.H * p.W));
-            const int rem = (int)(q - (long)b * p.H * p.W);
-            const int iy = rem / p.W, ix = rem - iy * p.W;
-            float xv[CH];
-            load16<XT>(xb + q * p.CinT + p.cin_off + cq * CH, xv);
+        // U pixels per trip: their activation loads and 9 * CO gradient loads are all issued before the first product (one pixel per trip
+        // made this a chain of ten dependent round trips per pixel: 390 us per head)
+        constexpr int U = 4;
+        for (long q0 = k0 + slot; q0 < k1; q0 += (long)slots * U) {
+            float xv[U][CH], dv[U][CO][KK];
 #pragma unroll
-            for (int k = 0; k < KK; ++k) {
-                const int r = k / KS, s2 = k - r * KS;
-                const int oy = iy - r + pad, ox = ix - s2 + pad;                 // the output pixel whose tap (r, s2) lands on q
-                if ((unsigned)oy >= (unsigned)p.Ho || (unsigned)ox >= (unsigned)p.Wo) continue;
-                const float* dq = dzb + (((long)b * p.Ho + oy) * p.Wo + ox) * p.CoutT + p.cout_off;
+            for (int u = 0; u < U; ++u) {
+                const long q = q0 + (long)u * slots;
+                const bool qok = q < k1;
+                const long qq = qok ? q : k0;
+                const int b = (int)(qq / ((long)p.H * p.W));
+                const int rem = (int)(qq - (long)b * p.H * p.W);
+                const int iy = rem / p.W, ix = rem - iy * p.W;
+                load16<XT>(xb + qq * p.CinT + p.cin_off + cq * CH, xv[u]);
 #pragma unroll
-                for (int c = 0; c < CO; ++c) {
-                    const float d = c < p.Cout ? dq[c] : 0.f;
+                for (int k = 0; k < KK; ++k) {
+                    const int r = k / KS, s2 = k - r * KS;
+                    const int oy = iy - r + pad, ox = ix - s2 + pad;             // the output pixel whose tap (r, s2) lands on q
+                    const bool ok = qok && (unsigned)oy < (unsigned)p.Ho && (unsigned)ox < (unsigned)p.Wo;
+                    const float* dq = dzb + (((long)b * p.Ho + (ok ? oy : 0)) * p.Wo + (ok ? ox : 0)) * p.CoutT + p.cout_off;
 #pragma unroll
-                    for (int e = 0; e < CH; ++e) acc[c][k][e] = fmaf(d, xv[e], acc[c][k][e]);
+                    for (int c = 0; c < CO; ++c) dv[u][c][k] = (ok && c < p.Cout) ? dq[c] : 0.f;
                 }
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < KK; ++k)
+#pragma unroll
+                    for (int c = 0; c < CO; ++c)
+#pragma unroll
+                        for (int e = 0; e < CH; ++e) acc[c][k][e] = fmaf(dv[u][c][k], xv[u][e], acc[c][k][e]);
         }
     }
     float* pp = p.part + (long)blockIdx.x * KK * p.Cout * p.Cin;
@@ -661,13 +915,39 @@ hipError_t launch_wgrad(const OpArgs& a, hipStream_t s) {
         const long total = (long)o.B * nseg * o.Ho;
         const long sps = (total + S - 1) / S;
         const dim3 g3((o.Cout + 63) / 64, (o.Cin + 63) / 64, S);
-        if (o.w_dtype == FTC_F16) hipLaunchKernelGGL(wgrad3_kernel<_Float16>, g3, dim3(256), 0, s, p, nseg, sps);
+        // everything 8-channel (16-byte) aligned: the transpose-read kernel; 0x200 forces the staged one (A/B measurements, tests)
+        const bool al8 = o.Cout % 8 == 0 && o.Cin % 8 == 0 && p.CoutT % 8 == 0 && p.CinT % 8 == 0 && p.cout_off % 8 == 0 && p.cin_off % 8 == 0 && !(o.flags & 0x200);
+        if (al8 && o.w_dtype == FTC_F16) hipLaunchKernelGGL(wgrad3t_kernel<_Float16>, g3, dim3(256), 0, s, p, nseg, sps);
+        else if (al8) hipLaunchKernelGGL(wgrad3t_kernel<__bf16>, g3, dim3(256), 0, s, p, nseg, sps);
+        else if (o.w_dtype == FTC_F16) hipLaunchKernelGGL(wgrad3_kernel<_Float16>, g3, dim3(256), 0, s, p, nseg, sps);
         else hipLaunchKernelGGL(wgrad3_kernel<__bf16>, g3, dim3(256), 0, s, p, nseg, sps);
         hipError_t e3 = hipGetLastError();
         if (e3 != hipSuccess) return e3;
         const long per3 = (long)KK * o.Cout * o.Cin;
         const long nb3 = (per3 + 255) / 256;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb3 > 8192 ? 8192 : nb3)), dim3(256), 0, s, a.aux, (float*)a.out, S, KK, o.Cout, o.Cin);
+        return hipGetLastError();
+    }
+    // 1x1 stride 1, 16-bit copies of both operands, 8-channel aligned, no per-element gate: the DMA-ring kernel (0x200: the generic one)
+    if (o.ksize == 1 && o.stride == 1 && ftc_is16(o.w_dtype) && o.in_dtype == o.w_dtype && o.res_dtype == o.w_dtype && (!p.se || p.se_epi) && !(o.flags & 0x300) &&
+        o.Cout % 8 == 0 && o.Cin % 8 == 0 && p.CoutT % 8 == 0 && p.CinT % 8 == 0 && p.cout_off % 8 == 0 && p.cin_off % 8 == 0 && o.Cout >= 64 && o.Cin >= 64 &&
+        p.P * p.CoutT * 2 < 0x7fffffffL && p.P * p.CinT * 2 < 0x7fffffffL && p.chunk % 32 == 0) {
+        const dim3 g1((o.Cout + 127) / 128, (o.Cin + 127) / 128, S);
+        const size_t lds = (size_t)4 * 32 * 256 * 2;
+        if (o.w_dtype == FTC_F16) {
+            static bool set16 = false;
+            if (!set16) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad1t_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set16 = true; }
+            hipLaunchKernelGGL(wgrad1t_kernel<_Float16>, g1, dim3(256), lds, s, p);
+        } else {
+            static bool setb = false;
+            if (!setb) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad1t_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); setb = true; }
+            hipLaunchKernelGGL(wgrad1t_kernel<__bf16>, g1, dim3(256), lds, s, p);
+        }
+        hipError_t e1 = hipGetLastError();
+        if (e1 != hipSuccess) return e1;
+        const long per1 = (long)o.Cout * o.Cin;
+        const long nb1 = (per1 + 255) / 256;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb1 > 8192 ? 8192 : nb1)), dim3(256), 0, s, a.aux, (float*)a.out, S, 1, o.Cout, o.Cin);
         return hipGetLastError();
     }
     WgCfg c = wgrad_cfg(o.Cout, o.Cin, o.ksize);

@@ -831,6 +831,38 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         out[((long)co * Cin + ci) * KK + tap] += s;
     }
 }
+// many splits of a small gradient (the thin kernel: 288 splits x 1728 weights): 16 elements x 16 split lanes per workgroup, lane k sums
+// splits k, k + 16, ... and the 16 lanes meet in LDS in a fixed order (one thread per element walked 288 dependent loads)
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ part, float* __restrict__ out, int S, int KK, int Cout, int Cin) {
+    __shared__ float red[16][16];
+    const long per = (long)KK * Cout * Cin;
+    const int el = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + el;
+    float s = 0.f;
+    if (i < per)
+        for (int k = kl; k < S; k += 16) s += part[(long)k * per + i];
+    red[kl][el] = s;
+    __syncthreads();
+    if (kl != 0 || i >= per) return;
+    s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][el];
+    const int ci = (int)(i % Cin);
+    const long t = i / Cin;
+    const int co = (int)(t % Cout), tap = (int)(t / Cout);
+    out[((long)co * Cin + ci) * KK + tap] += s;
+}
+
+inline hipError_t launch_wgrad_reduce(const void* part, float* out, int S, int KK, int Cout, int Cin, hipStream_t s) {
+    const long per = (long)KK * Cout * Cin;
+    if (S >= 48) {
+        hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3((unsigned)((per + 15) / 16)), dim3(256), 0, s, (const float*)part, out, S, KK, Cout, Cin);
+    } else {
+        const long nb = (per + 255) / 256;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, s, (const float*)part, out, S, KK, Cout, Cin);
+    }
+    return hipGetLastError();
+}
 
 struct WgCfg { int id, BM, BN; };
 inline WgCfg wgrad_cfg(int Cout, int Cin, int ksize) {
@@ -905,9 +937,7 @@ hipError_t launch_wgrad(const OpArgs& a, hipStream_t s) {
 #undef THIN
         hipError_t et = hipGetLastError();
         if (et != hipSuccess) return et;
-        const long pert = (long)KK * o.Cout * o.Cin;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((pert + 255) / 256)), dim3(256), 0, s, a.aux, (float*)a.out, S, KK, o.Cout, o.Cin);
-        return hipGetLastError();
+        return launch_wgrad_reduce(a.aux, (float*)a.out, S, KK, o.Cout, o.Cin, s);
     }
     if (wgrad3_shape(o.Wo, o.Cout, o.Cin, o.ksize) && o.stride == 1 && ftc_is16(o.w_dtype) && o.in_dtype == o.w_dtype && o.res_dtype == o.w_dtype && !p.se &&
         !(o.flags & 0x100)) {                                    // (0x100: the generic kernel, for A/B measurements)
@@ -923,10 +953,7 @@ hipError_t launch_wgrad(const OpArgs& a, hipStream_t s) {
         else hipLaunchKernelGGL(wgrad3_kernel<__bf16>, g3, dim3(256), 0, s, p, nseg, sps);
         hipError_t e3 = hipGetLastError();
         if (e3 != hipSuccess) return e3;
-        const long per3 = (long)KK * o.Cout * o.Cin;
-        const long nb3 = (per3 + 255) / 256;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb3 > 8192 ? 8192 : nb3)), dim3(256), 0, s, a.aux, (float*)a.out, S, KK, o.Cout, o.Cin);
-        return hipGetLastError();
+        return launch_wgrad_reduce(a.aux, (float*)a.out, S, KK, o.Cout, o.Cin, s);
     }
     // 1x1 stride 1, 16-bit copies of both operands, 8-channel aligned, no per-element gate: the DMA-ring kernel (0x200: the generic one)
     if (o.ksize == 1 && o.stride == 1 && ftc_is16(o.w_dtype) && o.in_dtype == o.w_dtype && o.res_dtype == o.w_dtype && (!p.se || p.se_epi) && !(o.flags & 0x300) &&
@@ -945,10 +972,7 @@ hipError_t launch_wgrad(const OpArgs& a, hipStream_t s) {
         }
         hipError_t e1 = hipGetLastError();
         if (e1 != hipSuccess) return e1;
-        const long per1 = (long)o.Cout * o.Cin;
-        const long nb1 = (per1 + 255) / 256;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb1 > 8192 ? 8192 : nb1)), dim3(256), 0, s, a.aux, (float*)a.out, S, 1, o.Cout, o.Cin);
-        return hipGetLastError();
+        return launch_wgrad_reduce(a.aux, (float*)a.out, S, 1, o.Cout, o.Cin, s);
     }
     WgCfg c = wgrad_cfg(o.Cout, o.Cin, o.ksize);
     // the 192 x 256 tile has one staging task per thread only with 16-byte accesses of 8 channels (16-bit copies) or the fp32 K step of 32
@@ -960,8 +984,5 @@ hipError_t launch_wgrad(const OpArgs& a, hipStream_t s) {
     else launch_io<__bf16>(p, c.id, grid, o.in_dtype == FTC_BF16, o.res_dtype == FTC_BF16, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const long per = (long)KK * o.Cout * o.Cin;
-    const long nb = (per + 255) / 256;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(nb > 8192 ? 8192 : nb)), dim3(256), 0, s, a.aux, (float*)a.out, S, KK, o.Cout, o.Cin);
-    return hipGetLastError();
+    return launch_wgrad_reduce(a.aux, (float*)a.out, S, KK, o.Cout, o.Cin, s);
 }

@@ -283,6 +283,8 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if (o.Cin <= 0) return "fill: Cin must be positive";
         if (!need(o.out, true, "out", pin * o.Cin * 4)) return why->c_str();
         return nullptr;
+    case FTC_OP_JOIN:
+        return nullptr;
     default:
         return "unknown op kind";
     }
@@ -331,6 +333,7 @@ hipError_t run_one(const ftc_op& o, void* const bases[FTC_NUM_BASES], hipStream_
     case FTC_OP_COLSUM: return launch_colsum(a, s);
     case FTC_OP_STEMWGRAD: return launch_stemwgrad(a, s);
     case FTC_OP_FILL: return launch_fill(a, s);
+    case FTC_OP_JOIN: return hipSuccess;
     default: return hipErrorInvalidValue;
     }
 }
@@ -414,6 +417,59 @@ int ftc_plan_run(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], void* s
     return FTC_OK;
 }
 
+int ftc_plan_run_streams(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], void* stream, void* side_stream, int first_op, int last_op) {
+    if (!side_stream) return ftc_plan_run(plan, bases, stream, first_op, last_op);
+    if (!plan || !bases) return fail(FTC_ERR_INVALID, "ftc_plan_run_streams: null arguments");
+    const int n = (int)plan->ops.size();
+    if (last_op < 0 || last_op >= n) last_op = n - 1;
+    if (first_op < 0) first_op = 0;
+    if (first_op > last_op) return fail(FTC_ERR_INVALID, "ftc_plan_run_streams: empty op range");
+    int rc = check_bases(plan, bases, first_op, last_op);
+    if (rc != FTC_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream), s2 = static_cast<hipStream_t>(side_stream);
+    // the two events belong to this call (a plan may be run from several host threads); destroying an event with work pending is legal
+    hipEvent_t fork = nullptr, join = nullptr;
+    hipError_t e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&join, hipEventDisableTiming);
+    bool pending = false;
+    int i = first_op;
+    auto do_join = [&]() {
+        if (!pending || e != hipSuccess) return;
+        e = hipEventRecord(join, s2);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, join, 0);
+        pending = false;
+    };
+    bool main_dirty = true;                                     // work issued on the main stream since the last fork
+    for (; i <= last_op && e == hipSuccess; ++i) {
+        const ftc_op& o = plan->ops[i];
+        if (o.kind == FTC_OP_JOIN) { do_join(); continue; }
+        if (o.flags & FTC_FLAG_SIDE_STREAM) {
+            if (main_dirty) {
+                e = hipEventRecord(fork, s);
+                if (e == hipSuccess) e = hipStreamWaitEvent(s2, fork, 0);
+                main_dirty = false;
+            }
+            if (e == hipSuccess) e = run_one(o, bases, s2);
+            pending = true;
+        } else {
+            e = run_one(o, bases, s);
+            main_dirty = true;
+        }
+    }
+    const int failed = i - 1;
+    hipError_t e_op = e;
+    e = hipSuccess;
+    do_join();
+    if (fork) (void)hipEventDestroy(fork);
+    if (join) (void)hipEventDestroy(join);
+    if (e_op != hipSuccess || e != hipSuccess) {
+        char buf[64];
+        std::snprintf(buf, sizeof buf, "ftc_plan_run_streams: op %d", failed);
+        return fail_hip(e_op != hipSuccess ? e_op : e, buf);
+    }
+    return FTC_OK;
+}
+
 int ftc_op_kernel_label(const ftc_op* op, char* buf, int len) {
     if (!op || !buf || len <= 0) return fail(FTC_ERR_INVALID, "ftc_op_kernel_label: null arguments");
     switch (op->kind) {
@@ -443,6 +499,7 @@ int ftc_op_kernel_label(const ftc_op* op, char* buf, int len) {
     case FTC_OP_COLSUM: std::snprintf(buf, len, "colsum_partial+final"); break;
     case FTC_OP_STEMWGRAD: std::snprintf(buf, len, "stemwgrad_partial+final"); break;
     case FTC_OP_FILL: std::snprintf(buf, len, "memset"); break;
+    case FTC_OP_JOIN: std::snprintf(buf, len, "join"); break;
     default: return fail(FTC_ERR_INVALID, "ftc_op_kernel_label: unknown op kind");
     }
     return FTC_OK;

@@ -40,8 +40,12 @@ class TrainStep:
     """``ts = TrainStep(model)``; per iteration ``loss, raw = ts.forward_backward(image, labelmap, idmap, fmask)`` then
     ``optimizer.step(); ts.zero_grad()`` -- the reference's loop body (train1.py:170-179) with ``train_step`` + ``backward`` fused."""
 
-    def __init__(self, module, precision: Optional[str] = None, cov=None):
+    def __init__(self, module, precision: Optional[str] = None, cov=None, two_streams: bool = True):
+        """two_streams: the backward's weight-gradient ops run on a second HIP stream beside the chain that produces their operands
+        (ftc_plan_run_streams; same kernels, same results -- False keeps everything on the caller's stream)."""
         self.module = module
+        self.two_streams = bool(two_streams)
+        self.side_stream = None
         self.precision = precision or module.detector.precision
         if self.precision == "fp16x3":
             raise ValueError("TrainStep: 'fp16x3' is an inference mode; train in 'bf16' (what the reference's autocast does), 'fp16' or 'fp32'")
@@ -202,6 +206,10 @@ class TrainStep:
             self.lib = L.load()
             self.h16 = ts.cdt != L.F32
             self.cdt = ts.cdt
+            # weight gradients on the side stream (ftc_plan_run_streams): nothing on the backward chain reads them, so they overlap its
+            # HBM-bound BatchNorm / depthwise passes.  An op's buffers stay allocated until the FTC_OP_JOIN after it (join()).
+            self.side = ts.two_streams
+            self.side_pending: List[int] = []
 
         def buf(self, nbytes: int) -> tuple:
             b = _Buf(nbytes)
@@ -221,6 +229,19 @@ class TrainStep:
                     v[1].first, v[1].last = min(v[1].first, idx), max(v[1].last, idx)
             self.ops.append(f)
             self.names.append(_name)
+
+        def join(self) -> None:
+            """FTC_OP_JOIN: the main stream waits for the side stream; every buffer a pending side op touches lives until here."""
+            if not self.side_pending:
+                return
+            j = len(self.ops)
+            self.ops.append(dict(kind=L.OP_JOIN, B=1, H=1, W=1, Ho=1, Wo=1))
+            self.names.append("join")
+            for i in self.side_pending:
+                for v in self.ops[i].values():
+                    if isinstance(v, tuple) and v[0] == "ws":
+                        v[1].last = max(v[1].last, j)
+            self.side_pending = []
 
         def pin(self, ref) -> None:
             ref[1].first, ref[1].last = 0, 1 << 29
@@ -296,7 +317,11 @@ class TrainStep:
                     S = B * kk
             xin, xdt = self.pick(x)
             din, ddt = self.pick(dz)
-            self.emit("wgrad:" + wname, kind=L.OP_WGRAD, flags=L.FLAG_SE_SCALE if se is not None else 0, w_dtype=self.cdt, in_dtype=xdt, res_dtype=ddt, B=B, H=h,
+            if self.side:
+                if self.side_pending and len(self.ops) - self.side_pending[0] >= 32:      # bounds how long operands outlive their last main-stream use
+                    self.join()
+                self.side_pending.append(len(self.ops))
+            self.emit("wgrad:" + wname, kind=L.OP_WGRAD, flags=(L.FLAG_SE_SCALE if se is not None else 0) | (L.FLAG_SIDE_STREAM if self.side else 0), w_dtype=self.cdt, in_dtype=xdt, res_dtype=ddt, B=B, H=h,
                       W=w, Ho=ho, Wo=wo, Cin=cin, Cin_total=cin_total, cin_off=cin_off, Cout=cout, Cout_total=cout_total, cout_off=cout_off, ksize=k,
                       stride=stride, aux0=S, in_=xin, in2=din, scale=se, out=self.g(wname), aux=self.buf(S * k * k * cout * cin * 4))
 
@@ -581,6 +606,7 @@ class TrainStep:
                 gz0 = g.bn_bwd(gout, rec["z0"], rec["ss0"], ho, wo, cout, b + ".0.1", L.ACT_SILU, keep=rec["keep"], **s2)
                 g.wgrad(rec["xin"], gz0, h_, w_, c_, cout, 3, stride, b + ".0.0.weight")
                 gx = g.dgrad(gz0, ho, wo, cout, b + ".0.0.weight", c_, 3, stride, h_, w_, add=skip)
+        g.join()
         plan = self._finish(g)
         plan.update(maps=maps[1], keep=keep_buf[1], res_names=res_names, mh=mh, mw=mw, sel=sel[1], lab=lab[1], idm=idm[1], lossv=lossv[1], alphas=alphas[1],
                     n_rows=n_rows, n_fwd=n_fwd, loss_bwd_op=lscale_slot, names=g.names, dec_outs=[d["out"][1] for d in dec])
@@ -712,8 +738,13 @@ class TrainStep:
                 loss = self.cov(raw)
                 a = self.cov.alphas
             self._view(plan["alphas"], (9,)).copy_(a)
+            side = None
+            if self.two_streams:
+                if self.side_stream is None or self.side_stream.device != dev:
+                    self.side_stream = torch.cuda.Stream(device=dev)
+                side = C.c_void_p(self.side_stream.cuda_stream)
             if backward and (ddp is None or world == 1 or not sync_grads):
-                L.check(lib.ftc_plan_run(plan["handle"], bases, stream, plan["n_fwd"], -1), "ftc_plan_run (train step, backward)")
+                L.check(lib.ftc_plan_run_streams(plan["handle"], bases, stream, side, plan["n_fwd"], -1), "ftc_plan_run_streams (train step, backward)")
             elif backward:
                 key = (B, H, W, float(loss_scale / world))
                 if key not in self._segments:
@@ -721,7 +752,7 @@ class TrainStep:
                 cur = torch.cuda.current_stream(dev)
                 for first, last, bi in self._segments[key]:
                     if first <= last:
-                        L.check(lib.ftc_plan_run(plan["handle"], bases, stream, first, last), "ftc_plan_run (train step, backward segment)")
+                        L.check(lib.ftc_plan_run_streams(plan["handle"], bases, stream, side, first, last), "ftc_plan_run_streams (train step, backward segment)")
                     if bi is not None:
                         self.comm_stream.wait_stream(cur)                 # the bucket is complete once everything enqueued so far has run
                         with torch.cuda.stream(self.comm_stream):

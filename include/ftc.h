@@ -33,8 +33,10 @@ extern "C" {
 /* 4: FTC_OP_BNSTAT / FTC_OP_BNACT (training-mode BatchNorm); FTC_OP_STEM and FTC_OP_DWCONV honour act = FTC_ACT_NONE (they applied SiLU
    unconditionally before); FTC_FLAG_W_FRAG
    5: the train step (BASELINE configs[4]): FTC_BASE_GRADS, FTC_OP_GATHER_ROWS .. FTC_OP_FILL (backward kernels), FTC_OP_BNSTAT writes
-      [4][Cin] (scale, shift, mean, 1/std), ftc_losses out[12..13] = the two weight normalisers, ftc_pack_train_weights */
-#define FTC_ABI_VERSION 5
+      [4][Cin] (scale, shift, mean, 1/std), ftc_losses out[12..13] = the two weight normalisers, ftc_pack_train_weights
+   6: ftc_plan_run_streams / FTC_FLAG_SIDE_STREAM / FTC_OP_JOIN (ops with no consumer on the main chain -- the weight gradients -- on a
+      second stream) */
+#define FTC_ABI_VERSION 6
 
 typedef enum ftc_status {
     FTC_OK = 0,
@@ -149,6 +151,8 @@ typedef enum ftc_op_kind {
     FTC_OP_STEMWGRAD = 22,
     /* out[0 .. B*H*W*Cin) fp32 = 0 */
     FTC_OP_FILL = 23,
+    /* no kernel: ftc_plan_run_streams makes the main stream wait for everything issued on the side stream so far (a no-op in ftc_plan_run) */
+    FTC_OP_JOIN = 24,
     FTC_OP_TAPSUM = 7          /* second half of a 3x3 convolution split as per-pixel taps + 9-point sum (FTC_FLAG_TOP_FUSE):
                                   out[b,y,x,ch_j] = bias[j] + sum_{r,s} in[g_j][b,y+r-1,x+s-1][(3r+s)*co_j + o_j] (zero outside),
                                   for the aux1 outputs j listed in `w` as int32 quadruples (g_j, o_j, co_j, ch_j);
@@ -193,6 +197,8 @@ enum {
                                   v_mfma_f32_32x32x16_f16 (hi.lo + lo.hi + hi.hi, fp32 accumulation) instead of eight v_mfma_f32_32x32x2_f32:
                                   22-bit operands at up to 5.3x the fp32 matrix rate.  Tensors, weights, epilogues: those of the fp32 mode */
     FTC_FLAG_ACCUM = 0x800000, /* BNBWD / CONV-as-dgrad helpers: the data-gradient output is added to what `out` holds */
+    FTC_FLAG_SIDE_STREAM = 0x4000000, /* any op: ftc_plan_run_streams enqueues it on the side stream (after everything issued on the main stream so
+                                  far); whoever builds the plan keeps the op's operands alive and unwritten until the next FTC_OP_JOIN */
     FTC_FLAG_SE_FOLD = 32      /* SE: besides scale[b,c], write out2[b][n][c] = bf16(in[n][c] * scale[b,c]) for the
                                   bf16 matrix `in` [Cout_total][C] -- the following 1x1 convolution then runs with
                                   FTC_FLAG_W_PER_IMAGE on unscaled activations (both operands by DMA) */
@@ -266,6 +272,12 @@ int ftc_plan_num_ops(const ftc_plan* plan);
    selects a sub-range, used by the per-op parity tests and the profiler harness. */
 int ftc_plan_run(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], void* stream,
                  int first_op, int last_op);
+/* ftc_plan_run on two streams: ops carrying FTC_FLAG_SIDE_STREAM go to `side_stream` (which first waits for the main stream's work so
+   far), FTC_OP_JOIN and the end of the range make `stream` wait for the side stream.  side_stream == NULL: exactly ftc_plan_run.
+   The train step's weight gradients -- a quarter of its time, nothing on the backward chain reads them -- overlap the HBM-bound
+   BatchNorm / depthwise passes this way (tools/train_two_stream_experiment.py: 126 -> 116 ms). */
+int ftc_plan_run_streams(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], void* stream, void* side_stream,
+                         int first_op, int last_op);
 /* Same as ftc_plan_run, bracketing every op with HIP events on `stream` and returning the
    per-op elapsed milliseconds in ms_out[n_ops] (synchronises; measurement only). */
 int ftc_plan_profile(const ftc_plan* plan, void* const bases[FTC_NUM_BASES], void* stream,

@@ -22,6 +22,7 @@ flipped data-gradient weights, in the compute type) are re-derived from the flat
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -318,7 +319,7 @@ class TrainStep:
             xin, xdt = self.pick(x)
             din, ddt = self.pick(dz)
             if self.side:
-                if self.side_pending and len(self.ops) - self.side_pending[0] >= 32:      # bounds how long operands outlive their last main-stream use
+                if self.side_pending and len(self.ops) - self.side_pending[0] >= int(os.environ.get("FTC_TRAIN_JOIN_EVERY", "32")):      # bounds how long operands outlive their last main-stream use
                     self.join()
                 self.side_pending.append(len(self.ops))
             self.emit("wgrad:" + wname, kind=L.OP_WGRAD, flags=(L.FLAG_SE_SCALE if se is not None else 0) | (L.FLAG_SIDE_STREAM if self.side else 0), w_dtype=self.cdt, in_dtype=xdt, res_dtype=ddt, B=B, H=h,

@@ -647,6 +647,23 @@ def main():
             recs[other] = {"dtype": other, "images_per_s": round(B * k2 / e2, 2), "ms_per_step": round(1000 * e2 / k2, 3), "steps": k2,
                            "path_frac_of_mfma_peak": round(B * k2 / e2 * GFLOP_PER_IMAGE / 1000 / PEAK[other], 4)}
             maps[other] = (heat2[:1].clone(), feat2[:1].clone())
+            if args.lanes > 1:                              # the same steps alternating over the lanes, as the headline does
+                from findtextcenternet_amd import DetectorLanes
+                ln2 = DetectorLanes(det2, B, 768, 768, lanes=args.lanes, max_boxes=args.max_boxes, device=dev)
+                for _ in range(2 * args.lanes):
+                    ln2.submit(x, tiles, cut_off=0.4, logit_cut=lcut)
+                ln2.wait()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(k2):
+                    ln2.submit(x, tiles, cut_off=0.4, logit_cut=lcut)
+                ln2.wait()
+                torch.cuda.synchronize()
+                e3 = time.perf_counter() - t0
+                recs[other].update({"single_stream_images_per_s": recs[other]["images_per_s"], "single_stream_ms_per_step": recs[other]["ms_per_step"],
+                                    "images_per_s": round(B * k2 / e3, 2), "ms_per_step": round(1000 * e3 / k2, 3), "lanes": args.lanes,
+                                    "path_frac_of_mfma_peak": round(B * k2 / e3 * GFLOP_PER_IMAGE / 1000 / PEAK[other], 4)})
+                del ln2
             del model2, det2, heat2, feat2, dws2
             torch.cuda.empty_cache()
         # ---- seam 2 exactly as the reference calls it (process_ocr_torch.py:43-49): call_detector(np [1,768,768,3] 0..255) ->

@@ -361,8 +361,8 @@ def train_bench(args, rank, local_rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="tiles per GPU per step")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp16", "fp16x3"])
     ap.add_argument("--max-boxes", type=int, default=2048)

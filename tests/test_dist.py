@@ -125,6 +125,40 @@ def test_train_plan_bucket_segments_follow_the_backward_order():
     assert end_of[0] < plan["n_fwd"] + (plan["n_ops"] - plan["n_fwd"]) * 0.6
 
 
+def test_train_plan_side_stream_ops_keep_their_buffers_until_the_join():
+    """The weight gradients run on a second stream (FTC_FLAG_SIDE_STREAM): no workspace buffer such an op touches may be handed to another
+    tensor before the FTC_OP_JOIN that follows it, every side op is followed by a join, and the plan ends joined."""
+    from findtextcenternet_amd import TextDetectorModel, TrainStep
+    from findtextcenternet_amd import _lib as L
+    ts = TrainStep(TextDetectorModel(pre_weights=False, precision="bf16").train())
+    plan = ts.plan_for(2, 128, 128)
+    ops, n = plan["ops"], plan["n_ops"]
+    side = [i for i in range(n) if ops[i].flags & L.FLAG_SIDE_STREAM]
+    joins = [i for i in range(n) if ops[i].kind == L.OP_JOIN]
+    assert len(side) > 200 and all(ops[i].kind == L.OP_WGRAD for i in side) and min(side) > plan["n_fwd"] and joins[-1] == n - 1
+    next_join = {i: next(j for j in joins if j > i) for i in side}
+    assert max(next_join[i] - i for i in side) <= 40
+
+    def extents(o):                                            # [lo, hi) of every workspace operand (hi: the next operand start is enough here)
+        for f in ("in_", "in2", "out", "out2", "aux", "scale", "shift", "w", "w2", "bias", "bias2"):
+            r = getattr(o, f)
+            if r.base == L.BASE_WORKSPACE:
+                yield r.offset
+    # a buffer START a side op reads or writes is not the start of any OUTPUT written between the op and its join
+    for i in side:
+        mine = set(extents(ops[i]))
+        for k in range(i + 1, next_join[i]):
+            for f in ("out", "out2", "aux"):
+                r = getattr(ops[k], f)
+                if r.base == L.BASE_WORKSPACE and not (ops[k].flags & L.FLAG_SIDE_STREAM):
+                    assert r.offset not in mine, (i, k, f)
+    # without the second stream the same plan has no joins and no flags
+    ts1 = TrainStep(TextDetectorModel(pre_weights=False, precision="bf16").train(), two_streams=False)
+    p1 = ts1.plan_for(2, 128, 128)
+    assert p1["n_ops"] == n - len(joins) and not any(p1["ops"][i].flags & L.FLAG_SIDE_STREAM for i in range(p1["n_ops"]))
+    assert p1["workspace_bytes"] <= plan["workspace_bytes"]
+
+
 class _NoHostSync:
     """Inside this context every host read of tensor DATA raises: the steady-state gather must not contain one."""
 

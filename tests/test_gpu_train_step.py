@@ -125,6 +125,30 @@ def test_train_step_accumulates_and_weights_like_the_oracle():
     assert len(rep) == len(ts.params) and not fails, (len(fails), fails[:10])
 
 
+def test_two_streams_give_the_same_gradients_bit_for_bit():
+    """Weight gradients on the side stream (the default) vs everything on one stream: same kernels, same order of every sum -> the flat
+    gradient buffers are identical bit for bit, over several steps (the second stream must also see the arena it was promised)."""
+    B, H, W = 2, 256, 256
+    x = torch.from_numpy(synth.page_images(7, B, H, W)).permute(0, 3, 1, 2).cuda()
+    label, idmap = synth.train_labels(8, B, H // 4, W // 4)
+    label, idmap = torch.from_numpy(label).cuda(), torch.from_numpy(idmap).cuda()
+    got = {}
+    for two in (False, True):
+        model = _model("bf16")
+        ts = TrainStep(model, two_streams=two)
+        probs = ts.stochastic_depth_probs()
+        rng = np.random.Generator(np.random.PCG64(5))
+        keep = {n: torch.from_numpy((rng.random(B) < 1 - p).astype(np.float32) / np.float32(1 - p)) for n, p in probs.items()}
+        alphas = torch.full((9,), 1.0 / 9)
+        ts.zero_grad()
+        for _ in range(3):
+            ts.forward_backward(x, label, idmap, keep=keep, alphas=alphas)
+        torch.cuda.synchronize()
+        got[two] = ts.grads.clone()
+        assert float(got[two].abs().max()) > 0
+    assert torch.equal(got[False].view(torch.int32), got[True].view(torch.int32))
+
+
 @pytest.mark.parametrize("precision,cos_min,cos_median", [("bf16", 0.55, 0.78), ("fp16", 0.98, 0.993)])
 def test_train_step_16bit_gradients_point_the_same_way(g10, precision, cos_min, cos_median):
     """bf16 / fp16 MFMA operands with fp32 activations, statistics and accumulation (the reference trains under bf16 autocast,

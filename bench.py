@@ -224,6 +224,17 @@ def train_dry_run(args, rank, world):
         dist.destroy_process_group()
 
 
+def emit_last_line(result) -> None:
+    """The ONE JSON line, as the last thing on stdout: RCCL writes its version banner through C stdio, which (piped) is flushed at exit,
+    i.e. AFTER anything Python printed earlier -- flush the C buffers first, print after the process group is gone."""
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(result), flush=True)
+
+
 def train_bench(args, rank, local_rank, world):
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -352,10 +363,10 @@ def train_bench(args, rank, local_rank, world):
         result["cpu_baseline"] = {"value": round(0.25 / e, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
                                   "sample": f"one train step (forward + loss + backward, no optimizer) of the CPU oracle on 1 x 384x384 "
                                             f"(= 1/4 of a 768x768 tile) in {e:.1f} s, scaled by pixel count"}
-    print(json.dumps(result), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    emit_last_line(result)
 
 
 def main():
@@ -701,11 +712,11 @@ def main():
             result[names[other]] = recs[other]
             if "parity" in result:
                 result[names[other]].update({k: result["parity"][other][k] for k in ("heatmap_linf", "features_linf", "peak_set_identical", "peak_jaccard")})
-    if rank == 0:
-        print(json.dumps(result), flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        emit_last_line(result)
 
 
 if __name__ == "__main__":

@@ -45,7 +45,7 @@ class TrainStep:
         """two_streams: the backward's weight-gradient ops run on a second HIP stream beside the chain that produces their operands
         (ftc_plan_run_streams; same kernels, same results -- False keeps everything on the caller's stream)."""
         self.module = module
-        self.two_streams = bool(two_streams)
+        self.two_streams = bool(two_streams) and os.environ.get("FTC_TRAIN_ONE_STREAM") != "1"      # (env: A/B measurements)
         self.side_stream = None
         self.precision = precision or module.detector.precision
         if self.precision == "fp16x3":

@@ -22,7 +22,8 @@ from .decode import DecodeWorkspace, decode_peaks
 
 class DetectorLanes:
     def __init__(self, detector, B: int, H: int = 768, W: int = 768, lanes: int = 2, max_boxes: int = 2048, device="cuda"):
-        """detector: a findtextcenternet_amd.CenterNetDetector in eval mode on `device`."""
+        """detector: a findtextcenternet_amd.CenterNetDetector in eval mode on `device`.  Its weights must not change while batches are in
+        flight (a parameter edit re-packs the weight blob every lane reads): call synchronize-then-edit, as with any stream of work."""
         self.det, self.B, self.H, self.W, self.n = detector, B, H, W, lanes
         dev = torch.device(device)
         self.dev = dev

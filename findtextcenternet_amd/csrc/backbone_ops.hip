@@ -223,15 +223,22 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, lds_ptr_t* dst, 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, 0, 0, 0);     // LDS[dst + lane*16] = 16 bytes at r[voff]; zeros when voff is out of range
 }
 
-template <typename T>
+// (round 3: also for fp32 tensors -- the fp32 / fp16x3 parity modes and the train step's forward: a 16-byte DMA lane then carries 4 channels,
+//  16 lanes per pixel, 7 passes per tile, a 51 KB LDS image; PRECISE = libm expf as the fp32 kernels use; act 0 = none (train mode: BatchNorm
+//  follows as its own op))
+template <typename T, bool PRECISE>
 __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__ in, const float* __restrict__ w,
                                                            const float* __restrict__ bias, T* __restrict__ out,
                                                            float* __restrict__ partial, int H, int W, int C, int tilesX,
-                                                           int P, int tiles_per_wg) {
+                                                           int P, int tiles_per_wg, int act) {
     constexpr int TH = 8, TW = 8, IW = 10, NPX = 100;
-    constexpr int NLD = 4;                                               // DMA passes: 4 waves x 8 pixels x (8 lanes x 16 B) each
+    constexpr int CHS = 16 / (int)sizeof(T);                             // channels per 16-byte DMA lane: 8 | 4
+    constexpr int LPS = 64 / CHS;                                        // lanes per pixel: 8 | 16
+    constexpr int PPW = 64 / LPS;                                        // pixels per wave-level DMA: 8 | 4
+    constexpr int PPP = 4 * PPW;                                         // pixels per pass of the four waves: 32 | 16
+    constexpr int NLD = (NPX + PPP - 1) / PPP;                           // DMA passes: 4 | 7
     constexpr int OOB = 0x7ffffff0;
-    __shared__ __attribute__((aligned(16))) T tile[2][NLD * 32 * 64];
+    __shared__ __attribute__((aligned(16))) T tile[2][NLD * PPP * 64];
     __shared__ __attribute__((aligned(16))) float red[16 * 64];
 
     const int t = threadIdx.x;
@@ -239,10 +246,10 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
     const int c0 = blockIdx.x * 64;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in + (long)b * H * W * C), 0,
-                                                                         H * W * C * 2, 0x00020000);
-    // staging role: pixel wave*8 + lane/8 of each 32-pixel pass, 8 channels (16 B)
-    const int s_px = wave * 8 + (lane >> 3);
-    const int s_coff = (c0 + (lane & 7) * 8 < C) ? (c0 + (lane & 7) * 8) * 2 : OOB;
+                                                                         H * W * C * (int)sizeof(T), 0x00020000);
+    // staging role: pixel wave*PPW + lane/LPS of each pass, CHS channels (16 B)
+    const int s_px = wave * PPW + lane / LPS;
+    const int s_coff = (c0 + (lane % LPS) * CHS < C) ? (c0 + (lane % LPS) * CHS) * (int)sizeof(T) : OOB;
     // compute role: 4 channels, column t/16 % 8, rows (t/128)*4 .. +3
     const int cq = t & 15, col = (t >> 4) & 7, rh = t >> 7;
     const int c = c0 + cq * 4;
@@ -255,11 +262,11 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
         const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
-            const int i = s_px + j * 32;
+            const int i = s_px + j * PPP;
             const int ry = i / IW, rx = i - ry * IW;
             const int iy = iy0 + ry, ix = ix0 + rx;
             const bool ok = i < NPX && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            dma16(rin, (lds_ptr_t*)&tile[buf][(j * 32 + wave * 8) * 64], ok ? (iy * W + ix) * C * 2 + s_coff : OOB);
+            dma16(rin, (lds_ptr_t*)&tile[buf][(j * PPP + wave * PPW) * 64], ok ? (iy * W + ix) * C * (int)sizeof(T) + s_coff : OOB);
         }
     };
 
@@ -306,8 +313,10 @@ __global__ __launch_bounds__(256) void dwconv_strip_kernel(const T* __restrict__
         for (int oo = 0; oo < 4; ++oo) {
             const int oy = oy0 + oo;
             if (cok && oy < H && ox < W) {
+                if (!PRECISE || act) {                                   // (16-bit tensors: always -- launch_dwconv sends act = none to the general kernel)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[oo][e] = act_silu_fast(acc[oo][e]);
+                    for (int e = 0; e < 4; ++e) acc[oo][e] = PRECISE ? act_silu_precise(acc[oo][e]) : act_silu_fast(acc[oo][e]);
+                }
                 store4<T>(out + (((long)b * H + oy) * W + ox) * C + c, acc[oo]);
                 sum += acc[oo];
             }
@@ -515,9 +524,10 @@ hipError_t launch_dwconv(const OpArgs& a, hipStream_t s) {
     if (P != o.aux0) return hipErrorInvalidValue;
     // Consecutive tiles per workgroup: the grid runs in ceil(workgroups / resident slots) rounds of `tpw` tile
     // times each; take the tpw that minimises rounds * tpw (ties: the larger, it amortises the tap loads).
-    const bool strip = ftc_is16(o.in_dtype) && o.stride == 1 && !(o.flags & 0x100) && o.act != FTC_ACT_NONE;
+    // stride 1: the strip kernel (16-bit: fast SiLU only; fp32: with or without activation).  0x100: the general kernel (A/B measurements, tests)
+    const bool strip = o.stride == 1 && !(o.flags & 0x100) && (ftc_is16(o.in_dtype) ? o.act != FTC_ACT_NONE : (o.Cin % 4 == 0));
     const long slabs = (long)((o.Cin + 63) / 64) * o.B;
-    const long slots = 256L * (strip ? 4 : o.in_dtype == FTC_F32 ? 3 : 2);     // workgroups resident on 256 CUs (VGPR-limited)
+    const long slots = 256L * (strip ? (o.in_dtype == FTC_F32 ? 2 : 4) : o.in_dtype == FTC_F32 ? 3 : 2);     // workgroups resident on 256 CUs (LDS / VGPR-limited)
     int tpw = 1;
     long best = -1;
     for (int cand = 1; cand <= (P < 16 ? P : 16); ++cand) {
@@ -529,13 +539,17 @@ hipError_t launch_dwconv(const OpArgs& a, hipStream_t s) {
 #define DW_LAUNCH(T, ST)                                                                                      \
     hipLaunchKernelGGL((dwconv_kernel<T, ST>), grid, dim3(256), 0, s, (const T*)a.in, (const float*)a.w, a.bias, \
                        (T*)a.out, a.aux, o.H, o.W, o.Ho, o.Wo, o.Cin, tilesX, P, tpw, o.act != FTC_ACT_NONE ? 1 : 0)
-    if (o.in_dtype == FTC_F32) { if (o.stride == 1) DW_LAUNCH(float, 1); else DW_LAUNCH(float, 2); }
+    const int act = o.act != FTC_ACT_NONE ? 1 : 0;
+    if (strip && o.in_dtype == FTC_F32)
+        hipLaunchKernelGGL((dwconv_strip_kernel<float, true>), grid, dim3(256), 0, s, (const float*)a.in, (const float*)a.w, a.bias,
+                           (float*)a.out, a.aux, o.H, o.W, o.Cin, tilesX, P, tpw, act);
+    else if (o.in_dtype == FTC_F32) { if (o.stride == 1) DW_LAUNCH(float, 1); else DW_LAUNCH(float, 2); }
     else if (strip && o.in_dtype == FTC_F16)
-        hipLaunchKernelGGL(dwconv_strip_kernel<_Float16>, grid, dim3(256), 0, s, (const _Float16*)a.in, (const float*)a.w, a.bias,
-                           (_Float16*)a.out, a.aux, o.H, o.W, o.Cin, tilesX, P, tpw);
+        hipLaunchKernelGGL((dwconv_strip_kernel<_Float16, false>), grid, dim3(256), 0, s, (const _Float16*)a.in, (const float*)a.w, a.bias,
+                           (_Float16*)a.out, a.aux, o.H, o.W, o.Cin, tilesX, P, tpw, act);
     else if (strip)
-        hipLaunchKernelGGL(dwconv_strip_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)a.in, (const float*)a.w, a.bias,
-                           (__bf16*)a.out, a.aux, o.H, o.W, o.Cin, tilesX, P, tpw);
+        hipLaunchKernelGGL((dwconv_strip_kernel<__bf16, false>), grid, dim3(256), 0, s, (const __bf16*)a.in, (const float*)a.w, a.bias,
+                           (__bf16*)a.out, a.aux, o.H, o.W, o.Cin, tilesX, P, tpw, act);
     else if (o.in_dtype == FTC_F16) { if (o.stride == 1) DW_LAUNCH(_Float16, 1); else DW_LAUNCH(_Float16, 2); }
     else { if (o.stride == 1) DW_LAUNCH(__bf16, 1); else DW_LAUNCH(__bf16, 2); }
 #undef DW_LAUNCH

@@ -476,7 +476,8 @@ int ftc_op_kernel_label(const ftc_op* op, char* buf, int len) {
     case FTC_OP_STEM: std::snprintf(buf, len, "stem_kernel"); break;
     case FTC_OP_CONV: conv_kernel_label(*op, buf, len); break;
     case FTC_OP_DWCONV:
-        if (ftc_is16(op->in_dtype) && op->stride == 1 && !(op->flags & 0x100) && op->act != FTC_ACT_NONE) std::snprintf(buf, len, "dwconv_strip_kernel<%s,s1>", ftc_dtname(op->in_dtype));
+        if (op->stride == 1 && !(op->flags & 0x100) && (ftc_is16(op->in_dtype) ? op->act != FTC_ACT_NONE : op->Cin % 4 == 0))
+            std::snprintf(buf, len, "dwconv_strip_kernel<%s,s1>", ftc_dtname(op->in_dtype));
         else std::snprintf(buf, len, "dwconv_kernel<%s,s%d>", ftc_dtname(op->in_dtype), op->stride);
         break;
     case FTC_OP_SE: std::snprintf(buf, len, "se_fc1+se_fc2"); break;

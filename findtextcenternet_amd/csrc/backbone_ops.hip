@@ -490,6 +490,72 @@ __global__ __launch_bounds__(256) void se_fc2_fold64_kernel(const float* __restr
     }
 }
 
+// FOLD for the fp16x3 mode (FTC_FLAG_SPLIT16; the fp32 plan): the project weights are stored PRE-SPLIT -- every 16-byte chunk of four
+// fp32 weights as [hi x4 | lo x4] IEEE halves (model.hip add_compute) -- so the folded per-image copy is too: w = hi + lo (exact in fp32),
+// w * scale, split again (same split as conv_igemm_impl.h chunk_hl).  With it the project convolution of the fp16x3 plan streams both
+// operands by DMA like the 16-bit plans do, instead of gating every activation element while staging it (87 us per stage-6 block).
+// Same prologue as se_fc2_fold64_kernel (64 channels per workgroup); 16 lanes x one chunk = the 64 channels, 16 rows per pass.
+__global__ __launch_bounds__(256) void se_fc2_foldx3_kernel(const float* __restrict__ hidden, const float* __restrict__ w2t,
+                                                            const float* __restrict__ b2, float* __restrict__ scale, int C, int S,
+                                                            const u32x4* __restrict__ wp, u32x4* __restrict__ wb, int N) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];      // [S] hidden | [4][64] partial dots | [64] scale
+    float* hid = lds_f;
+    float* part = lds_f + ((S + 3) & ~3);
+    float* lsc = part + 256;
+    const int b = blockIdx.y, t = threadIdx.x;
+    const int cl = t & 63, sg = t >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int s_lo = sg * ((S + 3) / 4), s_hi = min(S, s_lo + (S + 3) / 4);
+    constexpr int SMAX = 40;
+    float wreg[SMAX];
+#pragma unroll
+    for (int i = 0; i < SMAX; ++i) wreg[i] = (c < C && s_lo + i < s_hi) ? w2t[(long)(s_lo + i) * C + c] : 0.f;
+    for (int s = t; s < S; s += 256) hid[s] = hidden[(long)b * S + s];
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < SMAX; ++i)
+        if (s_lo + i < s_hi) acc += hid[s_lo + i] * wreg[i];
+    for (int s = s_lo + SMAX; s < s_hi; ++s) acc += hid[s] * w2t[(long)s * C + c];
+    part[sg * 64 + cl] = acc;
+    __syncthreads();
+    if (t < 64) {
+        float sc = 0.f;
+        if (c < C) {
+            sc = sigmoid_precise(b2[c] + ((part[cl] + part[64 + cl]) + (part[128 + cl] + part[192 + cl])));
+            if (blockIdx.z == 0) scale[(long)b * C + c] = sc;
+        }
+        lsc[cl] = sc;
+    }
+    __syncthreads();
+    const int chunk = t & 15, r0 = t >> 4;
+    const int cc = blockIdx.x * 64 + chunk * 4;
+    if (cc >= C) return;                                           // C % 4 == 0 (validated)
+    float f[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = lsc[chunk * 4 + e];
+    const int rows = (N + gridDim.z - 1) / gridDim.z;
+    const int n_lo = blockIdx.z * rows, n_hi = min(N, n_lo + rows);
+    u32x4* dst = wb + (long)b * N * (C >> 2);
+#pragma unroll 4
+    for (int n = n_lo + r0; n < n_hi; n += 16) {
+        const u32x4 v = wp[(long)n * (C >> 2) + (cc >> 2)];
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const u32x2 hu = {v[0], v[1]}, lu = {v[2], v[3]};
+        const h4 hi = __builtin_bit_cast(h4, hu), lo = __builtin_bit_cast(h4, lu);
+        h4 oh, ol;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = ((float)hi[e] + (float)lo[e]) * f[e];
+            const _Float16 hh = (_Float16)f16_sat(x);
+            oh[e] = hh;
+            ol[e] = (_Float16)(x - (float)hh);
+        }
+        const u32x2 ohu = __builtin_bit_cast(u32x2, oh), olu = __builtin_bit_cast(u32x2, ol);
+        dst[(long)n * (C >> 2) + (cc >> 2)] = u32x4{ohu[0], ohu[1], olu[0], olu[1]};
+    }
+}
+
 }  // namespace
 
 hipError_t launch_stem(const OpArgs& a, hipStream_t s) {
@@ -564,7 +630,14 @@ hipError_t launch_se(const OpArgs& a, hipStream_t s) {
                        (const float*)a.w, a.bias, hidden, C, S, P, 1.0f / (float)(o.H * o.W));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if ((o.flags & FTC_FLAG_SE_FOLD) && !(o.flags & 0x100)) {
+    if ((o.flags & FTC_FLAG_SE_FOLD) && o.w_dtype == FTC_F32) {    // fp16x3 plan: pre-split fp32 chunks in, pre-split per-image copies out
+        const int cb = (C + 63) / 64;
+        int nz = (768 + cb * o.B - 1) / (cb * o.B);
+        const int max_nz = (o.Cout_total + 15) / 16;
+        nz = nz < 1 ? 1 : nz > max_nz ? max_nz : nz;
+        hipLaunchKernelGGL(se_fc2_foldx3_kernel, dim3(cb, o.B, nz), dim3(256), (size_t)(((S + 3) & ~3) + 256 + 64) * sizeof(float), s, hidden,
+                           (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const u32x4*)a.in, (u32x4*)a.out2, o.Cout_total);
+    } else if ((o.flags & FTC_FLAG_SE_FOLD) && !(o.flags & 0x100)) {
         const int cb = (C + 63) / 64;
         int nz = (768 + cb * o.B - 1) / (cb * o.B);                  // ~3 workgroups per CU
         const int max_nz = (o.Cout_total + 31) / 32;

@@ -135,8 +135,11 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if ((size_t)o.Cin * 4 > 64000 || (size_t)o.aux0 * 4 > 64000) return "se: C or S too large for LDS";
         if (o.flags & FTC_FLAG_SE_FOLD) {
             if (o.Cout_total <= 0) return "se: SE_FOLD needs Cout_total (rows of the folded matrix)";
-            if (!need(o.in, true, "in", (int64_t)o.Cout_total * o.Cin * 2) || !need(o.out2, true, "out2", (int64_t)o.B * o.Cout_total * o.Cin * 2)) return why->c_str();
-            if (o.Cin % 8 || o.Cout_total <= 0 || !ftc_is16(o.w_dtype)) return "se: SE_FOLD needs a 16-bit [Cout_total][C] matrix with C % 8 == 0";
+            const bool x3 = o.w_dtype == FTC_F32 && (o.flags & FTC_FLAG_SPLIT16);      // fp16x3 plan: pre-split fp32 chunks
+            const int64_t eb = x3 ? 4 : 2;
+            if (!need(o.in, true, "in", (int64_t)o.Cout_total * o.Cin * eb) || !need(o.out2, true, "out2", (int64_t)o.B * o.Cout_total * o.Cin * eb)) return why->c_str();
+            if (o.Cin % 8 || o.Cout_total <= 0 || !(ftc_is16(o.w_dtype) || x3))
+                return "se: SE_FOLD needs a 16-bit (or, with FTC_FLAG_SPLIT16, pre-split fp32) [Cout_total][C] matrix with C % 8 == 0";
         }
         return nullptr;
     case FTC_OP_UPCAT:

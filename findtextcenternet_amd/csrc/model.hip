@@ -704,16 +704,19 @@ int Builder::build(ModelPlan* out) {
                 const R hid = buf((int64_t)B * blk.squeeze, FTC_F32);
                 // bf16 mode: the SE op also writes the project weights scaled per image, so that the project convolution streams both
                 // operands by DMA instead of rescaling activations while staging them.  Needs a 64-pixel tile that divides the image.
-                const bool foldse = dual && (ho * wo) % 64 == 0 && blk.exp % 8 == 0;
-                const R wb = foldse ? buf((int64_t)B * blk.cout * blk.exp, A) : R();
+                // (fp16x3 plan: the same with pre-split fp32 chunks -- FTC_NO_X3FOLD=1 keeps the gate in the project convolution's staging)
+                const bool x3fold = m_->split16 && cdt_ == FTC_F32 && !env_on("FTC_NO_X3FOLD");
+                const bool foldse = (dual || x3fold) && (ho * wo) % 64 == 0 && blk.exp % 8 == 0;
+                const int fdt = dual ? A : FTC_F32;
+                const R wb = foldse ? buf((int64_t)B * blk.cout * blk.exp, fdt) : R();
                 {
                     SymOp s;
                     ftc_op& o = s.o;
-                    o.kind = FTC_OP_SE; o.flags = foldse ? FTC_FLAG_SE_FOLD : 0; o.w_dtype = foldse ? A : 0; o.B = B; o.H = ho; o.W = wo;
+                    o.kind = FTC_OP_SE; o.flags = foldse ? FTC_FLAG_SE_FOLD | (dual ? 0 : FTC_FLAG_SPLIT16) : 0; o.w_dtype = foldse ? fdt : 0; o.B = B; o.H = ho; o.W = wo;
                     o.Cin = blk.exp; o.Cout = blk.exp; o.Cout_total = foldse ? blk.cout : 0; o.aux0 = blk.squeeze; o.aux1 = P;
                     s.aux = part; s.out = sc; s.in2 = hid; s.w = wref(p + ".2.w1"); s.w2 = wref(p + ".2.w2t"); s.bias = wref(p + ".2.b1");
                     s.bias2 = wref(p + ".2.b2"); s.in = foldse ? wref(p + ".3.w") : R(); s.out2 = wb;
-                    const double se_bytes = 8.0 * blk.exp * blk.squeeze + (double)B * P * blk.exp * 4 + (foldse ? (double)(B + 1) * blk.cout * blk.exp * 2 : 0.0);
+                    const double se_bytes = 8.0 * blk.exp * blk.squeeze + (double)B * P * blk.exp * 4 + (foldse ? (double)(B + 1) * blk.cout * blk.exp * esize(fdt) : 0.0);
                     emit({p + ".2", "se", 4.0 * B * blk.exp * blk.squeeze, se_bytes}, s);
                 }
                 ConvOpt pj = tail;

@@ -19,6 +19,10 @@ hipError_t launch_conv_f16_ff(const ConvP& p, const ftc_op& o, hipStream_t s);
 
 void conv_kernel_label(const ftc_op& op, char* buf, int len) {
     const char* dt[] = {"f32", "bf16", "f16", "?"};
+    if (ftc_thin_conv_legal(op)) {
+        snprintf(buf, len, op.groups > 1 ? "thin_conv3x3<%s,co=%d,groups=%d>" : "thin_conv3x3<%s,co=%d>", (op.flags & FTC_FLAG_SPLIT16) ? "f16x3" : "f32", op.Cout, op.groups);
+        return;
+    }
     if (uses_halo(op) && hint_wl1(op) && (op.flags & FTC_FLAG_W_FRAG)) {
         snprintf(buf, len, (op.flags & FTC_FLAG_TOP_FUSE) ? "conv3x3_wl1+top<%s,tile=192x16x16,bk=64>" : "conv3x3_wl1<%s,tile=192x16x16,bk=64>", dt[op.w_dtype & 3]);
         if (op.groups > 1) snprintf(buf + strlen(buf) - 1, len - strlen(buf) + 1, ",groups=%d>", op.groups);
@@ -68,9 +72,9 @@ const char* conv_validate(const ftc_op& op) {
     if ((op.flags & FTC_FLAG_W_PER_IMAGE) && (op.flags & (FTC_FLAG_SE_SCALE | FTC_FLAG_BORDER_BIAS))) return "conv: per-image weight sets exclude SE_SCALE / BORDER_BIAS";
     if (!wset_legal(op)) return "conv: per-image weight sets need a pixel tile that divides Ho*Wo";
     if (op.flags & FTC_FLAG_UPCAT_IN) {
-        const int bk = halo_cpr(op) * 8;
-        if (!uses_halo(op) || halo_sn(op) != 3 || !ftc_is16(op.w_dtype) || op.in_dtype != op.w_dtype || op.out_dtype != op.w_dtype)
-            return "conv: UPCAT_IN needs the 16-bit LDS-halo kernel with 192-channel tiles (aux0 = 65)";
+        const int bk = halo_cpr(op) * (ftc_is16(op.w_dtype) ? 8 : 4);
+        if (!uses_halo(op) || halo_sn(op) != 3 || op.in_dtype != op.w_dtype || op.out_dtype != op.w_dtype)
+            return "conv: UPCAT_IN needs the LDS-halo kernel with 192-channel tiles (aux0 = 65), input and output in the compute type";
         if ((op.H | op.W) & 1 || op.cin_off != 0 || op.Cin_total <= 0 || op.Cin_total >= op.Cin || op.Cin_total % bk || (op.Cin - op.Cin_total) % bk)
             return "conv: UPCAT_IN needs even H, W and both channel parts multiples of the K block";
         if (op.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_SE_SCALE | FTC_FLAG_W_PER_IMAGE)) return "conv: UPCAT_IN excludes RESIDUAL / SE_SCALE / W_PER_IMAGE";
@@ -104,6 +108,7 @@ const char* conv_validate(const ftc_op& op) {
 
 hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
+    if (ftc_thin_conv_legal(o)) return launch_thin_conv(a, s);
     ConvP p;
     p.in = a.in; p.w = a.w; p.bias = a.bias; p.res = a.in2; p.out = a.out; p.out2 = a.out2; p.se = a.scale;
     p.in_bytes = (unsigned)((long)o.B * o.H * o.W * o.Cin_total * (o.in_dtype == FTC_F32 ? 4 : 2));
@@ -137,10 +142,11 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
         p.Cy = o.Cin_total; p.Hi = o.H / 2; p.Wi = o.W / 2;
         p.ry = o.H > 1 ? (float)(p.Hi - 1) / (float)(o.H - 1) : 0.f;
         p.rx = o.W > 1 ? (float)(p.Wi - 1) / (float)(o.W - 1) : 0.f;
-        p.in_bytes = (unsigned)((long)o.B * p.Hi * p.Wi * p.Cy * 2);
+        const long esz = ftc_is16(o.w_dtype) ? 2 : 4;
+        p.in_bytes = (unsigned)((long)o.B * p.Hi * p.Wi * p.Cy * esz);
         p.in_gs = (long)p.in_bytes;
         p.in2u = a.in2;
-        p.in2u_bytes = (unsigned)((long)o.B * o.H * o.W * (o.Cin - p.Cy) * 2);
+        p.in2u_bytes = (unsigned)((long)o.B * o.H * o.W * (o.Cin - p.Cy) * esz);
         p.in2u_gs = (o.flags & FTC_FLAG_GROUP_IN2_SHARED) ? 0 : (long)p.in2u_bytes;
         p.res = nullptr;
     }

@@ -1249,7 +1249,6 @@ __global__ __launch_bounds__(128 * WMQ, (WMQ == 2) ? 2 : (CPR == 4 && !UPIN && !
             }
     };
     auto up_store = [&](int pass, int bufidx) {
-        static_assert(!UPIN || sizeof(WT) == 2, "in-loader upsample: 16-bit operands only");
         const int q = pass * NT + t;
         if (q >= HCH) return;
         float ly1 = 0.f, lx1 = 0.f;
@@ -1265,6 +1264,16 @@ __global__ __launch_bounds__(128 * WMQ, (WMQ == 2) ? 2 : (CPR == 4 && !UPIN && !
             for (int e = 0; e < 8; ++e)
                 v[e] = ly0 * (lx0 * (float)c0[e] + lx1 * (float)c1[e]) + ly1 * (lx0 * (float)c2[e] + lx1 * (float)c3[e]);
             store16<WT>(reinterpret_cast<WT*>(hbase + bufidx * HBUF + q * 16), v);
+        } else {
+            // fp32 tensors (the fp32 and fp16x3 plans, round 3): four channels per chunk; the fp16x3 halo image holds pre-split chunks,
+            // so an upsampled chunk is written split right away (halo_split only walks the DMA-sourced blocks)
+            const f32x4 c0 = __builtin_bit_cast(f32x4, st[0]), c1 = __builtin_bit_cast(f32x4, st[1]);
+            const f32x4 c2 = __builtin_bit_cast(f32x4, st[2]), c3 = __builtin_bit_cast(f32x4, st[3]);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ly0 * (lx0 * c0[e] + lx1 * c1[e]) + ly1 * (lx0 * c2[e] + lx1 * c3[e]);
+            if constexpr (is_x3<WT>) *reinterpret_cast<u32x4*>(hbase + bufidx * HBUF + q * 16) = chunk_hl(v);
+            else *reinterpret_cast<f32x4*>(hbase + bufidx * HBUF + q * 16) = v;
         }
     };
 
@@ -1315,7 +1324,7 @@ __global__ __launch_bounds__(128 * WMQ, (WMQ == 2) ? 2 : (CPR == 4 && !UPIN && !
             }
             if (k + 2 < nk) issue_w(k + 2);                              // slot (k+2)%3 was read in step k-1
             if constexpr (is_x3<WT>) {
-                if (tapj >= 2 && tapj - 2 < NLH && nxt < p.ncb) halo_split(tapj - 2, nxt & 1);
+                if (tapj >= 2 && tapj - 2 < NLH && nxt < (UPIN ? nb_dma : p.ncb)) halo_split(tapj - 2, nxt & 1);
             }
         };
         // Round-2 timeline of this loop (tools/conv_bench.py --timeline --ablate N, s_memtime per K step, last FPN level, 1536 = the
@@ -1938,6 +1947,9 @@ hipError_t launch_halo_dispatch(const ConvP& p, const ftc_op& o, hipStream_t s) 
     if (o.flags & FTC_FLAG_UPCAT_IN) {
         if constexpr (sizeof(WT) == 2 && sizeof(OutT) == 2) {
             if (sn == 3) return cpr == 8 ? launch_halo<WT, OutT, 8, 3, false, true>(p, s) : launch_halo<WT, OutT, 4, 3, false, true>(p, s);
+        }
+        if constexpr (sizeof(WT) == 4 && sizeof(OutT) == 4) {
+            if (sn == 3 && cpr == 8) return launch_halo<WT, OutT, 8, 3, false, true>(p, s);
         }
         return hipErrorInvalidValue;
     }

@@ -141,6 +141,92 @@ __global__ __launch_bounds__(256) void tapsum_kernel(const float* __restrict__ T
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// THIN 3x3 convolution: fp32 tensors, ONE to FOUR output channels (the map heads' top convolutions in the fp32 / fp16x3 plans, where they
+// are not fused into the last FPN level's epilogue).  On the matrix cores the 1-2 output channels were padded to a 32-row tile: 1.5 ms for
+// the six single-channel heads at 4 TFLOP/s.  Here thread = pixel of a 16x16 tile, the 18x18 halo of 32 input channels is DMA'd into LDS
+// per channel block (16-byte chunk slot = chunk ^ (pixel & 7): a wave's reads spread over the banks), the block's 9 x 32 x CO weights sit
+// in LDS and are read as broadcasts, the sums are plain fp32 FMAs.  fp16x3 plans store their weights pre-split ([hi x4 | lo x4] halves per
+// four fp32): w = hi + lo.  grid = (tiles, groups); a group's operands as in the MFMA kernels (in / w / bias strides, output channel slice).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(256) void thin_conv3x3_kernel(const float* __restrict__ in, const void* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ out, int B, int H, int W, int Cin, int Cout, int CoutT, int cout_off,
+                                                           int cout_gs, long in_gs, long w_gs, int split) {
+    constexpr int NH = 18 * 18, CB = 32, CPRW = CB / 4;          // halo pixels, channels per block, 16-byte chunks per pixel
+    __shared__ __attribute__((aligned(16))) float halo[(NH * CPRW + 63) / 64 * 256];      // whole wave-level DMAs (the last one is half padding)
+    __shared__ __attribute__((aligned(16))) float wl[9 * CB * CO];                        // [tap][4-channel group][co][4]
+    const int t = threadIdx.x, g = blockIdx.y;
+    const int tilesX = (W + 15) / 16, tilesY = (H + 15) / 16;
+    int bid = blockIdx.x;
+    const int b = bid / (tilesX * tilesY);
+    bid -= b * tilesX * tilesY;
+    const int y0 = (bid / tilesX) * 16, x0 = (bid % tilesX) * 16;
+    const int ly = t >> 4, lx = t & 15;
+    const float* inb = in + g * (in_gs >> 2) + (long)b * H * W * Cin;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inb), 0, H * W * Cin * 4, 0x00020000);
+    const char* wg = static_cast<const char*>(w) + g * w_gs;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    for (int cb = 0; cb < Cin; cb += CB) {
+        __syncthreads();                                             // the previous block's halo and weights are consumed
+        // halo: NH * 8 chunks; wave-level DMA k covers chunks [64 k, 64 k + 64); LDS slot (pixel, c') holds the pixel's chunk c' ^ (pixel & 7)
+        for (int k = wave; k * 64 < NH * CPRW; k += 4) {
+            const int q = k * 64 + lane, hp = q / CPRW, cs = (q % CPRW) ^ (hp & 7);
+            const int yy = y0 - 1 + hp / 18, xx = x0 - 1 + hp % 18;
+            const bool ok = q < NH * CPRW && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (__attribute__((address_space(3))) void*)(halo + k * 256), 16,
+                                                     ok ? ((yy * W + xx) * Cin + cb + cs * 4) * 4 : 0x7ffffff0, 0, 0, 0);
+        }
+        // weights of this block: wl[((tap * 8 + c4) * CO + co) * 4 + e] = W[co][tap][cb + 4 c4 + e]
+        for (int i = t; i < 9 * (CB / 4) * CO; i += 256) {
+            const int co = i % CO, r = i / CO, c4 = r % (CB / 4), tap = r / (CB / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (co < Cout) {
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(wg + (((long)co * 9 + tap) * Cin + cb + c4 * 4) * 4);
+                if (split) {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    const u32x2 hu = {raw[0], raw[1]}, lu = {raw[2], raw[3]};
+                    const h4 hi = __builtin_bit_cast(h4, hu), lo = __builtin_bit_cast(h4, lu);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (float)hi[e] + (float)lo[e];
+                } else {
+                    v = __builtin_bit_cast(f32x4, raw);
+                }
+            }
+            *reinterpret_cast<f32x4*>(wl + ((tap * (CB / 4) + c4) * CO + co) * 4) = v;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s2 = 0; s2 < 3; ++s2) {
+                const int hp = (ly + r) * 18 + lx + s2;
+                const float* hx = halo + hp * CB;
+                const float* wt = wl + (r * 3 + s2) * CB * CO;
+#pragma unroll
+                for (int c4 = 0; c4 < CB / 4; ++c4) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(hx + ((c4 ^ (hp & 7)) << 2));
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + ((c4 * CO + c) << 2));      // same address in every lane: a broadcast
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[c] = fmaf(xv[e], wv[e], acc[c]);
+                    }
+                }
+            }
+    }
+    const int y = y0 + ly, x = x0 + lx;
+    if (y >= H || x >= W) return;
+    float* op = out + (((long)b * H + y) * W + x) * CoutT + cout_off + g * cout_gs;
+#pragma unroll
+    for (int c = 0; c < CO; ++c)
+        if (c < Cout) op[c] = acc[c] + bias[g * Cout + c];
+}
+
 }  // namespace
 
 hipError_t launch_tapsum(const OpArgs& a, hipStream_t s) {
@@ -182,3 +268,27 @@ hipError_t launch_nms(const OpArgs& a, hipStream_t s) {
                        o.Cout_total);
     return hipGetLastError();
 }
+
+// FTC_OP_CONV, 3x3 stride 1, fp32 in / out / weights (plain or fp16x3 pre-split), 1..4 output channels, no activation / residual / gate
+bool ftc_thin_conv_legal(const ftc_op& o) {
+    return o.ksize == 3 && o.stride == 1 && o.Cout >= 1 && o.Cout <= 4 && o.in_dtype == FTC_F32 && o.out_dtype == FTC_F32 && o.w_dtype == FTC_F32 &&
+           o.act == FTC_ACT_NONE && o.Cin % 32 == 0 && o.Cin_total == o.Cin && o.cin_off == 0 && o.H == o.Ho && o.W == o.Wo &&
+           !(o.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_SE_SCALE | FTC_FLAG_BORDER_BIAS | FTC_FLAG_W_PER_IMAGE | FTC_FLAG_UPCAT_IN | FTC_FLAG_TOP_FUSE | 0x100)) &&
+           (long)o.H * o.W * o.Cin * 4 < 0x7ff00000L;
+}
+
+hipError_t launch_thin_conv(const OpArgs& a, hipStream_t s) {
+    const ftc_op& o = *a.op;
+    const int G = o.groups > 1 ? o.groups : 1;
+    const bool oslice = (o.flags & FTC_FLAG_GROUP_OUT_SLICE) != 0;
+    if (G > 1 && !oslice) return hipErrorInvalidValue;               // (stacked group outputs: not needed by any plan)
+    const dim3 grid((unsigned)(o.B * ((o.H + 15) / 16) * ((o.W + 15) / 16)), (unsigned)G);
+    const long in_gs = (long)o.B * o.H * o.W * o.Cin * 4, w_gs = (long)o.Cout * 9 * o.Cin * 4;
+    const int split = (o.flags & FTC_FLAG_SPLIT16) ? 1 : 0;
+#define THIN(CO) hipLaunchKernelGGL(thin_conv3x3_kernel<CO>, grid, dim3(256), 0, s, (const float*)a.in, a.w, a.bias, (float*)a.out, o.B, o.H, o.W, o.Cin, \
+                                    o.Cout, o.Cout_total, o.cout_off, oslice ? o.Cout : 0, in_gs, w_gs, split)
+    if (o.Cout == 1) THIN(1); else if (o.Cout == 2) THIN(2); else THIN(4);
+#undef THIN
+    return hipGetLastError();
+}
+

@@ -211,6 +211,9 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s);
 hipError_t launch_dwconv(const OpArgs& a, hipStream_t s);
 hipError_t launch_bnstat(const OpArgs& a, hipStream_t s);
 hipError_t launch_bnact(const OpArgs& a, hipStream_t s);
+// fpn_ops.hip: 3x3 convolutions with 1..4 output channels on fp32 tensors (vector units; see thin_conv3x3_kernel)
+bool ftc_thin_conv_legal(const ftc_op& o);
+hipError_t launch_thin_conv(const OpArgs& a, hipStream_t s);
 // FTC_OP_BNSTAT: number of row chunks the partial sums are split into
 // (64 rows per chunk up to 512 chunks: a 24x24-map layer has 4608 rows -- with 256-row chunks its partial pass was 200 workgroups of 64
 //  serial loads each, slower than the streaming it does)

@@ -753,7 +753,8 @@ int Builder::build(ModelPlan* out) {
     const int nmap = nh - 1;                   // the map heads (all but `feature`)
     const bool fuse_top = dual && taps[0].c + FPN_DIM == 256 && !env_on("FTC_NO_TOPFUSE");
     const int TW = 20;                         // floats per pixel of the tap tensor T (9 * 2 outputs, padded)
-    const bool fuse_up = dual && !env_on("FTC_NO_UPFUSE");
+    // (round 3: also in the fp32 / fp16x3 plans, whose last-level concatenated input is 2.7 GB: FTC_NO_UPFUSE32=1 materialises it)
+    const bool fuse_up = (dual || (cdt_ == FTC_F32 && !env_on("FTC_NO_UPFUSE32"))) && !env_on("FTC_NO_UPFUSE");
     bool heads_done = false;
     for (int i = 1; i < ntap; ++i) {
         const Tap& tp = taps[ntap - 1 - i];
@@ -786,7 +787,7 @@ int Builder::build(ModelPlan* out) {
             o.Cin = tc; o.Cout = tc; o.aux0 = 0; o.aux1 = tc; o.groups = nh;
             s.in2 = tp.buf; s.out = tapbn; s.scale = bn_s; s.shift = bn_t;
             emit({"heads.tapbn" + std::to_string(i), "upcat", 0.0, (double)nh * M * tc * esize(A) + (double)M * tc * esize(tdt)}, s);
-            src_bytes = (double)B * yh * yw * cy * 2 + (double)M * tc * 2;
+            src_bytes = (double)B * yh * yw * cy * esize(A) + (double)M * tc * esize(A);
         } else {
             cat = buf((int64_t)nh * M * cin, A);
             SymOp s;
@@ -821,7 +822,7 @@ int Builder::build(ModelPlan* out) {
             } else if (up_in) {
                 flags |= FTC_FLAG_UPCAT_IN;
                 o.Cin_total = cy; o.aux0 = 65;
-                s.in = sub(y, (int64_t)g0 * B * yh * yw * cy * 2); s.in2 = sub(tapbn, (int64_t)g0 * M * tc * 2);
+                s.in = sub(y, (int64_t)g0 * B * yh * yw * cy * esize(A)); s.in2 = sub(tapbn, (int64_t)g0 * M * tc * esize(A));
             } else {
                 o.Cin_total = cin;
                 s.in = sub(cat, (int64_t)g0 * M * cin * esize(A));

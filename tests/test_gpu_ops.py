@@ -6,6 +6,7 @@ Tolerances: fp32 kernels 2e-4 * max|ref| (summation order only: exact-f32 MFMA v
 bf16 kernels are compared with the CPU result on bf16-ROUNDED operands (so only accumulation
 order / output rounding differ): 1.5e-2 * max|ref|.
 """
+import ctypes as C
 import os
 import zlib
 
@@ -716,3 +717,74 @@ def test_nms_ties_golden(golden_dir):
     run_op(dict(kind=L.OP_NMS, B=B, H=h, W=w, Ho=h, Wo=w, Cout_total=10, out=o), ar)
     out = ar.read(o, (B, h, w, 10), torch.float32).permute(0, 3, 1, 2).numpy()
     assert np.array_equal(out, g["heatmap"])
+
+
+@pytest.mark.parametrize("x3", [False, True], ids=["f32", "f32x3"])
+@pytest.mark.parametrize("G,B,H,W,Cin,Cout", [(1, 2, 20, 12, 64, 1), (6, 1, 33, 17, 192, 1), (3, 2, 16, 48, 32, 2), (1, 1, 40, 24, 96, 4)],
+                         ids=["1x1ch", "6heads", "3x2ch", "4ch"])
+def test_thin_top_convolution(G, B, H, W, Cin, Cout, x3):
+    """3x3 convolutions with 1..4 output channels on fp32 tensors (no activation) run on thin_conv3x3_kernel (vector units) instead of a
+    padded MFMA tile: G heads with their own inputs / weights / biases writing consecutive channel slices of one [B,H,W,10] map;
+    fp16x3 plans hand it pre-split weights."""
+    g = torch.Generator().manual_seed(7 + Cin + Cout)
+    x = torch.randn(G, B, H, W, Cin, generator=g)
+    w = torch.randn(G, Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bias = torch.randn(G, Cout, generator=g) * 0.3
+    CoutT, coff = 10, 1
+    ref = torch.stack([F.conv2d(x[i].permute(0, 3, 1, 2), w[i], bias[i], 1, 1).permute(0, 2, 3, 1) for i in range(G)])
+    wk = w.permute(0, 1, 3, 4, 2).reshape(G, Cout, 9, Cin)
+    ar = Arena()
+    o_in, o_b = ar.put(x), ar.put(bias)
+    o_w = ar.put(presplit_f16x3(wk) if x3 else wk)
+    o_out = ar.put(torch.full((B, H, W, CoutT), 7.0))
+    ar.materialize()
+    op = dict(kind=L.OP_CONV, flags=(L.FLAG_GROUP_OUT_SLICE if G > 1 else 0) | (L.FLAG_SPLIT16 if x3 else 0), act=L.ACT_NONE, in_dtype=L.F32, out_dtype=L.F32,
+              w_dtype=L.F32, B=B, H=H, W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cin, Cout=Cout, Cout_total=CoutT, cout_off=coff, ksize=3, stride=1,
+              groups=G if G > 1 else 0, in_=o_in, out=o_out, w=o_w, bias=o_b)
+    lib = L.load()
+    buf = C.create_string_buffer(128)
+    o = L.Op()
+    for k_, v_ in op.items():
+        if not isinstance(v_, tuple) and k_ not in ("in_", "out", "w", "bias"):
+            setattr(o, k_, int(v_))
+    lib.ftc_op_kernel_label(C.byref(o), buf, 128)
+    assert buf.value.decode().startswith("thin_conv3x3<"), buf.value
+    run_op(op, ar)
+    full = ar.read(o_out, (B, H, W, CoutT), torch.float32)
+    out = torch.stack([full[..., coff + i * Cout:coff + (i + 1) * Cout] for i in range(G)])
+    err = _rel(out, ref)
+    _log(f"thin conv G={G} Cin={Cin} Cout={Cout} x3={x3} rel_err {err:.3e}")
+    assert err < (3e-6 if not x3 else 3e-5)                         # fp32 FMAs; the pre-split weights keep 22 bits
+    assert float((full[..., 0] - 7.0).abs().max()) == 0.0 and float((full[..., coff + G * Cout:] - 7.0).abs().max()) == 0.0      # other channels untouched
+
+
+@pytest.mark.parametrize("x3", [False, True], ids=["f32", "f32x3"])
+@pytest.mark.parametrize("shape", [(2, 2, 16, 24, 192, 64), (1, 1, 22, 10, 64, 32), (9, 1, 32, 32, 192, 64)], ids=lambda s: "x".join(map(str, s)))
+def test_upcat_in_conv_fp32_and_fp16x3(shape, x3):
+    """FTC_FLAG_UPCAT_IN on fp32 tensors (round 3: the fp32 / fp16x3 plans' last FPN level): four fp32 channels per halo chunk, the
+    fp16x3 halo written pre-split; against F.interpolate(align_corners=True) + cat + conv2d."""
+    G, B, H, W, Cy, Ct = shape
+    g = torch.Generator().manual_seed(59)
+    prev = torch.randn(G, B, H // 2, W // 2, Cy, generator=g)
+    tap = torch.randn(G, B, H, W, Ct, generator=g)
+    Cin, Cout = Cy + Ct, 192
+    w = torch.randn(G, Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    bias = torch.randn(G, Cout, generator=g) * 0.3
+    ref = []
+    for i in range(G):
+        up = F.interpolate(prev[i].permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True)
+        ref.append(F.gelu(F.conv2d(torch.cat([up, tap[i].permute(0, 3, 1, 2)], 1), w[i], bias[i], 1, 1)).permute(0, 2, 3, 1))
+    ref = torch.stack(ref)
+    wk = w.permute(0, 1, 3, 4, 2).reshape(G, Cout, 9, Cin)
+    ar = Arena()
+    o_prev, o_tap, o_b = ar.put(prev), ar.put(tap), ar.put(bias)
+    o_w = ar.put(presplit_f16x3(wk) if x3 else wk)
+    o_out = ar.reserve(G * B * H * W * Cout * 4)
+    ar.materialize()
+    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_UPCAT_IN | (L.FLAG_SPLIT16 if x3 else 0), act=L.ACT_GELU, in_dtype=L.F32, out_dtype=L.F32, w_dtype=L.F32, B=B, H=H,
+                W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cy, Cout=Cout, Cout_total=Cout, ksize=3, stride=1, aux0=65, groups=G if G > 1 else 0,
+                in_=o_prev, in2=o_tap, out=o_out, w=o_w, bias=o_b), ar)
+    out = ar.read(o_out, (G, B, H, W, Cout), torch.float32)
+    err = _rel(out, ref)
+    _log(f"upcat_in fp32 conv {shape} x3={x3} rel_err {err:.3e}")
+    assert err < 2e-5

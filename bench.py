@@ -700,6 +700,47 @@ def main():
                         "(16.2 MB), batch 1, synchronous -- the reference's own calling convention; compare cpu_baseline.b1_fwd_nms_images_per_s")
         if not args.no_seam2:
             result["seam2_call_detector_b1"] = seam
+            # ---- seam 3: one whole page through PageDetector (tile gather, batched forwards on two lanes, decode, canvases, page merge;
+            # host page in, boxes out) -- what OCR_Processer.run_detector does per page (process_ocr_base.py:496-540)
+            try:
+                from findtextcenternet_amd import PageDetector
+                page_u8 = synth.page_uint8(31, 3508, 2480)                              # A4 at 300 dpi
+                pd = PageDetector(det, step_ratio=0.6, cut_off=0.4, batch=B, max_boxes=4096, device=str(dev), lanes=args.lanes)
+                pd.detect_page(page_u8)
+                import findtextcenternet_amd.page as page_mod
+                merge_fn, merge_s = page_mod.page_merge_gpu, []
+
+                def timed_merge(*a_, **k_):                                               # the greedy page-level selection, timed on its own
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    r_ = merge_fn(*a_, **k_)
+                    torch.cuda.synchronize()
+                    merge_s.append(time.perf_counter() - t1)
+                    return r_
+                page_mod.page_merge_gpu = timed_merge
+                ts_ = []
+                try:
+                    for _ in range(3):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        loc, _gf, _li, _se = pd.detect_page(page_u8)
+                        ts_.append(time.perf_counter() - t0)
+                finally:
+                    page_mod.page_merge_gpu = merge_fn
+                from findtextcenternet_amd.page import padded_page_size, tile_origins
+                ph, pw = padded_page_size(3508, 2480, pd.stepx, pd.stepy)
+                nt = len(tile_origins(ph, pw, pd.stepx, pd.stepy))
+                med = sorted(ts_)[1]
+                mg = sorted(merge_s)[len(merge_s) // 2] if merge_s else 0.0
+                result["seam3_page_a4_300dpi"] = {"ms_per_page_median": round(1000 * med, 2), "ms_page_merge": round(1000 * mg, 2), "tiles": nt,
+                                                  "tiles_per_s": round(nt / med, 1), "tiles_per_s_without_page_merge": round(nt / max(1e-9, med - mg), 1),
+                                                  "boxes": int(len(loc)),
+                                                  "note": "PageDetector.detect_page(uint8 3508x2480 synthetic page): host page in, merged boxes out, synchronous; "
+                                                          "the random-init network finds ~1600 peaks per tile (56 k candidates per page), which is what the "
+                                                          "sequential greedy page merge (process_ocr_base.py:559-650) is timed on"}
+                del pd
+            except Exception as ex:                                                          # (never let the extra record break the line)
+                result["seam3_page_a4_300dpi"] = {"error": repr(ex)[:200]}
         if not args.no_cpu_baseline:
             cpu, o_hm, o_ft = cpu_baseline({k: v for k, v in sd.items()}, args.cpu_budget)
             result["cpu_baseline"] = cpu

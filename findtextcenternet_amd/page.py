@@ -123,9 +123,8 @@ class PageDetector:
         ph, pw = padded_page_size(h0, w0, self.stepx, self.stepy)
         origins = tile_origins(ph, pw, self.stepx, self.stepy)
         page_dev = torch.from_numpy(np.ascontiguousarray(im_u8[:, :, :3])).to(self.device)
-        org = np.full((ph, pw, 3), 255, np.uint8)
-        org[:h0, :w0] = im_u8[:, :, :3]
-        org_img = org.astype(np.float32)
+        org_img = np.full((ph, pw, 3), 255, np.uint8)               # stays uint8: _run widens it on the GPU (exact), a quarter of the upload
+        org_img[:h0, :w0] = im_u8[:, :, :3]
 
         def gather(lo, hi):
             o = torch.tensor(origins[lo:hi], dtype=torch.int32, device=self.device)
@@ -195,7 +194,10 @@ class PageDetector:
                 counts = torch.cat([c for c, _, _, _ in parts])
                 boxes = torch.cat([b.reshape(-1, 9) for _, b, _, _ in parts])
                 fts = torch.cat([f.reshape(-1, f.shape[-1]) for _, _, f, _ in parts])
-            page_dev = torch.from_numpy(np.ascontiguousarray(org_img, dtype=np.float32)).to(self.device)
+            if org_img.dtype == np.uint8:
+                page_dev = torch.from_numpy(np.ascontiguousarray(org_img)).to(self.device).float()
+            else:
+                page_dev = torch.from_numpy(np.ascontiguousarray(org_img, dtype=np.float32)).to(self.device)
             loc_d, glyph_d = page_merge_gpu(boxes, fts, page_dev, canv, self.cut_off)
             if int(counts.max().item()) > self.max_boxes:
                 raise RuntimeError(f"a tile produced {int(counts.max().item())} peaks > max_boxes={self.max_boxes}; raise max_boxes")

@@ -92,6 +92,7 @@ class _HipEngine:
         if self.model is not None:
             self.model.close()
         self.model, self.wdev, self.fingerprint = None, None, None
+        self.generation = getattr(self, "generation", 0) + 1       # (captured graphs key on it: object ids and device addresses get reused)
 
     def __del__(self):
         try:
@@ -118,6 +119,7 @@ class _HipEngine:
             self.fingerprint = self._fingerprint()
         if self.wdev is None or self.wdev.device != device:
             self.wdev = torch.from_numpy(self.model.weights_host()).to(device)              # one H2D copy of the packed blob
+            self.generation = getattr(self, "generation", 0) + 1
 
     @property
     def handle(self):
@@ -131,6 +133,7 @@ class _HipEngine:
         if self.workspace is None or self.workspace.device != device or self.workspace.numel() < need:
             self.workspace = None
             self.workspace = torch.empty(need, dtype=torch.uint8, device=device)
+            self.generation = getattr(self, "generation", 0) + 1
 
     def run(self, x: torch.Tensor, with_nms: bool = True, out=None, workspace: Optional[torch.Tensor] = None):
         """workspace: a caller-owned activation arena (>= model.workspace_bytes(B, H, W) bytes) instead of the engine's own -- what lets

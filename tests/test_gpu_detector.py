@@ -451,3 +451,30 @@ def test_other_model_sizes_match_the_reference(golden_dir, size):
         e2 = float(np.abs(h2[both] - g["heatmap"][both]).max()) / rng
         _log(f"model_size={size} 128x128 {prec}: heatmap Linf {100 * e2:.3f}% of range")
         assert e2 < lim
+
+
+def test_call_detector_graph_replay_is_bit_identical_and_follows_weight_edits(sd):
+    """HipDetectorBackend.call_detector replays the forward from a HIP graph (captured on the second call): same bits as the eager path on
+    every call, and an edited parameter re-packs and re-captures instead of replaying the old weights."""
+    m = TextDetectorModel(pre_weights=False, precision="bf16")
+    m.load_state_dict(sd)
+    det = CenterNetDetector(m.detector)
+    be, be_eager = HipDetectorBackend(det), HipDetectorBackend(det, graph=False)
+    tiles = [(synth.page_images(700 + i, 1, 768, 768) * np.float32(255.)).astype(np.float32) for i in range(4)]
+    for i, t in enumerate(tiles):
+        hm, ft = be.call_detector(t)
+        hr, fr = be_eager.call_detector(t)
+        assert hm.shape == (1, 10, 192, 192) and ft.shape == (1, 100, 192, 192)
+        assert np.array_equal(hm, hr, equal_nan=True) and np.array_equal(ft, fr, equal_nan=True), i
+    assert be._g is not None and be._g["graph"] is not None          # calls 3 and 4 were replays
+    before = be.call_detector(tiles[0])[1].copy()
+    with torch.no_grad():
+        dict(m.named_parameters())["detector.feature.top_conv.0.bias"].add_(0.5)
+    after = be.call_detector(tiles[0])[1]
+    assert np.abs(after - before - 0.5).max() < 1e-5                  # the feature head's output bias moved by exactly the edit
+    hr, fr = be_eager.call_detector(tiles[0])
+    assert np.array_equal(after, fr, equal_nan=True)
+    be.call_detector(tiles[1])
+    hm, ft = be.call_detector(tiles[2])                                # a replay of the re-captured graph
+    hr, fr = be_eager.call_detector(tiles[2])
+    assert be._g["graph"] is not None and np.array_equal(hm, hr, equal_nan=True) and np.array_equal(ft, fr, equal_nan=True)

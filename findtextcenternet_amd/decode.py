@@ -160,59 +160,21 @@ class HipDetectorBackend:
     as numpy arrays, plus ``detect_tiles`` which keeps the maps on the GPU and returns only the
     decoded peaks (what makes multi-tile batches feasible, SURVEY.md section 7 "Output volume")."""
 
-    def __init__(self, detector, device: str = "cuda", graph: bool = True):
-        """graph: replay the forward of ``call_detector`` from a HIP graph.  The reference calls the detector one tile at a time and waits
-        for the result; at batch 1 the 368 launches of a forward are launch-bound (tools/graph_experiment.py: 7.3 ms eager, 5.0 ms as a
-        graph, outputs identical).  The graph is captured on the second call with a given input shape and re-captured whenever the packed
-        weights or the arena move (a parameter edit re-packs: ``_HipEngine.ensure_model``).  FTC_NO_GRAPH=1 or graph=False: eager."""
+    def __init__(self, detector, device: str = "cuda"):
         self.device = torch.device(device)
         detector.to(device=self.device)
         detector.eval()
         self.detector = detector
-        self.graph = bool(graph) and os.environ.get("FTC_NO_GRAPH") != "1"
-        self._g = None
 
     def call_detector(self, image_input: np.ndarray):
-        x_host = torch.from_numpy(np.asarray(image_input, dtype=np.float32) / np.float32(255.))
-        eng = getattr(getattr(self.detector, "detector", None), "_engine", None)
-        if not self.graph or eng is None:
-            with torch.no_grad():
-                heatmap, features = self.detector(x_host.permute(0, 3, 1, 2).to(device=self.device))
-                return heatmap.cpu().numpy(), features.cpu().numpy()
-        B, H, W, _ = x_host.shape
-        dev = self.device
-        st = self._g
-        if st is None or st["shape"] != (B, H, W):
-            st = {"shape": (B, H, W), "x": torch.empty((B, H, W, 3), dtype=torch.float32, device=dev),
-                  "heat": torch.empty((B, H // scale, W // scale, 10), dtype=torch.float32, device=dev),
-                  "feat": torch.empty((B, H // scale, W // scale, feature_dim), dtype=torch.float32, device=dev), "graph": None, "key": None, "warm": None}
-            self._g = st
-        dev = st["x"].device                                          # ("cuda" -> "cuda:0": what the engine compares its buffers' devices with)
-        with torch.no_grad(), torch.cuda.device(dev):
-            st["x"].copy_(x_host)
-            # The graph is launched FIRST and the "did a parameter change?" walk over the module's 1376 tensors (1.8 ms of host time) runs
-            # while the GPU works; in the rare case that it did, ensure_model re-packs, the key changes and the eager forward below simply
-            # overwrites the outputs (same stream, so after the stale replay).
-            replayed = st["graph"] is not None
-            if replayed:
-                st["graph"].replay()
-            eng.ensure_model(dev)
-            eng.ensure_workspace(B, H, W, dev)
-            key = (eng.generation, eng.wdev.data_ptr(), eng.workspace.data_ptr())     # generation: bumped on every re-pack / re-upload / new arena
-            if not (replayed and st["key"] == key):
-                st["graph"] = None
-                self.detector.forward_nhwc(st["x"].permute(0, 3, 1, 2), out=(st["heat"], st["feat"]))
-                if st["warm"] == key:                               # every kernel of this plan has run once: capture (nothing executes here)
-                    try:
-                        g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g):
-                            self.detector.forward_nhwc(st["x"].permute(0, 3, 1, 2), out=(st["heat"], st["feat"]))
-                        st["graph"], st["key"] = g, key
-                    except Exception as ex:
-                        self.graph = False                          # (stays eager)
-                        self.graph_error = repr(ex)
-                st["warm"] = key
-            return st["heat"].permute(0, 3, 1, 2).cpu().numpy(), st["feat"].permute(0, 3, 1, 2).cpu().numpy()
+        """The reference's calling convention: one tile, synchronous, host arrays in and out.  (A one-tile forward is launch-bound; the
+        module replays it from a HIP graph -- ``_HipEngine._run_graph`` -- so this is 5.7 ms per tile instead of 7.7 in bf16.)"""
+        images = torch.from_numpy(np.asarray(image_input, dtype=np.float32) / np.float32(255.)).permute(0, 3, 1, 2).to(device=self.device)
+        with torch.no_grad():
+            heatmap, features = self.detector(images)
+            heatmap = heatmap.cpu().numpy()
+            features = features.cpu().numpy()
+        return heatmap, features
 
     def detect_tiles(self, images_u8_or_f32: np.ndarray, tiles: Sequence[TileGeom], cut_off: float = 0.4,
                      max_boxes: int = 4096):

@@ -453,28 +453,46 @@ def test_other_model_sizes_match_the_reference(golden_dir, size):
         assert e2 < lim
 
 
-def test_call_detector_graph_replay_is_bit_identical_and_follows_weight_edits(sd):
-    """HipDetectorBackend.call_detector replays the forward from a HIP graph (captured on the second call): same bits as the eager path on
-    every call, and an edited parameter re-packs and re-captures instead of replaying the old weights."""
+def test_small_module_calls_replay_a_graph_bit_identical_and_follow_weight_edits(sd, monkeypatch):
+    """One-tile module calls (the reference's loops; HipDetectorBackend.call_detector) replay the forward from a HIP graph captured on the
+    second call: same bits as the eager path on every call, fresh output tensors per call, and an edited parameter re-packs and
+    re-captures instead of replaying the old weights."""
     m = TextDetectorModel(pre_weights=False, precision="bf16")
     m.load_state_dict(sd)
     det = CenterNetDetector(m.detector)
-    be, be_eager = HipDetectorBackend(det), HipDetectorBackend(det, graph=False)
+    be = HipDetectorBackend(det)
+    eng = m.detector._engine
     tiles = [(synth.page_images(700 + i, 1, 768, 768) * np.float32(255.)).astype(np.float32) for i in range(4)]
+
+    def eager(t):
+        monkeypatch.setenv("FTC_NO_GRAPH", "1")
+        try:
+            return be.call_detector(t)
+        finally:
+            monkeypatch.delenv("FTC_NO_GRAPH")
     for i, t in enumerate(tiles):
         hm, ft = be.call_detector(t)
-        hr, fr = be_eager.call_detector(t)
+        hr, fr = eager(t)
         assert hm.shape == (1, 10, 192, 192) and ft.shape == (1, 100, 192, 192)
         assert np.array_equal(hm, hr, equal_nan=True) and np.array_equal(ft, fr, equal_nan=True), i
-    assert be._g is not None and be._g["graph"] is not None          # calls 3 and 4 were replays
+    ents = list(eng._graphs.values())
+    assert len(ents) == 1 and ents[0]["graph"] is not None              # calls 3 and 4 were replays
+    x = torch.from_numpy(tiles[0] / np.float32(255.)).permute(0, 3, 1, 2).cuda()
+    with torch.no_grad():
+        a1, _ = det(x)
+        a2, _ = det(x)
+    assert a1.data_ptr() != a2.data_ptr() and torch.equal(a1, a2)        # a module call returns its own tensors
     before = be.call_detector(tiles[0])[1].copy()
     with torch.no_grad():
         dict(m.named_parameters())["detector.feature.top_conv.0.bias"].add_(0.5)
     after = be.call_detector(tiles[0])[1]
-    assert np.abs(after - before - 0.5).max() < 1e-5                  # the feature head's output bias moved by exactly the edit
-    hr, fr = be_eager.call_detector(tiles[0])
-    assert np.array_equal(after, fr, equal_nan=True)
+    assert np.abs(after - before - 0.5).max() < 1e-5                    # the feature head's output bias moved by exactly the edit
+    assert np.array_equal(after, eager(tiles[0])[1], equal_nan=True)
     be.call_detector(tiles[1])
-    hm, ft = be.call_detector(tiles[2])                                # a replay of the re-captured graph
-    hr, fr = be_eager.call_detector(tiles[2])
-    assert be._g["graph"] is not None and np.array_equal(hm, hr, equal_nan=True) and np.array_equal(ft, fr, equal_nan=True)
+    hm, ft = be.call_detector(tiles[2])                                  # a replay of the re-captured graph
+    hr, fr = eager(tiles[2])
+    assert ents[0]["graph"] is not None and np.array_equal(hm, hr, equal_nan=True) and np.array_equal(ft, fr, equal_nan=True)
+    # dropping the packed model drops the graphs with it
+    eng.invalidate()
+    assert all(e["graph"] is None for e in eng._graphs.values())
+    assert np.array_equal(be.call_detector(tiles[2])[0], hr, equal_nan=True)

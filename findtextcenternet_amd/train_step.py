@@ -121,10 +121,14 @@ class TrainStep:
                 table[n + "#f"], table[n + "#d"] = f_off, d_off
         table["zeros"] = off
         off = _align(off + max(cmax, 4096) * 4, 256)
+        table["ones_zeros"] = off                             # [ones | zeros]: an identity (scale, shift) pair (FTC_TRAIN_EMULATE_Z16 experiment)
+        self._ones_n = max(cmax, 4096)
+        off = _align(off + 2 * self._ones_n * 4, 256)
         self.table, self.ptable = table, ptable
         blob = torch.zeros(off + 256, dtype=torch.uint8, device=dev)
         grads = torch.zeros(self.n_param_bytes // 4, dtype=torch.float32, device=dev)
         fl = blob.view(torch.float32) if blob.numel() % 4 == 0 else blob[: blob.numel() // 4 * 4].view(torch.float32)
+        fl[table["ones_zeros"] // 4: table["ones_zeros"] // 4 + self._ones_n] = 1.0
         with torch.no_grad():
             for n, p in params:
                 o = ptable[n] // 4
@@ -260,6 +264,18 @@ class TrainStep:
             self.emit(wname, kind=L.OP_CONV, flags=L.FLAG_SE_SCALE if se is not None else 0, act=L.ACT_NONE, in_dtype=xdt, out_dtype=L.F32,
                       w_dtype=self.cdt, B=B, H=h, W=w, Ho=ho, Wo=wo, Cin=cin, Cin_total=cin_total or cin, Cout=cout, Cout_total=cout_total or cout,
                       cout_off=cout_off, ksize=k, stride=stride, res_dtype=L.F32, in_=xin, out=z, w=self.w(wname + "#f"), bias=bias or self.w("zeros"), scale=se)
+            if self.h16 and out is None and cout_total is None and os.environ.get("FTC_TRAIN_EMULATE_Z16") == "1":
+                # EXPERIMENT (what would storing the conv outputs in 16 bits, as the reference's autocast does, cost in gradient agreement?):
+                # round z to the compute type and back in place -- two extra identity passes, numerics of a 16-bit z, storage unchanged
+                z16 = self.buf(B * ho * wo * cout * 2)
+                idn = self.w("ones_zeros")
+                ids = ("w", idn[1] + self.ts._ones_n * 4)
+                rows_p = max(1, min(2048, (ho * wo) // 64))
+                tc = L.F16 if self.cdt == L.F16 else L.BF16
+                self.emit("z16:" + wname, kind=L.OP_BNACT, act=L.ACT_NONE, in_dtype=L.F32, out_dtype=self.cdt, w_dtype=tc, res_dtype=L.F32, B=B, H=ho, W=wo, Cin=cout,
+                          aux0=rows_p, in_=z, scale=idn, shift=ids, out=z16)
+                self.emit("z32:" + wname, kind=L.OP_BNACT, act=L.ACT_NONE, in_dtype=self.cdt, out_dtype=L.F32, w_dtype=tc, res_dtype=L.F32, B=B, H=ho, W=wo, Cin=cout,
+                          aux0=rows_p, in_=z16, scale=idn, shift=ids, out=z)
             return z, ho, wo
 
         def bnstat(self, z, h, w, c, bn_name, eps, B=None):

@@ -149,14 +149,16 @@ def test_two_streams_give_the_same_gradients_bit_for_bit():
     assert torch.equal(got[False].view(torch.int32), got[True].view(torch.int32))
 
 
-@pytest.mark.parametrize("precision,cos_min,cos_median", [("bf16", 0.55, 0.78), ("fp16", 0.98, 0.993)])
+@pytest.mark.parametrize("precision,cos_min,cos_median", [("bf16", 0.58, 0.88), ("fp16", 0.985, 0.996)])
 def test_train_step_16bit_gradients_point_the_same_way(g10, precision, cos_min, cos_median):
     """bf16 / fp16 MFMA operands with fp32 activations, statistics and accumulation (the reference trains under bf16 autocast,
     train1.py:127, which additionally STORES activations in bf16).  Gate = direction of every stored gradient tensor against the
     reference's fp32 gradients.  Measured on this 100-block random-init network (batch statistics over as few as 128 samples):
-    fp16 cosine >= 0.989 everywhere (median 0.996); bf16 0.63 - 0.99 (median 0.83; the heads' last level 0.99, the backbone 0.65 - 0.78:
-    eight times the operand rounding of fp16 accumulated through 100 blocks of backward -- the same factor the inference path shows,
-    DESIGN section 3).  The gates sit just below the measurement so that a regression in either mode fails."""
+    fp16 cosine >= 0.990 everywhere (median 0.999); bf16 0.61 - 0.99 (10th percentile 0.64, median 0.93; the heads' last level 0.975+, the
+    backbone 0.61 - 0.8: eight times the operand rounding of fp16 accumulated through 100 blocks of backward -- the same factor the
+    inference path shows).  (End of round 3, tools/z16_experiment.py; the median rose from 0.83 when the SE gate of the
+    project convolutions' weight gradients moved from the staged bf16 elements to the fp32 partial tile.)  The gates sit just below the
+    measurement so that a regression in either mode fails."""
     B, H, W = 2, 256, 256
     model = _model(precision)
     ts = TrainStep(model)
@@ -181,4 +183,4 @@ def test_train_step_16bit_gradients_point_the_same_way(g10, precision, cos_min, 
     assert cosines[0][0] > cos_min, cosines[:5]
     assert cosines[len(cosines) // 2][0] > cos_median, cosines[len(cosines) // 2]
     top = [c for c, n in cosines if ".upsamplers.3." in n or ".top_conv." in n]
-    assert min(top) > (0.95 if precision == "bf16" else 0.99), min(top)
+    assert min(top) > (0.96 if precision == "bf16" else 0.99), min(top)

@@ -95,7 +95,9 @@ def all_gather_boxes_static(counts: torch.Tensor, records: torch.Tensor, n_tiles
     without asking), and the row count -- the whole decode capacity when the block is small (8 tiles x 2048 rows x 448 B = 7.3 MB:
     latency-bound on xGMI either way), else the caller's ``rows`` (e.g. last step's maximum, rounded up), with ``overflow`` (a device
     flag) telling afterwards whether a tile had more peaks than were sent.  The per-tile counts travel INSIDE the block, in the first
-    padding word (column 9) of every tile's row 0 -- the box occupies columns 0..8, the feature row starts at ``feat0`` = 12."""
+    padding word (column 9) of every tile's row 0 -- the box occupies columns 0..8, the feature row starts at ``feat0`` = 12.
+    NOTE: that word is written IN PLACE into the caller's ``records`` (also when there is only one rank); ``rows`` is the caller's
+    business -- ``bench.py`` and ``PageDetector`` send the whole block up to ``STATIC_GATHER_BYTES`` and a row hint above it."""
     cap = records.shape[1]
     n_rows = cap if rows is None else max(1, min(cap, int(rows)))
     records[:, 0, 9] = counts.view(torch.float32)                  # int32 bit patterns in a padding word (in place: rows are the caller's scratch)

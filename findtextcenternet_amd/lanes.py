@@ -43,12 +43,20 @@ class DetectorLanes:
     def submit(self, x: torch.Tensor, tiles, cut_off: float = 0.4, logit_cut: Optional[float] = None, then=None):
         """Enqueues forward + NMS + peak decode of batch x ([B,3,H,W], resident on the device, not modified) on the next lane and
         returns (lane index, Decoded of that lane) immediately; `then(decoded)` (e.g. the multi-GPU box gather) is called under the
-        lane's stream.  The Decoded views are valid until the same lane is submitted to again (`lanes` submissions later)."""
+        lane's stream.  The Decoded views are valid until the same lane is submitted to again (`lanes` submissions later).
+
+        Lifetime of the inputs: `x` (and `tiles` when it is a device tensor) are READ ON THE LANE'S STREAM after this call returns.
+        They are registered with the caching allocator (`Tensor.record_stream`), so the caller may drop or reassign them straight
+        away -- their memory is not handed to a new allocation before the lane's work has passed; overwriting them IN PLACE on the
+        caller's stream before `wait(lane)` is still a race, as with any asynchronous consumer."""
         i = self.k % self.n
         self.k += 1
         cur = torch.cuda.current_stream(self.dev)
         s = self.streams[i]
         s.wait_stream(cur)                                   # whatever produced x (and the caller's earlier work) comes first
+        for t in (x, tiles):                                 # allocated on the caller's stream, consumed on the lane's: tell the allocator
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(s)
         with torch.cuda.stream(s), torch.no_grad():
             self.det.forward_nhwc(x, out=(self.heat[i], self.feat[i]), workspace=self.ws[i])
             dec = decode_peaks(self.heat[i], self.feat[i], tiles, cut_off=cut_off, max_boxes=self.max_boxes, logit_cut=logit_cut, workspace=self.dws[i])

@@ -106,6 +106,7 @@ class PageDetector:
         # not depend on `lanes`.
         self.lanes = max(1, int(lanes))
         self._lane_streams, self._lane_ws = None, {}
+        self._row_hint = None                                  # rows per tile the last page needed (multi-GPU gather of large blocks)
         self.stepx, self.stepy = int(width * step_ratio), int(height * step_ratio)      # process_ocr_base.py:43-45
 
     # -- reference signature -----------------------------------------------------------------
@@ -143,7 +144,7 @@ class PageDetector:
         canv = torch.zeros((7, mh, mw), dtype=torch.float32, device=self.device)
         parts = []
         import torch.distributed as tdist
-        from .dist import all_gather_boxes_static, shard_range
+        from .dist import STATIC_GATHER_BYTES, all_gather_boxes_static, shard_range
         world = tdist.get_world_size(self.group) if (self.shard and tdist.is_available() and tdist.is_initialized()) else 1
         first, last = shard_range(len(origins), tdist.get_rank(self.group), world) if world > 1 else (0, len(origins))
         n_batches = (last - first + self.batch - 1) // self.batch if last > first else 0
@@ -185,7 +186,12 @@ class PageDetector:
                 n_feat = parts[0][2].shape[-1] if parts else 100
                 cnt_l = torch.cat([c for c, _, _, _ in parts]) if parts else torch.zeros(0, dtype=torch.int32, device=self.device)
                 rec_l = torch.cat([r for _, _, _, r in parts]) if parts else torch.zeros((0, self.max_boxes, 112), dtype=torch.float32, device=self.device)
-                g = all_gather_boxes_static(cnt_l, rec_l, len(origins), group=self.group)
+                # small blocks travel whole; above STATIC_GATHER_BYTES only the rows the last page needed (+25 %), and the device
+                # overflow flag -- identical on every rank, it is computed from the gathered counts -- sends the whole block after all
+                rows = self._row_hint if rec_l.numel() * 4 > STATIC_GATHER_BYTES else None
+                g = all_gather_boxes_static(cnt_l, rec_l, len(origins), group=self.group, rows=rows)
+                if rows is not None and bool(g.overflow):
+                    g = all_gather_boxes_static(cnt_l, rec_l, len(origins), group=self.group)
                 tdist.all_reduce(canv, op=tdist.ReduceOp.MAX, group=self.group)
                 counts = g.counts
                 boxes = g.records[:, :, :9].reshape(-1, 9)
@@ -199,8 +205,10 @@ class PageDetector:
             else:
                 page_dev = torch.from_numpy(np.ascontiguousarray(org_img, dtype=np.float32)).to(self.device)
             loc_d, glyph_d = page_merge_gpu(boxes, fts, page_dev, canv, self.cut_off)
-            if int(counts.max().item()) > self.max_boxes:
-                raise RuntimeError(f"a tile produced {int(counts.max().item())} peaks > max_boxes={self.max_boxes}; raise max_boxes")
+            cmax = int(counts.max().item())
+            if cmax > self.max_boxes:
+                raise RuntimeError(f"a tile produced {cmax} peaks > max_boxes={self.max_boxes}; raise max_boxes")
+            self._row_hint = min(self.max_boxes, (cmax + cmax // 4 + 64) // 64 * 64)      # next page's gather: rows sent when the block is large
             canv_h = canv[1:3].cpu().numpy()
             return loc_d.cpu().numpy(), glyph_d.cpu().numpy(), canv_h[0], canv_h[1]
 

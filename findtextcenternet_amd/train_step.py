@@ -185,6 +185,7 @@ class TrainStep:
     def zero_grad(self) -> None:
         """``optimizer.zero_grad()`` as one memset; re-attaches the ``.grad`` views when an optimizer set them to None."""
         self.grads.zero_()
+        self._grads_synced = False
         for n, p in self.params:
             if p.grad is None or p.grad.data_ptr() != self.grads.data_ptr() + self.ptable[n]:
                 o = self.ptable[n] // 4
@@ -699,7 +700,12 @@ class TrainStep:
         """image [B,3,H,W] fp32 0..1 (NHWC memory behind the NCHW view, or NCHW-contiguous); labelmap [B,5,h,w]; idmap [B,2,h,w]; fmask =
         ``model.get_fmask(labelmap, fmask)`` (computed here when None).  Runs the train()-mode forward, loss_function, the CoV weighting
         (``self.cov``; or explicit ``alphas`` [9]) and ADDS d(loss * loss_scale)/d(parameter) to every ``.grad``.
-        Returns (loss, rawloss dict) as 0-d device tensors -- what the reference's ``train_step`` returns (train1.py:125-131)."""
+        Returns (loss, rawloss dict) as 0-d device tensors -- what the reference's ``train_step`` returns (train1.py:125-131).
+
+        Gradient accumulation under ``enable_ddp`` (the reference's ``iters_to_accumulate``, train1.py:176-179): the all-reduce SUMS the
+        whole accumulated buffer in place, so pass ``sync_grads=False`` on every micro-batch but the LAST before ``optimizer.step()``;
+        a second synchronising call without ``zero_grad()`` in between would re-sum already-reduced gradients and raises.
+        A caller-supplied ``fmask`` must select exactly the plan's row count (min(1024 * B, B * h * w) pixels, what ``get_fmask`` selects)."""
         if not image.is_cuda:
             raise RuntimeError("findtextcenternet_amd: the train step runs on MI355X (gfx950) only (there is no CPU fallback)")
         lib = L.load()
@@ -716,10 +722,14 @@ class TrainStep:
             if self.workspace is None or self.workspace.numel() < plan["workspace_bytes"]:
                 self.workspace = torch.empty(plan["workspace_bytes"], dtype=torch.uint8, device=dev)
             mh, mw, n_rows = plan["mh"], plan["mw"], plan["n_rows"]
-            if fmask is None:
+            own_mask = fmask is None
+            if own_mask:
                 fmask = self.module.get_fmask(labelmap, None)
             from .loss_func import mask_to_index
             sel, _cnt = mask_to_index(fmask)
+            if not own_mask and int(_cnt.reshape(-1)[0].item()) != n_rows:       # (one host sync, only for masks this step did not compute)
+                raise ValueError(f"forward_backward: fmask selects {int(_cnt.reshape(-1)[0].item())} pixels, the plan gathers {n_rows} rows "
+                                 "(rows beyond the count would be read from uninitialised indices)")
             self._view(plan["sel"], (n_rows,), torch.int32).copy_(sel[:n_rows])
             self._view(plan["lab"], (B, 5, mh, mw)).copy_(labelmap.to(torch.float32))
             self._view(plan["idm"], (B, 2, mh, mw), torch.int32).copy_(idmap.to(torch.int32))
@@ -763,6 +773,10 @@ class TrainStep:
             if backward and (ddp is None or world == 1 or not sync_grads):
                 L.check(lib.ftc_plan_run_streams(plan["handle"], bases, stream, side, plan["n_fwd"], -1), "ftc_plan_run_streams (train step, backward)")
             elif backward:
+                if getattr(self, "_grads_synced", False):
+                    raise RuntimeError("forward_backward(sync_grads=True) twice without zero_grad(): the gradient buffer already holds the all-reduced "
+                                       "sum; accumulate with sync_grads=False on all but the last micro-batch")
+                self._grads_synced = True
                 key = (B, H, W, float(loss_scale / world))
                 if key not in self._segments:
                     self._segments[key] = self._bucket_segments(plan)
@@ -791,19 +805,44 @@ class TrainStep:
         self.comm_stream = torch.cuda.Stream(device=self.dev) if self.grads.is_cuda else None
         self._segments: Dict[tuple, list] = {}
 
+    @staticmethod
+    def _grad_write_extents(op) -> list:
+        """[(first element, one past the last)] of the flat gradient buffer an op writes: the FULL extent of every FTC_BASE_GRADS operand
+        (a parameter may straddle a bucket boundary, and FTC_OP_SEBWD writes four consecutive parameters through one operand)."""
+        k = op.kind
+        sizes = {}
+        if k == L.OP_WGRAD:
+            sizes["out"] = op.Cout * op.Cin * op.ksize * op.ksize
+        elif k == L.OP_BNBWD:
+            sizes["w"] = sizes["shift"] = op.Cin
+        elif k == L.OP_DWBWD:
+            sizes["out2"] = 9 * op.Cin
+        elif k == L.OP_SEBWD:
+            sizes["out2"] = 2 * op.aux0 * op.Cin + op.aux0 + op.Cin       # fc1.weight [S][C], fc1.bias [S], fc2.weight [C][S], fc2.bias [C]
+        elif k == L.OP_COLSUM:
+            sizes["out"] = op.Cin
+        elif k == L.OP_STEMWGRAD:
+            sizes["out"] = op.Cout * 27
+        ext = []
+        for f in ("in_", "in2", "out", "out2", "w", "w2", "bias", "bias2", "scale", "shift", "aux"):
+            r = getattr(op, f)
+            if r.base != L.BASE_GRADS:
+                continue
+            if f not in sizes:
+                raise RuntimeError(f"train plan: op kind {k} touches the gradient buffer through '{f}', whose extent _bucket_segments does not know")
+            ext.append((r.offset // 4, r.offset // 4 + int(sizes[f])))
+        return ext
+
     def _bucket_segments(self, plan: dict) -> list:
-        """[(first_op, last_op, bucket index)]: the backward ops in order, cut after the last op that writes into each bucket."""
+        """[(first_op, last_op, bucket index)]: the backward ops in order, cut after the last op that writes into each bucket.
+        An op counts as a writer of EVERY bucket its written extent intersects (bucket boundaries are not parameter boundaries)."""
         ops, n_fwd, n = plan["ops"], plan["n_fwd"], plan["n_ops"]
         last_writer = [n_fwd - 1] * len(self.ddp.ranges)
         for i in range(n_fwd, n):
-            for f in ("out", "out2", "w", "shift"):
-                r = getattr(ops[i], f)
-                if r.base == L.BASE_GRADS:
-                    e = r.offset // 4
-                    for bi, (lo, hi) in enumerate(self.ddp.ranges):
-                        if lo <= e < hi:
-                            last_writer[bi] = max(last_writer[bi], i)
-        # FTC_OP_SEBWD writes four consecutive parameters from one operand: they never straddle a bucket start by more than their size;
+            for e0, e1 in self._grad_write_extents(ops[i]):
+                for bi, (lo, hi) in enumerate(self.ddp.ranges):
+                    if e0 < hi and lo < e1:
+                        last_writer[bi] = max(last_writer[bi], i)
         # buckets complete in the order of `ranges` only if last_writer is monotone -- enforce it
         segs, start, done = [], n_fwd, n_fwd - 1
         for bi in range(len(self.ddp.ranges)):

@@ -123,6 +123,30 @@ def test_train_plan_bucket_segments_follow_the_backward_order():
                 assert i <= end_of[bi]
     # the last bucket (stem side) can only be complete at the very end, the first (decoder, heads) long before
     assert end_of[0] < plan["n_fwd"] + (plan["n_ops"] - plan["n_fwd"]) * 0.6
+    # ... and the same for the op's WHOLE written extent, derived independently from the parameter table: the operand starts at a
+    # parameter, and covers that parameter (FTC_OP_SEBWD: the four consecutive SE parameters) -- a parameter that straddles a bucket
+    # boundary has its tail in the bucket that is reduced EARLIER (round-3 advisor finding: three such ops in this plan)
+    starts = sorted((off // 4, p.numel()) for (n, p), off in ((np_, ts.ptable[np_[0]]) for np_ in ts.params))
+    numel_at = dict(starts)
+    order = [s0 for s0, _ in starts]
+    straddlers = 0
+    for i in range(plan["n_fwd"], plan["n_ops"]):
+        op = plan["ops"][i]
+        for f in ("out", "out2", "w", "shift"):
+            r = getattr(op, f)
+            if r.base != L.BASE_GRADS:
+                continue
+            e0 = r.offset // 4
+            assert e0 in numel_at
+            npar = 4 if op.kind == L.OP_SEBWD else 1
+            k0 = order.index(e0)
+            e1 = order[k0 + npar - 1] + numel_at[order[k0 + npar - 1]]
+            touched = [k for k, (lo, hi) in enumerate(ts.ddp.ranges) if e0 < hi and lo < e1]
+            straddlers += len(touched) > 1
+            for bi in touched:
+                assert i <= end_of[bi], (i, f, bi)
+            assert (e0, e1) in ts._grad_write_extents(op)
+    assert straddlers >= 1                                       # the case exists in this plan, i.e. the check above is not vacuous
 
 
 def test_train_plan_side_stream_ops_keep_their_buffers_until_the_join():
@@ -238,3 +262,48 @@ def test_static_gather_single_process_is_sync_free():
     with _NoHostSync():
         out = all_gather_boxes_static(counts, rec, 3)
     assert torch.equal(out.counts, counts) and out.records.shape == (3, 4, W) and bool(out.overflow) is True
+
+
+def _ddp_worker(rank, world, port, q):
+    """Replays the train plan's backward as the train step issues it -- segment by segment, each bucket all-reduced when its segment
+    ends (TrainStep.forward_backward) -- with every gradient-writing op ADDING a rank- and op-specific value over its written extent
+    (what the kernels do: +=), and compares the result with the sum over ranks of all writes."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from findtextcenternet_amd import TextDetectorModel, TrainStep
+    ts = TrainStep(TextDetectorModel(pre_weights=False, precision="bf16").train())
+    plan = ts.plan_for(2, 128, 128)
+    ts.enable_ddp(bucket_bytes=256 << 20)
+    segs = ts._bucket_segments(plan)
+    ts.grads.zero_()
+    want = torch.zeros_like(ts.grads)
+    for first, last, bi in segs:
+        for i in range(first, last + 1):
+            for e0, e1 in ts._grad_write_extents(plan["ops"][i]):
+                v = float(i % 97 + 1)
+                ts.grads[e0:e1] += v * (rank + 1)
+                want[e0:e1] += v * sum(r + 1 for r in range(world))
+        if bi is not None:
+            ts.ddp.reduce_bucket(bi, async_op=False)
+    bad = int((ts.grads != want).sum())
+    q.put((rank, bad, bool((want != 0).float().mean() > 0.99)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_bucket_segments_reduce_every_gradient_element_world2_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res == [(0, 0, True), (1, 0, True)]                  # no element kept a local-only (un-reduced) contribution

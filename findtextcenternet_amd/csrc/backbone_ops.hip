@@ -384,16 +384,40 @@ __global__ __launch_bounds__(512) void se_fc1_kernel(const float* __restrict__ p
     if (lane == 0) hidden[(long)b * S + sidx] = act_silu_precise(a + b1[sidx]);
 }
 
+// Hidden vector of the SE MLP into LDS: what se_fc1_kernel stored, or (FTC_FLAG_SE_HPART) SiLU(b1 + the C/64 per-slice partial products
+// FTC_OP_MBHEAD wrote, added in slice order: deterministic) -- the fc1 launch and its re-read of the channel sums disappear.
+__device__ __forceinline__ void se_load_hidden(float* hid, const float* __restrict__ hidden, const float* __restrict__ hpart,
+                                               const float* __restrict__ b1, int b, int S, int NS, int t, int nthreads) {
+    if (hpart) {
+        const float* hp = hpart + (long)b * NS * S;
+        for (int s = t; s < S; s += nthreads) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int j = 0;
+            for (; j + 4 <= NS; j += 4) {                      // four independent loads in flight; the association is fixed
+                a0 += hp[(long)j * S + s];
+                a1 += hp[(long)(j + 1) * S + s];
+                a2 += hp[(long)(j + 2) * S + s];
+                a3 += hp[(long)(j + 3) * S + s];
+            }
+            for (; j < NS; ++j) a0 += hp[(long)j * S + s];
+            hid[s] = act_silu_precise(((a0 + a1) + (a2 + a3)) + b1[s]);
+        }
+    } else {
+        for (int s = t; s < S; s += nthreads) hid[s] = hidden[(long)b * S + s];
+    }
+}
+
 // FOLD: additionally write the project weights scaled by this image's excitation, wb[b][n][c] = bf16(wp[n][c] * scale[b,c])
 // (FTC_FLAG_SE_FOLD).  The N rows are split over gridDim.z so that ~2 workgroups per CU share the copy; every z-slice
 // recomputes its 256 scale values (S coalesced loads per lane), slice 0 stores them.
 template <bool FOLD, typename T>
 __global__ __launch_bounds__(256) void se_fc2_kernel(const float* __restrict__ hidden, const float* __restrict__ w2t,
                                                      const float* __restrict__ b2, float* __restrict__ scale, int C, int S,
-                                                     const T* __restrict__ wp, T* __restrict__ wb, int N) {
+                                                     const T* __restrict__ wp, T* __restrict__ wb, int N,
+                                                     const float* __restrict__ hpart, const float* __restrict__ b1, int NS) {
     extern __shared__ __attribute__((aligned(16))) float hid[];    // [S] (+ [256] scale values when FOLD)
     const int b = blockIdx.y;
-    for (int s = threadIdx.x; s < S; s += 256) hid[s] = hidden[(long)b * S + s];
+    se_load_hidden(hid, hidden, hpart, b1, b, S, NS, threadIdx.x, 256);
     __syncthreads();
     const int c = blockIdx.x * 256 + threadIdx.x;
     float sc = 0.f;
@@ -437,7 +461,8 @@ __global__ __launch_bounds__(256) void se_fc2_kernel(const float* __restrict__ h
 template <typename T>
 __global__ __launch_bounds__(256) void se_fc2_fold64_kernel(const float* __restrict__ hidden, const float* __restrict__ w2t,
                                                             const float* __restrict__ b2, float* __restrict__ scale, int C, int S,
-                                                            const T* __restrict__ wp, T* __restrict__ wb, int N) {
+                                                            const T* __restrict__ wp, T* __restrict__ wb, int N,
+                                                            const float* __restrict__ hpart, const float* __restrict__ b1, int NS) {
     extern __shared__ __attribute__((aligned(16))) float lds_f[];      // [S] hidden | [4][64] partial dots | [64] scale
     float* hid = lds_f;
     float* part = lds_f + ((S + 3) & ~3);
@@ -453,7 +478,7 @@ __global__ __launch_bounds__(256) void se_fc2_fold64_kernel(const float* __restr
     float wreg[SMAX];
 #pragma unroll
     for (int i = 0; i < SMAX; ++i) wreg[i] = (c < C && s_lo + i < s_hi) ? w2t[(long)(s_lo + i) * C + c] : 0.f;
-    for (int s = t; s < S; s += 256) hid[s] = hidden[(long)b * S + s];
+    se_load_hidden(hid, hidden, hpart, b1, b, S, NS, t, 256);
     __syncthreads();
     float acc = 0.f;
 #pragma unroll
@@ -626,10 +651,16 @@ hipError_t launch_se(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
     const int C = o.Cin, S = o.aux0, P = o.aux1;
     float* hidden = const_cast<float*>(static_cast<const float*>(a.in2));      // [B,S] scratch
-    hipLaunchKernelGGL(se_fc1_kernel, dim3((S + 7) / 8, o.B), dim3(512), (size_t)C * sizeof(float), s, (const float*)a.aux,
-                       (const float*)a.w, a.bias, hidden, C, S, P, 1.0f / (float)(o.H * o.W));
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    // FTC_FLAG_SE_HPART: `aux` = the per-slice fc1 partial products of FTC_OP_MBHEAD, [B][P slices][S]: no fc1 launch
+    const bool hp = (o.flags & FTC_FLAG_SE_HPART) != 0;
+    const float* hpart = hp ? a.aux : nullptr;
+    if (!hp) {
+        hipLaunchKernelGGL(se_fc1_kernel, dim3((S + 7) / 8, o.B), dim3(512), (size_t)C * sizeof(float), s, (const float*)a.aux,
+                           (const float*)a.w, a.bias, hidden, C, S, P, 1.0f / (float)(o.H * o.W));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (hp && (o.flags & FTC_FLAG_SE_FOLD) && (o.w_dtype == FTC_F32 || (o.flags & 0x100))) return hipErrorInvalidValue;    // (validated: 16-bit fold64 or no fold)
     if ((o.flags & FTC_FLAG_SE_FOLD) && o.w_dtype == FTC_F32) {    // fp16x3 plan: pre-split fp32 chunks in, pre-split per-image copies out
         const int cb = (C + 63) / 64;
         int nz = (768 + cb * o.B - 1) / (cb * o.B);
@@ -644,23 +675,23 @@ hipError_t launch_se(const OpArgs& a, hipStream_t s) {
         nz = nz < 1 ? 1 : nz > max_nz ? max_nz : nz;
         if (o.w_dtype == FTC_F16)
             hipLaunchKernelGGL(se_fc2_fold64_kernel<_Float16>, dim3(cb, o.B, nz), dim3(256), (size_t)(((S + 3) & ~3) + 256 + 64) * sizeof(float), s, hidden,
-                               (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const _Float16*)a.in, (_Float16*)a.out2, o.Cout_total);
+                               (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const _Float16*)a.in, (_Float16*)a.out2, o.Cout_total, hpart, a.bias, P);
         else
             hipLaunchKernelGGL(se_fc2_fold64_kernel<__bf16>, dim3(cb, o.B, nz), dim3(256), (size_t)(((S + 3) & ~3) + 256 + 64) * sizeof(float), s, hidden,
-                               (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)a.in, (__bf16*)a.out2, o.Cout_total);
+                               (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)a.in, (__bf16*)a.out2, o.Cout_total, hpart, a.bias, P);
     } else if (o.flags & FTC_FLAG_SE_FOLD) {                         // 0x100: the first version (kept for A/B measurements)
         const int cb = (C + 255) / 256;
         int nz = 512 / (cb * o.B);
         nz = nz < 1 ? 1 : nz > 8 ? 8 : nz;
         if (o.w_dtype == FTC_F16)
             hipLaunchKernelGGL((se_fc2_kernel<true, _Float16>), dim3(cb, o.B, nz), dim3(256), (size_t)(S + 256) * sizeof(float), s, hidden,
-                               (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const _Float16*)a.in, (_Float16*)a.out2, o.Cout_total);
+                               (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const _Float16*)a.in, (_Float16*)a.out2, o.Cout_total, nullptr, nullptr, 0);
         else
             hipLaunchKernelGGL((se_fc2_kernel<true, __bf16>), dim3(cb, o.B, nz), dim3(256), (size_t)(S + 256) * sizeof(float), s, hidden,
-                               (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)a.in, (__bf16*)a.out2, o.Cout_total);
+                               (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)a.in, (__bf16*)a.out2, o.Cout_total, nullptr, nullptr, 0);
     } else {
         hipLaunchKernelGGL((se_fc2_kernel<false, __bf16>), dim3((C + 255) / 256, o.B), dim3(256), (size_t)S * sizeof(float), s, hidden,
-                           (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)nullptr, (__bf16*)nullptr, 0);
+                           (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)nullptr, (__bf16*)nullptr, 0, hpart, a.bias, P);
     }
     return hipGetLastError();
 }

@@ -199,6 +199,17 @@ __device__ __forceinline__ u32x4 load_act(__amdgpu_buffer_rsrc_t rin, int voff, 
     }
 }
 
+// Element index of channel n (a multiple of 4) of output pixel m in the 16-bit trunk copy `out2`: NHWC, or 32-channel planes per image
+// (FTC_FLAG_KBLOCK32: [B][Cout/32][Ho*Wo][32], what FTC_OP_MBHEAD streams as whole cache lines).
+__device__ __forceinline__ size_t out2_index(const ConvP& p, int m, int n) {
+    if (p.flags & FTC_FLAG_KBLOCK32) {
+        const int hw = p.Ho * p.Wo;
+        const int img = m / hw, r = m - img * hw;
+        return (((size_t)img * (p.Cout >> 5) + (n >> 5)) * hw + r) * 32 + (n & 31);
+    }
+    return (size_t)m * p.Cout + n;
+}
+
 // Epilogue shared by both kernels: lane owns pixel (l31) of each 32-pixel sub-tile and, per register
 // quad q, channels 8q + 4*half .. +3 of each 32-channel sub-tile (C/D layout of the 32x32 MFMA).
 template <typename WT, typename OutT, int SN, int SM>
@@ -249,7 +260,7 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvP& p, f32x16 (&acc)
                     }
                     store4<OutT>(orow + n, v);
                     if constexpr (sizeof(OutT) == 4) {
-                        if (p.out2) store4<typename Half16<WT>::type>(reinterpret_cast<typename Half16<WT>::type*>(p.out2) + (size_t)m * p.Cout + n, v);
+                        if (p.out2) store4<typename Half16<WT>::type>(reinterpret_cast<typename Half16<WT>::type*>(p.out2) + out2_index(p, m, n), v);
                     }
                 } else {
 #pragma unroll
@@ -347,7 +358,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvP& p, f32x16 (&acc)[
                 else v += load4<typename Half16<WT>::type>(reinterpret_cast<const typename Half16<WT>::type*>(p.res) + (size_t)m * p.Cout + n);
             }
             *reinterpret_cast<f32x4*>(outp + (size_t)m * p.CoutT + p.cout_off + n) = v;
-            if (p.out2) store4<typename Half16<WT>::type>(reinterpret_cast<typename Half16<WT>::type*>(p.out2) + (size_t)m * p.Cout + n, v);
+            if (p.out2) store4<typename Half16<WT>::type>(reinterpret_cast<typename Half16<WT>::type*>(p.out2) + out2_index(p, m, n), v);
         } else {
             if (has_res) {
                 float f[8], r[8];
@@ -506,7 +517,7 @@ __device__ __forceinline__ void conv_epilogue_splitk(const ConvP& p, f32x16 (&ac
             }
             store4<OutT>(outp + (size_t)m * p.CoutT + p.cout_off + n, v);
             if constexpr (sizeof(OutT) == 4) {
-                if (p.out2) store4<typename Half16<WT>::type>(reinterpret_cast<typename Half16<WT>::type*>(p.out2) + (size_t)m * p.Cout + n, v);
+                if (p.out2) store4<typename Half16<WT>::type>(reinterpret_cast<typename Half16<WT>::type*>(p.out2) + out2_index(p, m, n), v);
             }
         } else {
 #pragma unroll

@@ -110,6 +110,7 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if (!need(o.out2, false, "out2", pout * o.Cout * 2)) return why->c_str();
         if (!need(o.w2, topf, "w2", G * 32 * o.Cout * 2)) return why->c_str();
         if (o.out2.base != FTC_BASE_NULL && (o.out_dtype != FTC_F32 || o.Cout % 4)) return "conv: out2 (bf16 copy) needs an fp32 primary output and Cout % 4 == 0";
+        if ((o.flags & FTC_FLAG_KBLOCK32) && (o.out2.base == FTC_BASE_NULL || o.Cout % 32 || G > 1)) return "conv: KBLOCK32 describes out2 (the 16-bit copy) and needs Cout % 32 == 0, one group";
         return conv_validate(o);
     }
     case FTC_OP_DWCONV:
@@ -125,10 +126,24 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if (o.Ho != (o.H - 1) / o.stride + 1 || o.Wo != (o.W - 1) / o.stride + 1) return "dwconv: Ho/Wo inconsistent";
         if (o.in_dtype != o.out_dtype) return "dwconv: in/out dtype must match";
         return nullptr;
+    case FTC_OP_MBHEAD:
+        if (o.Cin <= 0 || o.Cout <= 0) return "mbhead: sizes must be positive";
+        if (!need(o.in, true, "in", pin * o.Cin * 2) || !need(o.out, true, "out", pin * o.Cout * 2) || !need(o.w2, true, "w2", (int64_t)o.Cout * o.Cin * 2) ||
+            !need(o.bias2, true, "bias2", (int64_t)o.Cout * 4) || !need(o.w, true, "w", (int64_t)9 * o.Cout * 4) ||
+            !need(o.bias, true, "bias", (int64_t)o.Cout * 4) || !need(o.aux, true, "aux", (int64_t)o.B * o.Cout * 4)) return why->c_str();
+        if (!ftc_mbhead_legal(o))
+            return "mbhead: needs 16-bit in/out/w of one type, stride 1, ksize 3, Ho = H, Wo = W, H*W <= 576, H*(W+1) < 601, Cin % 32 == 0, Cout % 128 == 0";
+        if ((o.scale.base != FTC_BASE_NULL) != (o.out2.base != FTC_BASE_NULL)) return "mbhead: scale (fc1 weight) and out2 (fc1 partial products) come together";
+        if (o.scale.base != FTC_BASE_NULL) {
+            if (o.aux0 <= 0) return "mbhead: aux0 (squeeze width S) must be positive when the fc1 partial products are requested";
+            if (!need(o.scale, true, "scale", (int64_t)o.aux0 * o.Cout * 4) || !need(o.out2, true, "out2", (int64_t)o.B * (o.Cout / FTC_MBHEAD_SLICE) * o.aux0 * 4)) return why->c_str();
+        }
+        if (o.flags & 0x1000) { if (!need(o.in2, true, "in2", (int64_t)o.B * (o.Cout / FTC_MBHEAD_SLICE) * 64)) return why->c_str(); }      // phase timeline (tools/mbslice_bench.py)
+        return nullptr;
     case FTC_OP_SE:
         if (o.aux0 <= 0 || o.aux1 <= 0 || o.Cin <= 0) return "se: C, S, P must be positive";
-        if (!need(o.aux, true, "aux", (int64_t)o.B * o.aux1 * o.Cin * 4) || !need(o.out, true, "out", (int64_t)o.B * o.Cin * 4) ||
-            !need(o.in2, true, "in2", (int64_t)o.B * o.aux0 * 4) || !need(o.w, true, "w", (int64_t)o.aux0 * o.Cin * 4) ||
+        if (!need(o.aux, true, "aux", (int64_t)o.B * o.aux1 * ((o.flags & FTC_FLAG_SE_HPART) ? o.aux0 : o.Cin) * 4) || !need(o.out, true, "out", (int64_t)o.B * o.Cin * 4) ||
+            !need(o.in2, true, "in2", (int64_t)o.B * o.aux0 * 4) || !need(o.w, !(o.flags & FTC_FLAG_SE_HPART), "w", (int64_t)o.aux0 * o.Cin * 4) ||
             !need(o.w2, true, "w2", (int64_t)o.aux0 * o.Cin * 4) || !need(o.bias, true, "bias", (int64_t)o.aux0 * 4) ||
             !need(o.bias2, true, "bias2", (int64_t)o.Cin * 4)) return why->c_str();
         if (o.Cin % 4) return "se: C must be a multiple of 4";
@@ -317,6 +332,7 @@ hipError_t run_one(const ftc_op& o, void* const bases[FTC_NUM_BASES], hipStream_
     case FTC_OP_CONV: return launch_conv(a, s);
     case FTC_OP_DWCONV: return launch_dwconv(a, s);
     case FTC_OP_SE: return launch_se(a, s);
+    case FTC_OP_MBHEAD: return launch_mbhead(a, s);
     case FTC_OP_UPCAT: return launch_upcat(a, s);
     case FTC_OP_NMS: return launch_nms(a, s);
     case FTC_OP_TAPSUM: return launch_tapsum(a, s);
@@ -483,7 +499,8 @@ int ftc_op_kernel_label(const ftc_op* op, char* buf, int len) {
             std::snprintf(buf, len, "dwconv_strip_kernel<%s,s1>", ftc_dtname(op->in_dtype));
         else std::snprintf(buf, len, "dwconv_kernel<%s,s%d>", ftc_dtname(op->in_dtype), op->stride);
         break;
-    case FTC_OP_SE: std::snprintf(buf, len, "se_fc1+se_fc2"); break;
+    case FTC_OP_SE: std::snprintf(buf, len, (op->flags & FTC_FLAG_SE_HPART) ? "se_gate" : "se_fc1+se_fc2"); break;
+    case FTC_OP_MBHEAD: std::snprintf(buf, len, "mbconv_slice<%s,128ch>", ftc_dtname(op->in_dtype)); break;
     case FTC_OP_UPCAT: std::snprintf(buf, len, "upcat_kernel<%s>", ftc_dtname(op->in_dtype)); break;
     case FTC_OP_NMS: std::snprintf(buf, len, "nms_kernel"); break;
     case FTC_OP_TAPSUM: std::snprintf(buf, len, "tapsum_kernel"); break;

@@ -14,3 +14,6 @@ struct ftc_plan {
 
 // Records the thread-local message returned by ftc_last_error() and returns `code`.
 int ftc_set_error(int code, const std::string& msg);
+
+// mbconv_slice.hip: shapes FTC_OP_MBHEAD accepts (the plan builder asks before it emits one)
+bool ftc_mbhead_legal(const ftc_op& o);

@@ -547,7 +547,7 @@ std::string conv_signature(const ftc_op& o, bool strip_split = false) {
     // fp16 operands run the same kernels at the same rate as bf16: they share the measured table (dtype 2 looks up as 1)
     auto d = [](int dt) { return dt == FTC_F16 ? (int)FTC_BF16 : dt; };
     int n = std::snprintf(buf, sizeof buf, "w%di%do%d_B%d_%dx%d_c%dof%d_n%dof%d_k%ds%d_f%d_a%d", d(o.w_dtype), d(o.in_dtype), d(o.out_dtype), o.B, o.H, o.W,
-                          o.Cin, o.Cin_total, o.Cout, o.Cout_total, o.ksize, o.stride, strip_split ? (o.flags & ~FTC_FLAG_SPLIT16) : o.flags, o.act);
+                          o.Cin, o.Cin_total, o.Cout, o.Cout_total, o.ksize, o.stride, (strip_split ? (o.flags & ~FTC_FLAG_SPLIT16) : o.flags) & ~FTC_FLAG_KBLOCK32, o.act);      // (KBLOCK32: where the 16-bit copy goes, not which kernel is fastest)
     if (o.groups > 1) std::snprintf(buf + n, sizeof buf - n, "_g%d", o.groups);
     return buf;
 }
@@ -669,6 +669,24 @@ int Builder::build(ModelPlan* out) {
     struct Tap { R buf; int c, h, w, dt; };
     std::vector<Tap> taps;
     std::vector<R> tap_copies;                  // bf16 trunk copies of the backbone taps (bf16 mode), same order
+    // Low-resolution MBConv stages (24x24 maps at 768x768: stages 6-7), 16-bit plans: expand + depthwise + squeeze + the block's share of
+    // the SE fc1 layer in ONE launch, a workgroup per (image, 128 expanded channels) -- csrc/mbconv_slice.hip; the expanded tensor never
+    // leaves the CU.  FTC_NO_MBSLICE=1: the three-kernel form; FTC_MBSLICE_MINWG: workgroups below which the three-kernel form is kept
+    // (small batches leave most CUs without a slice).  bh, bw = the block's INPUT map.
+    auto sliced = [&](const BlockSpec& blk, int bh, int bw) -> bool {
+        if (blk.fused || !dual || blk.stride != 1 || env_on("FTC_NO_MBSLICE")) return false;
+        ftc_op t{};
+        t.in_dtype = t.out_dtype = t.w_dtype = A; t.stride = blk.stride; t.ksize = 3; t.H = t.Ho = bh; t.W = t.Wo = bw;
+        t.Cin = blk.cin; t.Cout = blk.exp;
+        const char* mw_env = std::getenv("FTC_MBSLICE_MINWG");
+        const int min_wg = mw_env ? std::atoi(mw_env) : 128;
+        return ftc_mbhead_legal(t) && B * (blk.exp / FTC_MBHEAD_SLICE) >= min_wg;
+    };
+    std::vector<const BlockSpec*> flat;
+    for (const auto& st : stages)
+        for (const BlockSpec& blk : st) flat.push_back(&blk);
+    size_t bi = 0;
+    bool in_blocked = false;                    // the 16-bit trunk copy feeding the current block is in 32-channel planes (FTC_FLAG_KBLOCK32)
     for (size_t si = 0; si < stages.size(); ++si) {
         for (const BlockSpec& blk : stages[si]) {
             const std::string p = blk.prefix + ".block";
@@ -679,6 +697,10 @@ int Builder::build(ModelPlan* out) {
             trunk((int64_t)B * ho * wo * blk.cout, &y, &yb);
             ConvOpt tail;
             tail.residual = res; tail.res_dt = T; tail.out2 = yb;
+            // the consumer of this block's 16-bit copy is the next block's expand GEMM: FTC_OP_MBHEAD streams it in 32-channel planes
+            ++bi;
+            const bool out_blocked = bi < flat.size() && sliced(*flat[bi], ho, wo) && blk.cout % 32 == 0 && !env_on("FTC_NO_KBLOCK");
+            if (out_blocked) tail.extra_flags |= FTC_FLAG_KBLOCK32;
             if (blk.fused && blk.exp == blk.cin) {
                 conv(p + ".0", gin, G, h, w, blk.cin, blk.cin, 0, p + ".0", blk.cout, 3, blk.stride, FTC_ACT_SILU, y, T, tail);
             } else if (blk.fused) {
@@ -686,12 +708,24 @@ int Builder::build(ModelPlan* out) {
                 conv(p + ".0", gin, G, h, w, blk.cin, blk.cin, 0, p + ".0", blk.exp, 3, blk.stride, FTC_ACT_SILU, e, A);
                 conv(p + ".1", e, A, ho, wo, blk.exp, blk.exp, 0, p + ".1", blk.cout, 1, 1, FTC_ACT_NONE, y, T, tail);
             } else {
+                const bool slice = sliced(blk, h, w);
+                const int th = blk.stride == 1 ? 8 : 4;
+                const int P = slice ? blk.exp / FTC_MBHEAD_SLICE : ((ho + th - 1) / th) * ((wo + 7) / 8);
+                const R d = buf((int64_t)B * ho * wo * blk.exp, A);
+                const R part = buf((int64_t)B * P * (slice ? blk.squeeze : blk.exp), FTC_F32);
+                if (slice) {
+                    const R sums = buf((int64_t)B * blk.exp, FTC_F32);
+                    SymOp s;
+                    ftc_op& o = s.o;
+                    o.kind = FTC_OP_MBHEAD; o.act = FTC_ACT_SILU; o.in_dtype = A; o.out_dtype = A; o.w_dtype = A; o.B = B; o.H = h; o.W = w; o.Ho = ho; o.Wo = wo;
+                    o.Cin = blk.cin; o.Cout = blk.exp; o.ksize = 3; o.stride = 1; o.aux0 = blk.squeeze; o.flags = in_blocked ? FTC_FLAG_KBLOCK32 : 0;
+                    s.in = gin; s.out = d; s.w2 = wref(p + ".0.w"); s.bias2 = wref(p + ".0.b"); s.w = wref(p + ".1.w"); s.bias = wref(p + ".1.b"); s.aux = sums;
+                    s.scale = wref(p + ".2.w1"); s.out2 = part;
+                    emit({p + ".0+1", "conv1x1+dw3x3", 2.0 * B * h * w * blk.exp * (blk.cin + 9),
+                          (double)B * h * w * (blk.cin + blk.exp) * esize(A) + (double)blk.exp * blk.cin * esize(A) + blk.exp * 44.0 + 4.0 * blk.exp * blk.squeeze}, s);
+                } else {
                 const R e = buf((int64_t)B * h * w * blk.exp, A);
                 conv(p + ".0", gin, G, h, w, blk.cin, blk.cin, 0, p + ".0", blk.exp, 1, 1, FTC_ACT_SILU, e, A);
-                const int th = blk.stride == 1 ? 8 : 4;
-                const int P = ((ho + th - 1) / th) * ((wo + 7) / 8);
-                const R d = buf((int64_t)B * ho * wo * blk.exp, A);
-                const R part = buf((int64_t)B * P * blk.exp, FTC_F32);
                 {
                     SymOp s;
                     ftc_op& o = s.o;
@@ -699,6 +733,7 @@ int Builder::build(ModelPlan* out) {
                     o.Cin = blk.exp; o.Cout = blk.exp; o.ksize = 3; o.stride = blk.stride; o.aux0 = P;
                     s.in = e; s.out = d; s.w = wref(p + ".1.w"); s.bias = wref(p + ".1.b"); s.aux = part;
                     emit({p + ".1", "dwconv3x3", 2.0 * B * ho * wo * blk.exp * 9, (double)B * ((double)h * w + (double)ho * wo) * blk.exp * esize(A) + blk.exp * 40.0}, s);
+                }
                 }
                 const R sc = buf((int64_t)B * blk.exp, FTC_F32);
                 const R hid = buf((int64_t)B * blk.squeeze, FTC_F32);
@@ -712,11 +747,12 @@ int Builder::build(ModelPlan* out) {
                 {
                     SymOp s;
                     ftc_op& o = s.o;
-                    o.kind = FTC_OP_SE; o.flags = foldse ? FTC_FLAG_SE_FOLD | (dual ? 0 : FTC_FLAG_SPLIT16) : 0; o.w_dtype = foldse ? fdt : 0; o.B = B; o.H = ho; o.W = wo;
+                    o.kind = FTC_OP_SE; o.flags = (foldse ? FTC_FLAG_SE_FOLD | (dual ? 0 : FTC_FLAG_SPLIT16) : 0) | (slice ? FTC_FLAG_SE_HPART : 0); o.w_dtype = foldse ? fdt : 0; o.B = B; o.H = ho; o.W = wo;
                     o.Cin = blk.exp; o.Cout = blk.exp; o.Cout_total = foldse ? blk.cout : 0; o.aux0 = blk.squeeze; o.aux1 = P;
                     s.aux = part; s.out = sc; s.in2 = hid; s.w = wref(p + ".2.w1"); s.w2 = wref(p + ".2.w2t"); s.bias = wref(p + ".2.b1");
                     s.bias2 = wref(p + ".2.b2"); s.in = foldse ? wref(p + ".3.w") : R(); s.out2 = wb;
-                    const double se_bytes = 8.0 * blk.exp * blk.squeeze + (double)B * P * blk.exp * 4 + (foldse ? (double)(B + 1) * blk.cout * blk.exp * esize(fdt) : 0.0);
+                    const double se_bytes = (slice ? 4.0 : 8.0) * blk.exp * blk.squeeze + (double)B * P * (slice ? blk.squeeze : blk.exp) * 4 +
+                                            (foldse ? (double)(B + 1) * blk.cout * blk.exp * esize(fdt) : 0.0);
                     emit({p + ".2", "se", 4.0 * B * blk.exp * blk.squeeze, se_bytes}, s);
                 }
                 ConvOpt pj = tail;
@@ -725,6 +761,7 @@ int Builder::build(ModelPlan* out) {
                 conv(p + ".3", d, A, ho, wo, blk.exp, blk.exp, 0, p + ".3", blk.cout, 1, 1, FTC_ACT_NONE, y, T, pj);
             }
             x = y; xb = yb; h = ho; w = wo;
+            in_blocked = out_blocked;
         }
         if (si + 1 == 2 || si + 1 == 3 || si + 1 == 5) {          // BackboneModel.forward taps (models/detector.py:143)
             taps.push_back({x, stages[si].back().cout, h, w, T});

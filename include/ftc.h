@@ -35,8 +35,9 @@ extern "C" {
    5: the train step (BASELINE configs[4]): FTC_BASE_GRADS, FTC_OP_GATHER_ROWS .. FTC_OP_FILL (backward kernels), FTC_OP_BNSTAT writes
       [4][Cin] (scale, shift, mean, 1/std), ftc_losses out[12..13] = the two weight normalisers, ftc_pack_train_weights
    6: ftc_plan_run_streams / FTC_FLAG_SIDE_STREAM / FTC_OP_JOIN (ops with no consumer on the main chain -- the weight gradients -- on a
-      second stream) */
-#define FTC_ABI_VERSION 6
+      second stream)
+   7: FTC_OP_MBHEAD (expand 1x1 + depthwise 3x3 + SE squeeze of an MBConv block in one launch), FTC_FLAG_SE_HPART */
+#define FTC_ABI_VERSION 7
 
 typedef enum ftc_status {
     FTC_OK = 0,
@@ -67,6 +68,8 @@ typedef struct ftc_ref {
     int32_t reserved;
     int64_t offset;            /* bytes from the base */
 } ftc_ref;
+
+#define FTC_MBHEAD_SLICE 128   /* expanded channels one workgroup of FTC_OP_MBHEAD owns */
 
 typedef enum ftc_op_kind {
     /* conv3x3 stride 2 on the 3-channel image with x*2-1 fused (CenterNetDetection.forward,
@@ -153,6 +156,16 @@ typedef enum ftc_op_kind {
     FTC_OP_FILL = 23,
     /* no kernel: ftc_plan_run_streams makes the main stream wait for everything issued on the side stream so far (a no-op in ftc_plan_run) */
     FTC_OP_JOIN = 24,
+    /* MBConv head of a low-resolution stage in one launch (torchvision MBConv block[0], block[1] and the squeeze of block[2];
+       /root/reference/models/detector.py:17-20): e = SiLU(in . w2^T + bias2) rounded to the 16-bit type -- the expand 1x1 convolution with
+       its folded BatchNorm --, out = SiLU(depthwise3x3(e; w) + bias) (stride 1, zero padding), aux[b][c] = sum_{y,x} out[b,y,x,c] (fp32,
+       summed before the result is narrowed: the P = 1 form of FTC_OP_DWCONV's partial sums, consumed by FTC_OP_SE with aux1 = 1).
+       A workgroup owns one image x FTC_MBHEAD_SLICE expanded channels; the expanded tensor only ever exists in LDS (csrc/mbconv_slice.hip).
+       in [B,H,W,Cin] 16-bit, w2 [Cout][Cin] (K-major, same type), bias2 fp32 [Cout], w fp32 [9][Cout], bias fp32 [Cout], out [B,H,W,Cout]
+       16-bit; in_dtype == out_dtype == w_dtype; Cin % 32 == 0, Cout % FTC_MBHEAD_SLICE == 0, H*W <= 576 and H*(W+1) < 601 (a 24x24 map).
+       Optional: scale = the SE fc1 weight fp32 [aux0][Cout] and out2 = fp32 [B][Cout/FTC_MBHEAD_SLICE][aux0]: out2[b][j][s] = sum over the
+       channels c of slice j of scale[s][c] * mean_hw(out[b,:,:,c]) -- FTC_OP_SE with FTC_FLAG_SE_HPART adds the slices' vectors */
+    FTC_OP_MBHEAD = 25,
     FTC_OP_TAPSUM = 7          /* second half of a 3x3 convolution split as per-pixel taps + 9-point sum (FTC_FLAG_TOP_FUSE):
                                   out[b,y,x,ch_j] = bias[j] + sum_{r,s} in[g_j][b,y+r-1,x+s-1][(3r+s)*co_j + o_j] (zero outside),
                                   for the aux1 outputs j listed in `w` as int32 quadruples (g_j, o_j, co_j, ch_j);
@@ -199,6 +212,13 @@ enum {
     FTC_FLAG_ACCUM = 0x800000, /* BNBWD / CONV-as-dgrad helpers: the data-gradient output is added to what `out` holds */
     FTC_FLAG_SIDE_STREAM = 0x4000000, /* any op: ftc_plan_run_streams enqueues it on the side stream (after everything issued on the main stream so
                                   far); whoever builds the plan keeps the op's operands alive and unwritten until the next FTC_OP_JOIN */
+    FTC_FLAG_SE_HPART = 0x8000000, /* SE: `aux` holds per-slice partial products of the fc1 layer, fp32 [B][aux1][aux0] (FTC_OP_MBHEAD's out2, aux1 =
+                                  Cout/FTC_MBHEAD_SLICE slices), instead of partial channel sums: hidden = SiLU(bias + sum_j aux[b][j][:]); `w` (fc1 weight) unused */
+    FTC_FLAG_KBLOCK32 = 0x10000000, /* a 16-bit activation tensor stored in 32-channel planes, [B][C/32][H*W][32] instead of NHWC [B][H*W][C]: a pixel's 32
+                                  channels of one plane are 64 contiguous bytes and consecutive pixels follow each other, so the K step of 32 that
+                                  FTC_OP_MBHEAD streams per stage is whole cache lines (from NHWC it fetched half of every 128-byte line per step and
+                                  ran at the L1 fill rate).  On FTC_OP_CONV: the layout of `out2` (the 16-bit trunk copy; Cout % 32 == 0); on
+                                  FTC_OP_MBHEAD: the layout of `in` */
     FTC_FLAG_SE_FOLD = 32      /* SE: besides scale[b,c], write out2[b][n][c] = bf16(in[n][c] * scale[b,c]) for the
                                   bf16 matrix `in` [Cout_total][C] -- the following 1x1 convolution then runs with
                                   FTC_FLAG_W_PER_IMAGE on unscaled activations (both operands by DMA) */

@@ -296,3 +296,18 @@ def test_library_builds_plans_for_the_other_model_sizes(size):
         assert pl.h == 32 and pl.w == 40
     with pytest.raises(L.FtcError, match="shape|missing"):
         FtcModel(sd_, "fp32", "xl")                          # a checkpoint of another size is rejected, not mis-read
+
+
+def test_mbconv_slice_rejects_shapes_it_cannot_hold():
+    lib = L.load()
+    base = dict(kind=L.OP_MBHEAD, act=L.ACT_SILU, in_dtype=L.BF16, out_dtype=L.BF16, w_dtype=L.BF16, B=1, H=24, W=24, Ho=24, Wo=24, Cin=64, Cout=128,
+                ksize=3, stride=1, aux0=0)
+    for bad in (dict(H=25, Ho=25), dict(Cout=192), dict(Cin=48), dict(in_dtype=L.F32), dict(stride=2), dict(H=12, Ho=12, W=50, Wo=50)):
+        op = (L.Op * 1)()
+        for k, v in dict(base, **bad).items():
+            setattr(op[0], k, int(v))
+        for f in ("in_", "w2", "bias2", "w", "bias", "out", "aux"):
+            r = getattr(op[0], f)
+            r.base, r.offset = L.BASE_WORKSPACE, 0
+        h = C.c_void_p()
+        assert lib.ftc_plan_create(op, 1, 1 << 30, 0, C.byref(h)) != 0 and b"mbhead" in lib.ftc_last_error()

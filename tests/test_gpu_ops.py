@@ -506,10 +506,13 @@ def test_conv_border_bias_folds_preceding_batchnorm(dt):
     assert err < (1e-5 if dt == L.F32 else 2e-2)
 
 
-def test_conv_dual_output_bf16_copy():
-    """fp32 trunk output + bf16 copy (ftc_op.out2) written by the same epilogue."""
+@pytest.mark.parametrize("aux0", [0, 4 + 32 + 512, 2 + 16 + 512, 7 + 16 + 512 + 1024], ids=["default", "64x128_dma2", "128x128_reg", "64x64_splitk2"])
+@pytest.mark.parametrize("kblock", [False, True], ids=["nhwc", "kblock32"])
+def test_conv_dual_output_bf16_copy(kblock, aux0):
+    """fp32 trunk output + bf16 copy (ftc_op.out2) written by the same epilogue; with FTC_FLAG_KBLOCK32 the copy is stored in 32-channel
+    planes [B][Cout/32][H*W][32] (what FTC_OP_MBHEAD streams) -- every epilogue form (direct, LDS-staged, split-K)."""
     g = torch.Generator().manual_seed(77)
-    B, H, W, Cin, Cout = 2, 12, 12, 384, 64
+    B, H, W, Cin, Cout = 2, 16, 16, 384, 64
     x = bf16_round(torch.randn(B, H, W, Cin, generator=g))
     w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
     bias = torch.randn(Cout, generator=g) * 0.3
@@ -519,11 +522,14 @@ def test_conv_dual_output_bf16_copy():
     o_in, o_w, o_b, o_res = ar.put(to_dev_bytes(x, L.BF16)), ar.put(to_dev_bytes(w.reshape(Cout, 1, Cin), L.BF16)), ar.put(bias), ar.put(res)
     o_out, o_out2 = ar.reserve(B * H * W * Cout * 4), ar.reserve(B * H * W * Cout * 2)
     ar.materialize()
-    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_RESIDUAL, act=L.ACT_NONE, in_dtype=L.BF16, out_dtype=L.F32, w_dtype=L.BF16, B=B, H=H, W=W,
-                Ho=H, Wo=W, Cin=Cin, Cin_total=Cin, Cout=Cout, Cout_total=Cout, ksize=1, stride=1, res_dtype=L.F32,
+    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_RESIDUAL | (L.FLAG_KBLOCK32 if kblock else 0), act=L.ACT_NONE, in_dtype=L.BF16, out_dtype=L.F32, w_dtype=L.BF16,
+                B=B, H=H, W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cin, Cout=Cout, Cout_total=Cout, ksize=1, stride=1, res_dtype=L.F32, aux0=aux0,
                 in_=o_in, in2=o_res, out=o_out, out2=o_out2, w=o_w, bias=o_b), ar)
     out = ar.read(o_out, (B, H, W, Cout), torch.float32)
-    out2 = ar.read(o_out2, (B, H, W, Cout), torch.bfloat16)
+    if kblock:
+        out2 = ar.read(o_out2, (B, Cout // 32, H * W, 32), torch.bfloat16).permute(0, 2, 1, 3).reshape(B, H, W, Cout)
+    else:
+        out2 = ar.read(o_out2, (B, H, W, Cout), torch.bfloat16)
     assert _rel(out, ref) < 1.5e-2
     assert torch.equal(out2, out.to(torch.bfloat16))            # the copy is the RNE rounding of the fp32 value
 
@@ -598,6 +604,73 @@ def test_dwconv_and_se(shape, dt):
     err_se = float((sc - ref_sc).abs().max())
     _log(f"se {shape} abs_err {err_se:.3e}")
     assert err_se < 2e-6
+
+
+@pytest.mark.parametrize("kblock", [False, True], ids=["nhwc", "kblock32"])
+@pytest.mark.parametrize("dt", [L.BF16, L.F16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(8, 24, 24, 512, 384, 24), (3, 24, 24, 640, 128, 160), (2, 8, 8, 64, 128, 7), (5, 4, 4, 96, 256, 16), (1, 16, 20, 32, 128, 3),
+                                   (2, 24, 23, 64, 128, 5)],
+                         ids=["24x24_512_384", "24x24_640_128_s160", "8x8", "4x4", "16x20", "24x23"])
+def test_mbconv_slice_head_and_se_from_partial_products(shape, dt, kblock):
+    """FTC_OP_MBHEAD (csrc/mbconv_slice.hip): expand 1x1 + BN + SiLU -> depthwise 3x3 + BN + SiLU -> channel sums + per-slice fc1 partial
+    products in one launch, against the same chain in fp32 on the CPU (expanded tensor rounded to the 16-bit type, as the three-kernel
+    path stores it); then FTC_OP_SE with FTC_FLAG_SE_HPART (with and without the per-image weight fold) against the SE MLP on those
+    means.  torchvision MBConv block[0..2] as instantiated by /root/reference/models/detector.py:17-20."""
+    B, H, W, K, Cc, S = shape
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cc)
+    r16 = lambda t: round16(t, dt)
+    x = r16(torch.randn(B, H, W, K, generator=g))
+    we = r16(torch.randn(Cc, K, generator=g) / K ** 0.5 * 1.5)
+    be = torch.randn(Cc, generator=g) * 0.3
+    wd = torch.randn(Cc, 1, 3, 3, generator=g) * 0.4
+    bd = torch.randn(Cc, generator=g) * 0.2
+    w1 = torch.randn(S, Cc, generator=g) / Cc ** 0.5
+    b1 = torch.randn(S, generator=g) * 0.3
+    w2 = torch.randn(Cc, S, generator=g) / S ** 0.5
+    b2 = torch.randn(Cc, generator=g) * 0.3
+    e = r16(F.silu(x.reshape(-1, K) @ we.t() + be)).reshape(B, H, W, Cc)
+    ref = F.silu(F.conv2d(e.permute(0, 3, 1, 2), wd, bd, 1, 1, 1, Cc)).permute(0, 2, 3, 1)
+    NS = Cc // L.MBHEAD_SLICE
+    ar = Arena()
+    xdev = x.reshape(B, H * W, K // 32, 32).permute(0, 2, 1, 3) if kblock else x      # FTC_FLAG_KBLOCK32: [B][K/32][H*W][32]
+    o_x, o_we, o_be = ar.put(to_dev_bytes(xdev, dt)), ar.put(to_dev_bytes(we, dt)), ar.put(be)
+    o_wd, o_bd = ar.put(wd.reshape(Cc, 9).t().contiguous()), ar.put(bd)
+    o_w1, o_b1, o_w2t, o_b2 = ar.put(w1), ar.put(b1), ar.put(w2.t().contiguous()), ar.put(b2)
+    o_out = ar.reserve(B * H * W * Cc * 2)
+    o_sums, o_hp = ar.reserve(B * Cc * 4), ar.reserve(B * NS * S * 4)
+    o_scale, o_hid = ar.reserve(B * Cc * 4), ar.reserve(B * S * 4)
+    N = 96
+    wp = r16(torch.randn(N, Cc, generator=g) / Cc ** 0.5)
+    o_wp, o_wb = ar.put(to_dev_bytes(wp, dt)), ar.reserve(B * N * Cc * 2)
+    ar.materialize()
+    run_op(dict(kind=L.OP_MBHEAD, flags=L.FLAG_KBLOCK32 if kblock else 0, act=L.ACT_SILU, in_dtype=dt, out_dtype=dt, w_dtype=dt, B=B, H=H, W=W, Ho=H, Wo=W, Cin=K, Cout=Cc, ksize=3, stride=1,
+                aux0=S, in_=o_x, w2=o_we, bias2=o_be, w=o_wd, bias=o_bd, out=o_out, aux=o_sums, scale=o_w1, out2=o_hp), ar)
+    out = ar.read(o_out, (B, H, W, Cc), tdtype(dt)).float()
+    err = _rel(out, ref)
+    sums = ar.read(o_sums, (B, Cc), torch.float32)
+    mean = sums / (H * W)
+    err_mean = float((mean - ref.mean((1, 2))).abs().max())
+    hp = ar.read(o_hp, (B, NS, S), torch.float32)
+    want_hp = torch.einsum("bjc,sjc->bjs", mean.reshape(B, NS, L.MBHEAD_SLICE), w1.reshape(S, NS, L.MBHEAD_SLICE))
+    err_hp = float((hp - want_hp).abs().max())
+    _log(f"mbhead {shape} dt={dt} rel_err {err:.3e} mean_err {err_mean:.3e} hpart_err {err_hp:.3e}")
+    # one more rounding of the expanded tensor than the plain depthwise test: an element of e one ulp off moves 9 outputs
+    assert err < (1.2e-2 if dt == L.BF16 else 2e-3)
+    assert err_mean < (3e-3 if dt == L.BF16 else 5e-4)
+    assert err_hp < 2e-6 * max(1.0, float(want_hp.abs().max()))
+    ref_sc = torch.sigmoid(F.silu(mean @ w1.t() + b1) @ w2.t() + b2)
+    run_op(dict(kind=L.OP_SE, flags=L.FLAG_SE_HPART, B=B, H=H, W=W, Cin=Cc, Cout=Cc, aux0=S, aux1=NS, aux=o_hp, out=o_scale, in2=o_hid, w2=o_w2t,
+                bias=o_b1, bias2=o_b2), ar)
+    sc = ar.read(o_scale, (B, Cc), torch.float32)
+    assert float((sc - ref_sc).abs().max()) < 3e-6
+    ar.buf[o_scale:o_scale + B * Cc * 4] = 0xCD
+    run_op(dict(kind=L.OP_SE, flags=L.FLAG_SE_HPART | L.FLAG_SE_FOLD, w_dtype=dt, B=B, H=H, W=W, Cin=Cc, Cout=Cc, Cout_total=N, aux0=S, aux1=NS, aux=o_hp,
+                out=o_scale, in2=o_hid, w2=o_w2t, bias=o_b1, bias2=o_b2, in_=o_wp, out2=o_wb), ar)
+    sc2 = ar.read(o_scale, (B, Cc), torch.float32)
+    assert float((sc2 - ref_sc).abs().max()) < 3e-6
+    wb = ar.read(o_wb, (B, N, Cc), tdtype(dt)).float()
+    want = r16(wp[None] * sc2[:, None, :])
+    assert float((wb - want).abs().max()) <= float(want.abs().max()) * (2 ** -8 if dt == L.BF16 else 2 ** -11)
 
 
 def _fbits(v):

@@ -126,20 +126,23 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if (o.Ho != (o.H - 1) / o.stride + 1 || o.Wo != (o.W - 1) / o.stride + 1) return "dwconv: Ho/Wo inconsistent";
         if (o.in_dtype != o.out_dtype) return "dwconv: in/out dtype must match";
         return nullptr;
-    case FTC_OP_MBHEAD:
+    case FTC_OP_MBHEAD: {
         if (o.Cin <= 0 || o.Cout <= 0) return "mbhead: sizes must be positive";
+        if (!ftc_mbhead_legal(o))
+            return "mbhead: needs 16-bit in/out/w of one type, stride 1, ksize 3, Ho = H, Wo = W, Cin % 32 == 0, Cout % 128 == 0 and a map (or, with aux1 = "
+                   "output rows per band, a band + 2 halo rows) of <= 576 pixels and < 601 row-separated slots";
+        const int64_t nb = ftc_mbhead_bands(o), ns = o.Cout / FTC_MBHEAD_SLICE;
         if (!need(o.in, true, "in", pin * o.Cin * 2) || !need(o.out, true, "out", pin * o.Cout * 2) || !need(o.w2, true, "w2", (int64_t)o.Cout * o.Cin * 2) ||
             !need(o.bias2, true, "bias2", (int64_t)o.Cout * 4) || !need(o.w, true, "w", (int64_t)9 * o.Cout * 4) ||
-            !need(o.bias, true, "bias", (int64_t)o.Cout * 4) || !need(o.aux, true, "aux", (int64_t)o.B * o.Cout * 4)) return why->c_str();
-        if (!ftc_mbhead_legal(o))
-            return "mbhead: needs 16-bit in/out/w of one type, stride 1, ksize 3, Ho = H, Wo = W, H*W <= 576, H*(W+1) < 601, Cin % 32 == 0, Cout % 128 == 0";
+            !need(o.bias, true, "bias", (int64_t)o.Cout * 4) || !need(o.aux, true, "aux", (int64_t)o.B * nb * o.Cout * 4)) return why->c_str();
         if ((o.scale.base != FTC_BASE_NULL) != (o.out2.base != FTC_BASE_NULL)) return "mbhead: scale (fc1 weight) and out2 (fc1 partial products) come together";
         if (o.scale.base != FTC_BASE_NULL) {
             if (o.aux0 <= 0) return "mbhead: aux0 (squeeze width S) must be positive when the fc1 partial products are requested";
-            if (!need(o.scale, true, "scale", (int64_t)o.aux0 * o.Cout * 4) || !need(o.out2, true, "out2", (int64_t)o.B * (o.Cout / FTC_MBHEAD_SLICE) * o.aux0 * 4)) return why->c_str();
+            if (!need(o.scale, true, "scale", (int64_t)o.aux0 * o.Cout * 4) || !need(o.out2, true, "out2", (int64_t)o.B * nb * ns * o.aux0 * 4)) return why->c_str();
         }
-        if (o.flags & 0x1000) { if (!need(o.in2, true, "in2", (int64_t)o.B * (o.Cout / FTC_MBHEAD_SLICE) * 64)) return why->c_str(); }      // phase timeline (tools/mbslice_bench.py)
+        if (o.flags & 0x1000) { if (!need(o.in2, true, "in2", (int64_t)o.B * nb * ns * 64)) return why->c_str(); }      // phase timeline (tools/mbslice_bench.py)
         return nullptr;
+    }
     case FTC_OP_SE:
         if (o.aux0 <= 0 || o.aux1 <= 0 || o.Cin <= 0) return "se: C, S, P must be positive";
         if (!need(o.aux, true, "aux", (int64_t)o.B * o.aux1 * ((o.flags & FTC_FLAG_SE_HPART) ? o.aux0 : o.Cin) * 4) || !need(o.out, true, "out", (int64_t)o.B * o.Cin * 4) ||

@@ -240,6 +240,8 @@ int ftc_wgrad_splits_impl(int B, int Ho, int Wo, int Cout, int Cin, int ksize);
 hipError_t launch_se(const OpArgs& a, hipStream_t s);
 // mbconv_slice.hip: FTC_OP_MBHEAD (expand 1x1 + depthwise 3x3 + squeeze, one image x 64 channels per workgroup)
 bool ftc_mbhead_legal(const ftc_op& o);
+int ftc_mbhead_bands(const ftc_op& o);
+int ftc_mbhead_band_rows(int H, int W);
 hipError_t launch_mbhead(const OpArgs& a, hipStream_t s);
 hipError_t launch_upcat(const OpArgs& a, hipStream_t s);
 hipError_t launch_nms(const OpArgs& a, hipStream_t s);

@@ -42,6 +42,7 @@ struct MbsP {
     const float* w1;        // SE fc1 weight [S][C] (optional)
     float* hpart;           // [B][C/128][S] (optional)
     int B, H, W, K, C, S;
+    int R, nb;              // band mode: output rows per band, bands per image (R = H, nb = 1: the whole image)
     int kblock;             // FTC_FLAG_KBLOCK32: x is [B][K/32][H*W][32]
     unsigned img_bytes;
     float inv_hw;
@@ -73,14 +74,22 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     const int bid = blockIdx.x;
-    const int b = bid % p.B, sl = bid / p.B;               // consecutive workgroup ids = consecutive images: image b on XCD b % 8
+    const int b = bid % p.B;                               // consecutive workgroup ids = consecutive images: image b on XCD b % 8
+    const int band = FAST ? 0 : (bid / p.B) % p.nb, sl = FAST ? bid / p.B : bid / (p.B * p.nb);
     const int c0 = sl * MS_CC;
-    const int H = FAST ? 24 : p.H, W = FAST ? 24 : p.W;
+    // Band mode (maps larger than 576 pixels: the 48x48 stages): the workgroup owns the output rows [y0, y1) of its image and holds the
+    // expanded rows [ylo, yhi) = one halo row above and below (recomputed by the neighbouring band); H below = the rows it HOLDS.
+    const int W = FAST ? 24 : p.W;
+    const int y0 = FAST ? 0 : band * p.R, y1 = FAST ? 24 : min(p.H, y0 + p.R);
+    const int ylo = FAST ? 0 : max(0, y0 - 1), yhi = FAST ? 24 : min(p.H, y1 + 1);
+    const int H = yhi - ylo;
     const int M = H * W;
     const int W1 = W + 1;
+    const int Mfull = p.H * W;
 
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(p.x) + (size_t)b * p.img_bytes), 0,
-                                                                        p.img_bytes, 0x00020000);
+    const unsigned xbase = (unsigned)ylo * W * (p.kblock ? 64u : (unsigned)p.K * 2u);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(p.x) + (size_t)b * p.img_bytes + xbase), 0,
+                                                                        p.img_bytes - xbase, 0x00020000);
     const __amdgpu_buffer_rsrc_t rwe = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(p.we) + (size_t)c0 * p.K * 2), 0,
                                                                          (unsigned)(MS_CC * p.K * 2), 0x00020000);
 
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
         const int rowb = (isx && p.kblock) ? 64 : p.K * 2;
         s_off[i] = (!isx || row < M) ? row * rowb + kc * 16 : OOB;
     }
-    const int xstep = p.kblock ? M * 64 : 64;                            // bytes between consecutive K steps of x
+    const int xstep = p.kblock ? Mfull * 64 : 64;                        // bytes between consecutive K steps of x
     auto issue_piece = [&](int i, int step, int bufoff) {
         const int q0 = (i * 8 + wave) * 64;                              // wave-uniform
         if (i < 5 || wave < 4) {
@@ -214,14 +223,15 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const f32x4*>(smem_raw + MS_CONST + k * (MS_CC * 4) + cq * 16);
     const f32x4 bv = *reinterpret_cast<const f32x4*>(smem_raw + MS_CONST + 9 * (MS_CC * 4) + cq * 16);
-    const int nsr = (H + MS_R - 1) / MS_R;
+    const int yo = y0 - ylo, yend = y1 - ylo;                 // the output rows, as rows of the image held
+    const int nsr = (yend - yo + MS_R - 1) / MS_R;
     const int nstrips = nsr * W;
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    T* outp = reinterpret_cast<T*>(p.out) + (size_t)b * M * p.C + c;
+    T* outp = reinterpret_cast<T*>(p.out) + ((size_t)b * Mfull + (size_t)ylo * W) * p.C + c;
     const unsigned char* zslot = smem_raw + cq * 8;             // slot 0: zeros
     for (int s = pl; s < nstrips; s += 16) {
         const int sr = s / W, x = s - sr * W;
-        const int oy0 = sr * MS_R;
+        const int oy0 = yo + sr * MS_R;
         // window rows 0..6 from base0, 7.. from base1: the immediate offset of a DS instruction is 16 bits
         const unsigned char* base0 = smem_raw + ((oy0 - 1) * W1 + x) * MS_PITCH + cq * 8;      // slot of (oy0 - 1, x - 1)
         const unsigned char* base1 = base0 + 7 * W1 * MS_PITCH;
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
 #pragma unroll
         for (int r = 0; r < MS_R + 2; ++r) {
             bool rok;                                           // FAST: rows 1..R of a strip are inside the 24-row map by construction
-            if (FAST) rok = r == 0 ? oy0 > 0 : r == MS_R + 1 ? oy0 + MS_R < H : true;
+            if (FAST) rok = r == 0 ? oy0 > 0 : r == MS_R + 1 ? oy0 + MS_R < 24 : true;
             else rok = (unsigned)(oy0 - 1 + r) < (unsigned)H;
             const unsigned char* rp = (r < 7 ? base0 + r * W1 * MS_PITCH : base1 + (r - 7) * W1 * MS_PITCH);
             f32x4 xin[3];
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
 #pragma unroll
         for (int oo = 0; oo < MS_R; ++oo) {
             const int oy = oy0 + oo;
-            if (FAST || oy < H) {
+            if (FAST || oy < yend) {
                 a[oo] = act_silu_fast4(a[oo]);
                 store4<T>(outp + (oy * W + x) * p.C, a[oo]);
                 sum += a[oo];
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
         float tot = 0.f;
 #pragma unroll
         for (int w8 = 0; w8 < 8; ++w8) tot += red[w8 * MS_CC + t];
-        p.sums[(size_t)b * p.C + c0 + t] = tot;
+        p.sums[((size_t)b * p.nb + band) * p.C + c0 + t] = tot;
         lmean[t] = tot * p.inv_hw;
     }
     if (p.hpart) {
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
             float d = 0.f;
 #pragma unroll
             for (int q = 0; q < 32; ++q) d += fcb[t * 33 + q];
-            p.hpart[((size_t)b * (p.C / MS_CC) + sl) * p.S + t] = d;
+            p.hpart[(((size_t)b * p.nb + band) * (p.C / MS_CC) + sl) * p.S + t] = d;
         }
     }
     if (tl_on) tl[4] = __builtin_amdgcn_s_memtime();
@@ -302,10 +312,24 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
 
 }  // namespace
 
+// rows of the expanded image a workgroup holds: the whole map, or a band of aux1 output rows plus a halo row above and below
+static int mbhead_rows(const ftc_op& o) { return o.aux1 > 0 ? (o.aux1 + 2 < o.H ? o.aux1 + 2 : o.H) : o.H; }
+
 bool ftc_mbhead_legal(const ftc_op& o) {
+    const int rows = mbhead_rows(o);
     return ftc_is16(o.in_dtype) && o.in_dtype == o.out_dtype && o.in_dtype == o.w_dtype && o.stride == 1 && o.ksize == 3 && o.Ho == o.H &&
-           o.Wo == o.W && o.H * o.W <= MS_MAXPX && o.H * (o.W + 1) + 1 <= MS_MAXSLOT && o.Cout > 0 && o.Cout % MS_CC == 0 && o.Cin > 0 &&
-           o.Cin % 32 == 0;
+           o.Wo == o.W && o.aux1 >= 0 && rows * o.W <= MS_MAXPX && rows * (o.W + 1) + 1 <= MS_MAXSLOT && o.Cout > 0 && o.Cout % MS_CC == 0 &&
+           o.Cin > 0 && o.Cin % 32 == 0;
+}
+
+int ftc_mbhead_bands(const ftc_op& o) { return o.aux1 > 0 ? (o.H + o.aux1 - 1) / o.aux1 : 1; }
+
+// Band height for a map that does not fit a workgroup whole: as many output rows as leave room for the two halo rows (0 = the map fits)
+int ftc_mbhead_band_rows(int H, int W) {
+    if (H * W <= MS_MAXPX && H * (W + 1) + 1 <= MS_MAXSLOT) return 0;
+    int r = MS_MAXPX / W;
+    while (r > 2 && r * (W + 1) + 1 > MS_MAXSLOT) --r;
+    return r - 2 > 0 ? r - 2 : -1;
 }
 
 hipError_t launch_mbhead(const OpArgs& a, hipStream_t s) {
@@ -316,6 +340,7 @@ hipError_t launch_mbhead(const OpArgs& a, hipStream_t s) {
     p.w1 = a.scale; p.hpart = a.scale ? static_cast<float*>(a.out2) : nullptr;
     p.B = o.B; p.H = o.H; p.W = o.W; p.K = o.Cin; p.C = o.Cout; p.S = o.aux0;
     p.kblock = (o.flags & FTC_FLAG_KBLOCK32) ? 1 : 0;
+    p.R = o.aux1 > 0 ? o.aux1 : o.H; p.nb = ftc_mbhead_bands(o);
     p.img_bytes = (unsigned)((long)o.H * o.W * o.Cin * 2);
     p.inv_hw = 1.0f / (float)(o.H * o.W);
     p.tl = (o.flags & 0x1000) ? reinterpret_cast<unsigned long long*>(const_cast<void*>(a.in2)) : nullptr;
@@ -328,8 +353,8 @@ hipError_t launch_mbhead(const OpArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int nblk = o.B * (o.Cout / MS_CC);
-    const bool fast = o.H == 24 && o.W == 24 && !(o.flags & 0x100);          // 0x100: the general kernel (tests)
+    const int nblk = o.B * p.nb * (o.Cout / MS_CC);
+    const bool fast = o.H == 24 && o.W == 24 && p.nb == 1 && !(o.flags & 0x100);          // 0x100: the general kernel (tests)
 #define MBS_LAUNCH(T, F) hipLaunchKernelGGL((mbconv_slice_kernel<T, F>), dim3(nblk), dim3(MS_NT), MS_LDS, s, p)
     if (o.in_dtype == FTC_F16) { if (fast) MBS_LAUNCH(_Float16, true); else MBS_LAUNCH(_Float16, false); }
     else { if (fast) MBS_LAUNCH(__bf16, true); else MBS_LAUNCH(__bf16, false); }

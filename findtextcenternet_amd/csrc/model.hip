@@ -673,14 +673,17 @@ int Builder::build(ModelPlan* out) {
     // the SE fc1 layer in ONE launch, a workgroup per (image, 128 expanded channels) -- csrc/mbconv_slice.hip; the expanded tensor never
     // leaves the CU.  FTC_NO_MBSLICE=1: the three-kernel form; FTC_MBSLICE_MINWG: workgroups below which the three-kernel form is kept
     // (small batches leave most CUs without a slice).  bh, bw = the block's INPUT map.
-    auto sliced = [&](const BlockSpec& blk, int bh, int bw) -> bool {
-        if (blk.fused || !dual || blk.stride != 1 || env_on("FTC_NO_MBSLICE")) return false;
+    // (maps of more than 576 pixels -- the 48x48 stages 4-5 -- run in bands of R output rows: returns R, 0 = the whole map, -1 = not sliced)
+    auto sliced = [&](const BlockSpec& blk, int bh, int bw) -> int {
+        if (blk.fused || !dual || blk.stride != 1 || env_on("FTC_NO_MBSLICE")) return -1;
+        const int R = ftc_mbhead_band_rows(bh, bw);
+        if (R < 0 || (R > 0 && env_on("FTC_NO_MBBAND"))) return -1;
         ftc_op t{};
         t.in_dtype = t.out_dtype = t.w_dtype = A; t.stride = blk.stride; t.ksize = 3; t.H = t.Ho = bh; t.W = t.Wo = bw;
-        t.Cin = blk.cin; t.Cout = blk.exp;
+        t.Cin = blk.cin; t.Cout = blk.exp; t.aux1 = R;
         const char* mw_env = std::getenv("FTC_MBSLICE_MINWG");
         const int min_wg = mw_env ? std::atoi(mw_env) : 128;
-        return ftc_mbhead_legal(t) && B * (blk.exp / FTC_MBHEAD_SLICE) >= min_wg;
+        return ftc_mbhead_legal(t) && B * ftc_mbhead_bands(t) * (blk.exp / FTC_MBHEAD_SLICE) >= min_wg ? R : -1;
     };
     std::vector<const BlockSpec*> flat;
     for (const auto& st : stages)
@@ -699,7 +702,7 @@ int Builder::build(ModelPlan* out) {
             tail.residual = res; tail.res_dt = T; tail.out2 = yb;
             // the consumer of this block's 16-bit copy is the next block's expand GEMM: FTC_OP_MBHEAD streams it in 32-channel planes
             ++bi;
-            const bool out_blocked = bi < flat.size() && sliced(*flat[bi], ho, wo) && blk.cout % 32 == 0 && !env_on("FTC_NO_KBLOCK");
+            const bool out_blocked = bi < flat.size() && sliced(*flat[bi], ho, wo) >= 0 && blk.cout % 32 == 0 && !env_on("FTC_NO_KBLOCK");
             if (out_blocked) tail.extra_flags |= FTC_FLAG_KBLOCK32;
             if (blk.fused && blk.exp == blk.cin) {
                 conv(p + ".0", gin, G, h, w, blk.cin, blk.cin, 0, p + ".0", blk.cout, 3, blk.stride, FTC_ACT_SILU, y, T, tail);
@@ -708,17 +711,19 @@ int Builder::build(ModelPlan* out) {
                 conv(p + ".0", gin, G, h, w, blk.cin, blk.cin, 0, p + ".0", blk.exp, 3, blk.stride, FTC_ACT_SILU, e, A);
                 conv(p + ".1", e, A, ho, wo, blk.exp, blk.exp, 0, p + ".1", blk.cout, 1, 1, FTC_ACT_NONE, y, T, tail);
             } else {
-                const bool slice = sliced(blk, h, w);
+                const int band_rows = sliced(blk, h, w);
+                const bool slice = band_rows >= 0;
+                const int nbands = band_rows > 0 ? (h + band_rows - 1) / band_rows : 1;
                 const int th = blk.stride == 1 ? 8 : 4;
-                const int P = slice ? blk.exp / FTC_MBHEAD_SLICE : ((ho + th - 1) / th) * ((wo + 7) / 8);
+                const int P = slice ? nbands * (blk.exp / FTC_MBHEAD_SLICE) : ((ho + th - 1) / th) * ((wo + 7) / 8);
                 const R d = buf((int64_t)B * ho * wo * blk.exp, A);
                 const R part = buf((int64_t)B * P * (slice ? blk.squeeze : blk.exp), FTC_F32);
                 if (slice) {
-                    const R sums = buf((int64_t)B * blk.exp, FTC_F32);
+                    const R sums = buf((int64_t)B * nbands * blk.exp, FTC_F32);
                     SymOp s;
                     ftc_op& o = s.o;
                     o.kind = FTC_OP_MBHEAD; o.act = FTC_ACT_SILU; o.in_dtype = A; o.out_dtype = A; o.w_dtype = A; o.B = B; o.H = h; o.W = w; o.Ho = ho; o.Wo = wo;
-                    o.Cin = blk.cin; o.Cout = blk.exp; o.ksize = 3; o.stride = 1; o.aux0 = blk.squeeze; o.flags = in_blocked ? FTC_FLAG_KBLOCK32 : 0;
+                    o.Cin = blk.cin; o.Cout = blk.exp; o.ksize = 3; o.stride = 1; o.aux0 = blk.squeeze; o.aux1 = band_rows; o.flags = in_blocked ? FTC_FLAG_KBLOCK32 : 0;
                     s.in = gin; s.out = d; s.w2 = wref(p + ".0.w"); s.bias2 = wref(p + ".0.b"); s.w = wref(p + ".1.w"); s.bias = wref(p + ".1.b"); s.aux = sums;
                     s.scale = wref(p + ".2.w1"); s.out2 = part;
                     emit({p + ".0+1", "conv1x1+dw3x3", 2.0 * B * h * w * blk.exp * (blk.cin + 9),

@@ -164,7 +164,10 @@ typedef enum ftc_op_kind {
        in [B,H,W,Cin] 16-bit, w2 [Cout][Cin] (K-major, same type), bias2 fp32 [Cout], w fp32 [9][Cout], bias fp32 [Cout], out [B,H,W,Cout]
        16-bit; in_dtype == out_dtype == w_dtype; Cin % 32 == 0, Cout % FTC_MBHEAD_SLICE == 0, H*W <= 576 and H*(W+1) < 601 (a 24x24 map).
        Optional: scale = the SE fc1 weight fp32 [aux0][Cout] and out2 = fp32 [B][Cout/FTC_MBHEAD_SLICE][aux0]: out2[b][j][s] = sum over the
-       channels c of slice j of scale[s][c] * mean_hw(out[b,:,:,c]) -- FTC_OP_SE with FTC_FLAG_SE_HPART adds the slices' vectors */
+       channels c of slice j of scale[s][c] * mean_hw(out[b,:,:,c]) -- FTC_OP_SE with FTC_FLAG_SE_HPART adds the slices' vectors.
+       Band mode for larger maps (the 48x48 stages), aux1 = R > 0: a workgroup owns R output rows of an image (nb = ceil(H / R) bands) and
+       recomputes one expanded halo row above and below; (R + 2) * W <= 576 and (R + 2) * (W + 1) < 601 then replace the whole-map limits,
+       aux = [B][nb][Cout] per-band channel sums (FTC_OP_SE: aux1 = nb) and out2 = [B][nb * Cout/FTC_MBHEAD_SLICE][aux0] */
     FTC_OP_MBHEAD = 25,
     FTC_OP_TAPSUM = 7          /* second half of a 3x3 convolution split as per-pixel taps + 9-point sum (FTC_FLAG_TOP_FUSE):
                                   out[b,y,x,ch_j] = bias[j] + sum_{r,s} in[g_j][b,y+r-1,x+s-1][(3r+s)*co_j + o_j] (zero outside),

@@ -608,15 +608,20 @@ def test_dwconv_and_se(shape, dt):
 
 @pytest.mark.parametrize("kblock", [False, True], ids=["nhwc", "kblock32"])
 @pytest.mark.parametrize("dt", [L.BF16, L.F16], ids=["bf16", "f16"])
-@pytest.mark.parametrize("shape", [(8, 24, 24, 512, 384, 24), (3, 24, 24, 640, 128, 160), (2, 8, 8, 64, 128, 7), (5, 4, 4, 96, 256, 16), (1, 16, 20, 32, 128, 3),
-                                   (2, 24, 23, 64, 128, 5)],
-                         ids=["24x24_512_384", "24x24_640_128_s160", "8x8", "4x4", "16x20", "24x23"])
+@pytest.mark.parametrize("shape", [(8, 24, 24, 512, 384, 24, 0), (3, 24, 24, 640, 128, 160, 0), (2, 8, 8, 64, 128, 7, 0), (5, 4, 4, 96, 256, 16, 0),
+                                   (1, 16, 20, 32, 128, 3, 0), (2, 24, 23, 64, 128, 5, 0),
+                                   # band mode (aux1 = output rows per band, + one halo row above and below)
+                                   (2, 48, 48, 256, 256, 64, 10), (3, 48, 48, 192, 128, 48, 10), (2, 24, 24, 64, 128, 9, 7), (1, 40, 30, 32, 128, 4, 17),
+                                   (2, 12, 12, 32, 128, 4, 1)],
+                         ids=["24x24_512_384", "24x24_640_128_s160", "8x8", "4x4", "16x20", "24x23", "48x48_band10", "48x48_192_band10", "24x24_band7",
+                              "40x30_band17", "12x12_band1"])
 def test_mbconv_slice_head_and_se_from_partial_products(shape, dt, kblock):
     """FTC_OP_MBHEAD (csrc/mbconv_slice.hip): expand 1x1 + BN + SiLU -> depthwise 3x3 + BN + SiLU -> channel sums + per-slice fc1 partial
     products in one launch, against the same chain in fp32 on the CPU (expanded tensor rounded to the 16-bit type, as the three-kernel
     path stores it); then FTC_OP_SE with FTC_FLAG_SE_HPART (with and without the per-image weight fold) against the SE MLP on those
     means.  torchvision MBConv block[0..2] as instantiated by /root/reference/models/detector.py:17-20."""
-    B, H, W, K, Cc, S = shape
+    B, H, W, K, Cc, S, R = shape
+    NB = -(-H // R) if R else 1
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cc)
     r16 = lambda t: round16(t, dt)
     x = r16(torch.randn(B, H, W, K, generator=g))
@@ -637,34 +642,37 @@ def test_mbconv_slice_head_and_se_from_partial_products(shape, dt, kblock):
     o_wd, o_bd = ar.put(wd.reshape(Cc, 9).t().contiguous()), ar.put(bd)
     o_w1, o_b1, o_w2t, o_b2 = ar.put(w1), ar.put(b1), ar.put(w2.t().contiguous()), ar.put(b2)
     o_out = ar.reserve(B * H * W * Cc * 2)
-    o_sums, o_hp = ar.reserve(B * Cc * 4), ar.reserve(B * NS * S * 4)
+    o_sums, o_hp = ar.reserve(B * NB * Cc * 4), ar.reserve(B * NB * NS * S * 4)
     o_scale, o_hid = ar.reserve(B * Cc * 4), ar.reserve(B * S * 4)
     N = 96
     wp = r16(torch.randn(N, Cc, generator=g) / Cc ** 0.5)
     o_wp, o_wb = ar.put(to_dev_bytes(wp, dt)), ar.reserve(B * N * Cc * 2)
     ar.materialize()
     run_op(dict(kind=L.OP_MBHEAD, flags=L.FLAG_KBLOCK32 if kblock else 0, act=L.ACT_SILU, in_dtype=dt, out_dtype=dt, w_dtype=dt, B=B, H=H, W=W, Ho=H, Wo=W, Cin=K, Cout=Cc, ksize=3, stride=1,
-                aux0=S, in_=o_x, w2=o_we, bias2=o_be, w=o_wd, bias=o_bd, out=o_out, aux=o_sums, scale=o_w1, out2=o_hp), ar)
+                aux0=S, aux1=R, in_=o_x, w2=o_we, bias2=o_be, w=o_wd, bias=o_bd, out=o_out, aux=o_sums, scale=o_w1, out2=o_hp), ar)
     out = ar.read(o_out, (B, H, W, Cc), tdtype(dt)).float()
     err = _rel(out, ref)
-    sums = ar.read(o_sums, (B, Cc), torch.float32)
-    mean = sums / (H * W)
+    bsums = ar.read(o_sums, (B, NB, Cc), torch.float32)                      # per band: the channel sums of its output rows
+    mean = bsums.sum(1) / (H * W)
     err_mean = float((mean - ref.mean((1, 2))).abs().max())
-    hp = ar.read(o_hp, (B, NS, S), torch.float32)
-    want_hp = torch.einsum("bjc,sjc->bjs", mean.reshape(B, NS, L.MBHEAD_SLICE), w1.reshape(S, NS, L.MBHEAD_SLICE))
+    hp = ar.read(o_hp, (B, NB, NS, S), torch.float32)
+    want_hp = torch.einsum("bnjc,sjc->bnjs", (bsums / (H * W)).reshape(B, NB, NS, L.MBHEAD_SLICE), w1.reshape(S, NS, L.MBHEAD_SLICE))
     err_hp = float((hp - want_hp).abs().max())
+    if R:
+        want_b = torch.stack([ref[:, j * R:(j + 1) * R].sum((1, 2)) for j in range(NB)], 1)
+        assert float((bsums - want_b).abs().max()) < (3e-3 if dt == L.BF16 else 5e-4) * H * W
     _log(f"mbhead {shape} dt={dt} rel_err {err:.3e} mean_err {err_mean:.3e} hpart_err {err_hp:.3e}")
     # one more rounding of the expanded tensor than the plain depthwise test: an element of e one ulp off moves 9 outputs
     assert err < (1.2e-2 if dt == L.BF16 else 2e-3)
     assert err_mean < (3e-3 if dt == L.BF16 else 5e-4)
     assert err_hp < 2e-6 * max(1.0, float(want_hp.abs().max()))
     ref_sc = torch.sigmoid(F.silu(mean @ w1.t() + b1) @ w2.t() + b2)
-    run_op(dict(kind=L.OP_SE, flags=L.FLAG_SE_HPART, B=B, H=H, W=W, Cin=Cc, Cout=Cc, aux0=S, aux1=NS, aux=o_hp, out=o_scale, in2=o_hid, w2=o_w2t,
+    run_op(dict(kind=L.OP_SE, flags=L.FLAG_SE_HPART, B=B, H=H, W=W, Cin=Cc, Cout=Cc, aux0=S, aux1=NB * NS, aux=o_hp, out=o_scale, in2=o_hid, w2=o_w2t,
                 bias=o_b1, bias2=o_b2), ar)
     sc = ar.read(o_scale, (B, Cc), torch.float32)
     assert float((sc - ref_sc).abs().max()) < 3e-6
     ar.buf[o_scale:o_scale + B * Cc * 4] = 0xCD
-    run_op(dict(kind=L.OP_SE, flags=L.FLAG_SE_HPART | L.FLAG_SE_FOLD, w_dtype=dt, B=B, H=H, W=W, Cin=Cc, Cout=Cc, Cout_total=N, aux0=S, aux1=NS, aux=o_hp,
+    run_op(dict(kind=L.OP_SE, flags=L.FLAG_SE_HPART | L.FLAG_SE_FOLD, w_dtype=dt, B=B, H=H, W=W, Cin=Cc, Cout=Cc, Cout_total=N, aux0=S, aux1=NB * NS, aux=o_hp,
                 out=o_scale, in2=o_hid, w2=o_w2t, bias=o_b1, bias2=o_b2, in_=o_wp, out2=o_wb), ar)
     sc2 = ar.read(o_scale, (B, Cc), torch.float32)
     assert float((sc2 - ref_sc).abs().max()) < 3e-6

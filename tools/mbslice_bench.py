@@ -16,10 +16,11 @@ from findtextcenternet_amd import _lib as L  # noqa: E402
 lib = L.load()
 batches = [int(a) for a in sys.argv[1:]] or [8]
 for B in batches:
-    for (H, W, Cin, Cx, S, N) in [(24, 24, 512, 3072, 128, 512), (24, 24, 640, 3840, 160, 640)]:
-        ns = Cx // L.MBHEAD_SLICE
+    for (H, W, Cin, Cx, S, N, R) in [(24, 24, 512, 3072, 128, 512, 0), (24, 24, 640, 3840, 160, 640, 0), (48, 48, 256, 1536, 64, 256, 10), (48, 48, 192, 768, 48, 192, 10)]:
+        nb = -(-H // R) if R else 1
+        ns = nb * (Cx // L.MBHEAD_SLICE)
         nwg = B * ns
-        sizes = dict(x=B * H * W * Cin * 2, we=Cx * Cin * 2, be=Cx * 4, wd=9 * Cx * 4, bd=Cx * 4, out=B * H * W * Cx * 2, sums=B * Cx * 4, w1=S * Cx * 4,
+        sizes = dict(x=B * H * W * Cin * 2, we=Cx * Cin * 2, be=Cx * 4, wd=9 * Cx * 4, bd=Cx * 4, out=B * H * W * Cx * 2, sums=B * nb * Cx * 4, w1=S * Cx * 4,
                      hp=B * ns * S * 4, tl=nwg * 64, b1=S * 4, w2t=S * Cx * 4, b2=Cx * 4, sc=B * Cx * 4, hid=B * S * 4, wp=N * Cx * 2, wb=B * N * Cx * 2)
         off, cur = {}, 0
         for k, n in sizes.items():
@@ -40,7 +41,7 @@ for B in batches:
         o.kind, o.flags, o.act = L.OP_MBHEAD, 0x1000, L.ACT_SILU
         o.in_dtype = o.out_dtype = o.w_dtype = L.BF16
         o.B, o.H, o.W, o.Ho, o.Wo = B, H, W, H, W
-        o.Cin, o.Cout, o.ksize, o.stride, o.aux0 = Cin, Cx, 3, 1, S
+        o.Cin, o.Cout, o.ksize, o.stride, o.aux0, o.aux1 = Cin, Cx, 3, 1, S, R
         for fld, key in (("in_", "x"), ("w2", "we"), ("bias2", "be"), ("w", "wd"), ("bias", "bd"), ("out", "out"), ("aux", "sums"), ("in2", "tl"),
                          ("scale", "w1"), ("out2", "hp")):
             ref(o, fld, key)
@@ -64,7 +65,7 @@ for B in batches:
         d = np.diff(tl[:, :5], axis=1)
         span = (tl[:, 4].max() - tl[:, 0].min())
         fl = 2.0 * B * H * W * Cx * (Cin + 9)
-        print(f"B{B} {H}x{W} {Cin}->{Cx}: mbhead {np.median(ts) * 1e3:7.1f} us  {fl / np.median(ts) / 1e9:6.1f} TF  {nwg} workgroups;  cycles (median over workgroups): "
+        print(f"B{B} {H}x{W} {Cin}->{Cx} R{R}: mbhead {np.median(ts) * 1e3:7.1f} us  {fl / np.median(ts) / 1e9:6.1f} TF  {nwg} workgroups;  cycles (median over workgroups): "
               f"K loop {np.median(d[:, 0]):.0f}  expand epilogue {np.median(d[:, 1]):.0f}  depthwise {np.median(d[:, 2]):.0f}  sums+fc1 {np.median(d[:, 3]):.0f}  "
               f"total {np.median(tl[:, 4] - tl[:, 0]):.0f}  first-start to last-end {span};   se(hpart+fold) {np.median(tse) * 1e3:6.1f} us", flush=True)
         lib.ftc_plan_destroy(h)

@@ -140,7 +140,7 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
             if (o.aux0 <= 0) return "mbhead: aux0 (squeeze width S) must be positive when the fc1 partial products are requested";
             if (!need(o.scale, true, "scale", (int64_t)o.aux0 * o.Cout * 4) || !need(o.out2, true, "out2", (int64_t)o.B * nb * ns * o.aux0 * 4)) return why->c_str();
         }
-        if (o.flags & 0x1000) { if (!need(o.in2, true, "in2", (int64_t)o.B * nb * ns * 64)) return why->c_str(); }      // phase timeline (tools/mbslice_bench.py)
+        if (o.flags & 0x1000) { if (!need(o.in2, true, "in2", (int64_t)o.B * nb * ns * 256)) return why->c_str(); }      // phase timeline (tools/mbslice_bench.py)
         return nullptr;
     }
     case FTC_OP_SE:

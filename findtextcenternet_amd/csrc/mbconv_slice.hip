@@ -46,7 +46,7 @@ struct MbsP {
     int kblock;             // FTC_FLAG_KBLOCK32: x is [B][K/32][H*W][32]
     unsigned img_bytes;
     float inv_hw;
-    unsigned long long* tl;  // flags 0x1000: s_memtime of wave 0 at the phase boundaries, 8 values per workgroup (tools/mbslice_bench.py)
+    unsigned long long* tl;  // flags 0x1000: s_memtime of wave 0 at the phase boundaries and K steps, 32 values per workgroup (tools/mbslice_bench.py)
 };
 
 constexpr int MS_CC = FTC_MBHEAD_SLICE;     // expanded channels per workgroup (128)
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
     const int offB = (pg * 144 + l15) * 64 + swz;                       // + j * 1024
     const int nk = p.K >> 5;
     const bool tl_on = p.tl && t == 0;
-    unsigned long long* tl = p.tl + (size_t)blockIdx.x * 8;
+    unsigned long long* tl = p.tl + (size_t)blockIdx.x * 32;
     if (tl_on) tl[0] = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int i = 0; i < NLMAX; ++i) issue_piece(i, 0, 0);
@@ -154,12 +154,15 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
         for (int i = 0; i < NLMAX; ++i) issue_piece(i, 1, MS_STAGE);
     }
     int cur_off = 0, iss_off = 2 * MS_STAGE;
+    unsigned long long tw = 0, tw0 = 0;                         // timeline: cycles wave 0 spent waiting for data + barrier, all steps / the first
     for (int it = 0; it < nk; ++it) {
+        const unsigned long long ta = tl_on ? __builtin_amdgcn_s_memtime() : 0;
         // stage `it` has landed once at most the later-issued stage remains outstanding (per-wave piece counts)
         if (it + 1 >= nk) wait_vmcnt<0>();
         else if (wave < 4) wait_vmcnt<6>();
         else wait_vmcnt<5>();
         wg_barrier();
+        if (tl_on) { const unsigned long long d = __builtin_amdgcn_s_memtime() - ta; tw += d; if (it == 0) tw0 = d; if (it < 24) tl[8 + it] = ta; }
         const unsigned char* base = smem_raw + cur_off;
         const bool more = it + 2 < nk;                               // stage it + 2 goes to the slot consumed in step it - 1
         FragT af[4];
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
         cur_off = cur_off + MS_STAGE == MS_NSTAGE * MS_STAGE ? 0 : cur_off + MS_STAGE;
     }
     wg_barrier();                                               // every wave is done with the operand ring: it becomes the expanded image
-    if (tl_on) tl[1] = __builtin_amdgcn_s_memtime();
+    if (tl_on) { tl[1] = __builtin_amdgcn_s_memtime(); tl[5] = tw; tl[6] = tw0; }
 
     // ---- expanded image: SiLU, 16-bit, slot(y, x) = y (W+1) + x + 1 ----
     for (int idx = t; idx < (H + 1) * 32; idx += MS_NT) {       // the zero slots between the rows (and before the first / after the last)

@@ -41,10 +41,15 @@ class TrainStep:
     """``ts = TrainStep(model)``; per iteration ``loss, raw = ts.forward_backward(image, labelmap, idmap, fmask)`` then
     ``optimizer.step(); ts.zero_grad()`` -- the reference's loop body (train1.py:170-179) with ``train_step`` + ``backward`` fused."""
 
-    def __init__(self, module, precision: Optional[str] = None, cov=None, two_streams: bool = True):
+    def __init__(self, module, precision: Optional[str] = None, cov=None, two_streams: bool = True, decoder_only: bool = False):
         """two_streams: the backward's weight-gradient ops run on a second HIP stream beside the chain that produces their operands
-        (ftc_plan_run_streams; same kernels, same results -- False keeps everything on the caller's stream)."""
+        (ftc_plan_run_streams; same kernels, same results -- False keeps everything on the caller's stream).
+        decoder_only: the reference's ``decoder_only`` switch (train1.py:98-101, 163-164): the detector is frozen and runs in eval mode
+        (``module.detector.eval()``: the inference engine, running statistics, no StochasticDepth), only the SimpleDecoder trains -- the
+        step is detector forward (eval) -> gather rows -> decoder forward (train) -> loss_function -> backward through the decoder;
+        gradients of the detector's parameters stay zero (the reference sets requires_grad_(False) on them)."""
         self.module = module
+        self.decoder_only = bool(decoder_only)
         self.two_streams = bool(two_streams) and os.environ.get("FTC_TRAIN_ONE_STREAM") != "1"      # (env: A/B measurements)
         self.side_stream = None
         self.precision = precision or module.detector.precision
@@ -147,6 +152,7 @@ class TrainStep:
         self.blob, self.flat, self.grads = blob, fl, grads
         self.params = params
         self.counters = [b for k, b in self.module.named_buffers() if k.endswith("num_batches_tracked")]
+        self.decoder_counters = [b for k, b in self.module.named_buffers() if k.endswith("num_batches_tracked") and k.startswith("decoder.")]
         self.stat_buffers = [b for k, b in self.module.named_buffers() if k.endswith("running_mean") or k.endswith("running_var")]
         # pack-entry table on the device
         ents = (L.PackEntry * len(self.pack_specs))()
@@ -370,118 +376,127 @@ class TrainStep:
         res_names: List[str] = []
         keep_buf = g.buf(4096 * 4)
         g.pin(keep_buf)
-        c0 = sh[P + ".0.0.weight"][0]
-        h, w = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        z = g.buf(B * h * w * c0 * 4)
-        g.emit("stem", kind=L.OP_STEM, act=L.ACT_NONE, in_dtype=L.F32, out_dtype=L.F32, B=B, H=H, W=W, Ho=h, Wo=w, Cin=3, Cout=c0, ksize=3, stride=2,
-               in_=("in",), out=z, w=g.w(P + ".0.0.weight#stem"), bias=g.w("zeros"))
-        x, _, ss = g.bn(z, h, w, c0, P + ".0.1", BACKBONE_EPS, L.ACT_SILU)
-        tape: List[dict] = [dict(kind="stem", z=z, ss=ss, h=h, w=w, c=c0, out=x)]
-        c = c0
-        taps = []
-        pending_tap = None
-        i = 1
-        while f"{P}.{i}.0.block.0.0.weight" in sh:
-            j = 0
-            while f"{P}.{i}.{j}.block.0.0.weight" in sh:
-                p = f"{P}.{i}.{j}"
-                b = p + ".block"
-                stride = _STAGE_STRIDE[i] if j == 0 else 1
-                mb = f"{b}.2.fc1.weight" in sh
-                fused4 = (not mb) and f"{b}.1.0.weight" in sh
-                last = ".3" if mb else (".1" if fused4 else ".0")
-                cout = sh[b + last + ".0.weight"][0]
-                residual = x[0] if (stride == 1 and c == cout) else None
-                keep = None
-                if residual is not None:
-                    keep = ("ws", keep_buf[1], len(res_names) * _align(B, 4) * 4)
-                    res_names.append(p[len(pre):])
-                rec = dict(b=b, xin=x, h=h, w=w, c=c, cout=cout, stride=stride, residual=residual is not None, keep=keep)
-                if pending_tap is not None:                              # this block reads a tap: the heads' gradient of the tap joins its data gradient
-                    rec["xin_tap"], pending_tap = pending_tap, None
-                if mb:
-                    e = sh[b + ".0.0.weight"][0]
-                    z0, _, _ = g.conv(x, h, w, c, b + ".0.0.weight", e, 1)
-                    y0, _, ss0 = g.bn(z0, h, w, e, b + ".0.1", BACKBONE_EPS, L.ACT_SILU, **F32ONLY)       # read by the fp32 depthwise kernels
-                    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
-                    th = 8 if stride == 1 else 4
-                    pdw = -(-ho // th) * -(-wo // 8)
-                    zd = g.buf(B * ho * wo * e * 4)
-                    g.emit(b + ".1.0", kind=L.OP_DWCONV, act=L.ACT_NONE, in_dtype=L.F32, out_dtype=L.F32, B=B, H=h, W=w, Ho=ho, Wo=wo, Cin=e, Cout=e, ksize=3,
-                           stride=stride, aux0=pdw, in_=y0[0], out=zd, w=g.w(b + ".1.0.weight#dw"), bias=g.w("zeros"), aux=g.buf(B * pdw * e * 4))
-                    pse = max(1, min(16, (ho * wo) // 64))
-                    y1, sums, ss1 = g.bn(zd, ho, wo, e, b + ".1.1", BACKBONE_EPS, L.ACT_SILU, sums_p=pse)                 # fp32 for the SE backward + copy
-                    s = sh[b + ".2.fc1.weight"][0]
-                    sc = g.buf(B * e * 4)
-                    g.emit(b + ".2", kind=L.OP_SE, B=B, H=ho, W=wo, Cin=e, Cout=e, aux0=s, aux1=pse, aux=sums, out=sc, in2=g.buf(B * s * 4),
-                           w=g.w(b + ".2.fc1.weight"), w2=g.w(b + ".2.fc2.weight#t"), bias=g.w(b + ".2.fc1.bias"), bias2=g.w(b + ".2.fc2.bias"))
-                    z3, _, _ = g.conv(y1, ho, wo, e, b + ".3.0.weight", cout, 1, se=sc)
-                    x, _, ss3 = g.bn(z3, ho, wo, cout, b + ".3.1", BACKBONE_EPS, L.ACT_NONE, residual=residual, keep=keep)
-                    rec.update(kind="mb", e=e, z0=z0, y0=y0, ss0=ss0, zd=zd, y1=y1, ss1=ss1, sums=sums, pse=pse, s=s, sc=sc, z3=z3, ss3=ss3, ho=ho, wo=wo)
-                    h, w = ho, wo
-                elif fused4:
-                    e = sh[b + ".0.0.weight"][0]
-                    z0, ho, wo = g.conv(x, h, w, c, b + ".0.0.weight", e, 3, stride)
-                    y0, _, ss0 = g.bn(z0, ho, wo, e, b + ".0.1", BACKBONE_EPS, L.ACT_SILU, **GEMM_ONLY)
-                    z1, _, _ = g.conv(y0, ho, wo, e, b + ".1.0.weight", cout, 1)
-                    x, _, ss1 = g.bn(z1, ho, wo, cout, b + ".1.1", BACKBONE_EPS, L.ACT_NONE, residual=residual, keep=keep)
-                    rec.update(kind="f4", e=e, z0=z0, y0=y0, ss0=ss0, z1=z1, ss1=ss1, ho=ho, wo=wo)
-                    h, w = ho, wo
-                else:
-                    z0, ho, wo = g.conv(x, h, w, c, b + ".0.0.weight", cout, 3, stride)
-                    x, _, ss0 = g.bn(z0, ho, wo, cout, b + ".0.1", BACKBONE_EPS, L.ACT_SILU, residual=residual, keep=keep)
-                    rec.update(kind="f1", z0=z0, ss0=ss0, ho=ho, wo=wo)
-                    h, w = ho, wo
-                rec["out"] = x
-                tape.append(rec)
-                c = cout
-                j += 1
-            if i in (2, 3, 5):
-                taps.append((x[0], c, h, w))
-                pending_tap = len(taps) - 1
-            i += 1
-        cl = sh[f"{P}.{i}.0.weight"][0]
-        zl, _, _ = g.conv(x, h, w, c, f"{P}.{i}.0.weight", cl, 1)
-        xl, _, ssl = g.bn(zl, h, w, cl, f"{P}.{i}.1", BACKBONE_EPS, L.ACT_SILU, **F32ONLY)               # the last tap: read by the heads' fp32 tap path only
-        hc = dict(kind="headconv", name=f"{P}.{i}", xin=x, z=zl, ss=ssl, h=h, w=w, c=c, cout=cl, out=xl, tap=len(taps))
-        if pending_tap is not None:
-            hc["xin_tap"], pending_tap = pending_tap, None
-        tape.append(hc)
-        taps.append((xl[0], cl, h, w))
-        mh, mw = taps[0][2], taps[0][3]
-        maps = g.buf(B * mh * mw * 9 * 4)
-        feats = g.buf(B * mh * mw * 100 * 4)
-        g.pin(maps)
-        ch = 0
-        n = len(taps)
-        heads = []
         adt = g.cdt if g.h16 else L.F32                              # dtype of the FPN level tensors (read by convolutions / the upsampler only)
         aes = 2 if g.h16 else 4
-        for name in HEAD_NAMES + ["feature"]:
-            hp = pre + name
-            y, cy, yh, yw = None, 0, 0, 0
-            levels = []
-            for lvl, (tx, tc, th_, tw_) in enumerate(reversed(taps)):
-                ti = n - 1 - lvl
-                ssi = g.bnstat(tx, th_, tw_, tc, f"{hp}.in_bn.{ti}", HEAD_EPS)
-                catb = g.buf(B * th_ * tw_ * (cy + tc) * aes)
-                cat = (None, catb) if g.h16 else (catb, None)
-                g.emit(f"{hp}.upcat.{lvl}", kind=L.OP_UPCAT, in_dtype=adt, out_dtype=adt, res_dtype=L.F32, B=B, H=yh if y is not None else th_,
-                       W=yw if y is not None else tw_, Ho=th_, Wo=tw_, Cin=cy + tc, Cout=cy + tc, aux0=cy, aux1=tc, in_=g.pick(y)[0] if y is not None else None,
-                       in2=tx, out=catb, scale=ssi, shift=("ws", ssi[1], tc * 4))
-                cm = sh[f"{hp}.upsamplers.{lvl}.0.weight"][0]
-                zc, _, _ = g.conv(cat, th_, tw_, cy + tc, f"{hp}.upsamplers.{lvl}.0.weight", cm, 3)
-                yn, _, ssc = g.bn(zc, th_, tw_, cm, f"{hp}.upsamplers.{lvl}.1", HEAD_EPS, L.ACT_GELU, **GEMM_ONLY)
-                levels.append(dict(lvl=lvl, ti=ti, tx=tx, tc=tc, h=th_, w=tw_, cy=cy, yh=yh, yw=yw, ssi=ssi, cat=cat, cm=cm, z=zc, ss=ssc, y=yn))
-                y, cy, yh, yw = yn, cm, th_, tw_
-            co = sh[f"{hp}.top_conv.0.weight"][0]
-            if name == "feature":
-                g.conv(y, yh, yw, cy, f"{hp}.top_conv.0.weight", co, 3, bias=g.w(f"{hp}.top_conv.0.bias"), out=feats)
-                heads.append(dict(hp=hp, levels=levels, co=co, ch=None, y=y, cy=cy))
-            else:
-                g.conv(y, yh, yw, cy, f"{hp}.top_conv.0.weight", co, 3, bias=g.w(f"{hp}.top_conv.0.bias"), out=maps, cout_total=9, cout_off=ch)
-                heads.append(dict(hp=hp, levels=levels, co=co, ch=ch, y=y, cy=cy))
-                ch += co
+        tape: List[dict] = []
+        taps = []
+        heads = []
+        if self.decoder_only:
+            # the detector ran in eval mode through the inference engine: its maps and features are INPUTS of this plan
+            mh, mw = H // 4, W // 4
+            maps = g.buf(B * mh * mw * 9 * 4)
+            feats = g.buf(B * mh * mw * 100 * 4)
+            g.pin(maps)
+            g.pin(feats)
+        else:
+            c0 = sh[P + ".0.0.weight"][0]
+            h, w = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            z = g.buf(B * h * w * c0 * 4)
+            g.emit("stem", kind=L.OP_STEM, act=L.ACT_NONE, in_dtype=L.F32, out_dtype=L.F32, B=B, H=H, W=W, Ho=h, Wo=w, Cin=3, Cout=c0, ksize=3, stride=2,
+                   in_=("in",), out=z, w=g.w(P + ".0.0.weight#stem"), bias=g.w("zeros"))
+            x, _, ss = g.bn(z, h, w, c0, P + ".0.1", BACKBONE_EPS, L.ACT_SILU)
+            tape.append(dict(kind="stem", z=z, ss=ss, h=h, w=w, c=c0, out=x))
+            c = c0
+            pending_tap = None
+            i = 1
+            while f"{P}.{i}.0.block.0.0.weight" in sh:
+                j = 0
+                while f"{P}.{i}.{j}.block.0.0.weight" in sh:
+                    p = f"{P}.{i}.{j}"
+                    b = p + ".block"
+                    stride = _STAGE_STRIDE[i] if j == 0 else 1
+                    mb = f"{b}.2.fc1.weight" in sh
+                    fused4 = (not mb) and f"{b}.1.0.weight" in sh
+                    last = ".3" if mb else (".1" if fused4 else ".0")
+                    cout = sh[b + last + ".0.weight"][0]
+                    residual = x[0] if (stride == 1 and c == cout) else None
+                    keep = None
+                    if residual is not None:
+                        keep = ("ws", keep_buf[1], len(res_names) * _align(B, 4) * 4)
+                        res_names.append(p[len(pre):])
+                    rec = dict(b=b, xin=x, h=h, w=w, c=c, cout=cout, stride=stride, residual=residual is not None, keep=keep)
+                    if pending_tap is not None:                              # this block reads a tap: the heads' gradient of the tap joins its data gradient
+                        rec["xin_tap"], pending_tap = pending_tap, None
+                    if mb:
+                        e = sh[b + ".0.0.weight"][0]
+                        z0, _, _ = g.conv(x, h, w, c, b + ".0.0.weight", e, 1)
+                        y0, _, ss0 = g.bn(z0, h, w, e, b + ".0.1", BACKBONE_EPS, L.ACT_SILU, **F32ONLY)       # read by the fp32 depthwise kernels
+                        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+                        th = 8 if stride == 1 else 4
+                        pdw = -(-ho // th) * -(-wo // 8)
+                        zd = g.buf(B * ho * wo * e * 4)
+                        g.emit(b + ".1.0", kind=L.OP_DWCONV, act=L.ACT_NONE, in_dtype=L.F32, out_dtype=L.F32, B=B, H=h, W=w, Ho=ho, Wo=wo, Cin=e, Cout=e, ksize=3,
+                               stride=stride, aux0=pdw, in_=y0[0], out=zd, w=g.w(b + ".1.0.weight#dw"), bias=g.w("zeros"), aux=g.buf(B * pdw * e * 4))
+                        pse = max(1, min(16, (ho * wo) // 64))
+                        y1, sums, ss1 = g.bn(zd, ho, wo, e, b + ".1.1", BACKBONE_EPS, L.ACT_SILU, sums_p=pse)                 # fp32 for the SE backward + copy
+                        s = sh[b + ".2.fc1.weight"][0]
+                        sc = g.buf(B * e * 4)
+                        g.emit(b + ".2", kind=L.OP_SE, B=B, H=ho, W=wo, Cin=e, Cout=e, aux0=s, aux1=pse, aux=sums, out=sc, in2=g.buf(B * s * 4),
+                               w=g.w(b + ".2.fc1.weight"), w2=g.w(b + ".2.fc2.weight#t"), bias=g.w(b + ".2.fc1.bias"), bias2=g.w(b + ".2.fc2.bias"))
+                        z3, _, _ = g.conv(y1, ho, wo, e, b + ".3.0.weight", cout, 1, se=sc)
+                        x, _, ss3 = g.bn(z3, ho, wo, cout, b + ".3.1", BACKBONE_EPS, L.ACT_NONE, residual=residual, keep=keep)
+                        rec.update(kind="mb", e=e, z0=z0, y0=y0, ss0=ss0, zd=zd, y1=y1, ss1=ss1, sums=sums, pse=pse, s=s, sc=sc, z3=z3, ss3=ss3, ho=ho, wo=wo)
+                        h, w = ho, wo
+                    elif fused4:
+                        e = sh[b + ".0.0.weight"][0]
+                        z0, ho, wo = g.conv(x, h, w, c, b + ".0.0.weight", e, 3, stride)
+                        y0, _, ss0 = g.bn(z0, ho, wo, e, b + ".0.1", BACKBONE_EPS, L.ACT_SILU, **GEMM_ONLY)
+                        z1, _, _ = g.conv(y0, ho, wo, e, b + ".1.0.weight", cout, 1)
+                        x, _, ss1 = g.bn(z1, ho, wo, cout, b + ".1.1", BACKBONE_EPS, L.ACT_NONE, residual=residual, keep=keep)
+                        rec.update(kind="f4", e=e, z0=z0, y0=y0, ss0=ss0, z1=z1, ss1=ss1, ho=ho, wo=wo)
+                        h, w = ho, wo
+                    else:
+                        z0, ho, wo = g.conv(x, h, w, c, b + ".0.0.weight", cout, 3, stride)
+                        x, _, ss0 = g.bn(z0, ho, wo, cout, b + ".0.1", BACKBONE_EPS, L.ACT_SILU, residual=residual, keep=keep)
+                        rec.update(kind="f1", z0=z0, ss0=ss0, ho=ho, wo=wo)
+                        h, w = ho, wo
+                    rec["out"] = x
+                    tape.append(rec)
+                    c = cout
+                    j += 1
+                if i in (2, 3, 5):
+                    taps.append((x[0], c, h, w))
+                    pending_tap = len(taps) - 1
+                i += 1
+            cl = sh[f"{P}.{i}.0.weight"][0]
+            zl, _, _ = g.conv(x, h, w, c, f"{P}.{i}.0.weight", cl, 1)
+            xl, _, ssl = g.bn(zl, h, w, cl, f"{P}.{i}.1", BACKBONE_EPS, L.ACT_SILU, **F32ONLY)               # the last tap: read by the heads' fp32 tap path only
+            hc = dict(kind="headconv", name=f"{P}.{i}", xin=x, z=zl, ss=ssl, h=h, w=w, c=c, cout=cl, out=xl, tap=len(taps))
+            if pending_tap is not None:
+                hc["xin_tap"], pending_tap = pending_tap, None
+            tape.append(hc)
+            taps.append((xl[0], cl, h, w))
+            mh, mw = taps[0][2], taps[0][3]
+            maps = g.buf(B * mh * mw * 9 * 4)
+            feats = g.buf(B * mh * mw * 100 * 4)
+            g.pin(maps)
+            ch = 0
+            n = len(taps)
+            for name in HEAD_NAMES + ["feature"]:
+                hp = pre + name
+                y, cy, yh, yw = None, 0, 0, 0
+                levels = []
+                for lvl, (tx, tc, th_, tw_) in enumerate(reversed(taps)):
+                    ti = n - 1 - lvl
+                    ssi = g.bnstat(tx, th_, tw_, tc, f"{hp}.in_bn.{ti}", HEAD_EPS)
+                    catb = g.buf(B * th_ * tw_ * (cy + tc) * aes)
+                    cat = (None, catb) if g.h16 else (catb, None)
+                    g.emit(f"{hp}.upcat.{lvl}", kind=L.OP_UPCAT, in_dtype=adt, out_dtype=adt, res_dtype=L.F32, B=B, H=yh if y is not None else th_,
+                           W=yw if y is not None else tw_, Ho=th_, Wo=tw_, Cin=cy + tc, Cout=cy + tc, aux0=cy, aux1=tc, in_=g.pick(y)[0] if y is not None else None,
+                           in2=tx, out=catb, scale=ssi, shift=("ws", ssi[1], tc * 4))
+                    cm = sh[f"{hp}.upsamplers.{lvl}.0.weight"][0]
+                    zc, _, _ = g.conv(cat, th_, tw_, cy + tc, f"{hp}.upsamplers.{lvl}.0.weight", cm, 3)
+                    yn, _, ssc = g.bn(zc, th_, tw_, cm, f"{hp}.upsamplers.{lvl}.1", HEAD_EPS, L.ACT_GELU, **GEMM_ONLY)
+                    levels.append(dict(lvl=lvl, ti=ti, tx=tx, tc=tc, h=th_, w=tw_, cy=cy, yh=yh, yw=yw, ssi=ssi, cat=cat, cm=cm, z=zc, ss=ssc, y=yn))
+                    y, cy, yh, yw = yn, cm, th_, tw_
+                co = sh[f"{hp}.top_conv.0.weight"][0]
+                if name == "feature":
+                    g.conv(y, yh, yw, cy, f"{hp}.top_conv.0.weight", co, 3, bias=g.w(f"{hp}.top_conv.0.bias"), out=feats)
+                    heads.append(dict(hp=hp, levels=levels, co=co, ch=None, y=y, cy=cy))
+                else:
+                    g.conv(y, yh, yw, cy, f"{hp}.top_conv.0.weight", co, 3, bias=g.w(f"{hp}.top_conv.0.bias"), out=maps, cout_total=9, cout_off=ch)
+                    heads.append(dict(hp=hp, levels=levels, co=co, ch=ch, y=y, cy=cy))
+                    ch += co
         # decoder on the selected rows
         sel = g.buf(n_rows * 4)
         lab = g.buf(B * 5 * mh * mw * 4)
@@ -541,8 +556,9 @@ class TrainStep:
                     else:
                         g.wgrad(ly["x"], gz, n_rows, 1, 100, ly["cout"], 1, 1, ly["wname"], cin_total=128, B=1)
                         grows = g.dgrad(gz, n_rows, 1, ly["cout"], ly["wname"], 128, 1, 1, n_rows, 1, add=grows, B=1)
-            g.emit("scatter_rows", kind=L.OP_SCATTER_ROWS, B=B, H=mh, W=mw, Cout_total=128, aux0=n_rows, in_=grows, in2=sel, out=gfeat)
-        else:
+            if not self.decoder_only:
+                g.emit("scatter_rows", kind=L.OP_SCATTER_ROWS, B=B, H=mh, W=mw, Cout_total=128, aux0=n_rows, in_=grows, in2=sel, out=gfeat)
+        elif not self.decoder_only:
             g.emit("fill", kind=L.OP_FILL, B=B, H=mh, W=mw, Cin=128, out=gfeat)
         # heads
         gtap = [g.buf(B * th_ * tw_ * tc * 4) for (_, tc, th_, tw_) in taps]
@@ -626,7 +642,7 @@ class TrainStep:
                 gx = g.dgrad(gz0, ho, wo, cout, b + ".0.0.weight", c_, 3, stride, h_, w_, add=skip)
         g.join()
         plan = self._finish(g)
-        plan.update(maps=maps[1], keep=keep_buf[1], res_names=res_names, mh=mh, mw=mw, sel=sel[1], lab=lab[1], idm=idm[1], lossv=lossv[1], alphas=alphas[1],
+        plan.update(maps=maps[1], feats=feats[1], keep=keep_buf[1], res_names=res_names, mh=mh, mw=mw, sel=sel[1], lab=lab[1], idm=idm[1], lossv=lossv[1], alphas=alphas[1],
                     n_rows=n_rows, n_fwd=n_fwd, loss_bwd_op=lscale_slot, names=g.names, dec_outs=[d["out"][1] for d in dec])
         return plan
 
@@ -731,6 +747,15 @@ class TrainStep:
                 raise ValueError(f"forward_backward: fmask selects {int(_cnt.reshape(-1)[0].item())} pixels, the plan gathers {n_rows} rows "
                                  "(rows beyond the count would be read from uninitialised indices)")
             self._view(plan["sel"], (n_rows,), torch.int32).copy_(sel[:n_rows])
+            if self.decoder_only:
+                # the frozen detector in eval mode (train1.py:98-101): the inference engine's maps and features feed the plan
+                if self.module.detector.training:
+                    raise RuntimeError("TrainStep(decoder_only=True): put the detector in eval mode (model.detector.eval()), as train1.py:163-164 does")
+                with torch.no_grad():
+                    heat, feat = self.module.detector.forward_nhwc(x, with_nms=False)
+                idx9 = torch.tensor([0, 2, 3, 4, 5, 6, 7, 8, 9], device=dev)
+                self._view(plan["maps"], (B, mh, mw, 9)).copy_(heat.index_select(3, idx9))
+                self._view(plan["feats"], (B, mh, mw, 100)).copy_(feat)
             self._view(plan["lab"], (B, 5, mh, mw)).copy_(labelmap.to(torch.float32))
             self._view(plan["idm"], (B, 2, mh, mw), torch.int32).copy_(idmap.to(torch.int32))
             # StochasticDepth draw (torchvision "row" mode)
@@ -738,9 +763,11 @@ class TrainStep:
             Bp = _align(B, 4)
             if n_res * Bp > 4096:
                 raise ValueError("batch too large for the keep-scale table")
-            probs = self.stochastic_depth_probs()
+            probs = self.stochastic_depth_probs() if n_res else {}
             ks = torch.ones((n_res, B), dtype=torch.float32, device=dev)
-            if keep is None:
+            if n_res == 0:
+                pass                                               # decoder_only: the frozen detector has no StochasticDepth draw
+            elif keep is None:
                 surv = torch.tensor([1.0 - probs[nm] for nm in plan["res_names"]], dtype=torch.float32, device=dev).reshape(-1, 1)
                 ks = (torch.rand((n_res, B), device=dev, generator=generator) < surv).float() / surv
             else:
@@ -748,7 +775,8 @@ class TrainStep:
                     kv = keep.get(name, keep.get("detector." + name))
                     if kv is not None:
                         ks[r] = kv.to(device=dev, dtype=torch.float32)
-            self._view(plan["keep"], (n_res, Bp))[:, :B].copy_(ks)
+            if n_res:
+                self._view(plan["keep"], (n_res, Bp))[:, :B].copy_(ks)
             self.pack()
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             bases = (C.c_void_p * L.NUM_BASES)(None, self.workspace.data_ptr(), self.blob.data_ptr(), xn.data_ptr(), None, None, self.grads.data_ptr())
@@ -790,7 +818,7 @@ class TrainStep:
                             ddp.reduce_bucket(bi, async_op=True)
                 ddp.wait()
                 cur.wait_stream(self.comm_stream)
-            torch._foreach_add_(self.counters, 1)
+            torch._foreach_add_(self.counters if not self.decoder_only else self.decoder_counters, 1)
             from .optim import bump_versions
             bump_versions(self.stat_buffers)           # the kernels moved the running statistics in place
         return loss, {k: v.clone() for k, v in raw.items()}

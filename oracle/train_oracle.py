@@ -42,3 +42,26 @@ def train_step(sd: Dict[str, torch.Tensor], x: torch.Tensor, labelmap: torch.Ten
         (loss * loss_scale).backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
     return loss.detach(), {k: v.detach() for k, v in raw.items()}, grads, maps.detach()
+
+
+def train_step_decoder_only(sd: Dict[str, torch.Tensor], x: torch.Tensor, labelmap: torch.Tensor, idmap: torch.Tensor,
+                            alphas: Optional[Sequence[float]] = None, loss_scale: float = 1.0):
+    """The reference's ``decoder_only`` step (``/root/reference/train1.py:98-101, 163-164``): detector parameters frozen, detector in eval
+    mode (running statistics, no StochasticDepth), SimpleDecoder in train mode.  Returns (loss, raw losses, {decoder param: grad},
+    {decoder running-stat key: new value})."""
+    det = {k[len("detector."):]: v for k, v in sd.items() if k.startswith("detector.")}
+    with torch.no_grad():
+        maps, feats = detector_oracle.detection_forward(det, x)
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if k.startswith("decoder.") and is_parameter(k) and v.is_floating_point()}
+    full = dict(sd)
+    full.update(leaves)
+    with torch.enable_grad():
+        fmask = loss_oracle.get_fmask(labelmap)
+        rows = feats.permute(0, 2, 3, 1).flatten(0, -2)[fmask]
+        dec, new_stats = detector_oracle.decoder_forward_train.__wrapped__(full, rows)
+        raw = loss_oracle.loss_function(fmask, labelmap, idmap, maps, dec)
+        a = [1.0 / len(COV_KEYS)] * len(COV_KEYS) if alphas is None else [float(v) for v in alphas]
+        loss = sum(ai * raw[k] for ai, k in zip(a, COV_KEYS))
+        (loss * loss_scale).backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
+    return loss.detach(), {k: v.detach() for k, v in raw.items()}, grads, {k: v.detach() for k, v in new_stats.items()}

@@ -359,9 +359,9 @@ def gen_validation_step(model):
 
 
 def gen_small_models():
-    """g8: the reference's detector for model_size 's' and 'm' (models/detector.py:131-136, 149-158: torchvision's EfficientNetV2-S / -M
-    tables, other tap widths) at 128x128, batch 1 -- pins the library's non-XL plans."""
-    for size, seed in (("s", 11), ("m", 12)):
+    """g8: the reference's detector for model_size 's', 'm' and 'l' (models/detector.py:131-136, 149-158: torchvision's EfficientNetV2-S / -M
+    / -L tables, other tap widths) at 128x128, batch 1 -- pins the library's non-XL plans."""
+    for size, seed in (("s", 11), ("m", 12), ("l", 13)):
         torch.manual_seed(0)
         model = ref_detector.TextDetectorModel(pre_weights=False, model_size=size)
         model.load_state_dict(deterministic_state_dict(SEED_W, model_size=size))
@@ -510,12 +510,186 @@ def gen_train_step(model):
     save("g10_train_step.npz", **out)
 
 
+def _seeded_stochastic_depth(model, rng, B):
+    """Replaces the StochasticDepth draw of oracle/tv_efficientnet.py by a seeded keep-scale per (block, image); returns (keep dict, restore())."""
+    from oracle import tv_efficientnet as tv
+    sds = [(n, m) for n, m in model.named_modules() if isinstance(m, tv.StochasticDepth)]
+    keep = {}
+    for n, m in sds:
+        surv = 1.0 - m.p
+        keep[n[: -len(".stochastic_depth")]] = torch.from_numpy((rng.random(B) < surv).astype(np.float32) / np.float32(surv))
+    return keep, sds
+
+
+def gen_train_step_autocast(model):
+    """g11: the reference's train step EXACTLY as train1.py:125-131 runs it -- under torch.autocast(bfloat16) -- on the g10 inputs and
+    the g10 StochasticDepth draw (CPU autocast: convolutions / Linear layers in bf16 with bf16 outputs, as the CUDA policy; the
+    reference names device_type='cuda', which does not exist here).  Stored: for every parameter the cosine between ITS bf16-autocast
+    gradient and ITS fp32 gradient (the g10 run repeated here) and the ratio of their norms -- the envelope a bf16 train step of this
+    network has by the reference's own arithmetic, against which the GPU's bf16 mode is gated (instead of a bare number)."""
+    import loss_func as ref_loss  # noqa: E402  (reference code)
+    from oracle import tv_efficientnet as tv
+    g10 = np.load(os.path.join(HERE, "g10_train_step.npz"))
+    B, H, W = 2, 256, 256
+    x = synth.page_images(1029, B, H, W)
+    label, idmap = synth.train_labels(1030, B, H // 4, W // 4)
+    keep = {str(n): torch.from_numpy(k) for n, k in zip(g10["keep_names"], g10["keep"])}
+    sds = [(n, m) for n, m in model.named_modules() if isinstance(m, tv.StochasticDepth)]
+    by_id = {id(m): keep[n[: -len(".stochastic_depth")]] for n, m in sds}
+    orig = tv.StochasticDepth.forward
+
+    def fwd(self, t):
+        if not self.training or self.p == 0.0:
+            return t
+        return t * by_id[id(self)].reshape(-1, 1, 1, 1).to(t.dtype)
+    tv.StochasticDepth.forward = fwd
+    keys = ["keymap_loss", "size_loss", "textline_loss", "separator_loss", "id_loss", "code1_loss", "code2_loss", "code4_loss", "code8_loss"]
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    res = {}
+    try:
+        for mode in ("fp32", "bf16"):
+            model.load_state_dict(before)
+            model.train()
+            model.zero_grad(set_to_none=True)
+            lab_t, id_t = torch.from_numpy(label), torch.from_numpy(idmap).to(torch.long)
+            fmask = model.get_fmask(lab_t, None)
+            cov = ref_loss.CoVWeightingLoss(losses=keys)
+            cov.train()
+            with torch.autocast(device_type="cpu", dtype=torch.bfloat16, enabled=mode == "bf16"):
+                heatmap, dec = model(torch.from_numpy(x).permute(0, 3, 1, 2), fmask)
+                raw = ref_loss.loss_function(fmask, lab_t, id_t, heatmap, dec)
+                loss = cov(raw)
+            loss.backward()
+            res[mode] = ({n: p.grad.detach().float().clone() for n, p in model.named_parameters()}, float(loss), heatmap.detach().float().numpy())
+    finally:
+        tv.StochasticDepth.forward = orig
+        model.load_state_dict(before)
+        model.zero_grad(set_to_none=True)
+        model.eval()
+    g32, g16 = res["fp32"][0], res["bf16"][0]
+    names = list(g32)
+    cos = np.array([float((g32[n].double() * g16[n].double()).sum() / (g32[n].double().norm() * g16[n].double().norm() + 1e-300)) for n in names])
+    ratio = np.array([float(g16[n].double().norm() / (g32[n].double().norm() + 1e-300)) for n in names])
+    assert abs(res["fp32"][1] - float(g10["loss"])) < 1e-5 * abs(float(g10["loss"]))      # the fp32 leg IS the g10 run
+    hm_err = float(np.abs(res["bf16"][2] - res["fp32"][2]).max())
+    save("g11_train_step_bf16_autocast.npz", names=np.array(names), cosine=cos, norm_ratio=ratio, loss_fp32=np.array(res["fp32"][1]),
+         loss_bf16=np.array(res["bf16"][1]), heatmap_linf=np.array(hm_err), grad_absmax_fp32=np.array([float(g32[n].abs().max()) for n in names]))
+    pick = [str(n) for n in g10["pick_names"]]
+    pc = sorted(cos[names.index(n)] for n in pick)
+    print("g11: bf16-autocast vs fp32 gradient cosine over the g10 pick list: min %.3f p10 %.3f median %.3f; loss %.5f vs %.5f; heatmap Linf %.3e"
+          % (pc[0], pc[len(pc) // 10], pc[len(pc) // 2], res["bf16"][1], res["fp32"][1], hm_err))
+
+
+def gen_train_trajectory(model):
+    """g12: FOUR iterations of the reference's training loop (train1.py:165-179) on CPU in fp32 at 128x128, batch 2, with
+    iters_to_accumulate = 2: optimizer.train(); per iteration fmask = model.get_fmask(labelmap, fmask) -> train step (no autocast: the
+    parity mode) -> (loss / 2).backward() -> every second iteration AdamWScheduleFree.step() + zero_grad(), lr = 2.5e-4 (a tenth of
+    train1.py:18's: at 2.5e-3 ONE step on this random-init network doubles the loss, and two fp32 implementations whose gradients agree
+    to 1e-3 then differ by 19 % in the second moments -- the comparison would measure the loss surface, not the chain).  Fresh inputs and a fresh
+    seeded StochasticDepth draw per iteration (stored).  Stored: loss / raw losses / CoV alphas per iteration, a spread of parameter
+    tensors and running statistics after the last step, the optimizer's z / exp_avg_sq of two tensors.  What only a CHAINED run
+    shows: the weights the second step sees are the first step's output (a stale packed copy would not move), BatchNorm statistics
+    move four times, the schedule-free y / z / x bookkeeping (train()/eval() swap at the end) and the CoV statistics advance."""
+    import loss_func as ref_loss  # noqa: E402  (reference code)
+    from models.adamw_schedulefree import AdamWScheduleFree  # noqa: E402  (reference code)
+    from oracle import tv_efficientnet as tv
+    B, H, W, ITERS, ACC, LR = 2, 128, 128, 4, 2, 2.5e-4
+    keys = ["keymap_loss", "size_loss", "textline_loss", "separator_loss", "id_loss", "code1_loss", "code2_loss", "code4_loss", "code8_loss"]
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    sds = [(n, m) for n, m in model.named_modules() if isinstance(m, tv.StochasticDepth)]
+    cur = {}
+    orig = tv.StochasticDepth.forward
+
+    def fwd(self, t):
+        if not self.training or self.p == 0.0:
+            return t
+        return t * cur[id(self)].reshape(-1, 1, 1, 1)
+    tv.StochasticDepth.forward = fwd
+    out = {}
+    try:
+        model.train()
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = AdamWScheduleFree(params, lr=LR)
+        cov = ref_loss.CoVWeightingLoss(losses=keys)
+        cov.train()
+        opt.train()
+        opt.zero_grad()
+        fmask = None
+        losses, raws, alphas, keeps = [], [], [], []
+        names = sorted(n[: -len(".stochastic_depth")] for n, _ in sds)
+        for it in range(ITERS):
+            x = synth.page_images(2000 + it, B, H, W)
+            label, idmap = synth.train_labels(2100 + it, B, H // 4, W // 4)
+            rng = np.random.Generator(np.random.PCG64(2200 + it))
+            kd = {}
+            for n, m in sds:
+                surv = 1.0 - m.p
+                kd[n[: -len(".stochastic_depth")]] = torch.from_numpy((rng.random(B) < surv).astype(np.float32) / np.float32(surv))
+                cur[id(m)] = kd[n[: -len(".stochastic_depth")]]
+            lab_t, id_t = torch.from_numpy(label), torch.from_numpy(idmap).to(torch.long)
+            fmask = model.get_fmask(lab_t, fmask)
+            heatmap, dec = model(torch.from_numpy(x).permute(0, 3, 1, 2), fmask)
+            raw = ref_loss.loss_function(fmask, lab_t, id_t, heatmap, dec)
+            loss = cov(raw)
+            (loss / ACC).backward()
+            if (it + 1) % ACC == 0:
+                opt.step()
+                opt.zero_grad()
+            losses.append(float(loss))
+            raws.append([float(raw[k]) for k in keys + ["loss"]])
+            alphas.append(cov.alphas.numpy().copy())
+            keeps.append(np.stack([kd[n].numpy() for n in names]))
+        sd_train = {k: v.detach().clone() for k, v in model.state_dict().items()}          # y (where gradients are taken)
+        pick = train_step_pick([(n, tuple(p.shape)) for n, p in model.named_parameters()])[:40]
+        named = dict(model.named_parameters())
+        zs = {n: opt.state[named[n]]["z"].detach().clone() for n in pick[:2]}
+        vs = {n: opt.state[named[n]]["exp_avg_sq"].detach().clone() for n in pick[:2]}
+        opt.eval()                                                                           # x (the averaged iterate: what is saved)
+        sd_eval = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        out = {"keep_names": np.array(names), "keep": np.stack(keeps), "loss": np.array(losses), "raw": np.array(raws), "alphas": np.stack(alphas),
+               "lr": np.array(LR), "iters_to_accumulate": np.array(ACC), "pick_names": np.array(pick)}
+        for i, n in enumerate(pick):
+            for tag, sdx in (("y", sd_train), ("x", sd_eval)):
+                g = sdx[n].numpy().reshape(-1)
+                stride = max(1, g.size // 20000)
+                out[f"{tag}{i}"] = g[::stride].copy()
+                out[f"stride{i}"] = np.array(stride)
+            out[f"delta_absmax{i}"] = np.array(float((sd_train[n] - before[n]).abs().max()))
+        for j, n in enumerate(pick[:2]):
+            st = max(1, zs[n].numel() // 20000)
+            out[f"z{j}"] = zs[n].numpy().reshape(-1)[::st].copy()
+            out[f"v{j}"] = vs[n].numpy().reshape(-1)[::st].copy()
+        stats = [k for k in sd_train if k.endswith("running_mean") or k.endswith("running_var")]
+        stats = stats[:: max(1, len(stats) // 24)]
+        out["stat_names"] = np.array(stats)
+        for i, k in enumerate(stats):
+            out[f"stat{i}"] = sd_train[k].numpy().copy()
+        out["num_batches_tracked"] = np.array(int(sd_train["detector.backbone.features.0.1.num_batches_tracked"]))
+    finally:
+        tv.StochasticDepth.forward = orig
+        model.load_state_dict(before)
+        model.zero_grad(set_to_none=True)
+        model.eval()
+    save("g12_train_trajectory.npz", **out)
+    print("g12: losses", out["loss"], "largest parameter move", max(float(out[f"delta_absmax{i}"]) for i in range(len(out["pick_names"]))))
+
+
+
 def main():
     if "--train-step-only" in sys.argv:
         torch.manual_seed(0)
         model = ref_detector.TextDetectorModel(pre_weights=False)
         model.load_state_dict(deterministic_state_dict(SEED_W))
         gen_train_step(model)
+        return
+    if "--autocast-only" in sys.argv or "--trajectory-only" in sys.argv:
+        torch.manual_seed(0)
+        model = ref_detector.TextDetectorModel(pre_weights=False)
+        model.load_state_dict(deterministic_state_dict(SEED_W))
+        if "--autocast-only" in sys.argv:
+            gen_train_step_autocast(model)
+        else:
+            gen_train_trajectory(model)
         return
     if "--train-only" in sys.argv:
         torch.manual_seed(0)
@@ -554,6 +728,8 @@ def main():
     gen_validation_step(model)
     gen_train_forward(model)
     gen_train_step(model)
+    gen_train_step_autocast(model)
+    gen_train_trajectory(model)
     gen_small_models()
 
 

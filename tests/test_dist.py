@@ -307,3 +307,24 @@ def test_ddp_bucket_segments_reduce_every_gradient_element_world2_gloo():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res == [(0, 0, True), (1, 0, True)]                  # no element kept a local-only (un-reduced) contribution
+
+
+def test_decoder_only_train_plan_touches_only_decoder_gradients():
+    """TrainStep(decoder_only=True) (train1.py:98-101, 163-164: frozen detector in eval mode): the plan built on CPU starts at the row
+    gather, and every gradient it writes belongs to a ``decoder.*`` parameter."""
+    from findtextcenternet_amd import TextDetectorModel, TrainStep
+    from findtextcenternet_amd import _lib as L
+    m = TextDetectorModel(pre_weights=False, precision="bf16").train()
+    m.detector.eval()
+    ts = TrainStep(m, decoder_only=True)
+    plan = ts.plan_for(2, 128, 128)
+    kinds = [plan["ops"][i].kind for i in range(plan["n_ops"])]
+    assert kinds[0] == L.OP_GATHER_ROWS and L.OP_STEM not in kinds and L.OP_DWCONV not in kinds and L.OP_SCATTER_ROWS not in kinds
+    assert kinds.count(L.OP_LOSSES) == 1 and kinds.count(L.OP_LOSS_BWD) == 1 and plan["n_ops"] < 120
+    lo = min(ts.ptable[n] for n, _ in ts.params if n.startswith("decoder.")) // 4
+    wrote = 0
+    for i in range(plan["n_fwd"], plan["n_ops"]):
+        for e0, e1 in ts._grad_write_extents(plan["ops"][i]):
+            assert e0 >= lo
+            wrote += 1
+    assert wrote == 3 * (3 + 2 * 2 + 1)                          # per decoder MLP: 3 Linear weights, 2 BatchNorm1d (gamma, beta), the last bias

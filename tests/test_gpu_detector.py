@@ -426,9 +426,9 @@ def test_fp16_mode_same_plan_much_closer_to_the_reference(sd, golden_dir):
     assert float((h16[fin] - h32[fin]).abs().max()) < 0.03 and float((f16 - f32_).abs().max()) < 0.05
 
 
-@pytest.mark.parametrize("size", ["s", "m"])
+@pytest.mark.parametrize("size", ["s", "m", "l"])
 def test_other_model_sizes_match_the_reference(golden_dir, size):
-    """TextDetectorModel(model_size='s' | 'm') on the GPU against the reference's own outputs for those sizes (g8)."""
+    """TextDetectorModel(model_size='s' | 'm' | 'l') on the GPU against the reference's own outputs for those sizes (g8)."""
     g = np.load(os.path.join(golden_dir, f"g8_fwd128_{size}.npz"))
     sd_ = deterministic_state_dict(0, model_size=size)
     x = torch.from_numpy(synth.page_images(int(g["seed"]), 1, 128, 128)).permute(0, 3, 1, 2).to("cuda")

@@ -170,9 +170,9 @@ def test_validation_step_oracle_matches_reference():
         assert np.abs(cov.alphas - g["cov_alphas"][step]).max() < 2e-6
 
 
-@pytest.mark.parametrize("size", ["s", "m"])
+@pytest.mark.parametrize("size", ["s", "m", "l"])
 def test_small_model_sizes_match_reference(size):
-    """model_size 's' / 'm' (models/detector.py:131-136, 149-158): the schema loads strictly into the reference's own modules (the
+    """model_size 's' / 'm' / 'l' (models/detector.py:131-136, 149-158): the schema loads strictly into the reference's own modules (the
     fixture was generated that way), and the oracle reproduces the reference's outputs (tests/golden/g8_fwd128_<size>.npz)."""
     g = np.load(os.path.join(G, f"g8_fwd128_{size}.npz"))
     assert int(g["n_keys"]) == len(schema.text_detector_schema(size))
@@ -244,3 +244,20 @@ def test_train_step_oracle_matches_reference_backward():
         mine = grads[str(n)].numpy().reshape(-1)[::st]
         assert np.abs(mine - ref).max() <= 1e-3 * np.abs(ref).max() + 1e-7, n
     assert sum(1 for a in g["grad_absmax"] if a == 0.0) >= 13      # a block dropped for every image: exact zeros
+
+
+def test_oracle_reproduces_the_first_iterations_of_the_reference_training_loop():
+    """g12 (four iterations of the reference's loop, train1.py:165-179): iterations 0 and 1 run on the initial weights -- their losses are
+    what oracle/train_oracle.py computes with the CoV weights the fixture recorded (the oracle takes the alphas as an input)."""
+    from oracle import train_oracle
+    g = np.load(os.path.join(G, "g12_train_trajectory.npz"))
+    sd_full = deterministic_state_dict(0)
+    names = [str(n) for n in g["keep_names"]]
+    for it in range(int(g["iters_to_accumulate"])):
+        x = torch.from_numpy(synth.page_images(2000 + it, 2, 128, 128)).permute(0, 3, 1, 2)
+        label, idmap = synth.train_labels(2100 + it, 2, 32, 32)
+        keep = {n: torch.from_numpy(k) for n, k in zip(names, g["keep"][it])}
+        loss, raw, _, _ = train_oracle.train_step(sd_full, x, torch.from_numpy(label), torch.from_numpy(idmap).long(), keep, g["alphas"][it].tolist(), 1.0)
+        assert abs(float(loss) - float(g["loss"][it])) < 1e-5 * float(g["loss"][it]), it
+        for j, k in enumerate(train_oracle.COV_KEYS):
+            assert abs(float(raw[k]) - float(g["raw"][it][j])) < 2e-5 * max(1e-3, abs(float(g["raw"][it][j]))), (it, k)

@@ -21,7 +21,7 @@ for B in batches:
         ns = nb * (Cx // L.MBHEAD_SLICE)
         nwg = B * ns
         sizes = dict(x=B * H * W * Cin * 2, we=Cx * Cin * 2, be=Cx * 4, wd=9 * Cx * 4, bd=Cx * 4, out=B * H * W * Cx * 2, sums=B * nb * Cx * 4, w1=S * Cx * 4,
-                     hp=B * ns * S * 4, tl=nwg * 64, b1=S * 4, w2t=S * Cx * 4, b2=Cx * 4, sc=B * Cx * 4, hid=B * S * 4, wp=N * Cx * 2, wb=B * N * Cx * 2)
+                     hp=B * ns * S * 4, tl=nwg * 256, b1=S * 4, w2t=S * Cx * 4, b2=Cx * 4, sc=B * Cx * 4, hid=B * S * 4, wp=N * Cx * 2, wb=B * N * Cx * 2)
         off, cur = {}, 0
         for k, n in sizes.items():
             off[k] = cur
@@ -61,11 +61,14 @@ for B in batches:
             ts.append(ms[0])
             tse.append(ms[1])
         torch.cuda.synchronize()
-        tl = ws[off["tl"]:off["tl"] + nwg * 64].view(torch.int64).reshape(nwg, 8).cpu().numpy()
+        tl = ws[off["tl"]:off["tl"] + nwg * 256].view(torch.int64).reshape(nwg, 32).cpu().numpy()
         d = np.diff(tl[:, :5], axis=1)
         span = (tl[:, 4].max() - tl[:, 0].min())
         fl = 2.0 * B * H * W * Cx * (Cin + 9)
         print(f"B{B} {H}x{W} {Cin}->{Cx} R{R}: mbhead {np.median(ts) * 1e3:7.1f} us  {fl / np.median(ts) / 1e9:6.1f} TF  {nwg} workgroups;  cycles (median over workgroups): "
               f"K loop {np.median(d[:, 0]):.0f}  expand epilogue {np.median(d[:, 1]):.0f}  depthwise {np.median(d[:, 2]):.0f}  sums+fc1 {np.median(d[:, 3]):.0f}  "
-              f"total {np.median(tl[:, 4] - tl[:, 0]):.0f}  first-start to last-end {span};   se(hpart+fold) {np.median(tse) * 1e3:6.1f} us", flush=True)
+              f"total {np.median(tl[:, 4] - tl[:, 0]):.0f}  K-loop waits (vmcnt + barrier) {np.median(tl[:, 5]):.0f} of which the first {np.median(tl[:, 6]):.0f};   se(hpart+fold) {np.median(tse) * 1e3:6.1f} us", flush=True)
+        nkk = min(24, Cin // 32)
+        step = np.median(np.diff(np.concatenate([tl[:, 0:1], tl[:, 8:8 + nkk], tl[:, 1:2]], axis=1), axis=1), axis=0)
+        print("      wave 0: start -> top of step 0, then step durations (cycles):", " ".join(f"{v:.0f}" for v in step), flush=True)
         lib.ftc_plan_destroy(h)

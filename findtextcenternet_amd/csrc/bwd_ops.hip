@@ -33,7 +33,7 @@ __device__ __forceinline__ float dact(float t, int act) {
 // ------------------------------------------------------------------------------------------------------------------------
 struct BnBwdP {
     const float* gy; int gs, goff;      // incoming gradient, row stride / channel offset
-    const float* z;                     // BN input [M][C]
+    const void* z;                      // BN input [M][C]: fp32, or 16-bit in the plan's compute type (the template parameter ZT of the kernels)
     const float* ss;                    // [4][C] scale, shift, mean, invstd
     const float* keep;                  // [B] or null
     const float* ga;                    // [B][C] or null
@@ -79,7 +79,7 @@ template <bool FAST> __device__ __forceinline__ f32x4 dact4(f32x4 t, int act) {
     return r;
 }
 
-template <int Q, bool FAST>
+template <int Q, bool FAST, typename ZT>
 __global__ __launch_bounds__(256) void bnbwd_partial_kernel(BnBwdP p, double* __restrict__ part, int nchunk) {
     constexpr int RL = 256 / Q;
     __shared__ double red[2][RL][Q * 4];
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void bnbwd_partial_kernel(BnBwdP p, double* __
             const int rr = r + u * RL;
             const bool ok = rr < r1;
             gv[u] = ok ? *reinterpret_cast<const f32x4*>(p.gy + (long)rr * p.gs + p.goff + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-            zv[u] = ok ? *reinterpret_cast<const f32x4*>(p.z + (long)rr * p.C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            zv[u] = ok ? load4<ZT>(static_cast<const ZT*>(p.z) + (long)rr * p.C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void bnbwd_final_kernel(const double* __restri
 // out (fp32, optional) and / or out2 (16-bit copy in the plan's compute type, optional): the gradient of a convolution's output is only
 // ever read by that convolution's data- and weight-gradient GEMMs, which narrow it anyway -- writing it once in 16 bits halves their
 // operand streams and lets them run on the DMA-staged kernels
-template <int Q, bool FAST, typename TC>
+template <int Q, bool FAST, typename TC, typename ZT>
 __global__ __launch_bounds__(256) void bnbwd_apply_kernel(BnBwdP p, const float* __restrict__ coef, float* __restrict__ out, TC* __restrict__ out2, int accum,
                                                           int nchunk) {
     constexpr int RL = 256 / Q;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void bnbwd_apply_kernel(BnBwdP p, const float*
             if (p.keep) kp = p.keep[b];
         }
         const f32x4 g = (*reinterpret_cast<const f32x4*>(p.gy + (long)r * p.gs + p.goff + c) * ga + gb) * kp;
-        const f32x4 zv = *reinterpret_cast<const f32x4*>(p.z + (long)r * p.C + c);
+        const f32x4 zv = load4<ZT>(static_cast<const ZT*>(p.z) + (long)r * p.C + c);
         const f32x4 dt = g * dact4<FAST>(zv * sc + sh, p.act);
         f32x4 o = sc * (dt - c1 - (zv - mean) * istd * c2);
         if (out) {
@@ -718,10 +718,10 @@ hipError_t launch_pack_train(const ftc_pack_entry* entries, int n, long max_elem
 }
 
 namespace {
-template <int Q, bool FAST, typename TC>
+template <int Q, bool FAST, typename TC, typename ZT>
 hipError_t bnbwd_run(const BnBwdP& p, double* part, float* coef, float* ggamma, float* gbeta, float* out, TC* out2, int accum, int nchunk, hipStream_t s) {
     const dim3 grid(p.C / (4 * Q), nchunk);
-    hipLaunchKernelGGL((bnbwd_partial_kernel<Q, FAST>), grid, dim3(256), 0, s, p, part, nchunk);
+    hipLaunchKernelGGL((bnbwd_partial_kernel<Q, FAST, ZT>), grid, dim3(256), 0, s, p, part, nchunk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(bnbwd_final_kernel, dim3((p.C + 15) / 16), dim3(256), 0, s, part, ggamma, gbeta, coef, (long)p.M, p.C, nchunk);
@@ -730,19 +730,19 @@ hipError_t bnbwd_run(const BnBwdP& p, double* part, float* coef, float* ggamma, 
     // the apply pass streams: enough row chunks to fill the GPU (the partial pass is bound to the scratch layout's chunk count)
     int ach = (int)((4096L * 4 * Q) / p.C);
     ach = ach < 1 ? 1 : ach > p.M / 8 + 1 ? p.M / 8 + 1 : ach;
-    hipLaunchKernelGGL((bnbwd_apply_kernel<Q, FAST, TC>), dim3(p.C / (4 * Q), ach), dim3(256), 0, s, p, coef, out, out2, accum, ach);
+    hipLaunchKernelGGL((bnbwd_apply_kernel<Q, FAST, TC, ZT>), dim3(p.C / (4 * Q), ach), dim3(256), 0, s, p, coef, out, out2, accum, ach);
     return hipGetLastError();
 }
-template <bool FAST, typename TC>
+template <bool FAST, typename TC, typename ZT>
 hipError_t bnbwd_q(int q, const BnBwdP& p, double* part, float* coef, float* gg, float* gb, float* out, TC* out2, int accum, int nchunk, hipStream_t s) {
     switch (q) {
-    case 64: return bnbwd_run<64, FAST, TC>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
-    case 32: return bnbwd_run<32, FAST, TC>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
-    case 16: return bnbwd_run<16, FAST, TC>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
-    case 8: return bnbwd_run<8, FAST, TC>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
-    case 4: return bnbwd_run<4, FAST, TC>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
-    case 2: return bnbwd_run<2, FAST, TC>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
-    default: return bnbwd_run<1, FAST, TC>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
+    case 64: return bnbwd_run<64, FAST, TC, ZT>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
+    case 32: return bnbwd_run<32, FAST, TC, ZT>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
+    case 16: return bnbwd_run<16, FAST, TC, ZT>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
+    case 8: return bnbwd_run<8, FAST, TC, ZT>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
+    case 4: return bnbwd_run<4, FAST, TC, ZT>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
+    case 2: return bnbwd_run<2, FAST, TC, ZT>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
+    default: return bnbwd_run<1, FAST, TC, ZT>(p, part, coef, gg, gb, out, out2, accum, nchunk, s);
     }
 }
 }  // namespace
@@ -751,7 +751,7 @@ hipError_t launch_bnbwd(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
     BnBwdP p;
     p.gy = (const float*)a.in; p.gs = o.Cin_total > 0 ? o.Cin_total : o.Cin; p.goff = o.cin_off;
-    p.z = (const float*)a.in2; p.ss = a.scale; p.keep = (const float*)a.w2; p.ga = a.bias; p.gb = a.bias2;
+    p.z = a.in2; p.ss = a.scale; p.keep = (const float*)a.w2; p.ga = a.bias; p.gb = a.bias2;
     p.HW = o.H * o.W; p.M = o.B * o.H * o.W; p.C = o.Cin; p.act = o.act;
     const int nchunk = ftc_bnstat_chunks(p.M);
     double* part = reinterpret_cast<double*>(a.aux);
@@ -760,9 +760,15 @@ hipError_t launch_bnbwd(const OpArgs& a, hipStream_t s) {
     float* gg = (float*)const_cast<void*>(a.w);
     float* gb = const_cast<float*>(a.shift);
     const int accum = (o.flags & FTC_FLAG_ACCUM) ? 1 : 0;
-    if (o.w_dtype == FTC_F32) return bnbwd_q<false, float>(q, p, part, coef, gg, gb, (float*)a.out, (float*)nullptr, accum, nchunk, s);
-    if (o.w_dtype == FTC_F16) return bnbwd_q<true, _Float16>(q, p, part, coef, gg, gb, (float*)a.out, (_Float16*)a.out2, accum, nchunk, s);
-    return bnbwd_q<true, __bf16>(q, p, part, coef, gg, gb, (float*)a.out, (__bf16*)a.out2, accum, nchunk, s);
+    // in_dtype = the type z (in2) is STORED in: fp32, or the plan's 16-bit compute type (what the reference's autocast stores: the
+    // convolution wrote it in 16 bits, and the three BatchNorm passes -- statistics, normalise, backward -- stream half the bytes)
+    const bool z16 = ftc_is16(o.in_dtype);
+    if (o.w_dtype == FTC_F32) return bnbwd_q<false, float, float>(q, p, part, coef, gg, gb, (float*)a.out, (float*)nullptr, accum, nchunk, s);
+    if (o.w_dtype == FTC_F16)
+        return z16 ? bnbwd_q<true, _Float16, _Float16>(q, p, part, coef, gg, gb, (float*)a.out, (_Float16*)a.out2, accum, nchunk, s)
+                   : bnbwd_q<true, _Float16, float>(q, p, part, coef, gg, gb, (float*)a.out, (_Float16*)a.out2, accum, nchunk, s);
+    return z16 ? bnbwd_q<true, __bf16, __bf16>(q, p, part, coef, gg, gb, (float*)a.out, (__bf16*)a.out2, accum, nchunk, s)
+               : bnbwd_q<true, __bf16, float>(q, p, part, coef, gg, gb, (float*)a.out, (__bf16*)a.out2, accum, nchunk, s);
 }
 
 hipError_t launch_dwbwd(const OpArgs& a, hipStream_t s) {

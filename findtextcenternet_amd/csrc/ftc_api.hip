@@ -242,7 +242,8 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if (o.act != FTC_ACT_NONE && o.act != FTC_ACT_SILU && o.act != FTC_ACT_GELU) return "bnbwd: unknown activation";
         if (o.out.base == FTC_BASE_NULL && o.out2.base == FTC_BASE_NULL) return "bnbwd: needs out (fp32) and / or out2 (16-bit copy)";
         if (o.out2.base != FTC_BASE_NULL && !ftc_is16(o.w_dtype)) return "bnbwd: out2 is a 16-bit copy in the plan's compute type (w_dtype)";
-        if (!need(o.in, true, "in", pin * gs * 4) || !need(o.in2, true, "in2", pin * o.Cin * 4) || !need(o.scale, true, "scale", (int64_t)4 * o.Cin * 4) ||
+        if (o.in_dtype != FTC_F32 && !(ftc_is16(o.in_dtype) && o.in_dtype == o.w_dtype)) return "bnbwd: in_dtype (the type z is stored in) is fp32 or the plan's 16-bit compute type (w_dtype)";
+        if (!need(o.in, true, "in", pin * gs * 4) || !need(o.in2, true, "in2", pin * o.Cin * es(o.in_dtype)) || !need(o.scale, true, "scale", (int64_t)4 * o.Cin * 4) ||
             !need(o.out, false, "out", pin * o.Cin * 4) || !need(o.out2, false, "out2", pin * o.Cin * 2) || !need(o.w, false, "w", (int64_t)o.Cin * 4) || !need(o.shift, false, "shift", (int64_t)o.Cin * 4) ||
             !need(o.w2, false, "w2", (int64_t)o.B * 4) || !need(o.bias, false, "bias", (int64_t)o.B * o.Cin * 4) || !need(o.bias2, false, "bias2", (int64_t)o.B * o.Cin * 4) ||
             !need(o.aux, true, "aux", (int64_t)ftc_bnstat_chunks(pin) * 2 * o.Cin * 8 + (int64_t)2 * o.Cin * 4)) return why->c_str();

@@ -41,7 +41,8 @@ class TrainStep:
     """``ts = TrainStep(model)``; per iteration ``loss, raw = ts.forward_backward(image, labelmap, idmap, fmask)`` then
     ``optimizer.step(); ts.zero_grad()`` -- the reference's loop body (train1.py:170-179) with ``train_step`` + ``backward`` fused."""
 
-    def __init__(self, module, precision: Optional[str] = None, cov=None, two_streams: bool = True, decoder_only: bool = False):
+    def __init__(self, module, precision: Optional[str] = None, cov=None, two_streams: bool = True, decoder_only: bool = False,
+                 z16: Optional[bool] = None):
         """two_streams: the backward's weight-gradient ops run on a second HIP stream beside the chain that produces their operands
         (ftc_plan_run_streams; same kernels, same results -- False keeps everything on the caller's stream).
         decoder_only: the reference's ``decoder_only`` switch (train1.py:98-101, 163-164): the detector is frozen and runs in eval mode
@@ -50,6 +51,13 @@ class TrainStep:
         gradients of the detector's parameters stay zero (the reference sets requires_grad_(False) on them)."""
         self.module = module
         self.decoder_only = bool(decoder_only)
+        # z16 (opt-in; FTC_TRAIN_Z16=1): the convolution outputs (the inputs of the batch-statistics BatchNorms) are STORED in the 16-bit
+        # compute type, as the reference's autocast stores them (train1.py:127), so the statistics / normalise / backward passes of
+        # every BatchNorm read half the bytes of z.  Measured (round 4, batch 8 x 768x768, bf16): 121.7 -> 119.8 ms per step -- those
+        # passes are not bound by the z stream -- while the gradients move further from the fp32 reference (cosine min / p10 / median
+        # 0.61 / 0.64 / 0.93 -> 0.16 / 0.53 / 0.91; still inside the envelope of the reference's OWN bf16 autocast, tests/golden/g11:
+        # 0.07 / 0.32 / 0.86).  Not worth it by default.
+        self._z16_arg = z16
         self.two_streams = bool(two_streams) and os.environ.get("FTC_TRAIN_ONE_STREAM") != "1"      # (env: A/B measurements)
         self.side_stream = None
         self.precision = precision or module.detector.precision
@@ -57,6 +65,8 @@ class TrainStep:
             raise ValueError("TrainStep: 'fp16x3' is an inference mode; train in 'bf16' (what the reference's autocast does), 'fp16' or 'fp32'")
         self.cdt = PRECISIONS[self.precision]
         self.esz = 4 if self.cdt == L.F32 else 2
+        env_z = os.environ.get("FTC_TRAIN_Z16")
+        self.z16 = self.cdt != L.F32 and (self._z16_arg if self._z16_arg is not None else (env_z == "1"))
         self.cov = cov
         self.plans: Dict[Tuple[int, int, int], dict] = {}
         self.workspace: Optional[torch.Tensor] = None
@@ -266,12 +276,15 @@ class TrainStep:
         def conv(self, x, h, w, cin, wname, cout, k, stride=1, se=None, bias=None, out=None, cout_total=None, cout_off=0, cin_total=None, B=None):
             B = B or self.B
             ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
-            z = out if out is not None else self.buf(B * ho * wo * cout * 4)
+            zdt = self.cdt if (self.ts.z16 and out is None and cout_total is None) else L.F32
+            z = out if out is not None else self.buf(B * ho * wo * cout * (2 if zdt != L.F32 else 4))
+            if out is None:
+                z[1].dt = zdt                                     # the dtype travels with the buffer: BNSTAT / BNACT / BNBWD read it
             xin, xdt = self.pick(x)
-            self.emit(wname, kind=L.OP_CONV, flags=L.FLAG_SE_SCALE if se is not None else 0, act=L.ACT_NONE, in_dtype=xdt, out_dtype=L.F32,
+            self.emit(wname, kind=L.OP_CONV, flags=L.FLAG_SE_SCALE if se is not None else 0, act=L.ACT_NONE, in_dtype=xdt, out_dtype=zdt,
                       w_dtype=self.cdt, B=B, H=h, W=w, Ho=ho, Wo=wo, Cin=cin, Cin_total=cin_total or cin, Cout=cout, Cout_total=cout_total or cout,
                       cout_off=cout_off, ksize=k, stride=stride, res_dtype=L.F32, in_=xin, out=z, w=self.w(wname + "#f"), bias=bias or self.w("zeros"), scale=se)
-            if self.h16 and out is None and cout_total is None and os.environ.get("FTC_TRAIN_EMULATE_Z16") == "1":
+            if self.h16 and zdt == L.F32 and out is None and cout_total is None and os.environ.get("FTC_TRAIN_EMULATE_Z16") == "1":
                 # EXPERIMENT (what would storing the conv outputs in 16 bits, as the reference's autocast does, cost in gradient agreement?):
                 # round z to the compute type and back in place -- two extra identity passes, numerics of a 16-bit z, storage unchanged
                 z16 = self.buf(B * ho * wo * cout * 2)
@@ -290,7 +303,7 @@ class TrainStep:
             M = B * h * w
             nchunk = max(1, min(512, -(-M // 64)))
             ss = self.buf(4 * c * 4)
-            self.emit(bn_name, kind=L.OP_BNSTAT, in_dtype=L.F32, B=B, H=h, W=w, Cin=c, aux0=_fbits(eps), aux1=_fbits(0.1), in_=z, w=self.w(bn_name + ".weight"),
+            self.emit(bn_name, kind=L.OP_BNSTAT, in_dtype=getattr(z[1], "dt", L.F32), B=B, H=h, W=w, Cin=c, aux0=_fbits(eps), aux1=_fbits(0.1), in_=z, w=self.w(bn_name + ".weight"),
                       bias=self.w(bn_name + ".bias"), aux=self.w(bn_name + ".running"), out=ss, in2=self.buf(nchunk * 2 * c * 8))
             return ss
 
@@ -305,7 +318,7 @@ class TrainStep:
             y16 = self.buf(M * c * 2) if want16 else None
             sums = self.buf(B * sums_p * c * 4) if sums_p else None
             rows_p = sums_p if sums_p else max(1, min(2048, (h * w) // 64))
-            self.emit(bn_name, kind=L.OP_BNACT, flags=L.FLAG_RESIDUAL if residual is not None else 0, act=act, in_dtype=L.F32,
+            self.emit(bn_name, kind=L.OP_BNACT, flags=L.FLAG_RESIDUAL if residual is not None else 0, act=act, in_dtype=getattr(z[1], "dt", L.F32),
                       out_dtype=L.F32 if want32 else self.cdt, w_dtype=L.F16 if self.cdt == L.F16 else L.BF16, res_dtype=L.F32, B=B, H=h, W=w, Cin=c,
                       aux0=rows_p, in_=z, scale=ss, shift=("ws", ss[1], c * 4), in2=residual, w2=keep, out=y32 if want32 else y16,
                       out2=y16 if (want32 and want16) else None, aux=sums)
@@ -322,7 +335,7 @@ class TrainStep:
             want32 = want32 or not want16 or out is not None
             d32 = out if out is not None else (self.buf(M * c * 4) if want32 else None)
             d16 = self.buf(M * c * 2) if want16 else None
-            self.emit("bwd:" + bn_name, kind=L.OP_BNBWD, flags=L.FLAG_ACCUM if accum else 0, act=act, w_dtype=self.cdt, B=B, H=h, W=w, Cin=c,
+            self.emit("bwd:" + bn_name, kind=L.OP_BNBWD, flags=L.FLAG_ACCUM if accum else 0, act=act, w_dtype=self.cdt, in_dtype=getattr(z[1], "dt", L.F32), B=B, H=h, W=w, Cin=c,
                       Cin_total=gy_total, cin_off=gy_off, in_=gy, in2=z, scale=ss, w2=keep, bias=ga, bias2=gb, out=d32, out2=d16,
                       w=self.g(bn_name + ".weight"), shift=self.g(bn_name + ".bias"), aux=self.buf(nchunk * 2 * c * 8 + 2 * c * 4))
             return (d32, d16)

@@ -70,7 +70,7 @@ def apply(ops, table: Optional[Dict[str, int]] = None) -> int:
     return n
 
 
-def tune_train_step(ts, B: int, H: int, W: int, reps: int = 5, verbose: bool = False) -> Dict[str, int]:
+def tune_train_step(ts, B: int, H: int, W: int, reps: int = 5, verbose: bool = False, known: Optional[Dict[str, int]] = None) -> Dict[str, int]:
     """The convolutions of the TRAIN plan (forward with raw weights, data gradients): findtextcenternet_amd.train_step.TrainStep `ts`
     after one forward_backward at this shape (buffers filled), plan built with FTC_NO_TUNING=1."""
     import numpy as np
@@ -88,7 +88,7 @@ def tune_train_step(ts, B: int, H: int, W: int, reps: int = 5, verbose: bool = F
         if o.kind != L.OP_CONV:
             continue
         key = signature(o, merge16=True)
-        if key in choices:
+        if key in choices or (known is not None and key in known):      # (--merge: only the signatures the table does not hold yet)
             continue
         best, best_t, base_t = 0, 1e30, None
         one = (L.Op * 1)()
@@ -235,7 +235,7 @@ def main():
                 ts.zero_grad()
                 ts.forward_backward(x, torch.from_numpy(lab).cuda(), torch.from_numpy(idm).cuda())
                 torch.cuda.synchronize()
-                allc.update(tune_train_step(ts, B, a.size, a.size, verbose=True))
+                allc.update(tune_train_step(ts, B, a.size, a.size, verbose=True, known=allc if a.merge else None))
             del ts, model
             torch.cuda.empty_cache()
         with open(a.out, "w") as f:

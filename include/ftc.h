@@ -123,7 +123,8 @@ typedef enum ftc_op_kind {
     /* Backward of BNSTAT + BNACT: incoming gradient g = in[r][cin_off + c] (row stride Cin_total, 0 = Cin) * bias[b][c] + bias2[b][c]
        (both optional: the SE gate and the squeeze-mean gradient of an MBConv block), * w2[b] (optional StochasticDepth keep-scale);
        t = z * scale + shift; dt = g * act'(t); out (+= with FTC_FLAG_ACCUM) = scale * (dt - mean(dt) - zhat * mean(dt * zhat));
-       w (gamma grad) += sum dt * zhat, shift (beta grad) += sum dt.  in2 = z [B*H*W][Cin], scale = the [4][Cin] block of BNSTAT,
+       w (gamma grad) += sum dt * zhat, shift (beta grad) += sum dt.  in2 = z [B*H*W][Cin] (in_dtype: fp32, or stored in the 16-bit
+       compute type w_dtype as the reference's autocast stores convolution outputs), scale = the [4][Cin] block of BNSTAT,
        aux = scratch float64 [chunks][2][Cin] + fp32 [2][Cin] (chunks as BNSTAT) */
     FTC_OP_BNBWD = 14,
     /* Weight gradient of a dense 1x1 / 3x3 convolution on MFMA: out[co][ci][r][s] += sum_p in2[p][cout_off + co] * in[p @ (r,s)][cin_off + ci]

@@ -604,7 +604,7 @@ def main():
             d["ms"] += float(acc[i]); d["flops"] += pl.meta[i].flops; d["bytes"] += pl.meta[i].bytes; d["launches"] += 1
         total_ms = float(acc.sum())
         name, d = max(by.items(), key=lambda kv: kv[1]["ms"])
-        if name.startswith("conv"):
+        if name.startswith("conv") or name.startswith("mbconv"):
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK["fp32" if "<f32" in name else "bf16"], "unit": "TFLOP/s"}
         else:
@@ -634,10 +634,10 @@ def main():
         roof["algorithmic_mbytes_per_launch"] = round(d["bytes"] / d["launches"] / 1e6, 2)
         roof["share_of_forward_time"] = round(d["ms"] / total_ms, 3)
         result["roofline"] = roof
-        conv_ms = sum(v["ms"] for k, v in by.items() if k.startswith("conv"))
-        conv_fl = sum(v["flops"] for k, v in by.items() if k.startswith("conv"))
+        conv_ms = sum(v["ms"] for k, v in by.items() if k.startswith(("conv", "mbconv")))
+        conv_fl = sum(v["flops"] for k, v in by.items() if k.startswith(("conv", "mbconv")))
         result["all_conv_kernels"] = {"ms_per_step": round(conv_ms, 3), "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
-                                      "share_of_forward_time": round(conv_ms / total_ms, 3)}
+                                      "share_of_forward_time": round(conv_ms / total_ms, 3)}        # (incl. the fused MBConv heads)
         result["forward_ms_sum_of_kernels"] = round(total_ms, 3)
         if args.dump_ops:
             ops = [{"i": i, "name": pl.meta[i].name, "kind": pl.meta[i].kind, "ms": float(acc[i]), "gflop": pl.meta[i].flops / 1e9,

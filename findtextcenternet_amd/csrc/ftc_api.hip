@@ -504,7 +504,10 @@ int ftc_op_kernel_label(const ftc_op* op, char* buf, int len) {
         else std::snprintf(buf, len, "dwconv_kernel<%s,s%d>", ftc_dtname(op->in_dtype), op->stride);
         break;
     case FTC_OP_SE: std::snprintf(buf, len, (op->flags & FTC_FLAG_SE_HPART) ? "se_gate" : "se_fc1+se_fc2"); break;
-    case FTC_OP_MBHEAD: std::snprintf(buf, len, "mbconv_slice<%s,128ch>", ftc_dtname(op->in_dtype)); break;
+    case FTC_OP_MBHEAD:     // two instantiations, as the profiler sees them: the whole 24x24 map (FAST) / the general kernel (bands of rows)
+        std::snprintf(buf, len, "mbconv_slice<%s,128ch,%s>", ftc_dtname(op->in_dtype),
+                      op->H == 24 && op->W == 24 && op->aux1 == 0 && !(op->flags & 0x100) ? "24x24" : "bands");
+        break;
     case FTC_OP_UPCAT: std::snprintf(buf, len, "upcat_kernel<%s>", ftc_dtname(op->in_dtype)); break;
     case FTC_OP_NMS: std::snprintf(buf, len, "nms_kernel"); break;
     case FTC_OP_TAPSUM: std::snprintf(buf, len, "tapsum_kernel"); break;

@@ -6,7 +6,7 @@
 Writes profiles/<tag>_bf16_b8_pmc_kernels.json (+ .txt) and profiles/<tag>_bf16_b8_pmc_traffic.json.
 
 Dispatches are mapped to plan ops by sequence: every forward starts with the stem kernel and launches the plan's kernels in
-plan order (an SE op is two launches), so dispatch k after a stem dispatch belongs to a known op; its label is what
+plan order (an SE op is two launches, one after FTC_OP_MBHEAD), so dispatch k after a stem dispatch belongs to a known op; its label is what
 ftc_op_kernel_label reports for the plan the library builds for the same shape (host-only call, no GPU needed).
 
 Counters and corrections (/opt/skills/guides/MI355X_MICROARCH.md):
@@ -78,7 +78,7 @@ def main():
     labels, op_of = [], []
     for i in range(len(pl.ops)):
         lib.ftc_op_kernel_label(C.byref(pl.ops[i]), buf, 128)
-        n = 2 if pl.ops[i].kind == L.OP_SE else 1
+        n = 2 if pl.ops[i].kind == L.OP_SE and not (pl.ops[i].flags & L.FLAG_SE_HPART) else 1      # (SE after FTC_OP_MBHEAD: fc1 is done, one launch)
         labels += [buf.value.decode()] * n
         op_of += [i] * n
     n_k = len(labels)
@@ -95,7 +95,7 @@ def main():
             key = (counter, os.path.basename(path))
             for seq in fw:
                 for k, (_, kname, val) in enumerate(seq):
-                    stem = labels[k].split("<")[0].split("+")[0].replace("se_fc1", "se_fc").replace("conv_igemm_glds", "glds").replace("conv3x3_halo", "halo")
+                    stem = labels[k].split("<")[0].split("+")[0].replace("se_fc1", "se_fc").replace("se_gate", "se_fc2").replace("conv_igemm_glds", "glds").replace("conv3x3_halo", "halo")
                     if stem not in kname:
                         raise SystemExit(f"{path}: dispatch {k} is {kname!r} but the plan expects {labels[k]!r}")
                     agg[labels[k]][key] += val

@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
             CHECK(ftc_workspace_bytes(m, B, H, W) > 0);
             const ftc_plan* plan = NULL;
             ftc_plan_info info;
-            CHECK(ftc_model_plan(m, B, H, W, 0, &plan, &info) == FTC_OK && info.n_ops > 300 && info.map_h == H / 4);
+            CHECK(ftc_model_plan(m, B, H, W, 0, &plan, &info) == FTC_OK && info.n_ops > 250 && info.map_h == H / 4);
             for (int i = 0; i < info.n_ops; ++i) {
                 ftc_op op;
                 ftc_op_info oi;

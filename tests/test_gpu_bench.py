@@ -29,13 +29,23 @@ def test_detector_line_has_the_contract_fields():
     assert abs(j["value"] - 8 * 6 / (j["ms_per_step"] * 6e-3)) < 0.01 * j["value"]
     rf = j["roofline"]
     assert rf["bound"] in ("mfma", "hbm") and rf["unit"] in ("TFLOP/s", "GB/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
-    assert rf["kernel"].startswith("conv3x3_wl1+top") and 0.25 < rf["frac"] < 0.6
+    # the kernel instantiation with the largest share of the forward: the last FPN level (one 2 ms launch) or, if that ever gets faster
+    # than their sum, one of the two fused MBConv-head instantiations (39 launches each)
+    assert rf["kernel"].startswith(("conv3x3_wl1+top", "mbconv_slice")) and rf["bound"] == "mfma" and 0.1 < rf["frac"] < 0.6
+    assert rf["kernel"].startswith("mbconv_slice") or rf["frac"] > 0.25
 
 
 def test_one_lane_and_forced_process_group():
     j = _run("--steps", "4", "--warmup", "2", "--lanes", "1", "--no-cpu-baseline", "--no-fp32", "--no-seam2", "--no-sustained", "--no-profile",
              env={"FTC_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29533"})
     assert j["lanes"] == 1 and "single_stream" not in j and j["value"] > 100 and "RCCL all-gather" in j["config"]["workload"]
+
+
+def test_train_line_with_a_forced_process_group():
+    """BASELINE configs[4]'s N > 1 branches (DDP bucket segments, all-reduce on the communication stream, side-stream joins) on the one
+    GPU there is: a one-rank RCCL group."""
+    j = _run("--train", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", env={"FTC_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29534"})
+    assert j["metric"].startswith("768x768 images/s (train step") and j["finite"] is True and j["value"] > 20 and j["n_gpus"] == 1
 
 
 def test_train_line():

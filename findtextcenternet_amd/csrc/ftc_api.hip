@@ -1,5 +1,6 @@
 // C ABI (include/ftc.h): plan validation / execution and the decode entry point.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -18,8 +19,10 @@ hipError_t launch_adamw_sf(const ftc_mt_chunk* chunks, int n_chunks, float beta2
                            float decay, float ckp1, float y_alpha, float lr, int write_grad, hipStream_t s);
 hipError_t launch_box_hists(const float* loc, int N, const float* page, int PH, int PW, float cut_off, double* out, hipStream_t s);
 hipError_t launch_greedy(const float* loc, const int* order, int N, const double* hist1, const double* th, float cut_off, double* kept,
-                         int* keep_idx, int* n_keep, unsigned int* fill_big, long fill_big_words, const float* seps, const float* codes, int mh,
-                         int mw, int scale, float* out_loc, int* out_idx, int* out_n, hipStream_t s);
+                         int* keep_idx, int* hdr, double* rb, int* status, int* cnt, int* cursor, int* nbr, long edge_cap, unsigned int* fill_big,
+                         long fill_big_words, int force_seq, const float* seps, const float* codes, int mh, int mw, int scale, float* out_loc,
+                         int* out_idx, int* out_n, hipStream_t s);
+hipError_t launch_page_order(const float* loc, int N, const double* hist0, float cut_off, int* order, double* th, hipStream_t s);
 hipError_t launch_paste_maps(const float* heat, const ftc_tile* tiles, int B, int h, int w, int scale, float* canv, int ph, int pw,
                              hipStream_t s);
 
@@ -591,10 +594,45 @@ int ftc_paste_maps(const float* heatmap, const ftc_tile* tiles_dev, int B, int h
     return FTC_OK;
 }
 
+namespace {
+// scratch of ftc_page_merge: header | kept boxes [N][4] f64 + their source rows (sequential fallback, result list) | rank-ordered edge table
+// [N][6] f64 | status, neighbour counts / offsets, fill cursors | neighbour lists | a coverage bit image as large as the page
+struct PageScratch { int64_t hdr, kept, keep_idx, rb, status, cnt, cursor, fill, fill_words, nbr, nbr_cap, total; };
+PageScratch page_scratch_layout(int64_t n, int64_t page_h, int64_t page_w) {
+    PageScratch L{};
+    auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
+    int64_t o = 0;
+    L.hdr = o; o += 256;
+    L.kept = o; o = up(o + n * 32);
+    L.keep_idx = o; o = up(o + n * 4);
+    L.rb = o; o = up(o + n * 48);
+    L.status = o; o = up(o + n * 4);
+    L.cnt = o; o = up(o + (n + 1) * 4);
+    L.cursor = o; o = up(o + (n + 1) * 4);
+    L.fill_words = page_h * page_w / 32 + 64;
+    L.fill = o; o = up(o + L.fill_words * 4);
+    L.nbr = o;                                                   // the neighbour lists take the rest of the block
+    int64_t cap = n * 256;                                       // default: room for 256 earlier overlapping candidates per box on average
+    if (cap < (1 << 20)) cap = 1 << 20;
+    if (cap > (1ll << 28)) cap = 1ll << 28;
+    L.nbr_cap = cap;
+    o = up(o + L.nbr_cap * 4);
+    L.total = o;
+    return L;
+}
+}  // namespace
+
 int64_t ftc_page_merge_scratch_bytes(int n_boxes, int page_h, int page_w) {
     if (n_boxes <= 0 || page_h <= 0 || page_w <= 0) return 0;
-    // kept boxes (4 float64 each) + their source rows + the kept count + a coverage bit image as large as the page
-    return (int64_t)n_boxes * 32 + (int64_t)n_boxes * 4 + 256 + ((int64_t)page_h * page_w / 32 + 64) * 4;
+    return page_scratch_layout(n_boxes, page_h, page_w).total;
+}
+
+int ftc_page_order(const float* locations, int n_boxes, const double* hist0, float cut_off, int32_t* order_out, double* threshold_out, void* stream) {
+    if (!locations || !hist0 || !order_out || !threshold_out) return fail(FTC_ERR_INVALID, "ftc_page_order: null pointer argument");
+    if (n_boxes <= 0 || n_boxes > (1 << 20)) return fail(FTC_ERR_INVALID, "ftc_page_order: bad sizes");
+    hipError_t e = launch_page_order(locations, n_boxes, hist0, cut_off, order_out, threshold_out, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail_hip(e, "ftc_page_order");
+    return FTC_OK;
 }
 
 int ftc_box_hists(const float* locations, int n_boxes, const float* page, int page_h, int page_w, float cut_off, double* hist_out,
@@ -607,23 +645,25 @@ int ftc_box_hists(const float* locations, int n_boxes, const float* page, int pa
 }
 
 int ftc_page_merge(const float* locations, const int32_t* order, int n_boxes, const double* hist1, const double* threshold_dev,
-                   float cut_off, const float* seps, const float* codes, int mh, int mw, int scale, float* out_locations,
+                   float cut_off, const float* seps, const float* codes, int mh, int mw, int scale, int page_h, int page_w, float* out_locations,
                    int32_t* out_index, int32_t* out_count, void* scratch, int64_t scratch_bytes, void* stream) {
     if (!locations || !order || !hist1 || !threshold_dev || !seps || !codes || !out_locations || !out_index || !out_count || !scratch)
         return fail(FTC_ERR_INVALID, "ftc_page_merge: null pointer argument");
-    if (n_boxes <= 0 || mh <= 0 || mw <= 0 || scale <= 0) return fail(FTC_ERR_INVALID, "ftc_page_merge: bad sizes");
-    const int64_t fixed = (int64_t)n_boxes * 32 + (int64_t)n_boxes * 4 + 256;
-    if (scratch_bytes < fixed + 256) return fail(FTC_ERR_INVALID, "ftc_page_merge: scratch smaller than ftc_page_merge_scratch_bytes");
+    if (n_boxes <= 0 || mh <= 0 || mw <= 0 || scale <= 0 || page_h <= 0 || page_w <= 0) return fail(FTC_ERR_INVALID, "ftc_page_merge: bad sizes");
+    if (n_boxes > (1 << 20)) return fail(FTC_ERR_INVALID, "ftc_page_merge: more than 2^20 boxes");
+    // fixed part | coverage image of the page | neighbour lists: whatever the block has behind the image (ftc_page_merge_scratch_bytes leaves
+    // room for 256 per box).  A page whose lists do not fit goes through the sequential kernel on the device: same result, slower.
+    const PageScratch lay = page_scratch_layout(n_boxes, page_h, page_w);
+    if (scratch_bytes < lay.nbr + 4096) return fail(FTC_ERR_INVALID, "ftc_page_merge: scratch smaller than the fixed part of ftc_page_merge_scratch_bytes");
+    const int64_t nbr_cap = (scratch_bytes - lay.nbr) / 4;
     char* sp = static_cast<char*>(scratch);
-    double* kept = reinterpret_cast<double*>(sp);
-    int* keep_idx = reinterpret_cast<int*>(sp + (int64_t)n_boxes * 32);
-    int* n_keep = reinterpret_cast<int*>(sp + (int64_t)n_boxes * 36);
-    const int64_t fill_off = ((int64_t)n_boxes * 36 + 256 + 255) / 256 * 256;
-    unsigned int* fill_big = reinterpret_cast<unsigned int*>(sp + fill_off);
-    const long fill_words = (long)((scratch_bytes - fill_off) / 4);
-    hipError_t e = launch_greedy(locations, order, n_boxes, hist1, threshold_dev, cut_off, kept, keep_idx, n_keep, fill_big,
-                                 fill_words > 0 ? fill_words : 0, seps, codes, mh, mw, scale, out_locations, out_index, out_count,
-                                 static_cast<hipStream_t>(stream));
+    const char* fs_env = std::getenv("FTC_PAGE_MERGE_SEQ");                  // A/B and tests: "1" = the sequential (round-3) kernel
+    const bool force_seq = fs_env && fs_env[0] == '1';
+    hipError_t e = launch_greedy(locations, order, n_boxes, hist1, threshold_dev, cut_off, reinterpret_cast<double*>(sp + lay.kept),
+                                 reinterpret_cast<int*>(sp + lay.keep_idx), reinterpret_cast<int*>(sp + lay.hdr), reinterpret_cast<double*>(sp + lay.rb),
+                                 reinterpret_cast<int*>(sp + lay.status), reinterpret_cast<int*>(sp + lay.cnt), reinterpret_cast<int*>(sp + lay.cursor),
+                                 reinterpret_cast<int*>(sp + lay.nbr), (long)nbr_cap, reinterpret_cast<unsigned int*>(sp + lay.fill), (long)lay.fill_words,
+                                 force_seq ? 1 : 0, seps, codes, mh, mw, scale, out_locations, out_index, out_count, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(e, "ftc_page_merge");
     return FTC_OK;
 }

@@ -44,6 +44,8 @@ struct MbsP {
     int B, H, W, K, C, S;
     int R, nb;              // band mode: output rows per band, bands per image (R = H, nb = 1: the whole image)
     int kblock;             // FTC_FLAG_KBLOCK32: x is [B][K/32][H*W][32]
+    int imajor;             // experiment (flags 0x200): image-major workgroup order instead of image b on XCD b % 8
+    int ldstail;            // experiment (flags 0x400): LDS-only barriers behind the depthwise phase (the output stores drain in the background)
     unsigned img_bytes;
     float inv_hw;
     unsigned long long* tl;  // flags 0x1000: s_memtime of wave 0 at the phase boundaries and K steps, 32 values per workgroup (tools/mbslice_bench.py)
@@ -74,8 +76,10 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
     const int bid = blockIdx.x;
-    const int b = bid % p.B;                               // consecutive workgroup ids = consecutive images: image b on XCD b % 8
-    const int band = FAST ? 0 : (bid / p.B) % p.nb, sl = FAST ? bid / p.B : bid / (p.B * p.nb);
+    const int per_img = p.nb * (p.C / MS_CC);
+    const int b = p.imajor ? bid / per_img : bid % p.B;    // consecutive workgroup ids = consecutive images: image b on XCD b % 8
+    const int rest = p.imajor ? bid % per_img : bid / p.B;
+    const int band = FAST ? 0 : rest % p.nb, sl = FAST ? rest : rest / p.nb;
     const int c0 = sl * MS_CC;
     // Band mode (maps larger than 576 pixels: the 48x48 stages): the workgroup owns the output rows [y0, y1) of its image and holds the
     // expanded rows [ylo, yhi) = one halo row above and below (recomputed by the neighbouring band); H below = the rows it HOLDS.
@@ -274,7 +278,11 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
     if (tl_on) tl[3] = __builtin_amdgcn_s_memtime();
 
     // ---- squeeze: the image's channel sums, complete in this workgroup (the expanded image is dead: its memory holds the scratch) ----
-    __syncthreads();
+    auto tail_sync = [&]() {
+        if (p.ldstail) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); wg_barrier(); }
+        else __syncthreads();
+    };
+    tail_sync();
     float* red = reinterpret_cast<float*>(smem_raw);           // [8 waves][128]
     float* lmean = red + 8 * MS_CC;
     {
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
         for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], 32, 64);
         if (lane < 32) *reinterpret_cast<f32x4*>(red + wave * MS_CC + lane * 4) = v;
     }
-    __syncthreads();
+    tail_sync();
     if (t < MS_CC) {
         float tot = 0.f;
 #pragma unroll
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
         lmean[t] = tot * p.inv_hw;
     }
     if (p.hpart) {
-        __syncthreads();
+        tail_sync();
         // lane (4 channels) x unit products -> LDS [unit][32 + 1], then one thread per unit adds the 32 channel quads in order
         float* fcb = lmean + MS_CC;
         const f32x4 m4 = *reinterpret_cast<const f32x4*>(lmean + cq * 4);
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
             const int su = pl + 16 * i;
             if (su < p.S) fcb[su * 33 + cq] = (pr[0] + pr[1]) + (pr[2] + pr[3]);
         }
-        __syncthreads();
+        tail_sync();
         if (t < p.S) {
             float d = 0.f;
 #pragma unroll
@@ -343,6 +351,7 @@ hipError_t launch_mbhead(const OpArgs& a, hipStream_t s) {
     p.w1 = a.scale; p.hpart = a.scale ? static_cast<float*>(a.out2) : nullptr;
     p.B = o.B; p.H = o.H; p.W = o.W; p.K = o.Cin; p.C = o.Cout; p.S = o.aux0;
     p.kblock = (o.flags & FTC_FLAG_KBLOCK32) ? 1 : 0;
+    p.imajor = (o.flags & 0x200) ? 1 : 0; p.ldstail = (o.flags & 0x400) ? 1 : 0;
     p.R = o.aux1 > 0 ? o.aux1 : o.H; p.nb = ftc_mbhead_bands(o);
     p.img_bytes = (unsigned)((long)o.H * o.W * o.Cin * 2);
     p.inv_hw = 1.0f / (float)(o.H * o.W);

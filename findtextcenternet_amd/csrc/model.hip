@@ -746,7 +746,9 @@ int Builder::build(ModelPlan* out) {
                 // operands by DMA instead of rescaling activations while staging them.  Needs a 64-pixel tile that divides the image.
                 // (fp16x3 plan: the same with pre-split fp32 chunks -- FTC_NO_X3FOLD=1 keeps the gate in the project convolution's staging)
                 const bool x3fold = m_->split16 && cdt_ == FTC_F32 && !env_on("FTC_NO_X3FOLD");
-                const bool foldse = (dual || x3fold) && (ho * wo) % 64 == 0 && blk.exp % 8 == 0;
+                // FTC_EXPERIMENT_NOGATE=1 (timing experiment only, WRONG results): gates-only SE op + an UNGATED project convolution on the shared weights
+                const bool nogate = env_on("FTC_EXPERIMENT_NOGATE");
+                const bool foldse = !nogate && (dual || x3fold) && (ho * wo) % 64 == 0 && blk.exp % 8 == 0;
                 const int fdt = dual ? A : FTC_F32;
                 const R wb = foldse ? buf((int64_t)B * blk.cout * blk.exp, fdt) : R();
                 {
@@ -761,7 +763,7 @@ int Builder::build(ModelPlan* out) {
                     emit({p + ".2", "se", 4.0 * B * blk.exp * blk.squeeze, se_bytes}, s);
                 }
                 ConvOpt pj = tail;
-                pj.se = foldse ? R() : sc;
+                pj.se = foldse || nogate ? R() : sc;
                 pj.wsets = wb;
                 conv(p + ".3", d, A, ho, wo, blk.exp, blk.exp, 0, p + ".3", blk.cout, 1, 1, FTC_ACT_NONE, y, T, pj);
             }

@@ -60,14 +60,11 @@ def page_merge_gpu(boxes: torch.Tensor, feats: torch.Tensor, page: torch.Tensor,
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         hist = torch.empty((2, N), dtype=torch.float64, device=dev)
         L.check(lib.ftc_box_hists(boxes.data_ptr(), N, page.data_ptr(), ph, pw, C.c_float(cut_off), hist.data_ptr(), stream), "ftc_box_hists")
-        p = boxes[:, 0]
-        mask = p >= cut_off                                   # fp32 compare == the reference's float64 compare of fp32 values
-        M = mask.sum()
-        srt = torch.sort(torch.where(mask, hist[0], torch.full_like(hist[0], float("inf")))).values
-        lo = srt[torch.clamp((M - 1) // 2, min=0)]
-        hi = srt[torch.clamp(M // 2, max=N - 1)]
-        th = torch.where(M > 0, (lo + hi) / 2 / 5, torch.full_like(lo, float("nan"))).reshape(1).contiguous()   # np.median(hists) / 5
-        order = torch.sort(p, descending=True, stable=True).indices.to(torch.int32).contiguous()   # == np.argsort(-p, kind="stable")
+        # order = stable argsort of -p, threshold = np.median(hists) / 5 over the rows with p >= cut_off -- in-tree kernels (rank by
+        # counting, radix select), results identical to torch.sort / np.median
+        order = torch.empty((N,), dtype=torch.int32, device=dev)
+        th = torch.empty((1,), dtype=torch.float64, device=dev)
+        L.check(lib.ftc_page_order(boxes.data_ptr(), N, hist[0].data_ptr(), C.c_float(cut_off), order.data_ptr(), th.data_ptr(), stream), "ftc_page_order")
         out_loc = torch.empty((N, 9), dtype=torch.float32, device=dev)
         out_idx = torch.empty((N,), dtype=torch.int32, device=dev)
         out_n = torch.zeros((1,), dtype=torch.int32, device=dev)
@@ -75,7 +72,7 @@ def page_merge_gpu(boxes: torch.Tensor, feats: torch.Tensor, page: torch.Tensor,
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         codes = canv[3:7].contiguous()
         L.check(lib.ftc_page_merge(boxes.data_ptr(), order.data_ptr(), N, hist[1].data_ptr(), th.data_ptr(), C.c_float(cut_off),
-                                   canv[2].data_ptr(), codes.data_ptr(), mh, mw, scale, out_loc.data_ptr(), out_idx.data_ptr(),
+                                   canv[2].data_ptr(), codes.data_ptr(), mh, mw, scale, ph, pw, out_loc.data_ptr(), out_idx.data_ptr(),
                                    out_n.data_ptr(), scratch.data_ptr(), nbytes, stream), "ftc_page_merge")
         n = int(out_n.item())
         if n < 0:

@@ -37,7 +37,7 @@ extern "C" {
    6: ftc_plan_run_streams / FTC_FLAG_SIDE_STREAM / FTC_OP_JOIN (ops with no consumer on the main chain -- the weight gradients -- on a
       second stream)
    7: FTC_OP_MBHEAD (expand 1x1 + depthwise 3x3 + SE squeeze of an MBConv block in one launch), FTC_FLAG_SE_HPART */
-#define FTC_ABI_VERSION 7
+#define FTC_ABI_VERSION 8
 
 typedef enum ftc_status {
     FTC_OK = 0,
@@ -426,17 +426,27 @@ int ftc_paste_maps(const float* heatmap, const ftc_tile* tiles_dev, int B, int h
  *            included or not: a row with p < cut_off is inert);  page [page_h,page_w,3] fp32 0..255;
  * ftc_box_hists   -> hist_out [2][N] float64: row 0 = the contrast of the threshold sample (:563-571), row 1 = of the crop
  *                    tested in the loop (:579-582).  The caller takes threshold = median(row 0 over p >= cut_off) / 5.
+ * ftc_page_order  -> order_out [N] int32 = stable argsort of -p (ties: lower row first) and threshold_out [1] float64 =
+ *                    median(row 0 over p >= cut_off) / 5 (NaN without such rows), both on the device: rank by counting and a radix
+ *                    select, no library sort (round 4)
  * ftc_page_merge  <- order [N] int32 = stable argsort of -p;  hist1 = row 1 above;  threshold_dev = 1 float64 on the device
  *                    (NaN = no sample: nothing is dropped, as NumPy's comparison with NaN);  seps [mh,mw], codes [4][mh,mw]
  *                    fp32 page canvases (ftc_paste_maps rows 2 and 3..6)
  *                 -> out_locations [<=N,9] fp32 (codes updated), out_index [<=N] int32 source rows, out_count [1] int32
- *                    (-1: scratch too small for a box's coverage bitmap), all on the device; kept order = score order. */
+ *                    (-1: scratch too small for a box's coverage bitmap), all on the device; kept order = score order.
+ *                    Round 4: the suppression runs in parallel -- neighbour lists of overlapping candidates, then persistent waves
+ *                    resolve the candidates in rank order, each waiting only for its earlier overlapping neighbours; every comparison
+ *                    is the sequential loop's own float64 expression (bit-identical).  Neighbour lists that outgrow the scratch block
+ *                    route the page through the sequential kernel on the device (FTC_PAGE_MERGE_SEQ=1 forces it).  page_h, page_w
+ *                    (input pixels; ABI 8) size the coverage image inside `scratch`; the lists take the rest of the block. */
 int64_t ftc_page_merge_scratch_bytes(int n_boxes, int page_h, int page_w);
 int ftc_box_hists(const float* locations, int n_boxes, const float* page, int page_h, int page_w, float cut_off, double* hist_out,
                   void* stream);
+int ftc_page_order(const float* locations, int n_boxes, const double* hist0, float cut_off, int32_t* order_out, double* threshold_out,
+                   void* stream);
 int ftc_page_merge(const float* locations, const int32_t* order, int n_boxes, const double* hist1, const double* threshold_dev,
-                   float cut_off, const float* seps, const float* codes, int mh, int mw, int scale, float* out_locations,
-                   int32_t* out_index, int32_t* out_count, void* scratch, int64_t scratch_bytes, void* stream);
+                   float cut_off, const float* seps, const float* codes, int mh, int mw, int scale, int page_h, int page_w,
+                   float* out_locations, int32_t* out_index, int32_t* out_count, void* scratch, int64_t scratch_bytes, void* stream);
 
 /* Validation / training-step adjuncts (forward only) --------------------------------------------
  * The reference's validation step (train1.py:133-139 test_step, eval mode): fmask = model.get_fmask(labelmap) ->

@@ -97,6 +97,98 @@ def test_page_merge_gpu_is_bit_identical_to_the_oracle(seed, n_boxes, ph, pw):
     assert np.array_equal(got_gf, ref_gf)
 
 
+def _merge_case(seed, n_boxes, ph, pw, wmax, spread):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    img = synth.page_uint8(70 + seed, ph, pw).astype(np.float32)
+    mh, mw = ph // 4, pw // 4
+    centres = rng.uniform([0, 0], [pw, ph], size=(max(8, n_boxes // 6), 2))
+    cx = (centres[rng.integers(0, len(centres), n_boxes), 0] + rng.normal(0, spread, n_boxes)).astype(np.float32)
+    cy = (centres[rng.integers(0, len(centres), n_boxes), 1] + rng.normal(0, spread, n_boxes)).astype(np.float32)
+    w = np.exp(rng.uniform(np.log(6), np.log(wmax), n_boxes)).astype(np.float32)
+    h = np.exp(rng.uniform(np.log(6), np.log(wmax), n_boxes)).astype(np.float32)
+    pr = rng.uniform(0.2, 1.0, n_boxes).astype(np.float32)
+    pr[rng.integers(0, n_boxes, n_boxes // 10)] = np.float32(0.75)
+    codes = rng.uniform(0, 1, (n_boxes, 4)).astype(np.float32)
+    loc32 = np.concatenate([np.zeros((1, 9), np.float32), np.stack([pr, cx, cy, w, h, *codes.T], 1)])
+    feats = rng.standard_normal((n_boxes + 1, 100)).astype(np.float32)
+    seps = (rng.uniform(0, 1, (mh, mw)) ** 4).astype(np.float32)
+    code_all = [rng.uniform(0, 1, (mh, mw)).astype(np.float32) for _ in range(4)]
+    return loc32, feats, img, seps, code_all
+
+
+@pytest.mark.parametrize("mode", ["parallel", "sequential", "lists_overflow"])
+def test_page_merge_dense_page_large_boxes_and_the_sequential_fallback(mode, monkeypatch):
+    """Round 4: the parallel selection (neighbour lists + rank-ordered resolution by persistent waves) on a DENSE page -- thousands of
+    mutually overlapping candidates (long dependency chains), boxes of more than 65536 cells (the shared global coverage image behind its
+    lock) -- against the oracle; the same page through the sequential kernel (FTC_PAGE_MERGE_SEQ semantics, forced through the scratch
+    size here: neighbour lists that do not fit flip the device flag) gives the identical list."""
+    loc32, feats, img, seps, code_all = _merge_case(11, 6000, 1228, 1228, 420.0, 60.0)
+    ref_loc, ref_gf = decode_oracle.page_merge(loc32.astype(np.float64), feats.copy(), img, seps, code_all, 0.4)
+    dev = torch.device("cuda")
+    lib = L.load()
+    N = loc32.shape[0]
+    mh, mw = seps.shape
+    boxes = torch.from_numpy(loc32).to(dev)
+    page_d = torch.from_numpy(img).to(dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    hist = torch.empty((2, N), dtype=torch.float64, device=dev)
+    L.check(lib.ftc_box_hists(boxes.data_ptr(), N, page_d.data_ptr(), img.shape[0], img.shape[1], C.c_float(0.4), hist.data_ptr(), st), "hists")
+    order = torch.empty((N,), dtype=torch.int32, device=dev)
+    th = torch.empty((1,), dtype=torch.float64, device=dev)
+    L.check(lib.ftc_page_order(boxes.data_ptr(), N, hist[0].data_ptr(), C.c_float(0.4), order.data_ptr(), th.data_ptr(), st), "order")
+    # the in-tree order / threshold against the library sort / numpy median they replace
+    p = loc32[:, 0]
+    assert np.array_equal(order.cpu().numpy(), np.argsort(-p.astype(np.float64), kind="stable").astype(np.int32))
+    h0 = hist[0].cpu().numpy()
+    assert float(th.item()) == float(np.median(h0[p >= np.float32(0.4)]) / 5)
+    nbytes = int(lib.ftc_page_merge_scratch_bytes(N, img.shape[0], img.shape[1]))
+    if mode == "lists_overflow":                                 # room for a few thousand list entries only: the device falls back
+        nbytes -= (max(256 * N, 1 << 20) - 8192) * 4
+    if mode == "sequential":
+        monkeypatch.setenv("FTC_PAGE_MERGE_SEQ", "1")
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out_loc = torch.empty((N, 9), dtype=torch.float32, device=dev)
+    out_idx = torch.empty((N,), dtype=torch.int32, device=dev)
+    out_n = torch.zeros((1,), dtype=torch.int32, device=dev)
+    canv = torch.zeros((7, mh, mw), dtype=torch.float32, device=dev)
+    canv[2] = torch.from_numpy(seps).to(dev)
+    for k in range(4):
+        canv[3 + k] = torch.from_numpy(code_all[k]).to(dev)
+    codes = canv[3:7].contiguous()
+    L.check(lib.ftc_page_merge(boxes.data_ptr(), order.data_ptr(), N, hist[1].data_ptr(), th.data_ptr(), C.c_float(0.4), canv[2].data_ptr(),
+                               codes.data_ptr(), mh, mw, 4, img.shape[0], img.shape[1], out_loc.data_ptr(), out_idx.data_ptr(), out_n.data_ptr(), scratch.data_ptr(),
+                               nbytes, st), "merge")
+    n = int(out_n.item())
+    assert n == len(ref_loc) and n > 50
+    assert np.array_equal(out_loc[:n].cpu().numpy(), ref_loc.astype(np.float32))
+    assert np.array_equal(torch.from_numpy(feats).to(dev).index_select(0, out_idx[:n].long()).cpu().numpy(), ref_gf)
+    hdr = scratch[:32].view(torch.int32).cpu().numpy()           # n_keep, ticket, use_seq, lock, total_edges
+    assert hdr[2] == (0 if mode == "parallel" else 1) and (mode != "parallel" or hdr[4] > N)
+    assert (loc32[:, 3] * loc32[:, 4] > 65536 * 1.0).any()       # the case does hold boxes beyond a wave's LDS image
+
+
+def test_page_order_ties_padding_rows_and_empty_selection():
+    dev = torch.device("cuda")
+    lib = L.load()
+    rng = np.random.Generator(np.random.PCG64(5))
+    N = 3000
+    loc = np.zeros((N, 9), np.float32)
+    loc[:, 0] = rng.choice(np.array([0.0, 0.1, 0.4, 0.5, 0.75, 0.9], np.float32), N)       # heavy ties, rows below the cut-off, zero padding rows
+    h0 = rng.choice(np.array([0.0, 1.5, 2.0, 80.25, 200.0]), N)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for cut in (0.4, 0.95):                                                                  # 0.95: no row selected -> NaN threshold
+        order = torch.empty((N,), dtype=torch.int32, device=dev)
+        th = torch.empty((1,), dtype=torch.float64, device=dev)
+        loc_d, h0_d = torch.from_numpy(loc).to(dev), torch.from_numpy(h0).to(dev)
+        L.check(lib.ftc_page_order(loc_d.data_ptr(), N, h0_d.data_ptr(), C.c_float(cut), order.data_ptr(), th.data_ptr(), st), "order")
+        assert np.array_equal(order.cpu().numpy(), np.argsort(-loc[:, 0].astype(np.float64), kind="stable").astype(np.int32))
+        sel = loc[:, 0] >= np.float32(cut)
+        if sel.any():
+            assert float(th.item()) == float(np.median(h0[sel]) / 5)
+        else:
+            assert np.isnan(float(th.item()))
+
+
 def test_page_merge_gpu_no_boxes_and_nan_threshold():
     dev = torch.device("cuda")
     img = torch.full((768, 768, 3), 255.0, device=dev)

@@ -15,6 +15,7 @@ from findtextcenternet_amd import _lib as L  # noqa: E402
 
 lib = L.load()
 batches = [int(a) for a in sys.argv[1:]] or [8]
+XFLAGS = int(os.environ.get("MBS_FLAGS", "0"), 0)          # experiment switches of the kernel: 0x200 image-major order, 0x400 LDS-only tail barriers
 for B in batches:
     for (H, W, Cin, Cx, S, N, R) in [(24, 24, 512, 3072, 128, 512, 0), (24, 24, 640, 3840, 160, 640, 0), (48, 48, 256, 1536, 64, 256, 10), (48, 48, 192, 768, 48, 192, 10)]:
         nb = -(-H // R) if R else 1
@@ -38,7 +39,7 @@ for B in batches:
 
         op = (L.Op * 2)()
         o = op[0]
-        o.kind, o.flags, o.act = L.OP_MBHEAD, 0x1000, L.ACT_SILU
+        o.kind, o.flags, o.act = L.OP_MBHEAD, 0x1000 | XFLAGS, L.ACT_SILU
         o.in_dtype = o.out_dtype = o.w_dtype = L.BF16
         o.B, o.H, o.W, o.Ho, o.Wo = B, H, W, H, W
         o.Cin, o.Cout, o.ksize, o.stride, o.aux0, o.aux1 = Cin, Cx, 3, 1, S, R

@@ -879,7 +879,7 @@ hipError_t launch_stemwgrad(const OpArgs& a, hipStream_t s) {
 
 hipError_t launch_fill(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
-    return hipMemsetAsync(a.out, 0, (size_t)o.B * o.H * o.W * o.Cin * 4, s);
+    return hipMemsetAsync(a.out, o.aux0 & 255, (size_t)o.B * o.H * o.W * o.Cin * 4, s);      // aux0 = the byte (0 unless the plan says otherwise)
 }
 
 hipError_t launch_gather_rows_op(const OpArgs& a, hipStream_t s) {

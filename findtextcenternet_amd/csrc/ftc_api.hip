@@ -143,7 +143,15 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
             if (o.aux0 <= 0) return "mbhead: aux0 (squeeze width S) must be positive when the fc1 partial products are requested";
             if (!need(o.scale, true, "scale", (int64_t)o.aux0 * o.Cout * 4) || !need(o.out2, true, "out2", (int64_t)o.B * nb * ns * o.aux0 * 4)) return why->c_str();
         }
-        if (o.flags & 0x1000) { if (!need(o.in2, true, "in2", (int64_t)o.B * nb * ns * 256)) return why->c_str(); }      // phase timeline (tools/mbslice_bench.py)
+        const bool sei = (o.flags & FTC_FLAG_SE_INLINE) != 0;
+        if (sei) {
+            if (!(o.H == 24 && o.W == 24 && o.aux1 == 0) || (o.flags & 0x100)) return "mbhead: FTC_FLAG_SE_INLINE needs the whole-image form (24x24 map, aux1 = 0)";
+            if (o.scale.base == FTC_BASE_NULL || o.aux0 <= 0 || o.aux0 > 160 || o.B > 48 || o.cin_off < o.aux0 * o.Cout || o.cout_off < o.aux0 * o.Cout)
+                return "mbhead: FTC_FLAG_SE_INLINE needs scale (fc1 weight, bias cin_off floats behind), shift (fc2 weight, bias cout_off floats behind), S <= 160, B <= 48";
+            if (!need(o.scale, true, "scale", ((int64_t)o.cin_off + o.aux0) * 4) || !need(o.shift, true, "shift", ((int64_t)o.cout_off + o.Cout) * 4) ||
+                !need(o.in2, true, "in2", 256)) return why->c_str();
+        }
+        if (o.flags & 0x1000) { if (!need(o.in2, true, "in2", (int64_t)o.B * nb * ns * 256 + (sei ? 256 : 0))) return why->c_str(); }      // phase timeline (tools/mbslice_bench.py)
         return nullptr;
     }
     case FTC_OP_SE:

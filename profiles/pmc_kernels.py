@@ -95,7 +95,7 @@ def main():
             key = (counter, os.path.basename(path))
             for seq in fw:
                 for k, (_, kname, val) in enumerate(seq):
-                    stem = labels[k].split("<")[0].split("+")[0].replace("se_fc1", "se_fc").replace("se_gate", "se_fc2").replace("conv_igemm_glds", "glds").replace("conv3x3_halo", "halo")
+                    stem = labels[k].split("<")[0].split("+")[0].replace("se_fc1", "se_fc").replace("se_gate", "se_fc2").replace("memset", "fillBuffer").replace("conv_igemm_glds", "glds").replace("conv3x3_halo", "halo")
                     if stem not in kname:
                         raise SystemExit(f"{path}: dispatch {k} is {kname!r} but the plan expects {labels[k]!r}")
                     agg[labels[k]][key] += val

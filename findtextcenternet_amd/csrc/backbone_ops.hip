@@ -689,6 +689,11 @@ hipError_t launch_se(const OpArgs& a, hipStream_t s) {
         else
             hipLaunchKernelGGL((se_fc2_kernel<true, __bf16>), dim3(cb, o.B, nz), dim3(256), (size_t)(S + 256) * sizeof(float), s, hidden,
                                (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)a.in, (__bf16*)a.out2, o.Cout_total, nullptr, nullptr, 0);
+    } else if (hp && C % 64 == 0 && S <= 160) {
+        // gates only, from FTC_OP_MBHEAD's partial products (round 4: the project convolution applies them to its weight fragments): the
+        // 64-channel kernel with an EMPTY fold -- every load of its prologue in flight at once (the plain kernel below walks S dependent loads)
+        hipLaunchKernelGGL(se_fc2_fold64_kernel<__bf16>, dim3(C / 64, o.B, 1), dim3(256), (size_t)(((S + 3) & ~3) + 256 + 64) * sizeof(float), s, hidden,
+                           (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)nullptr, (__bf16*)nullptr, 0, hpart, a.bias, P);
     } else {
         hipLaunchKernelGGL((se_fc2_kernel<false, __bf16>), dim3((C + 255) / 256, o.B), dim3(256), (size_t)S * sizeof(float), s, hidden,
                            (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const __bf16*)nullptr, (__bf16*)nullptr, 0, hpart, a.bias, P);

@@ -713,7 +713,9 @@ inline int nblocks(long total, int cap = 16384) { const long nb = (total + 255) 
 }  // namespace
 
 hipError_t launch_pack_train(const ftc_pack_entry* entries, int n, long max_elems, hipStream_t s) {
-    hipLaunchKernelGGL(pack_train_kernel, dim3(nblocks(max_elems, 64), n), dim3(256), 0, s, entries);
+    // (round 4: up to 512 workgroups per entry -- with 64 the 20 M-element entries of the merged FPN level ran on a quarter of the GPU and the
+    //  launch took 3.3 ms for 2 GB of traffic; workgroups beyond a small entry's size fall through their loop)
+    hipLaunchKernelGGL(pack_train_kernel, dim3(nblocks(max_elems, 512), n), dim3(256), 0, s, entries);
     return hipGetLastError();
 }
 

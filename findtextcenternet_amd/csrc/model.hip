@@ -800,7 +800,10 @@ int Builder::build(ModelPlan* out) {
                 const bool x3fold = m_->split16 && cdt_ == FTC_F32 && !env_on("FTC_NO_X3FOLD");
                 // FTC_EXPERIMENT_NOGATE=1 (timing experiment only, WRONG results): gates-only SE op + an UNGATED project convolution on the shared weights
                 const bool nogate = env_on("FTC_EXPERIMENT_NOGATE");
-                const bool foldse = !nogate && (dual || x3fold) && (ho * wo) % 64 == 0 && blk.exp % 8 == 0;
+                // FTC_SE_GATEFRAG=1 (round 4): gates-only SE op; the project convolution multiplies its WEIGHT fragments by the image's gates
+                // (conv_igemm_glds_kernel GATE: the same rounded values as the folded copy, no 25 MB copy per block)
+                const bool gatefrag = dual && slice && env_on("FTC_SE_GATEFRAG");
+                const bool foldse = !nogate && !gatefrag && (dual || x3fold) && (ho * wo) % 64 == 0 && blk.exp % 8 == 0;
                 const int fdt = dual ? A : FTC_F32;
                 const R wb = foldse ? buf((int64_t)B * blk.cout * blk.exp, fdt) : R();
                 {

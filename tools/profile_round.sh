@@ -31,6 +31,6 @@ python profiles/summarize_rocpd.py "$OUT/x3_results.db" "profiles/${TAG}_fp16x3_
 cp profiles/${TAG}_* "$ROOT/gpurun_out/summ_$TAG/"
 cp "$OUT/bench_unprofiled.json" "$ROOT/gpurun_out/summ_$TAG/${TAG}_bf16_b8_bench.json"
 cp "$OUT/ops.json" "$ROOT/gpurun_out/summ_$TAG/ops.json"
-tail -2 "$OUT/train.log" > "$ROOT/gpurun_out/summ_$TAG/train_bench_line.txt"
-tail -2 "$OUT/x3.log" > "$ROOT/gpurun_out/summ_$TAG/x3_bench_line.txt"
+grep '^{"metric"' "$OUT/train.log" | tail -1 > "$ROOT/gpurun_out/summ_$TAG/train_bench_line.txt"
+grep '^{"metric"' "$OUT/x3.log" | tail -1 > "$ROOT/gpurun_out/summ_$TAG/x3_bench_line.txt"
 rm -rf "$OUT"

@@ -112,7 +112,9 @@ class PageDetector:
         tiles = np.concatenate([np.asarray(d["input"], dtype=np.float32) for d in ds], axis=0)
         origins = [(d["offsety"], d["offsetx"]) for d in ds]
         x_all = torch.from_numpy(tiles / np.float32(255.)).to(self.device)
-        return self._run(lambda lo, hi: x_all[lo:hi], origins, org_img)
+        org = np.ascontiguousarray(org_img)
+        return self._run(lambda lo, hi: x_all[lo:hi], origins, org.shape[:2],
+                         lambda: torch.from_numpy(org).to(self.device).float() if org.dtype == np.uint8 else torch.from_numpy(np.asarray(org, np.float32)).to(self.device))
 
     def detect_page(self, im_u8: np.ndarray):
         """uint8 RGB page [H,W,3] -> same outputs; pads with white and tiles like call_OCR (:63-76)."""
@@ -120,23 +122,29 @@ class PageDetector:
         h0, w0 = im_u8.shape[:2]
         ph, pw = padded_page_size(h0, w0, self.stepx, self.stepy)
         origins = tile_origins(ph, pw, self.stepx, self.stepy)
+        # One upload of the raw page; the white padding (:63-65) exists only on the GPU: the tile gather reads beyond the page as 255 and the
+        # padded fp32 page the contrast filter looks at is formed there too (round 4: the host-side pad + second upload cost 6 ms per page).
         page_dev = torch.from_numpy(np.ascontiguousarray(im_u8[:, :, :3])).to(self.device)
-        org_img = np.full((ph, pw, 3), 255, np.uint8)               # stays uint8: _run widens it on the GPU (exact), a quarter of the upload
-        org_img[:h0, :w0] = im_u8[:, :, :3]
+        o_all = torch.tensor(origins, dtype=torch.int32, device=self.device).reshape(-1, 2)      # ONE upload: nothing inside the batch loop may wait for the GPU
 
         def gather(lo, hi):
-            o = torch.tensor(origins[lo:hi], dtype=torch.int32, device=self.device)
             out = torch.empty((hi - lo, height, width, 3), dtype=torch.float32, device=self.device)
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            L.check(lib.ftc_tile_gather(page_dev.data_ptr(), h0, w0, o.data_ptr(), hi - lo, height, width, out.data_ptr(),
+            L.check(lib.ftc_tile_gather(page_dev.data_ptr(), h0, w0, o_all[lo:hi].data_ptr(), hi - lo, height, width, out.data_ptr(),
                                         C.c_void_p(stream)), "ftc_tile_gather")
             return out
-        return self._run(gather, origins, org_img)
+
+        def padded_page():
+            full = torch.full((ph, pw, 3), 255.0, dtype=torch.float32, device=self.device)
+            full[:h0, :w0] = page_dev.float()
+            return full
+        return self._run(gather, origins, (ph, pw), padded_page)
 
     # -- shared ------------------------------------------------------------------------------------
-    def _run(self, get_tiles, origins, org_img):
+    def _run(self, get_tiles, origins, page_hw, page_f32):
+        """get_tiles(lo, hi) -> [n,768,768,3] fp32 0..1 on the GPU; page_hw = (padded) page size; page_f32() -> the padded fp32 page on the GPU."""
         lib = L.load()
-        page_h, page_w = org_img.shape[:2]
+        page_h, page_w = page_hw
         mh, mw = page_h // scale, page_w // scale
         canv = torch.zeros((7, mh, mw), dtype=torch.float32, device=self.device)
         parts = []
@@ -158,18 +166,22 @@ class PageDetector:
                 for i in range(n_lanes):
                     if i not in self._lane_ws or self._lane_ws[i].numel() < need:
                         self._lane_ws[i] = torch.empty(need, dtype=torch.uint8, device=self.device)
-                for s_ in streams:
-                    s_.wait_stream(main)
             else:
                 streams = [main]
+            # every tile's geometry record in ONE upload, before any forward is enqueued: a host-to-device copy from pageable memory waits for
+            # the stream it is issued on, and inside the loop that was the forward just enqueued (round 4: 2-4 ms of GPU idle per batch)
+            geoms = [TileGeom(ox, oy, page_w, page_h, tile_keep_rect(ox, oy, page_w, page_h, self.step_ratio)) for (oy, ox) in origins[first:last]]
+            tl_all = tiles_to_device(geoms, self.device, height // scale, width // scale) if geoms else None
+            if n_lanes > 1:
+                for s_ in streams:
+                    s_.wait_stream(main)
             for k, lo in enumerate(range(first, last, self.batch)):
                 hi = min(last, lo + self.batch)
                 lane = k % n_lanes
                 with torch.cuda.stream(streams[lane]):
                     x = get_tiles(lo, hi).permute(0, 3, 1, 2)
                     heat, feat = self.detector.forward_nhwc(x, workspace=self._lane_ws[lane] if n_lanes > 1 else None)
-                    geoms = [TileGeom(ox, oy, page_w, page_h, tile_keep_rect(ox, oy, page_w, page_h, self.step_ratio)) for (oy, ox) in origins[lo:hi]]
-                    tl = tiles_to_device(geoms, self.device, heat.shape[1], heat.shape[2])
+                    tl = tl_all[lo - first:hi - first]
                     stream = torch.cuda.current_stream(self.device).cuda_stream
                     L.check(lib.ftc_paste_maps(heat.data_ptr(), tl.data_ptr(), hi - lo, heat.shape[1], heat.shape[2], scale, canv.data_ptr(),
                                                mh, mw, C.c_void_p(stream)), "ftc_paste_maps")
@@ -197,11 +209,7 @@ class PageDetector:
                 counts = torch.cat([c for c, _, _, _ in parts])
                 boxes = torch.cat([b.reshape(-1, 9) for _, b, _, _ in parts])
                 fts = torch.cat([f.reshape(-1, f.shape[-1]) for _, _, f, _ in parts])
-            if org_img.dtype == np.uint8:
-                page_dev = torch.from_numpy(np.ascontiguousarray(org_img)).to(self.device).float()
-            else:
-                page_dev = torch.from_numpy(np.ascontiguousarray(org_img, dtype=np.float32)).to(self.device)
-            loc_d, glyph_d = page_merge_gpu(boxes, fts, page_dev, canv, self.cut_off)
+            loc_d, glyph_d = page_merge_gpu(boxes, fts, page_f32(), canv, self.cut_off)
             cmax = int(counts.max().item())
             if cmax > self.max_boxes:
                 raise RuntimeError(f"a tile produced {cmax} peaks > max_boxes={self.max_boxes}; raise max_boxes")

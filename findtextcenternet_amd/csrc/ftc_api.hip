@@ -22,7 +22,7 @@ hipError_t launch_greedy(const float* loc, const int* order, int N, const double
                          int* keep_idx, int* hdr, double* rb, int* status, int* cnt, int* cursor, int* nbr, long edge_cap, unsigned int* fill_big,
                          long fill_big_words, int force_seq, const float* seps, const float* codes, int mh, int mw, int scale, float* out_loc,
                          int* out_idx, int* out_n, hipStream_t s);
-hipError_t launch_page_order(const float* loc, int N, const double* hist0, float cut_off, int* order, double* th, hipStream_t s);
+hipError_t launch_page_order(const float* loc, int N, const double* hist0, float cut_off, int* order, double* th, void* scratch, hipStream_t s);
 hipError_t launch_paste_maps(const float* heat, const ftc_tile* tiles, int B, int h, int w, int scale, float* canv, int ph, int pw,
                              hipStream_t s);
 
@@ -635,10 +635,14 @@ int64_t ftc_page_merge_scratch_bytes(int n_boxes, int page_h, int page_w) {
     return page_scratch_layout(n_boxes, page_h, page_w).total;
 }
 
-int ftc_page_order(const float* locations, int n_boxes, const double* hist0, float cut_off, int32_t* order_out, double* threshold_out, void* stream) {
-    if (!locations || !hist0 || !order_out || !threshold_out) return fail(FTC_ERR_INVALID, "ftc_page_order: null pointer argument");
+int64_t ftc_page_order_scratch_bytes(int n_boxes) { return n_boxes > 0 ? 256 + (int64_t)n_boxes * 16 : 0; }
+
+int ftc_page_order(const float* locations, int n_boxes, const double* hist0, float cut_off, int32_t* order_out, double* threshold_out, void* scratch,
+                   int64_t scratch_bytes, void* stream) {
+    if (!locations || !hist0 || !order_out || !threshold_out || !scratch) return fail(FTC_ERR_INVALID, "ftc_page_order: null pointer argument");
     if (n_boxes <= 0 || n_boxes > (1 << 20)) return fail(FTC_ERR_INVALID, "ftc_page_order: bad sizes");
-    hipError_t e = launch_page_order(locations, n_boxes, hist0, cut_off, order_out, threshold_out, static_cast<hipStream_t>(stream));
+    if (scratch_bytes < ftc_page_order_scratch_bytes(n_boxes)) return fail(FTC_ERR_INVALID, "ftc_page_order: scratch smaller than ftc_page_order_scratch_bytes");
+    hipError_t e = launch_page_order(locations, n_boxes, hist0, cut_off, order_out, threshold_out, scratch, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(e, "ftc_page_order");
     return FTC_OK;
 }

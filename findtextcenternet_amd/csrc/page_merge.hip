@@ -511,29 +511,15 @@ __device__ __forceinline__ unsigned long long pm_key(float p, int i) {
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                    // order-preserving map of a float to an unsigned
     return ((unsigned long long)u << 32) | (unsigned int)(~i);
 }
-__global__ __launch_bounds__(256) void pm_rank_kernel(const float* __restrict__ loc, int N, int* __restrict__ order) {
-    __shared__ unsigned long long sk[1024];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const unsigned long long mine = i < N ? pm_key(loc[(long)i * 9], i) : 0ull;
-    int rank = 0;
-    for (int j0 = 0; j0 < N; j0 += 1024) {
-        for (int q = threadIdx.x; q < 1024; q += 256) sk[q] = j0 + q < N ? pm_key(loc[(long)(j0 + q) * 9], j0 + q) : 0ull;
-        __syncthreads();
-        const int jn = min(1024, N - j0);
-        for (int q = 0; q < jn; ++q) rank += sk[q] > mine ? 1 : 0;
-        __syncthreads();
-    }
-    if (i < N) order[rank] = i;
-}
-
-// threshold = median(hist0 over the rows with p >= cut_off) / 5 (NaN without rows): the two middle order statistics by an MSB-first
-// radix select over the float64 bit patterns (contrasts are >= 0: the patterns order like the values)
-__global__ __launch_bounds__(1024) void pm_median_kernel(const float* __restrict__ loc, int N, const double* __restrict__ hist0, float cut_off, double* th_out) {
-    __shared__ unsigned int hist[256];
-    __shared__ unsigned long long s_prefix;
-    __shared__ long long s_k;
-    __shared__ int s_M;
-    const int t = threadIdx.x;
+// Rows with p >= cut_off first (the only ones the selection looks at: it stops at the first score below the cut-off), compacted by one
+// workgroup-wide scan: their 64-bit keys and contrasts become dense arrays, so that the rank and median kernels walk M entries, not the N rows of
+// the record blocks (an A4 page: 56 k of 143 k).  order[M + k] = the k-th row below the cut-off, in row order.
+struct PoHdr { int M, pad[3]; };
+__global__ __launch_bounds__(1024) void pm_select_kernel(const float* __restrict__ loc, int N, const double* __restrict__ hist0, float cut_off,
+                                                         unsigned long long* __restrict__ keys, double* __restrict__ hv, int* __restrict__ order, PoHdr* hdr) {
+    __shared__ int wsum[16];
+    __shared__ int s_base, s_M;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) s_M = 0;
     __syncthreads();
     int m = 0;
@@ -541,6 +527,56 @@ __global__ __launch_bounds__(1024) void pm_median_kernel(const float* __restrict
     atomicAdd(&s_M, m);
     __syncthreads();
     const int M = s_M;
+    if (t == 0) { s_base = 0; hdr->M = M; }
+    __syncthreads();
+    for (int k0 = 0; k0 < N; k0 += 1024) {
+        const int k = k0 + t;
+        const float p = k < N ? loc[(long)k * 9] : 0.f;
+        const int v = (k < N && (double)p >= (double)cut_off) ? 1 : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int q = 0; q < wave; ++q) woff += wsum[q];
+        const int base = s_base;
+        const int pos = base + woff + inc - v;                       // eligible rows before this one
+        if (k < N) {
+            if (v) { keys[pos] = pm_key(p, k); hv[pos] = hist0[k]; }
+            else order[M + (k - pos)] = k;
+        }
+        __syncthreads();
+        if (t == 1023) s_base = base + woff + inc;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void pm_rank_kernel(const unsigned long long* __restrict__ keys, const PoHdr* __restrict__ hdr, int* __restrict__ order) {
+    __shared__ unsigned long long sk[1024];
+    const int M = hdr->M;
+    if ((int)blockIdx.x * 256 >= M) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long mine = i < M ? keys[i] : 0ull;
+    int rank = 0;
+    for (int j0 = 0; j0 < M; j0 += 1024) {
+        for (int q = threadIdx.x; q < 1024; q += 256) sk[q] = j0 + q < M ? keys[j0 + q] : 0ull;
+        __syncthreads();
+        const int jn = min(1024, M - j0);
+        for (int q = 0; q < jn; ++q) rank += sk[q] > mine ? 1 : 0;
+        __syncthreads();
+    }
+    if (i < M) order[rank] = (int)~(unsigned int)(mine & 0xffffffffull);          // the row index sits (complemented) in the key's low word
+}
+
+// threshold = median(contrasts of the rows with p >= cut_off) / 5 (NaN without rows): the two middle order statistics by an MSB-first
+// radix select over the float64 bit patterns (contrasts are >= 0: the patterns order like the values)
+__global__ __launch_bounds__(1024) void pm_median_kernel(const double* __restrict__ hv, const PoHdr* __restrict__ hdr, double* th_out) {
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ long long s_k;
+    const int t = threadIdx.x;
+    const int M = hdr->M;
     if (M == 0) { if (t == 0) *th_out = __longlong_as_double(0x7ff8000000000000ll); return; }
     double v[2];
     for (int which = 0; which < 2; ++which) {
@@ -550,9 +586,8 @@ __global__ __launch_bounds__(1024) void pm_median_kernel(const float* __restrict
             if (t < 256) hist[t] = 0u;
             __syncthreads();
             const unsigned long long prefix = s_prefix;
-            for (int i = t; i < N; i += 1024) {
-                if (!((double)loc[(long)i * 9] >= (double)cut_off)) continue;
-                const unsigned long long key = (unsigned long long)__double_as_longlong(hist0[i]);
+            for (int i = t; i < M; i += 1024) {
+                const unsigned long long key = (unsigned long long)__double_as_longlong(hv[i]);
                 if (shift == 56 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
             }
             __syncthreads();
@@ -665,8 +700,12 @@ hipError_t launch_greedy(const float* loc, const int* order, int N, const double
     return hipGetLastError();
 }
 
-hipError_t launch_page_order(const float* loc, int N, const double* hist0, float cut_off, int* order, double* th, hipStream_t s) {
-    hipLaunchKernelGGL(pm_rank_kernel, dim3((N + 255) / 256), dim3(256), 0, s, loc, N, order);
-    hipLaunchKernelGGL(pm_median_kernel, dim3(1), dim3(1024), 0, s, loc, N, hist0, cut_off, th);
+hipError_t launch_page_order(const float* loc, int N, const double* hist0, float cut_off, int* order, double* th, void* scratch, hipStream_t s) {
+    PoHdr* hdr = static_cast<PoHdr*>(scratch);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(static_cast<char*>(scratch) + 256);
+    double* hv = reinterpret_cast<double*>(keys + N);
+    hipLaunchKernelGGL(pm_select_kernel, dim3(1), dim3(1024), 0, s, loc, N, hist0, cut_off, keys, hv, order, hdr);
+    hipLaunchKernelGGL(pm_rank_kernel, dim3((N + 255) / 256), dim3(256), 0, s, keys, hdr, order);
+    hipLaunchKernelGGL(pm_median_kernel, dim3(1), dim3(1024), 0, s, hv, hdr, th);
     return hipGetLastError();
 }

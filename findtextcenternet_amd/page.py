@@ -60,11 +60,14 @@ def page_merge_gpu(boxes: torch.Tensor, feats: torch.Tensor, page: torch.Tensor,
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         hist = torch.empty((2, N), dtype=torch.float64, device=dev)
         L.check(lib.ftc_box_hists(boxes.data_ptr(), N, page.data_ptr(), ph, pw, C.c_float(cut_off), hist.data_ptr(), stream), "ftc_box_hists")
-        # order = stable argsort of -p, threshold = np.median(hists) / 5 over the rows with p >= cut_off -- in-tree kernels (rank by
+        # order = the rows with p >= cut_off in stable score order (then the rest), threshold = np.median(hists) / 5 over the rows with p >= cut_off -- in-tree kernels (rank by
         # counting, radix select), results identical to torch.sort / np.median
         order = torch.empty((N,), dtype=torch.int32, device=dev)
         th = torch.empty((1,), dtype=torch.float64, device=dev)
-        L.check(lib.ftc_page_order(boxes.data_ptr(), N, hist[0].data_ptr(), C.c_float(cut_off), order.data_ptr(), th.data_ptr(), stream), "ftc_page_order")
+        ob = int(lib.ftc_page_order_scratch_bytes(N))
+        osc = torch.empty(ob, dtype=torch.uint8, device=dev)
+        L.check(lib.ftc_page_order(boxes.data_ptr(), N, hist[0].data_ptr(), C.c_float(cut_off), order.data_ptr(), th.data_ptr(), osc.data_ptr(), ob, stream),
+                "ftc_page_order")
         out_loc = torch.empty((N, 9), dtype=torch.float32, device=dev)
         out_idx = torch.empty((N,), dtype=torch.int32, device=dev)
         out_n = torch.zeros((1,), dtype=torch.int32, device=dev)

@@ -435,7 +435,8 @@ int ftc_paste_maps(const float* heatmap, const ftc_tile* tiles_dev, int B, int h
  *            included or not: a row with p < cut_off is inert);  page [page_h,page_w,3] fp32 0..255;
  * ftc_box_hists   -> hist_out [2][N] float64: row 0 = the contrast of the threshold sample (:563-571), row 1 = of the crop
  *                    tested in the loop (:579-582).  The caller takes threshold = median(row 0 over p >= cut_off) / 5.
- * ftc_page_order  -> order_out [N] int32 = stable argsort of -p (ties: lower row first) and threshold_out [1] float64 =
+ * ftc_page_order  -> order_out [N] int32 = the rows with p >= cut_off in stable score order (= the front of the stable argsort of -p; ties:
+ *                    lower row first), then the rows below the cut-off in row order (the selection never reaches them), and threshold_out [1] float64 =
  *                    median(row 0 over p >= cut_off) / 5 (NaN without such rows), both on the device: rank by counting and a radix
  *                    select, no library sort (round 4)
  * ftc_page_merge  <- order [N] int32 = stable argsort of -p;  hist1 = row 1 above;  threshold_dev = 1 float64 on the device
@@ -451,8 +452,9 @@ int ftc_paste_maps(const float* heatmap, const ftc_tile* tiles_dev, int B, int h
 int64_t ftc_page_merge_scratch_bytes(int n_boxes, int page_h, int page_w);
 int ftc_box_hists(const float* locations, int n_boxes, const float* page, int page_h, int page_w, float cut_off, double* hist_out,
                   void* stream);
+int64_t ftc_page_order_scratch_bytes(int n_boxes);
 int ftc_page_order(const float* locations, int n_boxes, const double* hist0, float cut_off, int32_t* order_out, double* threshold_out,
-                   void* stream);
+                   void* scratch, int64_t scratch_bytes, void* stream);
 int ftc_page_merge(const float* locations, const int32_t* order, int n_boxes, const double* hist1, const double* threshold_dev,
                    float cut_off, const float* seps, const float* codes, int mh, int mw, int scale, int page_h, int page_w,
                    float* out_locations, int32_t* out_index, int32_t* out_count, void* scratch, int64_t scratch_bytes, void* stream);

@@ -97,6 +97,14 @@ def test_page_merge_gpu_is_bit_identical_to_the_oracle(seed, n_boxes, ph, pw):
     assert np.array_equal(got_gf, ref_gf)
 
 
+def _check_order(order, p, cut):
+    """ftc_page_order: the rows with p >= cut in stable score order (the front of np.argsort(-p, kind="stable")), then the others in row order."""
+    want = np.argsort(-p.astype(np.float64), kind="stable").astype(np.int32)
+    M = int((p >= np.float32(cut)).sum())
+    assert np.array_equal(order[:M], want[:M])
+    assert np.array_equal(order[M:], np.nonzero(~(p >= np.float32(cut)))[0].astype(np.int32))
+
+
 def _merge_case(seed, n_boxes, ph, pw, wmax, spread):
     rng = np.random.Generator(np.random.PCG64(seed))
     img = synth.page_uint8(70 + seed, ph, pw).astype(np.float32)
@@ -135,10 +143,12 @@ def test_page_merge_dense_page_large_boxes_and_the_sequential_fallback(mode, mon
     L.check(lib.ftc_box_hists(boxes.data_ptr(), N, page_d.data_ptr(), img.shape[0], img.shape[1], C.c_float(0.4), hist.data_ptr(), st), "hists")
     order = torch.empty((N,), dtype=torch.int32, device=dev)
     th = torch.empty((1,), dtype=torch.float64, device=dev)
-    L.check(lib.ftc_page_order(boxes.data_ptr(), N, hist[0].data_ptr(), C.c_float(0.4), order.data_ptr(), th.data_ptr(), st), "order")
+    ob = int(lib.ftc_page_order_scratch_bytes(N))
+    osc = torch.empty(ob, dtype=torch.uint8, device=dev)
+    L.check(lib.ftc_page_order(boxes.data_ptr(), N, hist[0].data_ptr(), C.c_float(0.4), order.data_ptr(), th.data_ptr(), osc.data_ptr(), ob, st), "order")
     # the in-tree order / threshold against the library sort / numpy median they replace
     p = loc32[:, 0]
-    assert np.array_equal(order.cpu().numpy(), np.argsort(-p.astype(np.float64), kind="stable").astype(np.int32))
+    _check_order(order.cpu().numpy(), p, 0.4)
     h0 = hist[0].cpu().numpy()
     assert float(th.item()) == float(np.median(h0[p >= np.float32(0.4)]) / 5)
     nbytes = int(lib.ftc_page_merge_scratch_bytes(N, img.shape[0], img.shape[1]))
@@ -180,8 +190,10 @@ def test_page_order_ties_padding_rows_and_empty_selection():
         order = torch.empty((N,), dtype=torch.int32, device=dev)
         th = torch.empty((1,), dtype=torch.float64, device=dev)
         loc_d, h0_d = torch.from_numpy(loc).to(dev), torch.from_numpy(h0).to(dev)
-        L.check(lib.ftc_page_order(loc_d.data_ptr(), N, h0_d.data_ptr(), C.c_float(cut), order.data_ptr(), th.data_ptr(), st), "order")
-        assert np.array_equal(order.cpu().numpy(), np.argsort(-loc[:, 0].astype(np.float64), kind="stable").astype(np.int32))
+        ob = int(lib.ftc_page_order_scratch_bytes(N))
+        osc = torch.empty(ob, dtype=torch.uint8, device=dev)
+        L.check(lib.ftc_page_order(loc_d.data_ptr(), N, h0_d.data_ptr(), C.c_float(cut), order.data_ptr(), th.data_ptr(), osc.data_ptr(), ob, st), "order")
+        _check_order(order.cpu().numpy(), loc[:, 0], cut)
         sel = loc[:, 0] >= np.float32(cut)
         if sel.any():
             assert float(th.item()) == float(np.median(h0[sel]) / 5)

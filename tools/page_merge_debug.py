@@ -30,9 +30,12 @@ hist = torch.empty((2, N), dtype=torch.float64, device=dev)
 L.check(lib.ftc_box_hists(boxes.data_ptr(), N, page_d.data_ptr(), img.shape[0], img.shape[1], C.c_float(0.4), hist.data_ptr(), st), "hists")
 order = torch.empty((N,), dtype=torch.int32, device=dev)
 th = torch.empty((1,), dtype=torch.float64, device=dev)
-L.check(lib.ftc_page_order(boxes.data_ptr(), N, hist[0].data_ptr(), C.c_float(0.4), order.data_ptr(), th.data_ptr(), st), "order")
+ob = int(lib.ftc_page_order_scratch_bytes(N))
+osc = torch.empty(ob, dtype=torch.uint8, device=dev)
+L.check(lib.ftc_page_order(boxes.data_ptr(), N, hist[0].data_ptr(), C.c_float(0.4), order.data_ptr(), th.data_ptr(), osc.data_ptr(), ob, st), "order")
 torch.cuda.synchronize()
-print("order ok:", np.array_equal(order.cpu().numpy(), np.argsort(-loc32[:, 0].astype(np.float64), kind="stable").astype(np.int32)), "th", float(th.item()), flush=True)
+M = int((loc32[:, 0] >= np.float32(0.4)).sum())
+print("order ok:", np.array_equal(order.cpu().numpy()[:M], np.argsort(-loc32[:, 0].astype(np.float64), kind="stable").astype(np.int32)[:M]), "th", float(th.item()), flush=True)
 nbytes = int(lib.ftc_page_merge_scratch_bytes(N, img.shape[0], img.shape[1]))
 scratch = torch.full((nbytes,), 0xCD, dtype=torch.uint8, device=dev)           # garbage: nothing may rely on a zeroed block
 out_loc = torch.empty((N, 9), dtype=torch.float32, device=dev)

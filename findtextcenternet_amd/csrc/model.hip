@@ -756,7 +756,7 @@ int Builder::build(ModelPlan* out) {
                 const int th = blk.stride == 1 ? 8 : 4;
                 const int P = slice ? nbands * (blk.exp / FTC_MBHEAD_SLICE) : ((ho + th - 1) / th) * ((wo + 7) / 8);
                 const R d = buf((int64_t)B * ho * wo * blk.exp, A);
-                const R part = buf((int64_t)B * P * (slice ? blk.squeeze : blk.exp), FTC_F32);
+                const R part = se_in ? R() : buf((int64_t)B * P * (slice ? blk.squeeze : blk.exp), FTC_F32);      // (SE inline: the exchange slots live in hpbuf)
                 if (slice) {
                     const R sums = buf((int64_t)B * nbands * blk.exp, FTC_F32);
                     SymOp s;

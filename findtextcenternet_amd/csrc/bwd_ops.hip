@@ -777,10 +777,16 @@ hipError_t launch_dwbwd(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
     const long M = (long)o.B * o.Ho * o.Wo;
     const int nchunk = ftc_chunks256(M), C = o.Cin;
-    hipLaunchKernelGGL(dwbwd_data_kernel, dim3(nblocks((long)o.B * o.H * o.W * (C / 4))), dim3(256), 0, s, (const float*)a.in2, (const float*)a.w, (float*)a.out,
-                       o.B, o.H, o.W, o.Ho, o.Wo, C, o.stride);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    // `out` (data gradient) and `out2` + `aux` (weight gradient) are each optional (round 4): the train plan emits the weight half as its own op on
+    // the side stream -- nothing on the backward chain reads a depthwise weight gradient (7.4 ms of the step's main stream)
+    hipError_t e = hipSuccess;
+    if (a.out) {
+        hipLaunchKernelGGL(dwbwd_data_kernel, dim3(nblocks((long)o.B * o.H * o.W * (C / 4))), dim3(256), 0, s, (const float*)a.in2, (const float*)a.w, (float*)a.out,
+                           o.B, o.H, o.W, o.Ho, o.Wo, C, o.stride);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (!a.out2) return hipSuccess;
     double* part = reinterpret_cast<double*>(a.aux);
     const int Q = pick_quads(C) > 16 ? 16 : pick_quads(C);        // 9 x 4 accumulators per lane: keep the LDS image at 36 KB
 #define DWW(QQ) hipLaunchKernelGGL(dwbwd_weight_partial_kernel<QQ>, dim3(C / (4 * QQ), nchunk), dim3(256), 0, s, (const float*)a.in, (const float*)a.in2, part, \

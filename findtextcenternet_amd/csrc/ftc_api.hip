@@ -277,9 +277,12 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
     case FTC_OP_DWBWD:
         if (o.Cin <= 0 || (o.Cin & 3) || (o.stride != 1 && o.stride != 2)) return "dwbwd: Cin % 4 == 0, stride 1 | 2";
         if (o.Ho != (o.H - 1) / o.stride + 1 || o.Wo != (o.W - 1) / o.stride + 1) return "dwbwd: Ho/Wo inconsistent";
-        if (!need(o.in, true, "in", pin * o.Cin * 4) || !need(o.in2, true, "in2", pout * o.Cin * 4) || !need(o.w, true, "w", (int64_t)9 * o.Cin * 4) ||
-            !need(o.out, true, "out", pin * o.Cin * 4) || !need(o.out2, true, "out2", (int64_t)9 * o.Cin * 4) ||
-            !need(o.aux, true, "aux", (int64_t)ftc_chunks256(pout) * 9 * o.Cin * 8)) return why->c_str();
+        // data gradient (out; needs w) and weight gradient (out2 + aux; needs in) are each optional, at least one is there
+        if (o.out.base == FTC_BASE_NULL && o.out2.base == FTC_BASE_NULL) return "dwbwd: neither out (data gradient) nor out2 (weight gradient)";
+        if (!need(o.in2, true, "in2", pout * o.Cin * 4)) return why->c_str();
+        if (o.out.base != FTC_BASE_NULL && (!need(o.out, true, "out", pin * o.Cin * 4) || !need(o.w, true, "w", (int64_t)9 * o.Cin * 4))) return why->c_str();
+        if (o.out2.base != FTC_BASE_NULL && (!need(o.in, true, "in", pin * o.Cin * 4) || !need(o.out2, true, "out2", (int64_t)9 * o.Cin * 4) ||
+                                             !need(o.aux, true, "aux", (int64_t)ftc_chunks256(pout) * 9 * o.Cin * 8))) return why->c_str();
         return nullptr;
     case FTC_OP_SEBWD:
         if (o.Cin <= 0 || (o.Cin & 3) || o.aux0 <= 0 || o.aux1 <= 0) return "sebwd: C (% 4 == 0), S, P must be positive";

@@ -265,6 +265,12 @@ class TrainStep:
                         v[1].last = max(v[1].last, j)
             self.side_pending = []
 
+        def side_op(self) -> None:
+            """The op emitted next goes to the side stream: registered for the next join (emitted first when the oldest pending op is far behind)."""
+            if self.side_pending and len(self.ops) - self.side_pending[0] >= int(os.environ.get("FTC_TRAIN_JOIN_EVERY", "32")):      # bounds how long operands outlive their last main-stream use
+                self.join()
+            self.side_pending.append(len(self.ops))
+
         def pin(self, ref) -> None:
             ref[1].first, ref[1].last = 0, 1 << 29
 
@@ -355,9 +361,7 @@ class TrainStep:
             xin, xdt = self.pick(x)
             din, ddt = self.pick(dz)
             if self.side:
-                if self.side_pending and len(self.ops) - self.side_pending[0] >= int(os.environ.get("FTC_TRAIN_JOIN_EVERY", "32")):      # bounds how long operands outlive their last main-stream use
-                    self.join()
-                self.side_pending.append(len(self.ops))
+                self.side_op()
             self.emit("wgrad:" + wname, kind=L.OP_WGRAD, flags=(L.FLAG_SE_SCALE if se is not None else 0) | (L.FLAG_SIDE_STREAM if self.side else 0), w_dtype=self.cdt, in_dtype=xdt, res_dtype=ddt, B=B, H=h,
                       W=w, Ho=ho, Wo=wo, Cin=cin, Cin_total=cin_total, cin_off=cin_off, Cout=cout, Cout_total=cout_total, cout_off=cout_off, ksize=k,
                       stride=stride, aux0=S, in_=xin, in2=din, scale=se, out=self.g(wname), aux=self.buf(S * k * k * cout * cin * 4))
@@ -636,8 +640,16 @@ class TrainStep:
                        out2=g.g(b + ".2.fc1.weight"))
                 gzd = g.bn_bwd(gys, rec["zd"], rec["ss1"], ho, wo, e, b + ".1.1", L.ACT_SILU, ga=rec["sc"], gb=("ws", scr[1], 3 * B * e * 4), want32=True, want16=False)
                 gy0 = g.buf(B * h_ * w_ * e * 4)
-                g.emit("dwbwd:" + b, kind=L.OP_DWBWD, B=B, H=h_, W=w_, Ho=ho, Wo=wo, Cin=e, stride=stride, in_=rec["y0"][0], in2=gzd[0], w=g.w(b + ".1.0.weight#dw"),
-                       out=gy0, out2=g.g(b + ".1.0.weight"), aux=g.buf(max(1, min(512, -(-(B * ho * wo) // 256))) * 9 * e * 8))
+                dw_aux = g.buf(max(1, min(512, -(-(B * ho * wo) // 256))) * 9 * e * 8)
+                if g.side:
+                    # the weight half on the side stream, like the dense weight gradients (nothing on the chain reads it); the data half stays
+                    g.emit("dwbwd:" + b, kind=L.OP_DWBWD, B=B, H=h_, W=w_, Ho=ho, Wo=wo, Cin=e, stride=stride, in2=gzd[0], w=g.w(b + ".1.0.weight#dw"), out=gy0)
+                    g.side_op()
+                    g.emit("dwwgrad:" + b, kind=L.OP_DWBWD, flags=L.FLAG_SIDE_STREAM, B=B, H=h_, W=w_, Ho=ho, Wo=wo, Cin=e, stride=stride, in_=rec["y0"][0], in2=gzd[0],
+                           out2=g.g(b + ".1.0.weight"), aux=dw_aux)
+                else:
+                    g.emit("dwbwd:" + b, kind=L.OP_DWBWD, B=B, H=h_, W=w_, Ho=ho, Wo=wo, Cin=e, stride=stride, in_=rec["y0"][0], in2=gzd[0], w=g.w(b + ".1.0.weight#dw"),
+                           out=gy0, out2=g.g(b + ".1.0.weight"), aux=dw_aux)
                 gz0 = g.bn_bwd(gy0, rec["z0"], rec["ss0"], h_, w_, e, b + ".0.1", L.ACT_SILU)
                 g.wgrad(rec["xin"], gz0, h_, w_, c_, e, 1, 1, b + ".0.0.weight")
                 gx = g.dgrad(gz0, h_, w_, e, b + ".0.0.weight", c_, 1, 1, h_, w_, add=skip)

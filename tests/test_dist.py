@@ -159,7 +159,9 @@ def test_train_plan_side_stream_ops_keep_their_buffers_until_the_join():
     ops, n = plan["ops"], plan["n_ops"]
     side = [i for i in range(n) if ops[i].flags & L.FLAG_SIDE_STREAM]
     joins = [i for i in range(n) if ops[i].kind == L.OP_JOIN]
-    assert len(side) > 200 and all(ops[i].kind == L.OP_WGRAD for i in side) and min(side) > plan["n_fwd"] and joins[-1] == n - 1
+    # (round 4: also the weight half of the depthwise backward -- an FTC_OP_DWBWD without a data-gradient output)
+    assert len(side) > 200 and all(ops[i].kind == L.OP_WGRAD or (ops[i].kind == L.OP_DWBWD and ops[i].out.base == L.BASE_NULL) for i in side)
+    assert sum(ops[i].kind == L.OP_DWBWD for i in side) == 80 and min(side) > plan["n_fwd"] and joins[-1] == n - 1
     next_join = {i: next(j for j in joins if j > i) for i in side}
     assert max(next_join[i] - i for i in side) <= 40
 
@@ -179,7 +181,7 @@ def test_train_plan_side_stream_ops_keep_their_buffers_until_the_join():
     # without the second stream the same plan has no joins and no flags
     ts1 = TrainStep(TextDetectorModel(pre_weights=False, precision="bf16").train(), two_streams=False)
     p1 = ts1.plan_for(2, 128, 128)
-    assert p1["n_ops"] == n - len(joins) and not any(p1["ops"][i].flags & L.FLAG_SIDE_STREAM for i in range(p1["n_ops"]))
+    assert p1["n_ops"] == n - len(joins) - 80 and not any(p1["ops"][i].flags & L.FLAG_SIDE_STREAM for i in range(p1["n_ops"]))
     assert p1["workspace_bytes"] <= plan["workspace_bytes"]
 
 

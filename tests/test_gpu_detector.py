@@ -382,6 +382,57 @@ def test_opt_in_mbconv_plans_agree_with_the_shipped_plan(sd, golden_dir, monkeyp
     assert d_h < lin_gate and d_f < lin_gate and jmin >= 0.85 and jac >= BF16_JACCARD_GATE - 0.01
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16x3"])
+def test_forward_stays_inside_its_buffers(sd, prec):
+    """Device-side bounds check of the whole forward (the ASan build of the shim only sees host code): workspace, both
+    outputs and the input sit between 1 MiB guard bands of a known pattern inside ONE allocation; after forwards at several shapes -- the
+    benchmarked batch 8, an odd batch whose plan takes other kernels (no FTC_OP_MBHEAD below 128 workgroups), a non-square tile -- every
+    guard byte is unchanged, and a forward into a NaN-poisoned workspace gives the same result as into a zeroed one (nothing reads what
+    the plan did not write first)."""
+    m = TextDetectorModel(pre_weights=False, precision=prec)
+    m.load_state_dict(sd)
+    det = CenterNetDetector(m.detector).to("cuda").eval()
+    eng = m.detector._engine
+    G = 1 << 20
+    for (B, H, W) in [(8, 768, 768), (3, 768, 768), (2, 512, 640)]:
+        x_h = torch.from_numpy(synth.page_images(77 + B, B, H, W))
+        with torch.no_grad():
+            det.forward_nhwc(x_h[:1].permute(0, 3, 1, 2).to("cuda"))                      # (builds the model on the device)
+        ws_n = eng.model.workspace_bytes(B, H, W)
+        h, w = H // 4, W // 4
+        sizes = [B * H * W * 3 * 4, ws_n, B * h * w * 10 * 4, B * h * w * 100 * 4]
+        offs, cur = [], G
+        for n in sizes:
+            offs.append(cur)
+            cur += (n + 255) // 256 * 256 + G
+        big = torch.full((cur,), 0xA5, dtype=torch.uint8, device="cuda")
+        x = big[offs[0]:offs[0] + sizes[0]].view(torch.float32).reshape(B, H, W, 3)
+        x.copy_(x_h.to("cuda"))
+        ws = big[offs[1]:offs[1] + sizes[1]]
+        heat = big[offs[2]:offs[2] + sizes[2]].view(torch.float32).reshape(B, h, w, 10)
+        feat = big[offs[3]:offs[3] + sizes[3]].view(torch.float32).reshape(B, h, w, 100)
+        results = []
+        for fill in (0x00, 0xFF):                                                           # 0xFF = NaN patterns in every fp32 / 16-bit slot
+            ws.fill_(fill)
+            heat.fill_(float("nan")); feat.fill_(float("nan"))
+            with torch.no_grad():
+                det.forward_nhwc(x.permute(0, 3, 1, 2), out=(heat, feat), workspace=ws)
+            torch.cuda.synchronize()
+            results.append((heat.clone(), feat.clone()))
+        assert torch.equal(results[0][1], results[1][1]) and bool(torch.isfinite(results[1][1]).all())
+        assert torch.equal(torch.nan_to_num(results[0][0], nan=7.0, neginf=-7.0), torch.nan_to_num(results[1][0], nan=7.0, neginf=-7.0))
+        bands, lo = [], 0
+        for o, n in zip(offs, sizes):
+            bands.append((lo, o))
+            lo = o + n
+        bands.append((lo, cur))
+        for a_, b_ in bands:
+            assert bool((big[a_:b_] == 0xA5).all()), f"a kernel wrote outside its buffers at B={B} {H}x{W} ({prec}): band [{a_}, {b_})"
+        _log(f"{prec} B={B} {H}x{W}: {sum(b_ - a_ for a_, b_ in bands)} guard bytes around input / workspace / outputs intact; NaN-poisoned workspace gives the same maps")
+        del big, x, ws, heat, feat, results
+        torch.cuda.empty_cache()
+
+
 def test_parameter_edits_are_noticed(sd):
     """The packed weight blob must follow the module: in-place edits on the parameter (p.add_(), optimizer.step() incl. this repo's
     raw-pointer AdamWScheduleFree), re-allocations, load_state_dict (also assign=True) all change the next forward; a deep copy gets

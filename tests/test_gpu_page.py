@@ -177,6 +177,43 @@ def test_page_merge_dense_page_large_boxes_and_the_sequential_fallback(mode, mon
     assert (loc32[:, 3] * loc32[:, 4] > 65536 * 1.0).any()       # the case does hold boxes beyond a wave's LDS image
 
 
+def test_page_merge_adversarial_chains_duplicates_and_degenerate_boxes():
+    """Worst cases of the parallel selection against the oracle: (a) a STAIRCASE of 2500 boxes in score order, each overlapping only its predecessor
+    with IoU just under 0.5 -- every box is kept and every decision waits for the previous one (one dependency chain through the whole page);
+    (b) 1500 exact duplicates of one box (all but the first dropped by their first kept neighbour, equal scores: the stable order decides which
+    is first); (c) boxes of zero width / height and boxes hanging far over the page border.  Same list, bit for bit."""
+    rng = np.random.Generator(np.random.PCG64(3))
+    ph, pw = 1228, 4096
+    img = synth.page_uint8(91, ph, pw).astype(np.float32)
+    mh, mw = ph // 4, pw // 4
+    n1, n2 = 2500, 1500
+    # (a) staircase along x: 30 x 30 boxes shifted by 11 pixels: inter / union = 19*30 / (2*900 - 570) = 0.46, inter / a0 = 0.63; coverage 63 % by ONE kept box
+    #     would drop it -- so alternate the rows: neighbours in the chain overlap by 19 x 14 (IoU 0.17, coverage 30 %)
+    cx1 = 40 + 11.0 * np.arange(n1) % (pw - 80)
+    cy1 = 100 + 16.0 * (np.arange(n1) % 2) + 60.0 * (11 * np.arange(n1) // (pw - 80))
+    b1 = np.stack([np.linspace(0.99, 0.5, n1), cx1, cy1, np.full(n1, 30.0), np.full(n1, 30.0)], 1)
+    b2 = np.tile(np.array([[0.75, 700.0, 900.0, 41.0, 37.0]]), (n2, 1))
+    b3 = np.array([[0.9, 300.0, 1000.0, 0.0, 20.0], [0.9, 320.0, 1000.0, 20.0, 0.0], [0.8, -5.0, 1100.0, 60.0, 60.0], [0.8, pw + 3.0, 1100.0, 90.0, 30.0],
+                   [0.85, 2000.0, ph + 10.0, 50.0, 80.0], [0.3, 100.0, 100.0, 30.0, 30.0]])
+    rows = np.concatenate([b3, b2, b1]).astype(np.float32)
+    rows = rows[rng.permutation(len(rows))]                              # row order is not score order
+    codes = rng.uniform(0, 1, (len(rows), 4)).astype(np.float32)
+    loc32 = np.concatenate([np.zeros((1, 9), np.float32), np.concatenate([rows, codes], 1)])
+    feats = rng.standard_normal((len(loc32), 100)).astype(np.float32)
+    seps = np.zeros((mh, mw), np.float32)
+    code_all = [rng.uniform(0, 1, (mh, mw)).astype(np.float32) for _ in range(4)]
+    ref_loc, ref_gf = decode_oracle.page_merge(loc32.astype(np.float64), feats.copy(), img, seps, code_all, 0.4)
+    dev = torch.device("cuda")
+    canv = torch.zeros((7, mh, mw), dtype=torch.float32, device=dev)
+    for k in range(4):
+        canv[3 + k] = torch.from_numpy(code_all[k]).to(dev)
+    got_loc, got_gf = page.page_merge_gpu(torch.from_numpy(loc32).to(dev), torch.from_numpy(feats).to(dev), torch.from_numpy(img).to(dev), canv, 0.4)
+    with open("gpurun_out/test_detector.log", "a") as f:
+        f.write(f"page_merge adversarial: {len(loc32)} rows -> kept gpu {len(got_loc)} oracle {len(ref_loc)}\n")
+    assert len(ref_loc) > 500
+    assert np.array_equal(got_loc.cpu().numpy(), ref_loc.astype(np.float32)) and np.array_equal(got_gf.cpu().numpy(), ref_gf)
+
+
 def test_page_order_ties_padding_rows_and_empty_selection():
     dev = torch.device("cuda")
     lib = L.load()

@@ -235,12 +235,13 @@ def emit_last_line(result) -> None:
     print(json.dumps(result), flush=True)
 
 
-def train_bench(args, rank, local_rank, world):
+def train_bench(args, rank, local_rank, world, emit=True):
+    """emit=False: the short `train_step` record of the default (inference) line -- one rank, no process group, returns the dict."""
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     # FTC_BENCH_FORCE_DIST=1: take the N > 1 code path (process group, box gather under the lane streams, barriers) with one rank --
     # the only way to exercise it on a 1-GPU box
-    dist_on = world > 1 or os.environ.get("FTC_BENCH_FORCE_DIST") == "1"
+    dist_on = emit and (world > 1 or os.environ.get("FTC_BENCH_FORCE_DIST") == "1")
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -351,6 +352,10 @@ def train_bench(args, rank, local_rank, world):
         result["kernel_time_by_label_ms"] = {k: round(v["ms"], 2) for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])[:12]}
         result["forward_ms_sum_of_kernels"] = round(float(acc[:plan["n_fwd"]].sum()), 2)
         result["backward_ms_sum_of_kernels"] = round(float(acc[plan["n_fwd"]:].sum()), 2)
+    if not emit:
+        del ts, opt, model
+        torch.cuda.empty_cache()
+        return result
     if world == 1 and not args.no_cpu_baseline:
         # the CPU oracle of the same step (torch autograd, fp32) on a bounded sample: batch 1, 384x384 (a quarter of a tile), once
         from oracle import train_oracle
@@ -387,6 +392,7 @@ def main():
     ap.add_argument("--no-seam2", action="store_true", help="skip the batch-1 host-in / host-out call_detector latency record")
     ap.add_argument("--no-sustained", action="store_true", help="skip the >= 300-step / >= 4 s sustained-rate record")
     ap.add_argument("--train", action="store_true", help="BASELINE configs[4]: the train step (fwd + loss + bwd + optimizer, DDP all-reduce when N > 1)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config3_b32 (batch 32 + decode + gather) and train_step (5 steps) records of the default line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -581,14 +587,16 @@ def main():
         result["path_frac_of_mfma_peak"] = round(value / world * GFLOP_PER_IMAGE / 1000 / PEAK[args.precision], 4)
 
     # ---- per-kernel attribution with HIP events on the launch stream (rank 0) -------------------
-    if rank == 0 and not args.no_profile:
+    def kernel_profile(model_, x_, heat_, feat_, precision, reps, dump=""):
+        """Per-op HIP-event times of one forward of `model_`'s plan (ftc_plan_profile), grouped by kernel-instantiation label.  Returns the
+        roofline record of the label with the largest share and the summary fields."""
         lib = L.load()
-        eng = model.detector._engine
-        pl = eng.plan(B, 768, 768, False)
-        bases = (C.c_void_p * L.NUM_BASES)(None, eng.workspace.data_ptr(), eng.wdev.data_ptr(), x.data_ptr(), heat.data_ptr(), feat.data_ptr())
+        eng = model_.detector._engine
+        Bp = x_.shape[0]
+        pl = eng.plan(Bp, 768, 768, False)
+        bases = (C.c_void_p * L.NUM_BASES)(None, eng.workspace.data_ptr(), eng.wdev.data_ptr(), x_.data_ptr(), heat_.data_ptr(), feat_.data_ptr())
         n_ops = len(pl.ops)
         ms = (C.c_float * n_ops)()
-        reps = max(3, min(args.steps, 10))
         acc = np.zeros((reps, n_ops))
         stream = torch.cuda.current_stream(dev).cuda_stream
         for r in range(reps):
@@ -603,10 +611,21 @@ def main():
             d = by.setdefault(k, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
             d["ms"] += float(acc[i]); d["flops"] += pl.meta[i].flops; d["bytes"] += pl.meta[i].bytes; d["launches"] += 1
         total_ms = float(acc.sum())
-        name, d = max(by.items(), key=lambda kv: kv[1]["ms"])
+        # The roofline kernel = the kernel FAMILY with the largest share of the forward (round-4 verdict: the two instantiations of
+        # mbconv_slice -- whole 24x24 maps / bands of 48x48 maps -- are one kernel and together outweigh the largest single launch):
+        # labels are merged on the part before the first '<' plus the tile, except that mbconv_slice merges on its name alone.
+        fam = {}
+        for k, v in by.items():
+            fk = "mbconv_slice" if k.startswith("mbconv_slice") else k
+            f_ = fam.setdefault(fk, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0, "labels": []})
+            for q in ("ms", "flops", "bytes", "launches"):
+                f_[q] += v[q]
+            f_["labels"].append(k)
+        name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
         if name.startswith("conv") or name.startswith("mbconv"):
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK["fp32" if "<f32" in name else "bf16"], "unit": "TFLOP/s"}
+            pk = "fp32" if ("<f32" in name and "x3" not in name and precision == "fp32") else precision
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[pk], "unit": "TFLOP/s"}
         else:
             ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s"}
@@ -619,31 +638,45 @@ def main():
             import glob
             for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
                 prof = json.load(open(pth))
-                if prof.get("source_hash") != result["source_hash"] or prof.get("batch") != B or prof.get("precision") != args.precision:
+                if prof.get("source_hash") != source_hash() or prof.get("batch") != Bp or prof.get("precision") != precision:
                     continue
+                tr, nl_ = 0.0, 0
                 for lab, rec in prof.get("by_label", {}).items():
-                    if lab.split("|")[0] == name:
-                        roof["traffic"] = rec["traffic_bytes"]
-                        roof["traffic_note"] = f"bytes/launch, {os.path.basename(pth)} (source_hash {prof['source_hash']})"
+                    if lab.split("|")[0] in d["labels"]:
+                        tr += rec["traffic_bytes"] * rec.get("launches", 1); nl_ += rec.get("launches", 1)
+                if nl_:
+                    roof["traffic"] = int(tr / nl_)
+                    roof["traffic_note"] = f"bytes/launch, {os.path.basename(pth)} (source_hash {prof['source_hash']})"
         except Exception:
             pass
-        roof["kernel"] = name
+        roof["kernel"] = name if len(d["labels"]) == 1 else name + " (" + " + ".join(sorted(d["labels"])) + ")"
         roof["launches_per_step"] = d["launches"]
         roof["avg_launch_ms"] = round(d["ms"] / d["launches"], 4)
         roof["algorithmic_gflop_per_launch"] = round(d["flops"] / d["launches"] / 1e9, 3)
         roof["algorithmic_mbytes_per_launch"] = round(d["bytes"] / d["launches"] / 1e6, 2)
         roof["share_of_forward_time"] = round(d["ms"] / total_ms, 3)
-        result["roofline"] = roof
+        # ... and the largest SINGLE launch, as rounds 1-4 reported it
+        n1, d1 = max(by.items(), key=lambda kv: kv[1]["ms"] / kv[1]["launches"])
+        if n1.startswith(("conv", "mbconv")):
+            roof["largest_launch"] = {"kernel": n1, "avg_launch_ms": round(d1["ms"] / d1["launches"], 4),
+                                      "achieved": round(d1["flops"] / (d1["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+                                      "frac": round(d1["flops"] / (d1["ms"] * 1e-3) / 1e12 / PEAK[precision], 4)}
         conv_ms = sum(v["ms"] for k, v in by.items() if k.startswith(("conv", "mbconv")))
         conv_fl = sum(v["flops"] for k, v in by.items() if k.startswith(("conv", "mbconv")))
-        result["all_conv_kernels"] = {"ms_per_step": round(conv_ms, 3), "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
-                                      "share_of_forward_time": round(conv_ms / total_ms, 3)}        # (incl. the fused MBConv heads)
-        result["forward_ms_sum_of_kernels"] = round(total_ms, 3)
-        if args.dump_ops:
+        allconv = {"ms_per_step": round(conv_ms, 3), "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                   "share_of_forward_time": round(conv_ms / total_ms, 3)}        # (incl. the fused MBConv heads)
+        if dump:
             ops = [{"i": i, "name": pl.meta[i].name, "kind": pl.meta[i].kind, "ms": float(acc[i]), "gflop": pl.meta[i].flops / 1e9,
                     "mbytes": pl.meta[i].bytes / 1e6} for i in range(n_ops)]
-            with open(args.dump_ops, "w") as f:
+            with open(dump, "w") as f:
                 json.dump({"by_kernel": by, "ops": ops}, f, indent=1)
+        return roof, allconv, round(total_ms, 3)
+
+    if rank == 0 and not args.no_profile:
+        roof, allconv, total_ms = kernel_profile(model, x, heat, feat, args.precision, max(3, min(args.steps, 10)), args.dump_ops)
+        result["roofline"] = roof
+        result["all_conv_kernels"] = allconv
+        result["forward_ms_sum_of_kernels"] = total_ms
 
     # ---- the other numeric mode, parity of both against the CPU oracle, CPU baseline (rank 0, N = 1) -------------
     if rank == 0 and world == 1:
@@ -670,6 +703,12 @@ def main():
             recs[other] = {"dtype": other, "images_per_s": round(B * k2 / e2, 2), "ms_per_step": round(1000 * e2 / k2, 3), "steps": k2,
                            "path_frac_of_mfma_peak": round(B * k2 / e2 * GFLOP_PER_IMAGE / 1000 / PEAK[other], 4)}
             maps[other] = (heat2[:1].clone(), feat2[:1].clone())
+            if other == "fp16x3" and not args.no_profile:      # the contract-grade mode's own dominant kernel (north_star_value below)
+                try:
+                    r3, c3, t3 = kernel_profile(model2, x, heat2, feat2, other, 3, args.dump_ops.replace(".json", "_fp16x3.json") if args.dump_ops else "")
+                    recs[other].update({"roofline": r3, "all_conv_kernels": c3, "forward_ms_sum_of_kernels": t3})
+                except Exception as ex:
+                    recs[other]["roofline"] = {"error": repr(ex)[:200]}
             if args.lanes > 1:                              # the same steps alternating over the lanes, as the headline does
                 from findtextcenternet_amd import DetectorLanes
                 ln2 = DetectorLanes(det2, B, 768, 768, lanes=args.lanes, max_boxes=args.max_boxes, device=dev)
@@ -788,6 +827,94 @@ def main():
             result[names[other]] = recs[other]
             if "parity" in result:
                 result[names[other]].update({k: result["parity"][other][k] for k in ("heatmap_linf", "features_linf", "peak_set_identical", "peak_jaccard")})
+        # ---- north_star_value: the fastest mode of this line that meets BASELINE.json's north_star tolerance ("within fp32 1e-3, peak indices
+        # bit-exact") against the CPU oracle.  `value` above is the bf16 configuration BASELINE configs[1] names; bf16 arithmetic is outside that
+        # tolerance (parity.bf16), so the contract-grade rate is quoted beside it, with the roofline of ITS dominant kernel.
+        if "parity" in result:
+            cands = []
+            for prec_ in [args.precision] + list(others):
+                pr = result["parity"].get(prec_)
+                rate = result["value"] if prec_ == args.precision else recs[prec_]["images_per_s"]
+                if pr and pr["heatmap_linf"] < 1e-3 and pr["features_linf"] < 1e-3 and pr["peak_set_identical"]:
+                    cands.append((rate, prec_))
+            if cands:
+                rate, prec_ = max(cands)
+                rec_ = result if prec_ == args.precision else recs[prec_]
+                result["north_star_value"] = {
+                    "value": rate, "unit": "images/s", "dtype": prec_, "tolerance": "heatmap and features L-inf < 1e-3 vs the CPU oracle, peak index set identical",
+                    "heatmap_linf": result["parity"][prec_]["heatmap_linf"], "features_linf": result["parity"][prec_]["features_linf"],
+                    "peak_set_identical": True, "ms_per_step": rec_["ms_per_step"],
+                    "single_stream_images_per_s": rec_.get("single_stream_images_per_s", (rec_.get("single_stream") or {}).get("value")),
+                    "path_frac_of_mfma_peak": rec_["path_frac_of_mfma_peak"], "roofline": rec_.get("roofline"),
+                    "modes_in_tolerance": {p_: r_ for r_, p_ in sorted(cands, reverse=True)}}
+        # ---- BASELINE configs[3]: "detector fwd + keyheatmap peak-NMS + 100-d feature gather end-to-end, batch=32, 1 GPU" -- the same step at batch 32
+        # (the step above already is forward + NMS + decode + gather), bf16 and the contract-grade fp16x3; and configs[4]: a short train step record
+        if not args.no_configs:
+            cfg3 = {"workload": "BASELINE configs[3]: batch=32 synthetic 768x768x3 tiles, forward + NMS + GPU peak decode + 100-d feature gather, 1 GPU; "
+                                "outputs [32,max,9] boxes, [32,max,100] features, counts"}
+            try:
+                B3 = 32
+                x3 = torch.from_numpy(synth.noise_images(777, B3, 768, 768)).to(dev).permute(0, 3, 1, 2)
+                tiles3 = tiles_to_device([TileGeom(0, 0, 768, 768, rect) for _ in range(B3)], dev, 192, 192)
+                from findtextcenternet_amd import DetectorLanes
+                for prec_, k3 in ((args.precision, 6), ("fp16x3", 4)):
+                    if prec_ != args.precision and args.no_fp32:
+                        continue
+                    m3, d3 = (model, det) if prec_ == args.precision else make(prec_)
+                    h3 = torch.empty((B3, 192, 192, 10), dtype=torch.float32, device=dev)
+                    f3 = torch.empty((B3, 192, 192, 100), dtype=torch.float32, device=dev)
+                    w3 = DecodeWorkspace(B3, 192, 192, 100, args.max_boxes, dev)
+
+                    def step3():
+                        with torch.no_grad():
+                            d3.forward_nhwc(x3, out=(h3, f3))
+                        return decode_peaks(h3, f3, tiles3, cut_off=0.4, max_boxes=args.max_boxes, logit_cut=lcut, workspace=w3)
+                    step3(); step3()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(k3):
+                        o3 = step3()
+                    torch.cuda.synchronize()
+                    e3 = time.perf_counter() - t0
+                    r3 = {"single_stream_images_per_s": round(B3 * k3 / e3, 2), "single_stream_ms_per_step": round(1000 * e3 / k3, 3), "steps": k3,
+                          "mean_peaks_per_tile": round(float(o3.counts.float().mean().item()), 1)}
+                    del h3, f3, w3
+                    if args.lanes > 1:
+                        ln3 = DetectorLanes(d3, B3, 768, 768, lanes=args.lanes, max_boxes=args.max_boxes, device=dev)
+                        for _ in range(args.lanes):
+                            ln3.submit(x3, tiles3, cut_off=0.4, logit_cut=lcut)
+                        ln3.wait()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(k3):
+                            ln3.submit(x3, tiles3, cut_off=0.4, logit_cut=lcut)
+                        ln3.wait()
+                        torch.cuda.synchronize()
+                        e4 = time.perf_counter() - t0
+                        r3.update({"images_per_s": round(B3 * k3 / e4, 2), "ms_per_step": round(1000 * e4 / k3, 3), "lanes": args.lanes})
+                        del ln3
+                    else:
+                        r3.update({"images_per_s": r3["single_stream_images_per_s"], "ms_per_step": r3["single_stream_ms_per_step"], "lanes": 1})
+                    r3["path_frac_of_mfma_peak"] = round(r3["images_per_s"] * GFLOP_PER_IMAGE / 1000 / PEAK[prec_], 4)
+                    cfg3[prec_] = r3
+                    if prec_ != args.precision:
+                        del m3, d3
+                    torch.cuda.empty_cache()
+                del x3
+            except Exception as ex:
+                cfg3["error"] = repr(ex)[:200]
+            result["config3_b32"] = cfg3
+            try:
+                lanes = None                                     # (the lanes' arenas go back to the allocator before the train step's 30 GB arena is made)
+                torch.cuda.empty_cache()
+                ta = argparse.Namespace(batch=B, steps=5, warmup=2, precision=args.precision, no_profile=args.no_profile, no_cpu_baseline=True)
+                tr = train_bench(ta, 0, local_rank, 1, emit=False)
+                result["train_step"] = {k: tr[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_median", "dtype", "finite",
+                                                           "loss_last_step", "path_tflops_per_gpu", "path_frac_of_mfma_peak", "roofline", "kernel_time_by_label_ms",
+                                                           "forward_ms_sum_of_kernels", "backward_ms_sum_of_kernels", "workspace_gb") if k in tr}
+                result["train_step"]["workload"] = tr["config"]["workload"]
+            except Exception as ex:
+                result["train_step"] = {"error": repr(ex)[:200]}
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libftc_hip.so")
 
-FTC_ABI_VERSION = 8
+FTC_ABI_VERSION = 9
 F32, BF16, F16 = 0, 1, 2
 (BASE_NULL, BASE_WORKSPACE, BASE_WEIGHTS, BASE_INPUT, BASE_HEATMAP, BASE_FEATURES, BASE_GRADS, NUM_BASES) = range(8)
 OP_STEM, OP_CONV, OP_DWCONV, OP_SE, OP_UPCAT, OP_NMS, OP_TAPSUM, OP_BNSTAT, OP_BNACT = 1, 2, 3, 4, 5, 6, 7, 8, 9
@@ -22,7 +22,6 @@ FLAG_TOP_FUSE, FLAG_UPCAT_IN, FLAG_GROUP_IN2_SHARED, FLAG_W_FRAG, FLAG_ACCUM, FL
 FLAG_SIDE_STREAM = 0x4000000
 FLAG_SE_HPART = 0x8000000
 FLAG_KBLOCK32 = 0x10000000
-FLAG_SE_INLINE = 0x20000000
 MBHEAD_SLICE = 128
 
 EXPORTS = ["ftc_abi_version", "ftc_last_error", "ftc_device_info", "ftc_plan_create", "ftc_plan_destroy",

@@ -790,11 +790,9 @@ __device__ __forceinline__ void wg_barrier() { __builtin_amdgcn_s_barrier(); }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// GATE (round 4; 1x1 convolutions on 16-bit operands, FTC_FLAG_SE_SCALE): the SE gate scale[b][cin] multiplies the WEIGHT fragments as they
-// come out of LDS -- w * g in fp32, rounded to the compute type: the very values FTC_FLAG_SE_FOLD writes as a per-image weight copy
-// (bit-identical results), without the 25 MB copy per block.  The image's gates sit in LDS behind the operand ring (fp32 [Cin]); a
-// workgroup's pixel tile lies inside one image (validated: Ho*Wo % TM == 0).
-template <typename WT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF, bool GATE = false>
+// (Round 4 measured a GATE variant -- the SE gate multiplied into the weight fragments as they leave LDS instead of a per-image folded
+// weight copy: 49.0 vs 33.3 us on the stage-6 project GEMM, bf16 has no packed multiply on gfx950 -- and round 5 removed it: DESIGN.md appendix.)
+template <typename WT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF>
 __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p_launch) {
     ConvP p = p_launch;
     constexpr int E = 16 / (int)sizeof(WT);
@@ -916,8 +914,7 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p_laun
         offA[g] = (wn * SN * 32 + l31) * ROWB + sl;
         offB[g] = (TN + wm * SM * 32 + l31) * ROWB + sl;
     }
-    const float* gate_lds = reinterpret_cast<const float*>(smem_raw + NBUF * BUFB);      // GATE: fp32 [Cin] of this workgroup's image
-    auto compute = [&](int bufoff, int kstep) {
+    auto compute = [&](int bufoff) {
         const unsigned char* base = smem_raw + bufoff;
         if constexpr (is_x3<WT>) {
             static_assert(!is_x3<WT> || G % 2 == 0, "fp16x3 pairs the K groups of the fp32 kernel");
@@ -944,14 +941,6 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p_laun
             for (int i = 0; i < SN; ++i) af[i] = *reinterpret_cast<const FragT*>(base + offA[g] + i * 32 * ROWB);
 #pragma unroll
             for (int j = 0; j < SM; ++j) bf[j] = *reinterpret_cast<const FragT*>(base + offB[g] + j * 32 * ROWB);
-            if constexpr (GATE && sizeof(WT) == 2) {
-                const float* gp = gate_lds + kstep * BK + (g * 2 + half) * 8;            // the 8 K positions of this lane's fragment
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
-#pragma unroll
-                for (int i = 0; i < SN; ++i)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) af[i][e] = from_f32<WT>((float)af[i][e] * (e < 4 ? g0[e] : g1[e - 4]));
-            }
             if constexpr (sizeof(WT) == 4) {
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
@@ -979,19 +968,13 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p_laun
         if (j < p.nk) issue(iss_off);
         iss_off += BUFB;
     }
-    if constexpr (GATE) {                                     // (behind the first DMA issues: its latency hides under theirs)
-        const float* gsrc = p.se + (size_t)(m0 / HoWo) * p.Cin;
-        float* gdst = reinterpret_cast<float*>(smem_raw + NBUF * BUFB);
-        for (int i = t; i < p.ncb * BK; i += 256) gdst[i] = i < p.Cin ? gsrc[i] : 0.f;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (published by the first step's barrier; the global loads above are consumed
-    }                                                         //  by then -- their vmcnt wait comes with the ds_write)
     for (int it = 0; it < p.nk; ++it) {
         // tile `it` has landed once at most the later-issued tiles remain outstanding
-        if (D == 1 || it + 1 >= p.nk || (GATE && it == 0)) wait_vmcnt<0>(); else wait_vmcnt<NL>();
+        if (D == 1 || it + 1 >= p.nk) wait_vmcnt<0>(); else wait_vmcnt<NL>();
         wg_barrier();
         if (it + D < p.nk) issue(iss_off);                   // that slot was consumed in step it-1
         iss_off = iss_off + BUFB == NBUF * BUFB ? 0 : iss_off + BUFB;
-        compute(cur_off, it);
+        compute(cur_off);
         cur_off = cur_off + BUFB == NBUF * BUFB ? 0 : cur_off + BUFB;
     }
     if constexpr (DUAL) {
@@ -1797,21 +1780,20 @@ hipError_t launch_cfg2(ConvP p, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <typename WT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF, bool GATE = false>
+template <typename WT, typename OutT, int BK, int WN, int WM, int SN, int SM, int NBUF>
 hipError_t launch_glds(ConvP p, hipStream_t s) {
     constexpr int E = 16 / (int)sizeof(WT);
     constexpr int TN = WN * SN * 32, TM = WM * SM * 32;
-    constexpr size_t lds_stage = (size_t)NBUF * (TN + TM) * (BK / E) * 16 + (GATE ? 4096 * 4 : 0);        // GATE: + the image's gates, Cin <= 4096
+    constexpr size_t lds_stage = (size_t)NBUF * (TN + TM) * (BK / E) * 16;
     constexpr size_t lds_epi = (size_t)TM * epi_pitch<OutT>(TN) + (size_t)16 * TN * 4;
     constexpr size_t lds_bytes = lds_stage > lds_epi ? lds_stage : lds_epi;
-    auto kern = conv_igemm_glds_kernel<WT, OutT, BK, WN, WM, SN, SM, NBUF, GATE>;
+    auto kern = conv_igemm_glds_kernel<WT, OutT, BK, WN, WM, SN, SM, NBUF>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (GATE && (p.KS != 1 || p.Cin > 4096 || (p.Ho * p.Wo) % TM != 0 || !p.se)) return hipErrorInvalidValue;      // (glds_legal keeps such ops away)
     p.ncb = (p.Cin + BK - 1) / BK;
     p.nk = p.KS * p.KS * p.ncb;
     p.nN = (p.Cout + TN - 1) / TN;
@@ -1828,13 +1810,7 @@ hipError_t launch_cfg(const ConvP& p, hipStream_t s) {
                              (((WN * SN + WM * SM) * 32 * (BK / E)) % 256 == 0) && ((WN * SN * 32 * (BK / E)) % 64 == 0);
     if constexpr (glds_ok) {
         if (p.use_glds) {
-            if constexpr (sizeof(WT) == 2 && BK == 64 && WN * SN * WM * SM <= 12) {     // (the tiles the project convolutions run on)
-                if (p.flags & FTC_FLAG_SE_SCALE) {
-                    if (p.glds_nbuf == 3) return launch_glds<WT, OutT, BK, WN, WM, SN, SM, 3, true>(p, s);
-                    return launch_glds<WT, OutT, BK, WN, WM, SN, SM, 2, true>(p, s);
-                }
-            }
-            if (p.flags & FTC_FLAG_SE_SCALE) return hipErrorInvalidValue;
+            if (p.flags & FTC_FLAG_SE_SCALE) return hipErrorInvalidValue;      // (glds_legal keeps such ops away: the DMA cannot rescale)
             if (p.glds_nbuf == 3) return launch_glds<WT, OutT, BK, WN, WM, SN, SM, 3>(p, s);
             return launch_glds<WT, OutT, BK, WN, WM, SN, SM, 2>(p, s);
         }
@@ -1911,10 +1887,7 @@ inline bool glds_legal(const ftc_op& o) {
     if (bk == 128) return false;
     const int cpr = bk / (ftc_is16(o.w_dtype) ? 8 : 4);
     const int cfg = select_cfg(o);
-    if (o.flags & FTC_FLAG_SE_SCALE) {         // the gate on the weight fragments (GATE): 16-bit 1x1, K step 64, tiles of <= 12 MFMA sub-tiles inside one image
-        const int subtiles = (kCfgTN[cfg] / 32) * (kCfgTM[cfg] / 32);
-        if (!ftc_is16(o.w_dtype) || o.ksize != 1 || bk != 64 || subtiles > 12 || o.Cin > 4096 || (o.Ho * o.Wo) % kCfgTM[cfg] != 0) return false;
-    }
+    if (o.flags & FTC_FLAG_SE_SCALE) return false;      // the SE scale is applied while staging through registers
     // tiles must be a whole number of workgroup-level DMA passes
     return ((kCfgTN[cfg] + kCfgTM[cfg]) * cpr) % 256 == 0 && (kCfgTN[cfg] * cpr) % 64 == 0;
 }

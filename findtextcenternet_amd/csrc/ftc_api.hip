@@ -113,7 +113,9 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if (!need(o.out2, false, "out2", pout * o.Cout * 2)) return why->c_str();
         if (!need(o.w2, topf, "w2", G * 32 * o.Cout * 2)) return why->c_str();
         if (o.out2.base != FTC_BASE_NULL && (o.out_dtype != FTC_F32 || o.Cout % 4)) return "conv: out2 (bf16 copy) needs an fp32 primary output and Cout % 4 == 0";
-        if ((o.flags & FTC_FLAG_KBLOCK32) && (o.out2.base == FTC_BASE_NULL || o.Cout % 32 || G > 1)) return "conv: KBLOCK32 describes out2 (the 16-bit copy) and needs Cout % 32 == 0, one group";
+        // out2_index (conv_igemm_impl.h) lays the planes out from Cout alone: no channel slice, no groups, a 16-bit compute type
+        if ((o.flags & FTC_FLAG_KBLOCK32) && (o.out2.base == FTC_BASE_NULL || !ftc_is16(o.w_dtype) || o.Cout % 32 || o.Cout != o.Cout_total || o.cout_off != 0 || G > 1))
+            return "conv: KBLOCK32 describes out2 (the 16-bit copy) and needs a 16-bit w_dtype, Cout % 32 == 0, Cout == Cout_total, cout_off == 0, one group";
         return conv_validate(o);
     }
     case FTC_OP_DWCONV:
@@ -140,18 +142,11 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
             !need(o.bias, true, "bias", (int64_t)o.Cout * 4) || !need(o.aux, true, "aux", (int64_t)o.B * nb * o.Cout * 4)) return why->c_str();
         if ((o.scale.base != FTC_BASE_NULL) != (o.out2.base != FTC_BASE_NULL)) return "mbhead: scale (fc1 weight) and out2 (fc1 partial products) come together";
         if (o.scale.base != FTC_BASE_NULL) {
-            if (o.aux0 <= 0) return "mbhead: aux0 (squeeze width S) must be positive when the fc1 partial products are requested";
+            // the kernel forms the partial products of at most 10 passes x 16 = 160 squeeze units (w1r[NU], mbconv_slice.hip); units beyond that were never written
+            if (o.aux0 <= 0 || o.aux0 > FTC_MBHEAD_MAX_SQUEEZE) return "mbhead: aux0 (squeeze width S) must be in 1..160 when the fc1 partial products are requested";
             if (!need(o.scale, true, "scale", (int64_t)o.aux0 * o.Cout * 4) || !need(o.out2, true, "out2", (int64_t)o.B * nb * ns * o.aux0 * 4)) return why->c_str();
         }
-        const bool sei = (o.flags & FTC_FLAG_SE_INLINE) != 0;
-        if (sei) {
-            if (!(o.H == 24 && o.W == 24 && o.aux1 == 0) || (o.flags & 0x100)) return "mbhead: FTC_FLAG_SE_INLINE needs the whole-image form (24x24 map, aux1 = 0)";
-            if (o.scale.base == FTC_BASE_NULL || o.aux0 <= 0 || o.aux0 > 160 || o.B > 48 || o.cin_off < o.aux0 * o.Cout || o.cout_off < o.aux0 * o.Cout)
-                return "mbhead: FTC_FLAG_SE_INLINE needs scale (fc1 weight, bias cin_off floats behind), shift (fc2 weight, bias cout_off floats behind), S <= 160, B <= 48";
-            if (!need(o.scale, true, "scale", ((int64_t)o.cin_off + o.aux0) * 4) || !need(o.shift, true, "shift", ((int64_t)o.cout_off + o.Cout) * 4) ||
-                !need(o.in2, true, "in2", 256)) return why->c_str();
-        }
-        if (o.flags & 0x1000) { if (!need(o.in2, true, "in2", (int64_t)o.B * nb * ns * 256 + (sei ? 256 : 0))) return why->c_str(); }      // phase timeline (tools/mbslice_bench.py)
+        if (o.flags & 0x1000) { if (!need(o.in2, true, "in2", (int64_t)o.B * nb * ns * 256)) return why->c_str(); }      // phase timeline (tools/mbslice_bench.py)
         return nullptr;
     }
     case FTC_OP_SE:

@@ -44,13 +44,6 @@ struct MbsP {
     int B, H, W, K, C, S;
     int R, nb;              // band mode: output rows per band, bands per image (R = H, nb = 1: the whole image)
     int kblock;             // FTC_FLAG_KBLOCK32: x is [B][K/32][H*W][32]
-    // FTC_FLAG_SE_INLINE (24x24 maps): the whole SqueezeExcitation inside this launch -- see "SE inline" below
-    const float* b1;        // fc1 bias [S]
-    const float* w2t;       // fc2 weight transposed [S][C]
-    const float* b2;        // fc2 bias [C]
-    int* sync;              // [0] ticket counter, [1] departures, [2] stall flag   (zero before the launch; left zero)
-    int imajor;             // experiment (flags 0x200): image-major workgroup order instead of image b on XCD b % 8
-    int ldstail;            // experiment (flags 0x400): LDS-only barriers behind the depthwise phase (the output stores drain in the background)
     unsigned img_bytes;
     float inv_hw;
     unsigned long long* tl;  // flags 0x1000: s_memtime of wave 0 at the phase boundaries and K steps, 32 values per workgroup (tools/mbslice_bench.py)
@@ -72,55 +65,21 @@ constexpr int MS_R = 6;                     // outputs per depthwise strip (12: 
 __device__ __forceinline__ f32x4 mfma16x16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma16x16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
-// four activations <-> two registers of 16-bit values (what store4 / load4 do through memory)
-template <typename T> __device__ __forceinline__ u32x2 pack4(f32x4 v);
-template <> __device__ __forceinline__ u32x2 pack4<__bf16>(f32x4 v) {
-    const bf16x4 r = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-    return __builtin_bit_cast(u32x2, r);
-}
-template <> __device__ __forceinline__ u32x2 pack4<_Float16>(f32x4 v) {
-    const f16x4 r = {(_Float16)f16_sat(v[0]), (_Float16)f16_sat(v[1]), (_Float16)f16_sat(v[2]), (_Float16)f16_sat(v[3])};
-    return __builtin_bit_cast(u32x2, r);
-}
-template <typename T> __device__ __forceinline__ f32x4 unpack4(u32x2 u);
-template <> __device__ __forceinline__ f32x4 unpack4<__bf16>(u32x2 u) {
-    return f32x4{__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16), __uint_as_float(u[1] & 0xffff0000u)};
-}
-template <> __device__ __forceinline__ f32x4 unpack4<_Float16>(u32x2 u) {
-    const f16x4 r = __builtin_bit_cast(f16x4, u);
-    return f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
-}
-
 // FAST: the 24x24 map of the 768x768 plans (H, W compile-time: row offsets of the depthwise window are instruction immediates)
-// SE inline (SEI, FTC_FLAG_SE_INLINE; 24x24 maps): the excitation needs the channel means of the WHOLE image, i.e. of every slice's
-// workgroup -- a grid-wide dependency that used to be a kernel boundary (FTC_OP_SE: 13-19 us of dependent round trips per block, which
-// nothing overlaps, not even the other lane) plus a per-image copy of the project weights (25 MB per block).  Here the workgroups of an
-// image meet inside the launch: each publishes its fc1 partial products (agent-scope atomic stores into slots that hold a NaN pattern
-// until then) and polls the other slices' slots until all C/128 of them are there; then every workgroup forms the hidden vector, the
-// gates of ITS 128 channels (its fc2 columns were requested before the wait) and multiplies its depthwise outputs -- held in registers as packed 16-bit values since the depthwise phase, nothing was stored
-// yet -- before the one store.  The project convolution that follows is a plain GEMM on the shared weights.
-// Forward progress: a workgroup takes its work item from a TICKET counter (item = ticket, image-major), so the slices of the image an
-// arrived workgroup waits for were all drawn earlier by workgroups that are running -- no assumption about dispatch order or about how
-// many workgroups fit beside another stream's kernels; the wait is bounded all the same (stall flag, sync[2]).
-constexpr int MS_SPIN_LIMIT = 1 << 22;
-
-template <typename T, bool FAST, bool SEI = false>
+// (Two forms of the SqueezeExcitation INSIDE this launch were built, measured and removed: round 4's FTC_FLAG_SE_INLINE -- gated output, plain
+// project GEMM: 60.0 vs 41.7 + 14.9 us -- and round 5's FTC_FLAG_SE_TAIL -- ungated output, the last workgroups of an image fold the project
+// weights: 61.9 vs 42.5 + 14.8 us on one stream and waits that run into their bound under two lanes; profiles/r04_mbhead_se_inline_experiment.txt,
+// profiles/r05_se_tail_experiment.txt, DESIGN.md appendix.)
+template <typename T, bool FAST>
 __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l15 = lane & 15, lq = lane >> 4;
-    int bid = blockIdx.x;
-    const int per_img = p.nb * (p.C / MS_CC);
-    if constexpr (SEI) {
-        if (t == 0) *reinterpret_cast<volatile int*>(smem_raw) = atomicAdd(p.sync, 1);
-        __syncthreads();
-        bid = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem_raw));
-        __syncthreads();                                   // (the operand ring is about to land on that word)
-    }
-    const int b = (SEI || p.imajor) ? bid / per_img : bid % p.B;    // consecutive workgroup ids = consecutive images: image b on XCD b % 8
-    const int rest = (SEI || p.imajor) ? bid % per_img : bid / p.B;
+    const int bid = blockIdx.x;
+    const int b = bid % p.B;                               // consecutive workgroup ids = consecutive images: image b on XCD b % 8
+    const int rest = bid / p.B;
     const int band = FAST ? 0 : rest % p.nb, sl = FAST ? rest : rest / p.nb;
     const int c0 = sl * MS_CC;
     // Band mode (maps larger than 576 pixels: the 48x48 stages): the workgroup owns the output rows [y0, y1) of its image and holds the
@@ -259,7 +218,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
     const int c = c0 + cq * 4;
     // this slice's columns of the SE fc1 matrix, requested now: they arrive under the depthwise phase (behind its stores they would
     // wait for every store to drain: vmcnt is in order).  Lane = 4 channels, 16 units s apart per pass.
-    constexpr int NU = 10;                                      // S <= 160
+    constexpr int NU = FTC_MBHEAD_MAX_SQUEEZE / 16;             // S <= 160 (validated: ftc_api.hip)
     f32x4 w1r[NU];
     auto load_w1 = [&]() {
 #pragma unroll
@@ -268,7 +227,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
             w1r[i] = su < p.S ? *reinterpret_cast<const f32x4*>(p.w1 + (size_t)su * p.C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    if (!SEI && p.hpart) load_w1();                             // (SEI: nothing is stored during the depthwise phase -- loaded behind it, 40 registers less)
+    if (p.hpart) load_w1();
     f32x4 wv[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const f32x4*>(smem_raw + MS_CONST + k * (MS_CC * 4) + cq * 16);
@@ -279,12 +238,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     T* outp = reinterpret_cast<T*>(p.out) + ((size_t)b * Mfull + (size_t)ylo * W) * p.C + c;
     const unsigned char* zslot = smem_raw + cq * 8;             // slot 0: zeros
-    constexpr int NIT = 6;                                      // SEI: 96 strips of the 24x24 map over 16 strip lanes
-    u32x2 keep[SEI ? NIT : 1][SEI ? MS_R : 1];                  // SEI: the outputs, packed 16-bit, until the gates are known
-#pragma unroll
-    for (int it = 0; it < (SEI ? NIT : 1); ++it)
-    for (int s0 = pl + (SEI ? 16 * it : 0), s = s0; s < (SEI ? s0 + 1 : nstrips); s += 16) {
-        if constexpr (SEI) asm volatile("" : "+v"(s));          // (opaque: keeps the six unrolled strips' address arithmetic inside their strip)
+    for (int s = pl; s < nstrips; s += 16) {
         const int sr = s / W, x = s - sr * W;
         const int oy0 = yo + sr * MS_R;
         // window rows 0..6 from base0, 7.. from base1: the immediate offset of a DS instruction is 16 bits
@@ -318,37 +272,15 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
             const int oy = oy0 + oo;
             if (FAST || oy < yend) {
                 a[oo] = act_silu_fast4(a[oo]);
-                if constexpr (SEI) {
-                    keep[it][oo] = pack4<T>(a[oo]);
-                } else {
-                    store4<T>(outp + (oy * W + x) * p.C, a[oo]);
-                }
+                store4<T>(outp + (oy * W + x) * p.C, a[oo]);
                 sum += a[oo];
             }
-        }
-        if constexpr (SEI) __builtin_amdgcn_sched_barrier(0);   // one strip at a time: interleaved, the six unrolled strips spilled 456 registers
-    }
-    if constexpr (SEI) load_w1();
-    // SEI: this slice's fc2 columns, requested now (they do not depend on anything): thread = (channel t & 127, quarter of S t >> 7)
-    constexpr int SQMAX = 40;                                   // S <= 160
-    float w2r[SEI ? SQMAX : 1];
-    const int sq = (p.S + 3) / 4;
-    if constexpr (SEI) {
-        const int gc = t & 127, sg = t >> 7;
-#pragma unroll
-        for (int i = 0; i < SQMAX; ++i) {
-            const int su = sg * sq + i;
-            w2r[i] = (i < sq && su < p.S) ? p.w2t[(size_t)su * p.C + c0 + gc] : 0.f;
         }
     }
     if (tl_on) tl[3] = __builtin_amdgcn_s_memtime();
 
     // ---- squeeze: the image's channel sums, complete in this workgroup (the expanded image is dead: its memory holds the scratch) ----
-    auto tail_sync = [&]() {
-        if (p.ldstail) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); wg_barrier(); }
-        else __syncthreads();
-    };
-    tail_sync();
+    __syncthreads();
     float* red = reinterpret_cast<float*>(smem_raw);           // [8 waves][128]
     float* lmean = red + 8 * MS_CC;
     {
@@ -357,7 +289,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
         for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], 32, 64);
         if (lane < 32) *reinterpret_cast<f32x4*>(red + wave * MS_CC + lane * 4) = v;
     }
-    tail_sync();
+    __syncthreads();
     if (t < MS_CC) {
         float tot = 0.f;
 #pragma unroll
@@ -366,7 +298,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
         lmean[t] = tot * p.inv_hw;
     }
     if (p.hpart) {
-        tail_sync();
+        __syncthreads();
         // lane (4 channels) x unit products -> LDS [unit][32 + 1], then one thread per unit adds the 32 channel quads in order
         float* fcb = lmean + MS_CC;
         const f32x4 m4 = *reinterpret_cast<const f32x4*>(lmean + cq * 4);
@@ -376,97 +308,13 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
             const int su = pl + 16 * i;
             if (su < p.S) fcb[su * 33 + cq] = (pr[0] + pr[1]) + (pr[2] + pr[3]);
         }
-        tail_sync();
+        __syncthreads();
         if (t < p.S) {
             float d = 0.f;
 #pragma unroll
             for (int q = 0; q < 32; ++q) d += fcb[t * 33 + q];
             float* dst = p.hpart + (((size_t)b * p.nb + band) * (p.C / MS_CC) + sl) * p.S + t;
-            if constexpr (SEI) __hip_atomic_store(dst, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (read by the image's other workgroups, see below)
-            else *dst = d;
-        }
-    }
-    if constexpr (SEI) {
-        // ---- meet the other slices of this image ----
-        // No fences: an agent-scope release / acquire pair writes back and invalidates the XCD's whole L2 (measured: 88 k cycles per
-        // workgroup instead of ~3 k).  The partial products themselves are the message: they were stored with agent-scope atomic stores
-        // (below, where hpart is written), the slots hold a NaN pattern no sum can produce until then (the plan's memset), and a reader
-        // polls every value it needs until it is there.
-        const int nper = per_img;
-        float* hidv = reinterpret_cast<float*>(smem_raw + 96 * 1024);      // [S] | part4 [4][128] | gate [128] | hpl [nper][S]   (far behind the scratch above)
-        float* part4 = hidv + 160;
-        float* gate = part4 + 4 * MS_CC;
-        float* hpl = gate + MS_CC;
-        {
-            const unsigned* hp = reinterpret_cast<const unsigned*>(p.hpart + (size_t)b * nper * p.S);
-            const int total = nper * p.S;
-            constexpr int NV = 10;                                // 30 slices x 160 units over 512 threads
-            unsigned v[NV];
-            unsigned pending = 0;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                v[i] = 0xffffffffu;
-                if (t + i * MS_NT < total) pending |= 1u << i;
-            }
-            for (int polls = 0; pending; ++polls) {
-#pragma unroll
-                for (int i = 0; i < NV; ++i)
-                    if (pending & (1u << i)) v[i] = __hip_atomic_load(hp + t + i * MS_NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int i = 0; i < NV; ++i)
-                    if ((pending & (1u << i)) && v[i] != 0xffffffffu) pending &= ~(1u << i);
-                if (pending) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (polls > MS_SPIN_LIMIT) { atomicExch(p.sync + 2, 1); break; }      // never a hang: the host finds the flag
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-                if (t + i * MS_NT < total) hpl[t + i * MS_NT] = __uint_as_float(v[i]);
-        }
-        __syncthreads();
-        if (tl_on) tl[7] = __builtin_amdgcn_s_memtime();
-        // hidden vector: SiLU(b1 + the slices' partial products), the association of se_load_hidden (backbone_ops.hip)
-        for (int s2 = t; s2 < p.S; s2 += MS_NT) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            int j = 0;
-            for (; j + 4 <= nper; j += 4) {
-                a0 += hpl[j * p.S + s2];
-                a1 += hpl[(j + 1) * p.S + s2];
-                a2 += hpl[(j + 2) * p.S + s2];
-                a3 += hpl[(j + 3) * p.S + s2];
-            }
-            for (; j < nper; ++j) a0 += hpl[j * p.S + s2];
-            hidv[s2] = act_silu_precise(((a0 + a1) + (a2 + a3)) + p.b1[s2]);
-        }
-        __syncthreads();
-        {   // gates of this slice: sigmoid(b2 + fc2 . hidden), four partial dots of S/4 terms as se_fc2_fold64_kernel
-            const int gc = t & 127, sg = t >> 7;
-            float acc = 0.f;
-#pragma unroll
-            for (int i = 0; i < SQMAX; ++i)
-                if (i < sq && sg * sq + i < p.S) acc += hidv[sg * sq + i] * w2r[i];
-            part4[sg * MS_CC + gc] = acc;
-        }
-        __syncthreads();
-        if (t < MS_CC) gate[t] = sigmoid_precise(p.b2[c0 + t] + ((part4[t] + part4[MS_CC + t]) + (part4[2 * MS_CC + t] + part4[3 * MS_CC + t])));
-        __syncthreads();
-        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gate + cq * 4);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int s = pl + 16 * it;
-            const int sr = s / W, x = s - sr * W;
-#pragma unroll
-            for (int oo = 0; oo < MS_R; ++oo) {
-                store4<T>(outp + ((sr * MS_R + oo) * W + x) * p.C, unpack4<T>(keep[it][oo]) * g4);
-            }
-        }
-        // the last workgroup past its wait leaves the counters at zero for the next launch
-        if (t == 0) {
-            if (atomicAdd(p.sync + 1, 1) == (int)gridDim.x - 1) {
-                p.sync[0] = 0;
-                p.sync[1] = 0;
-            }
+            *dst = d;
         }
     }
     if (tl_on) tl[4] = __builtin_amdgcn_s_memtime();
@@ -501,24 +349,16 @@ hipError_t launch_mbhead(const OpArgs& a, hipStream_t s) {
     p.x = a.in; p.we = a.w2; p.be = a.bias2; p.wd = static_cast<const float*>(a.w); p.bd = a.bias; p.out = a.out; p.sums = a.aux;
     p.w1 = a.scale; p.hpart = a.scale ? static_cast<float*>(a.out2) : nullptr;
     p.B = o.B; p.H = o.H; p.W = o.W; p.K = o.Cin; p.C = o.Cout; p.S = o.aux0;
-    const bool sei = (o.flags & FTC_FLAG_SE_INLINE) != 0;
-    p.b1 = p.w2t = p.b2 = nullptr; p.sync = nullptr;
-    if (sei) {
-        p.b1 = a.scale + o.cin_off; p.w2t = a.shift; p.b2 = a.shift + o.cout_off;
-        p.sync = static_cast<int*>(const_cast<void*>(a.in2));
-    }
     p.kblock = (o.flags & FTC_FLAG_KBLOCK32) ? 1 : 0;
-    p.imajor = (o.flags & 0x200) ? 1 : 0; p.ldstail = (o.flags & 0x400) ? 1 : 0;
     p.R = o.aux1 > 0 ? o.aux1 : o.H; p.nb = ftc_mbhead_bands(o);
     p.img_bytes = (unsigned)((long)o.H * o.W * o.Cin * 2);
     p.inv_hw = 1.0f / (float)(o.H * o.W);
-    p.tl = (o.flags & 0x1000) ? reinterpret_cast<unsigned long long*>(static_cast<char*>(const_cast<void*>(a.in2)) + (sei ? 256 : 0)) : nullptr;
+    p.tl = (o.flags & 0x1000) ? reinterpret_cast<unsigned long long*>(const_cast<void*>(a.in2)) : nullptr;      // phase timeline (tools/mbslice_bench.py)
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipSuccess;
         for (const void* f : {reinterpret_cast<const void*>(mbconv_slice_kernel<__bf16, true>), reinterpret_cast<const void*>(mbconv_slice_kernel<__bf16, false>),
-                              reinterpret_cast<const void*>(mbconv_slice_kernel<_Float16, true>), reinterpret_cast<const void*>(mbconv_slice_kernel<_Float16, false>),
-                              reinterpret_cast<const void*>(mbconv_slice_kernel<__bf16, true, true>), reinterpret_cast<const void*>(mbconv_slice_kernel<_Float16, true, true>)})
+                              reinterpret_cast<const void*>(mbconv_slice_kernel<_Float16, true>), reinterpret_cast<const void*>(mbconv_slice_kernel<_Float16, false>)})
             if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MS_LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -526,12 +366,7 @@ hipError_t launch_mbhead(const OpArgs& a, hipStream_t s) {
     const int nblk = o.B * p.nb * (o.Cout / MS_CC);
     const bool fast = o.H == 24 && o.W == 24 && p.nb == 1 && !(o.flags & 0x100);          // 0x100: the general kernel (tests)
 #define MBS_LAUNCH(T, F) hipLaunchKernelGGL((mbconv_slice_kernel<T, F>), dim3(nblk), dim3(MS_NT), MS_LDS, s, p)
-    if (sei) {
-        if (!fast || !p.hpart) return hipErrorInvalidValue;                               // (validated)
-        if (o.in_dtype == FTC_F16) hipLaunchKernelGGL((mbconv_slice_kernel<_Float16, true, true>), dim3(nblk), dim3(MS_NT), MS_LDS, s, p);
-        else hipLaunchKernelGGL((mbconv_slice_kernel<__bf16, true, true>), dim3(nblk), dim3(MS_NT), MS_LDS, s, p);
-    }
-    else if (o.in_dtype == FTC_F16) { if (fast) MBS_LAUNCH(_Float16, true); else MBS_LAUNCH(_Float16, false); }
+    if (o.in_dtype == FTC_F16) { if (fast) MBS_LAUNCH(_Float16, true); else MBS_LAUNCH(_Float16, false); }
     else { if (fast) MBS_LAUNCH(__bf16, true); else MBS_LAUNCH(__bf16, false); }
 #undef MBS_LAUNCH
     return hipGetLastError();

@@ -675,7 +675,7 @@ int Builder::build(ModelPlan* out) {
     // (small batches leave most CUs without a slice).  bh, bw = the block's INPUT map.
     // (maps of more than 576 pixels -- the 48x48 stages 4-5 -- run in bands of R output rows: returns R, 0 = the whole map, -1 = not sliced)
     auto sliced = [&](const BlockSpec& blk, int bh, int bw) -> int {
-        if (blk.fused || !dual || blk.stride != 1 || env_on("FTC_NO_MBSLICE")) return -1;
+        if (blk.fused || !dual || blk.stride != 1 || blk.squeeze > FTC_MBHEAD_MAX_SQUEEZE || env_on("FTC_NO_MBSLICE")) return -1;
         const int R = ftc_mbhead_band_rows(bh, bw);
         if (R < 0 || (R > 0 && env_on("FTC_NO_MBBAND"))) return -1;
         ftc_op t{};
@@ -688,44 +688,6 @@ int Builder::build(ModelPlan* out) {
     std::vector<const BlockSpec*> flat;
     for (const auto& st : stages)
         for (const BlockSpec& blk : st) flat.push_back(&blk);
-    // SE inside FTC_OP_MBHEAD (FTC_FLAG_SE_INLINE, the whole-image form: 24x24 maps): the workgroups of an image meet through counters that
-    // must be zero before the launch -- one 256-byte slot per such block, cleared by ONE memset at the head of the plan (the kernel leaves its
-    // counters zero as well, so a single op can be re-run).  MEASURED AND NOT ADOPTED (round 4, profiles/r04_mbhead_se_inline_experiment.txt):
-    // the gated store cannot start before the last slice of the image has finished its depthwise phase, so the 147 KB a workgroup writes
-    // (~15 us at the 1.7 TB/s the chip sustains on this write stream) no longer overlap the depthwise arithmetic: 60.0 us per stage-6 block
-    // against 41.7 + 14.9 (FTC_OP_SE) before.  FTC_SEINLINE=1 builds the plan with it (tests, measurements).
-    const bool se_inline_on = dual && B <= 48 && env_on("FTC_SEINLINE");
-    int n_inline = 0;
-    if (se_inline_on) {
-        int hh = h, ww = w;
-        for (const BlockSpec* bp : flat) {
-            if (sliced(*bp, hh, ww) == 0 && bp->squeeze <= 160) ++n_inline;
-            hh = (hh - 1) / bp->stride + 1; ww = (ww - 1) / bp->stride + 1;
-        }
-    }
-    // ... and exchange their fc1 partial products through slots that hold a NaN pattern (bytes 0xFF) until a workgroup stores its sums
-    // there: a second memset; the slots of all such blocks live in one buffer that nothing else reuses during the forward.
-    int64_t hp_floats = 0;
-    std::vector<int64_t> hp_off;
-    if (se_inline_on) {
-        int hh = h, ww = w;
-        for (const BlockSpec* bp : flat) {
-            if (sliced(*bp, hh, ww) == 0 && bp->squeeze <= 160) { hp_off.push_back(hp_floats); hp_floats += align_up((int64_t)B * (bp->exp / FTC_MBHEAD_SLICE) * bp->squeeze * 4) / 4; }
-            hh = (hh - 1) / bp->stride + 1; ww = (ww - 1) / bp->stride + 1;
-        }
-    }
-    const R syncbuf = n_inline ? buf((int64_t)n_inline * 64, FTC_F32) : R();
-    const R hpbuf = n_inline ? buf(hp_floats, FTC_F32) : R();
-    if (n_inline) {
-        for (int which = 0; which < 2; ++which) {
-            SymOp s;
-            ftc_op& o = s.o;
-            o.kind = FTC_OP_FILL; o.B = 1; o.H = 1; o.W = 1; o.Cin = which ? (int)hp_floats : n_inline * 64; o.Cout = o.Cin; o.aux0 = which ? 0xFF : 0;
-            s.out = which ? hpbuf : syncbuf;
-            emit({which ? "backbone.se_slots" : "backbone.se_sync", "memset", 0.0, (double)o.Cin * 4}, s);
-        }
-    }
-    int inline_idx = 0;
     size_t bi = 0;
     bool in_blocked = false;                    // the 16-bit trunk copy feeding the current block is in 32-channel planes (FTC_FLAG_KBLOCK32)
     for (size_t si = 0; si < stages.size(); ++si) {
@@ -751,12 +713,11 @@ int Builder::build(ModelPlan* out) {
             } else {
                 const int band_rows = sliced(blk, h, w);
                 const bool slice = band_rows >= 0;
-                const bool se_in = se_inline_on && band_rows == 0 && blk.squeeze <= 160;          // SE inside the MBHEAD launch, gated output
                 const int nbands = band_rows > 0 ? (h + band_rows - 1) / band_rows : 1;
                 const int th = blk.stride == 1 ? 8 : 4;
                 const int P = slice ? nbands * (blk.exp / FTC_MBHEAD_SLICE) : ((ho + th - 1) / th) * ((wo + 7) / 8);
                 const R d = buf((int64_t)B * ho * wo * blk.exp, A);
-                const R part = se_in ? R() : buf((int64_t)B * P * (slice ? blk.squeeze : blk.exp), FTC_F32);      // (SE inline: the exchange slots live in hpbuf)
+                const R part = buf((int64_t)B * P * (slice ? blk.squeeze : blk.exp), FTC_F32);
                 if (slice) {
                     const R sums = buf((int64_t)B * nbands * blk.exp, FTC_F32);
                     SymOp s;
@@ -765,13 +726,6 @@ int Builder::build(ModelPlan* out) {
                     o.Cin = blk.cin; o.Cout = blk.exp; o.ksize = 3; o.stride = 1; o.aux0 = blk.squeeze; o.aux1 = band_rows; o.flags = in_blocked ? FTC_FLAG_KBLOCK32 : 0;
                     s.in = gin; s.out = d; s.w2 = wref(p + ".0.w"); s.bias2 = wref(p + ".0.b"); s.w = wref(p + ".1.w"); s.bias = wref(p + ".1.b"); s.aux = sums;
                     s.scale = wref(p + ".2.w1"); s.out2 = part;
-                    if (se_in) {
-                        const R w1r = wref(p + ".2.w1"), b1r = wref(p + ".2.b1"), w2r = wref(p + ".2.w2t"), b2r = wref(p + ".2.b2");
-                        o.flags |= FTC_FLAG_SE_INLINE;
-                        o.cin_off = (int)((b1r.v - w1r.v) / 4); o.cout_off = (int)((b2r.v - w2r.v) / 4);
-                        s.shift = w2r; s.in2 = sub(syncbuf, (int64_t)inline_idx * 256); s.out2 = sub(hpbuf, hp_off[inline_idx] * 4);
-                        ++inline_idx;
-                    }
                     emit({p + ".0+1", "conv1x1+dw3x3", 2.0 * B * h * w * blk.exp * (blk.cin + 9),
                           (double)B * h * w * (blk.cin + blk.exp) * esize(A) + (double)blk.exp * blk.cin * esize(A) + blk.exp * 44.0 + 4.0 * blk.exp * blk.squeeze}, s);
                 } else {
@@ -786,24 +740,13 @@ int Builder::build(ModelPlan* out) {
                     emit({p + ".1", "dwconv3x3", 2.0 * B * ho * wo * blk.exp * 9, (double)B * ((double)h * w + (double)ho * wo) * blk.exp * esize(A) + blk.exp * 40.0}, s);
                 }
                 }
-                if (se_in) {
-                    conv(p + ".3", d, A, ho, wo, blk.exp, blk.exp, 0, p + ".3", blk.cout, 1, 1, FTC_ACT_NONE, y, T, tail);
-                    x = y; xb = yb; h = ho; w = wo;
-                    in_blocked = out_blocked;
-                    continue;
-                }
                 const R sc = buf((int64_t)B * blk.exp, FTC_F32);
                 const R hid = buf((int64_t)B * blk.squeeze, FTC_F32);
                 // bf16 mode: the SE op also writes the project weights scaled per image, so that the project convolution streams both
                 // operands by DMA instead of rescaling activations while staging them.  Needs a 64-pixel tile that divides the image.
                 // (fp16x3 plan: the same with pre-split fp32 chunks -- FTC_NO_X3FOLD=1 keeps the gate in the project convolution's staging)
                 const bool x3fold = m_->split16 && cdt_ == FTC_F32 && !env_on("FTC_NO_X3FOLD");
-                // FTC_EXPERIMENT_NOGATE=1 (timing experiment only, WRONG results): gates-only SE op + an UNGATED project convolution on the shared weights
-                const bool nogate = env_on("FTC_EXPERIMENT_NOGATE");
-                // FTC_SE_GATEFRAG=1 (round 4): gates-only SE op; the project convolution multiplies its WEIGHT fragments by the image's gates
-                // (conv_igemm_glds_kernel GATE: the same rounded values as the folded copy, no 25 MB copy per block)
-                const bool gatefrag = dual && slice && env_on("FTC_SE_GATEFRAG");
-                const bool foldse = !nogate && !gatefrag && (dual || x3fold) && (ho * wo) % 64 == 0 && blk.exp % 8 == 0;
+                const bool foldse = (dual || x3fold) && (ho * wo) % 64 == 0 && blk.exp % 8 == 0;
                 const int fdt = dual ? A : FTC_F32;
                 const R wb = foldse ? buf((int64_t)B * blk.cout * blk.exp, fdt) : R();
                 {
@@ -818,7 +761,7 @@ int Builder::build(ModelPlan* out) {
                     emit({p + ".2", "se", 4.0 * B * blk.exp * blk.squeeze, se_bytes}, s);
                 }
                 ConvOpt pj = tail;
-                pj.se = foldse || nogate ? R() : sc;
+                pj.se = foldse ? R() : sc;
                 pj.wsets = wb;
                 conv(p + ".3", d, A, ho, wo, blk.exp, blk.exp, 0, p + ".3", blk.cout, 1, 1, FTC_ACT_NONE, y, T, pj);
             }

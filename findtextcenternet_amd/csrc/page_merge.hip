@@ -320,30 +320,34 @@ __global__ __launch_bounds__(PM_T) void pm_pairs_kernel(const double* __restrict
 // exclusive prefix sum of cnt[0..N] in place -> offsets (cnt[N] = total); cursor = a copy for the fill pass
 __global__ __launch_bounds__(1024) void pm_scan_kernel(int* cnt, int* cursor, int N, long cap, PmHdr* hdr) {
     __shared__ int wsum[16];
-    __shared__ int s_base;
+    __shared__ long long s_base;           // 64-bit running total: 2^20 candidates can have more than 2^31 overlapping pairs, and a wrapped
+    __shared__ int s_over;                 // 32-bit total could pass the `total > cap` test with wrapped offsets in between (round-4 advisor finding)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t == 0) s_base = 0;
+    if (t == 0) { s_base = 0; s_over = 0; }
     __syncthreads();
-    long total = 0;
+    const long long lim = cap < 0x7fffffffL ? (long long)cap : 0x7fffffffLL;      // offsets are ints: more edges than that go to the sequential kernel
     for (int k0 = 0; k0 <= N; k0 += 1024) {
         const int k = k0 + t;
-        const int v = k < N ? cnt[k] : 0;
+        const int v = k < N ? cnt[k] : 0;                       // <= N <= 2^20: a 1024-row chunk sums to < 2^31
         int inc = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();
-        int woff = 0;
+        long long woff = 0;
         for (int q = 0; q < wave; ++q) woff += wsum[q];
-        const int base = s_base;
-        const int excl = base + woff + inc - v;
-        if (k <= N) { cnt[k] = excl; cursor[k] = excl; }
+        const long long base = s_base;
+        const long long excl = base + woff + inc - v;
+        if (k <= N) { const int e = (int)(excl < lim ? excl : lim); cnt[k] = e; cursor[k] = e; }      // saturated: never a negative or wrapped offset
         __syncthreads();
-        if (t == 1023) { s_base = base + woff + inc; }
+        if (t == 1023) { s_base = base + woff + inc; if (base + woff + inc > lim) s_over = 1; }
         __syncthreads();
     }
-    total = s_base;
-    if (t == 0) { hdr->total_edges = (int)total; if (total > cap || total < 0) hdr->use_seq = 1; }
+    if (t == 0) {
+        const long long total = s_base;
+        hdr->total_edges = (int)(total < 0x7fffffffLL ? total : 0x7fffffffLL);
+        if (total > lim || s_over) hdr->use_seq = 1;
+    }
 }
 
 // bits [start, end) of a bit image, word by word

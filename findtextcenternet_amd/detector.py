@@ -21,6 +21,8 @@ BASELINE.json's config 2 names) and ``"fp16"`` (the same plan with IEEE-half ope
 """
 from __future__ import annotations
 
+import itertools
+
 import ctypes as C
 import math
 import os
@@ -115,8 +117,9 @@ class _HipEngine:
         # objects (load_state_dict(assign=True), m.backbone = ..., parametrizations) change id().  The tensors are re-enumerated on
         # every call (~2 ms of host time for the 2400 tensors, hidden behind the previous forward's GPU work).  NOT seen: in-place
         # writes through `p.data` (its own version counter) -- call invalidate() after those.
-        ts = list(module.parameters()) + list(module.buffers())
-        return (sum(t._version for t in ts), sum(t.data_ptr() for t in ts), sum(id(t) for t in ts))
+        # The fingerprint is the exact per-tensor record (object, address, version), compared as a tuple: sums over the tensors (rounds 3-4)
+        # let two offsetting changes cancel.
+        return tuple((id(t), t.data_ptr(), t._version) for t in itertools.chain(module.parameters(), module.buffers()))
 
     def ensure_model(self, device) -> None:
         fp = self._fingerprint()

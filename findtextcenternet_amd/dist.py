@@ -85,21 +85,35 @@ def all_gather_boxes(counts: torch.Tensor, records: torch.Tensor, group: Optiona
 STATIC_GATHER_BYTES = 8 << 20      # per-rank message up to which the whole fixed-capacity record block is sent as it is
 
 
+def static_gather_rows(n_tiles: int, world: int, cap: int, row_words: int, row_hint: Optional[int]) -> int:
+    """Rows per tile that every rank sends in ``all_gather_boxes_static`` -- computed from RANK-INDEPENDENT quantities only (the global
+    tile count, the world size, the decode capacity and the caller's hint), never from the local shard: ``shard_range`` hands out uneven
+    shards, and a decision taken on the local block size can land two ranks on opposite sides of ``STATIC_GATHER_BYTES`` -- RCCL does not
+    check message sizes, the collective would hang or corrupt memory.  The whole capacity when the LARGEST shard's block is small, else
+    the hint (None: the whole capacity)."""
+    b_pad = max(1, -(-int(n_tiles) // max(1, int(world))))
+    if row_hint is None or b_pad * cap * row_words * 4 <= STATIC_GATHER_BYTES:
+        return cap
+    return max(1, min(cap, int(row_hint)))
+
+
 def all_gather_boxes_static(counts: torch.Tensor, records: torch.Tensor, n_tiles: int, group: Optional[dist.ProcessGroup] = None,
-                            feat0: int = 12, rows: Optional[int] = None) -> GatheredBoxes:
+                            feat0: int = 12, rows: Optional[int] = None, row_hint: Optional[int] = None) -> GatheredBoxes:
     """The steady-state form of ``all_gather_boxes``: NO host synchronisation, ONE collective, no copy of the record block.
 
     The counts-first protocol above needs two host round trips per step (``.item()`` for the row count, ``.cpu()`` for the other
     ranks' batch sizes), which serialise the host enqueue behind the GPU every step.  Here everything the host needs is static:
     ``n_tiles`` (the global tile count; ``shard_range`` gives every rank's share, so the padding to the largest shard is known
     without asking), and the row count -- the whole decode capacity when the block is small (8 tiles x 2048 rows x 448 B = 7.3 MB:
-    latency-bound on xGMI either way), else the caller's ``rows`` (e.g. last step's maximum, rounded up), with ``overflow`` (a device
-    flag) telling afterwards whether a tile had more peaks than were sent.  The per-tile counts travel INSIDE the block, in the first
-    padding word (column 9) of every tile's row 0 -- the box occupies columns 0..8, the feature row starts at ``feat0`` = 12.
-    NOTE: that word is written IN PLACE into the caller's ``records`` (also when there is only one rank); ``rows`` is the caller's
-    business -- ``bench.py`` and ``PageDetector`` send the whole block up to ``STATIC_GATHER_BYTES`` and a row hint above it."""
+    latency-bound on xGMI either way), else ``row_hint`` (e.g. last step's GLOBAL maximum, rounded up; it must be the same number on
+    every rank), with ``overflow`` (a device flag, identical on every rank) telling afterwards whether a tile had more peaks than were
+    sent.  ``rows`` forces a row count (tests; the caller guarantees it is rank-independent).  The per-tile counts travel INSIDE the
+    block, in the first padding word (column 9) of every tile's row 0 -- the box occupies columns 0..8, the feature row starts at
+    ``feat0`` = 12.  NOTE: that word is written IN PLACE into the caller's ``records`` (also when there is only one rank)."""
     cap = records.shape[1]
-    n_rows = cap if rows is None else max(1, min(cap, int(rows)))
+    world_ = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    n_rows = (max(1, min(cap, int(rows))) if rows is not None
+              else static_gather_rows(n_tiles, world_, cap, records.shape[2], row_hint))
     records[:, 0, 9] = counts.view(torch.float32)                  # int32 bit patterns in a padding word (in place: rows are the caller's scratch)
     block = records if n_rows == cap else records[:, :n_rows].contiguous()
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:

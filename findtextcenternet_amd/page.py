@@ -152,7 +152,7 @@ class PageDetector:
         canv = torch.zeros((7, mh, mw), dtype=torch.float32, device=self.device)
         parts = []
         import torch.distributed as tdist
-        from .dist import STATIC_GATHER_BYTES, all_gather_boxes_static, shard_range
+        from .dist import all_gather_boxes_static, shard_range
         world = tdist.get_world_size(self.group) if (self.shard and tdist.is_available() and tdist.is_initialized()) else 1
         first, last = shard_range(len(origins), tdist.get_rank(self.group), world) if world > 1 else (0, len(origins))
         n_batches = (last - first + self.batch - 1) // self.batch if last > first else 0
@@ -200,9 +200,10 @@ class PageDetector:
                 rec_l = torch.cat([r for _, _, _, r in parts]) if parts else torch.zeros((0, self.max_boxes, 112), dtype=torch.float32, device=self.device)
                 # small blocks travel whole; above STATIC_GATHER_BYTES only the rows the last page needed (+25 %), and the device
                 # overflow flag -- identical on every rank, it is computed from the gathered counts -- sends the whole block after all
-                rows = self._row_hint if rec_l.numel() * 4 > STATIC_GATHER_BYTES else None
-                g = all_gather_boxes_static(cnt_l, rec_l, len(origins), group=self.group, rows=rows)
-                if rows is not None and bool(g.overflow):
+                # (the choice is made inside all_gather_boxes_static from the GLOBAL tile count: shards are uneven, a choice on the local block
+                # size would let two ranks disagree about the message size -- round-4 advisor finding)
+                g = all_gather_boxes_static(cnt_l, rec_l, len(origins), group=self.group, row_hint=self._row_hint)
+                if g.records.shape[1] < self.max_boxes and bool(g.overflow):
                     g = all_gather_boxes_static(cnt_l, rec_l, len(origins), group=self.group)
                 tdist.all_reduce(canv, op=tdist.ReduceOp.MAX, group=self.group)
                 counts = g.counts

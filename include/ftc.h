@@ -37,8 +37,9 @@ extern "C" {
    6: ftc_plan_run_streams / FTC_FLAG_SIDE_STREAM / FTC_OP_JOIN (ops with no consumer on the main chain -- the weight gradients -- on a
       second stream)
    7: FTC_OP_MBHEAD (expand 1x1 + depthwise 3x3 + SE squeeze of an MBConv block in one launch), FTC_FLAG_SE_HPART
-   8: ftc_page_order, page_h / page_w arguments of ftc_page_merge (parallel page-level selection); FTC_FLAG_SE_INLINE */
-#define FTC_ABI_VERSION 8
+   8: ftc_page_order, page_h / page_w arguments of ftc_page_merge (parallel page-level selection); FTC_FLAG_SE_INLINE
+   9: FTC_FLAG_SE_INLINE removed (flag bit 0x20000000 is free again); FTC_MBHEAD_MAX_SQUEEZE; KBLOCK32 validation on CONV */
+#define FTC_ABI_VERSION 9
 
 typedef enum ftc_status {
     FTC_OK = 0,
@@ -71,6 +72,7 @@ typedef struct ftc_ref {
 } ftc_ref;
 
 #define FTC_MBHEAD_SLICE 128   /* expanded channels one workgroup of FTC_OP_MBHEAD owns */
+#define FTC_MBHEAD_MAX_SQUEEZE 160   /* largest SE squeeze width (aux0) for which FTC_OP_MBHEAD forms the fc1 partial products */
 
 typedef enum ftc_op_kind {
     /* conv3x3 stride 2 on the 3-channel image with x*2-1 fused (CenterNetDetection.forward,
@@ -224,14 +226,6 @@ enum {
                                   FTC_OP_MBHEAD streams per stage is whole cache lines (from NHWC it fetched half of every 128-byte line per step and
                                   ran at the L1 fill rate).  On FTC_OP_CONV: the layout of `out2` (the 16-bit trunk copy; Cout % 32 == 0); on
                                   FTC_OP_MBHEAD: the layout of `in` */
-    FTC_FLAG_SE_INLINE = 0x20000000, /* MBHEAD on a 24x24 map (aux1 = 0; ABI 8): the whole SqueezeExcitation inside the launch -- the workgroups of an image
-                                  exchange their fc1 partial products (out2) through an arrival counter, every workgroup computes the gates of
-                                  its 128 channels and `out` is written GATED (out * sigmoid(fc2(SiLU(fc1(mean)))): the project convolution
-                                  that follows needs neither FTC_OP_SE nor per-image weights.  Operands: scale = fc1 weight [S][C] with the fc1
-                                  bias [S] cin_off floats behind it, shift = fc2 weight transposed [S][C] with the fc2 bias [C] cout_off floats
-                                  behind it, in2 = 256 bytes of int32 counters that are ZERO before the launch (the launch leaves them zero;
-                                  word 2 = 1 reports a wait that ran into its bound), out2 = the exchange slots, every byte 0xFF before the
-                                  launch (FTC_OP_FILL with aux0 = 0xFF), B <= 48 */
     FTC_FLAG_SE_FOLD = 32      /* SE: besides scale[b,c], write out2[b][n][c] = bf16(in[n][c] * scale[b,c]) for the
                                   bf16 matrix `in` [Cout_total][C] -- the following 1x1 convolution then runs with
                                   FTC_FLAG_W_PER_IMAGE on unscaled activations (both operands by DMA) */

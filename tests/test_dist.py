@@ -202,18 +202,23 @@ class _NoHostSync:
             setattr(torch.Tensor, n, f)
 
 
-def _worker_static(rank, world, port, q, n_tiles, rows):
+def _worker_static(rank, world, port, q, n_tiles, rows, hint=None, thresh=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cap = 16
+    if thresh is not None:
+        import findtextcenternet_amd.dist as D
+        D.STATIC_GATHER_BYTES = thresh
     shards = [shard_range(n_tiles, r, world) for r in range(world)]
     Bs = [hi - lo for lo, hi in shards]
     counts, rec = _rank_data(rank, Bs[rank], cap)
     rec = rec.clone()
     with _NoHostSync():
-        out = all_gather_boxes_static(counts, rec, n_tiles, rows=rows)
+        out = all_gather_boxes_static(counts, rec, n_tiles, rows=rows, row_hint=hint)
     n_rows = cap if rows is None else rows
+    if hint is not None:
+        n_rows = hint if max(Bs) * cap * W * 4 > thresh else cap
     ok = out.counts.shape == (n_tiles,) and out.records.shape == (n_tiles, n_rows, W) and out.counts.dtype == torch.int32
     over = False
     for r in range(world):
@@ -233,14 +238,14 @@ def _worker_static(rank, world, port, q, n_tiles, rows):
     dist.destroy_process_group()
 
 
-def _run_static(n_tiles, rows):
+def _run_static(n_tiles, rows, hint=None, thresh=None):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker_static, args=(r, 2, port, q, n_tiles, rows)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_static, args=(r, 2, port, q, n_tiles, rows, hint, thresh)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(2))
@@ -256,6 +261,16 @@ def test_static_gather_world2_one_collective_no_host_sync():
 
 def test_static_gather_uneven_shards_and_row_hint_with_overflow_flag():
     _run_static(5, 8)                                          # shards of 3 and 2; 8 of 16 rows sent: some tiles overflow -> flag
+
+
+def test_static_gather_row_choice_is_rank_independent_when_shards_straddle_the_threshold():
+    """Round-4 advisor finding: 5 tiles over 2 ranks = shards of 3 and 2 tiles (21504 and 14336 bytes of records at 16 rows); with the
+    whole-block threshold between the two, a choice made on the LOCAL block would send 8 rows from rank 0 and 16 from rank 1 -- a
+    collective with mismatched message sizes.  The choice is made on the largest shard: both ranks send the hinted 8 rows."""
+    from findtextcenternet_amd.dist import static_gather_rows
+    assert static_gather_rows(5, 2, 16, W, 8) == 16                      # default 8 MiB threshold: small blocks travel whole
+    _run_static(5, None, hint=8, thresh=16000)
+    _run_static(4, None, hint=8, thresh=16000)                           # even shards of 2 (14336 B each): the whole 16 rows on both
 
 
 def test_static_gather_single_process_is_sync_free():

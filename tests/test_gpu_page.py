@@ -297,3 +297,81 @@ def test_page_lanes_give_the_same_page(detector):
         assert len(one[0]) > 50
         for a, b in zip(one, got):
             assert np.array_equal(a, b)
+
+
+LINEDETECT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "linedetect")
+
+
+def _linedetect(loc, lines, seps):
+    """One round trip through the REFERENCE's own consumer of the path's outputs: the `linedetect` CLI built by oracle/Makefile from
+    /root/reference/textline_detect (request format: process_ocr_base.py:80-88, parser textline_detect/src/main.cpp:100-180; reply :91-112)."""
+    import subprocess
+    req = page.linedetect_request(loc, lines, seps)
+    out = subprocess.run([LINEDETECT], input=req, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300).stdout
+    res = page.linedetect_parse(out)
+    ids = sorted(r[0] for r in res if 0 <= r[0] < len(loc))
+    assert ids == list(range(len(loc))), "every box comes back exactly once"
+    return res
+
+
+def _line_groups(res, loc):
+    """box key (ix, iy) -> the set of box keys the parser put on the same (block, line)."""
+    key = [(int(r[1]), int(r[2])) for r in loc]
+    by_line = {}
+    for r in res:
+        if 0 <= r[0] < len(loc):
+            by_line.setdefault((r[1], r[2]), []).append(key[r[0]])
+    out = {}
+    for members in by_line.values():
+        fs = frozenset(members)
+        for k in members:
+            out[k] = fs
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(LINEDETECT), reason="oracle/_ref/linedetect not built (make -C oracle; needs /root/reference in the build container)")
+def test_detect_page_output_through_the_reference_linedetect(detector):
+    """SURVEY 8(f) row 2, end to end on the GPU: PageDetector.detect_page(page) -> linedetect_request -> the reference's C++ parser ->
+    linedetect_parse, next to the same request built by the CPU path -- (a) decode_oracle.run_detector over the GPU detector's maps (the
+    host NumPy decode + merge of process_ocr_base.py:474-650: the boxes must be the SAME rows, so the parser must return the same
+    structure), (b) decode_oracle.run_detector over the CPU oracle detector's maps (the whole reference path on the CPU: the greedy merge
+    is discontinuous in its inputs, so a few boxes differ; the line structure over the common boxes must agree)."""
+    from findtextcenternet_amd.decode import HipDetectorBackend
+    step = int(768 * 0.6)
+    ph, pw = 768, 768 + step
+    img_u8 = synth.page_uint8(55, ph, pw)
+    img = img_u8.astype(np.float32)
+    ds = [{"input": img[None, :, x:x + 768], "offsetx": x, "offsety": 0} for x in (0, step)]
+    pd = page.PageDetector(detector, step_ratio=0.6, cut_off=0.4, batch=1)      # one tile per forward, as the reference's loop (and call_detector below) runs them
+    loc, gf, lines, seps = pd.detect_page(img_u8)
+    assert len(loc) > 50
+    res = _linedetect(loc, lines, seps)
+    n_lines = len({(r[1], r[2]) for r in res if r[0] >= 0})
+    # (a) the reference's host decode + merge on the GPU detector's maps
+    be = HipDetectorBackend(detector)
+    a_loc, a_gf, a_lines, a_seps, _ = decode_oracle.run_detector(ds, img, be.call_detector, 0.6, 0.4)
+    assert np.array_equal(a_loc, loc) and np.array_equal(a_gf, gf)
+    assert np.abs(a_lines - lines).max() < 1e-6 and np.abs(a_seps - seps).max() < 1e-6
+    res_a = _linedetect(a_loc, a_lines, a_seps)
+    ga, gg = _line_groups(res_a, a_loc), _line_groups(res, loc)
+    same_a = sum(ga[k] == gg[k] for k in gg) / len(gg)
+    # (b) the whole path on the CPU oracle
+    sd = deterministic_state_dict(0)
+
+    def cpu_call_detector(image_input):
+        x = torch.from_numpy(image_input / np.float32(255.)).permute(0, 3, 1, 2)
+        h, f = detector_oracle.detector_forward(sd, x)
+        return h.numpy(), f.numpy()
+    o_loc, _, o_lines, o_seps, _ = decode_oracle.run_detector(ds, img, cpu_call_detector, 0.6, 0.4)
+    res_o = _linedetect(o_loc, o_lines, o_seps)
+    go = _line_groups(res_o, o_loc)
+    common = set(go) & set(gg)
+    same_o = sum((go[k] & common) == (gg[k] & common) for k in common) / max(1, len(common))
+    n_lines_o = len({(r[1], r[2]) for r in res_o if r[0] >= 0})
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/test_detector.log", "a") as f:
+        f.write(f"linedetect end to end: gpu {len(loc)} boxes -> {n_lines} lines ({len(res)} reply rows); host decode of the GPU maps: same boxes, "
+                f"{100 * same_a:.2f}% of boxes with identical line-mates; CPU oracle path: {len(o_loc)} boxes ({len(common)} common) -> {n_lines_o} lines, "
+                f"{100 * same_o:.2f}% of common boxes with identical line-mates\n")
+    assert same_a >= 0.999
+    assert len(common) >= 0.98 * max(len(loc), len(o_loc)) and same_o >= 0.9 and abs(n_lines - n_lines_o) <= max(3, 0.1 * n_lines_o)

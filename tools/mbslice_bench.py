@@ -15,8 +15,7 @@ from findtextcenternet_amd import _lib as L  # noqa: E402
 
 lib = L.load()
 batches = [int(a) for a in sys.argv[1:]] or [8]
-XFLAGS = int(os.environ.get("MBS_FLAGS", "0"), 0)          # experiment switches of the kernel: 0x200 image-major order, 0x400 LDS-only tail barriers
-SEI = os.environ.get("MBS_SEI", "0") == "1"                # FTC_FLAG_SE_INLINE on the 24x24 shapes: the SE inside the launch, gated output
+XFLAGS = int(os.environ.get("MBS_FLAGS", "0"), 0)          # 0x100: the general (band) kernel on the 24x24 shapes
 for B in batches:
     for (H, W, Cin, Cx, S, N, R) in [(24, 24, 512, 3072, 128, 512, 0), (24, 24, 640, 3840, 160, 640, 0), (48, 48, 256, 1536, 64, 256, 10), (48, 48, 192, 768, 48, 192, 10)]:
         nb = -(-H // R) if R else 1
@@ -44,12 +43,6 @@ for B in batches:
         o.in_dtype = o.out_dtype = o.w_dtype = L.BF16
         o.B, o.H, o.W, o.Ho, o.Wo = B, H, W, H, W
         o.Cin, o.Cout, o.ksize, o.stride, o.aux0, o.aux1 = Cin, Cx, 3, 1, S, R
-        sei = SEI and R == 0
-        if sei:
-            o.flags |= L.FLAG_SE_INLINE
-            o.cin_off, o.cout_off = (off["b1"] - off["w1"]) // 4, (off["b2"] - off["w2t"]) // 4
-            ref(o, "shift", "w2t")
-            ws[off["tl"]:off["tl"] + 256] = 0
         for fld, key in (("in_", "x"), ("w2", "we"), ("bias2", "be"), ("w", "wd"), ("bias", "bd"), ("out", "out"), ("aux", "sums"), ("in2", "tl"),
                          ("scale", "w1"), ("out2", "hp")):
             ref(o, fld, key)
@@ -65,17 +58,12 @@ for B in batches:
         ms = (C.c_float * 2)()
         ts, tse = [], []
         for _ in range(15):
-            if sei:
-                ws[off["hp"]:off["hp"] + sizes["hp"]] = 0xFF                 # the exchange slots: "nothing here yet" (the plan does it with one memset)
             L.check(lib.ftc_plan_profile(h, bases, st, ms), "profile")
             ts.append(ms[0])
             tse.append(ms[1])
         torch.cuda.synchronize()
-        t0 = off["tl"] + (256 if sei else 0)
+        t0 = off["tl"]
         tl = ws[t0:t0 + nwg * 256].view(torch.int64).reshape(nwg, 32).cpu().numpy()
-        if sei:
-            print(f"      SE inline: counters after the runs {ws[off['tl']:off['tl'] + 64].view(torch.int32).cpu().numpy()[:4].tolist()}, "
-                  f"sums+fc1 -> all slices arrived {np.median(tl[:, 7] - tl[:, 3]):.0f} cycles, gates + gated store {np.median(tl[:, 4] - tl[:, 7]):.0f}", flush=True)
         d = np.diff(tl[:, :5], axis=1)
         span = (tl[:, 4].max() - tl[:, 0].min())
         fl = 2.0 * B * H * W * Cx * (Cin + 9)

@@ -26,7 +26,7 @@ MBHEAD_SLICE = 128
 
 EXPORTS = ["ftc_abi_version", "ftc_last_error", "ftc_device_info", "ftc_plan_create", "ftc_plan_destroy",
            "ftc_plan_num_ops", "ftc_plan_run", "ftc_plan_run_streams", "ftc_plan_profile", "ftc_op_kernel_label", "ftc_decode_scratch_bytes", "ftc_decode", "ftc_tile_gather", "ftc_paste_maps",
-           "ftc_page_merge_scratch_bytes", "ftc_box_hists", "ftc_page_order_scratch_bytes", "ftc_page_order", "ftc_page_merge", "ftc_adamw_schedulefree_step",
+           "ftc_page_merge_scratch_bytes", "ftc_box_hists", "ftc_page_order_scratch_bytes", "ftc_page_order", "ftc_page_merge", "ftc_page_merge_variant", "ftc_adamw_schedulefree_step",
            "ftc_create", "ftc_destroy", "ftc_weights_bytes", "ftc_weights_host", "ftc_weights_offset", "ftc_workspace_bytes", "ftc_forward",
            "ftc_model_plan", "ftc_model_op_info", "ftc_plan_op",
            "ftc_topk_mask", "ftc_mask_compact", "ftc_gather_rows", "ftc_decoder_workspace_bytes", "ftc_decoder_forward",
@@ -119,6 +119,7 @@ def load():
     lib.ftc_page_order_scratch_bytes.restype = i64
     lib.ftc_page_order.argtypes = [vp, i32, vp, C.c_float, vp, vp, vp, i64, vp]
     lib.ftc_page_merge.argtypes = [vp, vp, i32, vp, vp, C.c_float, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i64, vp]
+    lib.ftc_page_merge_variant.argtypes = [vp, vp, i32, vp, vp, C.c_float, vp, vp, i32, i32, i32, i32, i32, i32, i32, C.c_double, vp, vp, vp, vp, vp, i64, vp]
     lib.ftc_create.argtypes = [C.POINTER(Tensor), i32, C.c_char_p, i32, C.POINTER(vp)]
     lib.ftc_destroy.argtypes = [vp]
     lib.ftc_destroy.restype = None

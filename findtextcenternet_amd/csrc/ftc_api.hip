@@ -21,7 +21,7 @@ hipError_t launch_box_hists(const float* loc, int N, const float* page, int PH, 
 hipError_t launch_greedy(const float* loc, const int* order, int N, const double* hist1, const double* th, float cut_off, double* kept,
                          int* keep_idx, int* hdr, double* rb, int* status, int* cnt, int* cursor, int* nbr, long edge_cap, unsigned int* fill_big,
                          long fill_big_words, int force_seq, const float* seps, const float* codes, int mh, int mw, int scale, float* out_loc,
-                         int* out_idx, int* out_n, hipStream_t s);
+                         int* out_idx, int* out_n, int variant, int seed_start, double seed_scale, float* out_cmax, hipStream_t s);
 hipError_t launch_page_order(const float* loc, int N, const double* hist0, float cut_off, int* order, double* th, void* scratch, hipStream_t s);
 hipError_t launch_paste_maps(const float* heat, const ftc_tile* tiles, int B, int h, int w, int scale, float* canv, int ph, int pw,
                              hipStream_t s);
@@ -654,11 +654,15 @@ int ftc_box_hists(const float* locations, int n_boxes, const float* page, int pa
     return FTC_OK;
 }
 
-int ftc_page_merge(const float* locations, const int32_t* order, int n_boxes, const double* hist1, const double* threshold_dev,
-                   float cut_off, const float* seps, const float* codes, int mh, int mw, int scale, int page_h, int page_w, float* out_locations,
-                   int32_t* out_index, int32_t* out_count, void* scratch, int64_t scratch_bytes, void* stream) {
-    if (!locations || !order || !hist1 || !threshold_dev || !seps || !codes || !out_locations || !out_index || !out_count || !scratch)
+int ftc_page_merge_variant(const float* locations, const int32_t* order, int n_boxes, const double* hist1, const double* threshold_dev,
+                           float cut_off, const float* seps, const float* codes, int mh, int mw, int scale, int page_h, int page_w, int variant,
+                           int seed_start, double seed_scale, float* out_locations, int32_t* out_index, float* out_code_max, int32_t* out_count,
+                           void* scratch, int64_t scratch_bytes, void* stream) {
+    if (!locations || !order || !seps || !codes || !out_locations || !out_index || !out_count || !scratch)
         return fail(FTC_ERR_INVALID, "ftc_page_merge: null pointer argument");
+    if (variant != FTC_PAGE_MERGE_PRODUCTION && variant != FTC_PAGE_MERGE_DEMO) return fail(FTC_ERR_INVALID, "ftc_page_merge: unknown variant");
+    if (variant == FTC_PAGE_MERGE_PRODUCTION && (!hist1 || !threshold_dev)) return fail(FTC_ERR_INVALID, "ftc_page_merge: the production variant needs hist1 and threshold_dev");
+    if (variant == FTC_PAGE_MERGE_PRODUCTION && seed_start >= 0 && seed_start < n_boxes) return fail(FTC_ERR_INVALID, "ftc_page_merge: seed rows exist only in the demo variant");
     if (n_boxes <= 0 || mh <= 0 || mw <= 0 || scale <= 0 || page_h <= 0 || page_w <= 0) return fail(FTC_ERR_INVALID, "ftc_page_merge: bad sizes");
     if (n_boxes > (1 << 20)) return fail(FTC_ERR_INVALID, "ftc_page_merge: more than 2^20 boxes");
     // fixed part | coverage image of the page | neighbour lists: whatever the block has behind the image (ftc_page_merge_scratch_bytes leaves
@@ -673,9 +677,17 @@ int ftc_page_merge(const float* locations, const int32_t* order, int n_boxes, co
                                  reinterpret_cast<int*>(sp + lay.keep_idx), reinterpret_cast<int*>(sp + lay.hdr), reinterpret_cast<double*>(sp + lay.rb),
                                  reinterpret_cast<int*>(sp + lay.status), reinterpret_cast<int*>(sp + lay.cnt), reinterpret_cast<int*>(sp + lay.cursor),
                                  reinterpret_cast<int*>(sp + lay.nbr), (long)nbr_cap, reinterpret_cast<unsigned int*>(sp + lay.fill), (long)lay.fill_words,
-                                 force_seq ? 1 : 0, seps, codes, mh, mw, scale, out_locations, out_index, out_count, static_cast<hipStream_t>(stream));
+                                 force_seq ? 1 : 0, seps, codes, mh, mw, scale, out_locations, out_index, out_count, variant, seed_start, seed_scale,
+                                 out_code_max, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail_hip(e, "ftc_page_merge");
     return FTC_OK;
+}
+
+int ftc_page_merge(const float* locations, const int32_t* order, int n_boxes, const double* hist1, const double* threshold_dev,
+                   float cut_off, const float* seps, const float* codes, int mh, int mw, int scale, int page_h, int page_w, float* out_locations,
+                   int32_t* out_index, int32_t* out_count, void* scratch, int64_t scratch_bytes, void* stream) {
+    return ftc_page_merge_variant(locations, order, n_boxes, hist1, threshold_dev, cut_off, seps, codes, mh, mw, scale, page_h, page_w,
+                                  FTC_PAGE_MERGE_PRODUCTION, -1, 1.0, out_locations, out_index, nullptr, out_count, scratch, scratch_bytes, stream);
 }
 
 int ftc_adamw_schedulefree_step(const ftc_mt_chunk* chunks_dev, int n_chunks, float beta2, float one_minus_beta2, float bias_correction2,

@@ -125,6 +125,28 @@ __global__ __launch_bounds__(256) void box_hist_kernel(const float* __restrict__
     }
 }
 
+// ---- variants of the selection -------------------------------------------------------------------------------------
+// demo = 0: OCR_Processer.run_detector (process_ocr_base.py:559-650), what the rest of this file describes.
+// demo = 1: the demo script's eval() (/root/reference/test_image1_torch.py:152-240): NO contrast filter; the coverage image is filled with
+//           different offsets (p2x WITHOUT the +1, p1y WITH a +1: :196-200); and rows [seed_start, N) are the boxes a coarse first pass found
+//           on the page shrunk by `seed_scale` (twopass, :313-332: locations0[:,1:] * s) -- their columns 1..8 are multiplied by seed_scale
+//           in float64 before anything looks at them (the fp32 rows hold the unscaled values, so that the products are NumPy's).
+struct PmVar { int demo; int seed_start; double seed_scale; };
+__device__ __forceinline__ double pm_col(const float* __restrict__ loc, int i, int c, const PmVar& v) {
+    const double x = loc[(long)i * 9 + c];
+    return (c > 0 && i >= v.seed_start) ? x * v.seed_scale : x;
+}
+// coverage run of a kept box (edges d[0..3] = x0, x1, y0, y1) inside the candidate (edges c[0..3]), Python slice semantics on an fw x fh image
+__device__ __forceinline__ void pm_cover(const double* d, const double* c, long fw, long fh, int demo, long* p1x, long* p2x, long* p1y, long* p2y) {
+    long a = (long)(fmax(d[0], c[0]) - c[0]), b = (long)(fmin(d[1], c[1]) - c[0]) + (demo ? 0 : 1);
+    long e = (long)(fmax(d[2], c[2]) - c[2]) + (demo ? 1 : 0), f = (long)(fmin(d[3], c[3]) - c[2]) + 1;
+    if (a < 0) a = 0;                                               // (cannot happen: d >= c edge after fmax; kept for the cast of a NaN)
+    if (e < 0) e = 0;
+    if (b > fw) b = fw;
+    if (f > fh) f = fh;
+    *p1x = a; *p2x = b; *p1y = e; *p2y = f;
+}
+
 // ---- the greedy pass: one workgroup, boxes in score order ----
 constexpr int GT = 1024;
 constexpr int FILL_WORDS = 8192;          // LDS bit image of the candidate box: up to 262144 cells (512 x 512)
@@ -146,19 +168,19 @@ __device__ __forceinline__ double block_max(double v, double* red, int t) {
 __global__ __launch_bounds__(GT) void greedy_kernel(const float* __restrict__ loc, const int* __restrict__ order, int N,
                                                     const double* __restrict__ hist1, const double* __restrict__ th_ptr, float cut_off,
                                                     double* kept /*[N][4]: written by lane 0, read by all after a barrier*/, int* keep_idx,
-                                                    int* __restrict__ n_keep, unsigned int* fill_big, long fill_big_words, const int* use_seq) {
+                                                    int* __restrict__ n_keep, unsigned int* fill_big, long fill_big_words, const int* use_seq, const PmVar var) {
     __shared__ double red[GT / 64];
     __shared__ unsigned int fill[FILL_WORDS];
     __shared__ long long s_cnt;
     if (use_seq && !*use_seq) return;                            // (round 4) the parallel selection handled this page
     const int t = threadIdx.x;
-    const double th = *th_ptr;
+    const double th = var.demo ? 0.0 : *th_ptr;
     int nk = 0;
     for (int oi = 0; oi < N; ++oi) {
         const int i = order[oi];
-        const double p = loc[i * 9], cx = loc[i * 9 + 1], cy = loc[i * 9 + 2], w = loc[i * 9 + 3], h = loc[i * 9 + 4];
+        const double p = loc[i * 9], cx = pm_col(loc, i, 1, var), cy = pm_col(loc, i, 2, var), w = pm_col(loc, i, 3, var), h = pm_col(loc, i, 4, var);
         if (p < (double)cut_off) break;
-        if (hist1[i] < th) continue;                             // NaN threshold (no sample): never true, as in NumPy
+        if (!var.demo && hist1[i] < th) continue;                // NaN threshold (no sample): never true, as in NumPy
         const double a0 = w * h;
         const double bx0 = cx - w / 2, bx1 = cx + w / 2, by0 = cy - h / 2, by1 = cy + h / 2;
         bool drop = false;
@@ -197,10 +219,9 @@ __global__ __launch_bounds__(GT) void greedy_kernel(const float* __restrict__ lo
                         const double uni = a0 + a1 - inter;
                         const double iou = uni > 0.0 ? inter / uni : 0.0;
                         if (!(iou > 0.0)) continue;
-                        long p1x = (long)(fmax(dcx - dw / 2, bx0) - bx0), p2x = (long)(fmin(dcx + dw / 2, bx1) - bx0) + 1;
-                        long p1y = (long)(fmax(dcy - dh / 2, by0) - by0), p2y = (long)(fmin(dcy + dh / 2, by1) - by0) + 1;
-                        if (p2x > fw) p2x = fw;
-                        if (p2y > fh) p2y = fh;
+                        const double de[4] = {dcx - dw / 2, dcx + dw / 2, dcy - dh / 2, dcy + dh / 2}, ce[4] = {bx0, bx1, by0, by1};
+                        long p1x, p2x, p1y, p2y;
+                        pm_cover(de, ce, fw, fh, var.demo, &p1x, &p2x, &p1y, &p2y);
                         for (long x = p1x; x < p2x; ++x)
                             for (long y = p1y; y < p2y; ++y) {
                                 const long c = x * fh + y;
@@ -266,14 +287,14 @@ __device__ __forceinline__ PmPair pm_pair(const double* c, const double* k) {
 
 __global__ __launch_bounds__(256) void pm_prep_kernel(const float* __restrict__ loc, const int* __restrict__ order, int N, const double* __restrict__ hist1,
                                                       const double* __restrict__ th_ptr, float cut_off, double* __restrict__ rb, int* __restrict__ status,
-                                                      int* __restrict__ cnt, PmHdr* hdr, int force_seq) {
+                                                      int* __restrict__ cnt, PmHdr* hdr, int force_seq, const PmVar var) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r == 0) { hdr->n_keep = 0; hdr->ticket = 0; hdr->use_seq = force_seq; hdr->big_lock = 0; hdr->total_edges = 0; hdr->stall_r = hdr->stall_j = -1; hdr->stall_n = 0; }
     if (r > N) return;
     if (r == N) { cnt[N] = 0; return; }
     const int i = order[r];
-    const double p = loc[i * 9], cx = loc[i * 9 + 1], cy = loc[i * 9 + 2], w = loc[i * 9 + 3], h = loc[i * 9 + 4];
-    const bool elig = p >= (double)cut_off && !(hist1[i] < *th_ptr);
+    const double p = loc[i * 9], cx = pm_col(loc, i, 1, var), cy = pm_col(loc, i, 2, var), w = pm_col(loc, i, 3, var), h = pm_col(loc, i, 4, var);
+    const bool elig = p >= (double)cut_off && (var.demo || !(hist1[i] < *th_ptr));
     double* o = rb + (long)r * 6;
     o[0] = cx - w / 2; o[1] = cx + w / 2; o[2] = cy - h / 2; o[3] = cy + h / 2; o[4] = w; o[5] = h;
     status[r] = elig ? 0 : 2;
@@ -363,7 +384,7 @@ __device__ __forceinline__ void pm_set_run(long start, long end, OrFn&& orf) {
 }
 
 __global__ __launch_bounds__(256) void pm_resolve_kernel(const double* __restrict__ rb, int* status, const int* __restrict__ off, const int* __restrict__ nbr,
-                                                         int N, PmHdr* hdr, unsigned int* big_bits, long big_words) {
+                                                         int N, PmHdr* hdr, unsigned int* big_bits, long big_words, int demo) {
     __shared__ unsigned int lbits[4][PM_WAVE_WORDS];
     if (hdr->use_seq) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -454,12 +475,8 @@ __global__ __launch_bounds__(256) void pm_resolve_kernel(const double* __restric
                             double d[4];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) d[e] = __shfl(kb[e], src, 64);
-                            long p1x = (long)(fmax(d[0], c[0]) - c[0]), p2x = (long)(fmin(d[1], c[1]) - c[0]) + 1;
-                            long p1y = (long)(fmax(d[2], c[2]) - c[2]), p2y = (long)(fmin(d[3], c[3]) - c[2]) + 1;
-                            if (p2x > fw) p2x = fw;
-                            if (p2y > fh) p2y = fh;
-                            if (p1y < 0) p1y = 0;                    // (cannot happen: d >= c edge after fmax; kept for the cast of a NaN)
-                            if (p1x < 0) p1x = 0;
+                            long p1x, p2x, p1y, p2y;
+                            pm_cover(d, c, fw, fh, demo, &p1x, &p2x, &p1y, &p2y);
                             for (long x = p1x + lane; x < p2x; x += 64)
                                 pm_set_run(x * fh + p1y, x * fh + p2y, [&](long w, unsigned v) { atomicOr(&bits[w], v); });
                         }
@@ -613,7 +630,8 @@ __global__ __launch_bounds__(1024) void pm_median_kernel(const double* __restric
 // ---- separator filter (:636-643) and 3x3 maximum of the code maps (:644-650); one lane per kept box, order preserved ----
 __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ loc, const int* __restrict__ keep_idx, const int* __restrict__ n_keep,
                                                      const float* __restrict__ seps, const float* __restrict__ codes, int mh, int mw, int scale,
-                                                     float* __restrict__ out_loc, int* __restrict__ out_idx, int* __restrict__ out_n) {
+                                                     float* __restrict__ out_loc, int* __restrict__ out_idx, int* __restrict__ out_n, const PmVar var,
+                                                     float* __restrict__ out_cmax) {
     // a single workgroup keeps the output order with a prefix count
     __shared__ int s_base;
     __shared__ int s_scan[256];
@@ -628,7 +646,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ l
         bool ok = false;
         if (k < nk) {
             i = keep_idx[k];
-            const double cx = loc[i * 9 + 1], cy = loc[i * 9 + 2];
+            const double cx = pm_col(loc, i, 1, var), cy = pm_col(loc, i, 2, var);
             const long x = (long)(cx / scale), y = (long)(cy / scale);
             ok = !(x >= 0 && x < mw && y >= 0 && y < mh && seps[y * mw + x] > 0.5f);
         }
@@ -642,9 +660,10 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ l
         }
         const int pos = s_base + s_scan[t] - 1;
         if (ok) {
-            const double cx = loc[i * 9 + 1], cy = loc[i * 9 + 2];
+            const double cx = pm_col(loc, i, 1, var), cy = pm_col(loc, i, 2, var);
             float r[9];
             for (int e = 0; e < 9; ++e) r[e] = loc[i * 9 + e];
+            float cm4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};    // out_cmax: the 3x3 maxima themselves (-inf: centre outside the page, no update)
             const long x = (long)(cx / scale), y = (long)(cy / scale);
             if (x >= 0 && x < mw && y >= 0 && y < mh) {
                 const long x0 = max(0L, (long)(cx / scale - 1)), y0 = max(0L, (long)(cy / scale - 1));
@@ -660,11 +679,13 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ l
                             mx = any ? (v > mx ? v : mx) : v;
                             any = true;
                         }
-                    if (any) m = mx > m ? mx : m;
+                    if (any) { m = mx > m ? mx : m; cm4[c] = mx; }
                     r[5 + c] = m;
                 }
             }
             for (int e = 0; e < 9; ++e) out_loc[(long)pos * 9 + e] = r[e];
+            if (out_cmax)
+                for (int c = 0; c < 4; ++c) out_cmax[(long)pos * 4 + c] = cm4[c];
             out_idx[pos] = i;
         }
         __syncthreads();
@@ -686,21 +707,22 @@ hipError_t launch_box_hists(const float* loc, int N, const float* page, int PH, 
 hipError_t launch_greedy(const float* loc, const int* order, int N, const double* hist1, const double* th, float cut_off, double* kept,
                          int* keep_idx, int* hdr_, double* rb, int* status, int* cnt, int* cursor, int* nbr, long edge_cap, unsigned int* fill_big,
                          long fill_big_words, int force_seq, const float* seps, const float* codes, int mh, int mw, int scale, float* out_loc,
-                         int* out_idx, int* out_n, hipStream_t s) {
+                         int* out_idx, int* out_n, int variant, int seed_start, double seed_scale, float* out_cmax, hipStream_t s) {
     PmHdr* hdr = reinterpret_cast<PmHdr*>(hdr_);
+    const PmVar var{variant ? 1 : 0, (variant && seed_start >= 0) ? seed_start : N, seed_scale};
     const int T = (N + PM_T - 1) / PM_T;
-    hipLaunchKernelGGL(pm_prep_kernel, dim3((N + 256) / 256), dim3(256), 0, s, loc, order, N, hist1, th, cut_off, rb, status, cnt, hdr, force_seq);
+    hipLaunchKernelGGL(pm_prep_kernel, dim3((N + 256) / 256), dim3(256), 0, s, loc, order, N, hist1, th, cut_off, rb, status, cnt, hdr, force_seq, var);
     hipLaunchKernelGGL(pm_pairs_kernel<false>, dim3(T, T), dim3(PM_T), 0, s, rb, status, N, cnt, nbr, hdr);
     hipLaunchKernelGGL(pm_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, cursor, N, edge_cap, hdr);
     hipLaunchKernelGGL(pm_pairs_kernel<true>, dim3(T, T), dim3(PM_T), 0, s, rb, status, N, cursor, nbr, hdr);
     int ncu = 256;
-    hipLaunchKernelGGL(pm_resolve_kernel, dim3(ncu * 2), dim3(256), 0, s, rb, status, cnt, nbr, N, hdr, fill_big, fill_big_words);
+    hipLaunchKernelGGL(pm_resolve_kernel, dim3(ncu * 2), dim3(256), 0, s, rb, status, cnt, nbr, N, hdr, fill_big, fill_big_words, var.demo);
     hipLaunchKernelGGL(greedy_kernel, dim3(1), dim3(GT), 0, s, loc, order, N, hist1, th, cut_off, kept, keep_idx, &hdr->n_keep, fill_big, fill_big_words,
-                       (const int*)&hdr->use_seq);
+                       (const int*)&hdr->use_seq, var);
     hipLaunchKernelGGL(pm_compact_kernel, dim3(1), dim3(1024), 0, s, status, order, N, keep_idx, hdr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, s, loc, keep_idx, (const int*)&hdr->n_keep, seps, codes, mh, mw, scale, out_loc, out_idx, out_n);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, s, loc, keep_idx, (const int*)&hdr->n_keep, seps, codes, mh, mw, scale, out_loc, out_idx, out_n, var, out_cmax);
     return hipGetLastError();
 }
 

@@ -46,20 +46,32 @@ def tile_origins(page_h: int, page_w: int, stepx: int, stepy: int) -> List[Tuple
 # ------------------------------------------------------------------------------------------------
 # page-level selection on the GPU (process_ocr_base.py:540-648)
 # ------------------------------------------------------------------------------------------------
-def page_merge_gpu(boxes: torch.Tensor, feats: torch.Tensor, page: torch.Tensor, canv: torch.Tensor, cut_off: float):
+def page_merge_gpu(boxes: torch.Tensor, feats: torch.Tensor, page, canv: torch.Tensor, cut_off: float, variant: str = "production",
+                   seed_start: int = -1, seed_scale: float = 1.0):
     """GPU page-level selection.  boxes [N,9] fp32 (rows with p < cut_off are inert, e.g. the zero padding of
     ``decode_peaks``), feats [N,C] fp32, page [H,W,3] fp32 0..255, canv [7,mh,mw] fp32 (``ftc_paste_maps``), all on the GPU.
-    Returns device tensors (locations [M,9] fp32, glyphfeatures [M,C] fp32); one host sync (the kept count)."""
+    Returns device tensors (locations [M,9] fp32, glyphfeatures [M,C] fp32); one host sync (the kept count).
+
+    ``variant="demo"``: the selection of the demo script's ``eval()`` (``/root/reference/test_image1_torch.py:152-240``: no contrast filter --
+    ``page`` may be a ``(page_h, page_w)`` tuple --, its ``fill_map`` offsets) with rows ``[seed_start, N)`` = the UNSCALED boxes of a coarse
+    first pass, multiplied by ``seed_scale`` in float64 inside the kernels (``:313-332``); returns (locations float64 [M,9] numpy -- eval()'s own
+    result rows: seed rows scaled, ``max(code maximum, code)`` in float64 --, glyphfeatures [M,C] device tensor)."""
     lib = L.load()
     dev = boxes.device
     boxes = boxes.contiguous()
     N = boxes.shape[0]
-    ph, pw = page.shape[:2]
+    demo = variant == "demo"
+    if variant not in ("production", "demo"):
+        raise ValueError("variant must be 'production' or 'demo'")
+    ph, pw = (page if demo and isinstance(page, tuple) else page.shape[:2])
     mh, mw = canv.shape[1:]
     with torch.cuda.device(dev):
         stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        hist = torch.empty((2, N), dtype=torch.float64, device=dev)
-        L.check(lib.ftc_box_hists(boxes.data_ptr(), N, page.data_ptr(), ph, pw, C.c_float(cut_off), hist.data_ptr(), stream), "ftc_box_hists")
+        if demo:
+            hist = torch.zeros((2, N), dtype=torch.float64, device=dev)            # (no contrast filter: ftc_page_order only ranks)
+        else:
+            hist = torch.empty((2, N), dtype=torch.float64, device=dev)
+            L.check(lib.ftc_box_hists(boxes.data_ptr(), N, page.data_ptr(), ph, pw, C.c_float(cut_off), hist.data_ptr(), stream), "ftc_box_hists")
         # order = the rows with p >= cut_off in stable score order (then the rest), threshold = np.median(hists) / 5 over the rows with p >= cut_off -- in-tree kernels (rank by
         # counting, radix select), results identical to torch.sort / np.median
         order = torch.empty((N,), dtype=torch.int32, device=dev)
@@ -74,14 +86,31 @@ def page_merge_gpu(boxes: torch.Tensor, feats: torch.Tensor, page: torch.Tensor,
         nbytes = int(lib.ftc_page_merge_scratch_bytes(N, ph, pw))
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         codes = canv[3:7].contiguous()
-        L.check(lib.ftc_page_merge(boxes.data_ptr(), order.data_ptr(), N, hist[1].data_ptr(), th.data_ptr(), C.c_float(cut_off),
-                                   canv[2].data_ptr(), codes.data_ptr(), mh, mw, scale, ph, pw, out_loc.data_ptr(), out_idx.data_ptr(),
-                                   out_n.data_ptr(), scratch.data_ptr(), nbytes, stream), "ftc_page_merge")
+        if not demo:
+            L.check(lib.ftc_page_merge(boxes.data_ptr(), order.data_ptr(), N, hist[1].data_ptr(), th.data_ptr(), C.c_float(cut_off),
+                                       canv[2].data_ptr(), codes.data_ptr(), mh, mw, scale, ph, pw, out_loc.data_ptr(), out_idx.data_ptr(),
+                                       out_n.data_ptr(), scratch.data_ptr(), nbytes, stream), "ftc_page_merge")
+        else:
+            out_cm = torch.empty((N, 4), dtype=torch.float32, device=dev)
+            L.check(lib.ftc_page_merge_variant(boxes.data_ptr(), order.data_ptr(), N, None, None, C.c_float(cut_off), canv[2].data_ptr(), codes.data_ptr(),
+                                               mh, mw, scale, ph, pw, 1, int(seed_start), C.c_double(seed_scale), out_loc.data_ptr(), out_idx.data_ptr(),
+                                               out_cm.data_ptr(), out_n.data_ptr(), scratch.data_ptr(), nbytes, stream), "ftc_page_merge_variant")
         n = int(out_n.item())
         if n < 0:
             raise RuntimeError("ftc_page_merge: a box is larger than the page-sized coverage bitmap")
         sel = out_idx[:n].long()
-        return out_loc[:n], feats.index_select(0, sel)
+        if not demo:
+            return out_loc[:n], feats.index_select(0, sel)
+        # eval()'s float64 rows (test_image1_torch.py:147-151, :233): the selected INPUT rows, seed rows scaled in float64, codes = max(3x3 maximum, code)
+        rows = boxes.index_select(0, sel).cpu().numpy().astype(np.float64)
+        src = sel.cpu().numpy()
+        if 0 <= seed_start < N:
+            seeded = src >= seed_start
+            rows[seeded, 1:] = rows[seeded, 1:] * float(seed_scale)
+        cm = out_cm[:n].cpu().numpy().astype(np.float64)
+        upd = np.isfinite(cm[:, 0])
+        rows[upd, 5:9] = np.where(rows[upd, 5:9] > cm[upd], rows[upd, 5:9], cm[upd])          # max(a, b) of Python: b only if b > a
+        return rows, feats.index_select(0, sel)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -91,7 +120,16 @@ class PageDetector:
     """``run_detector`` / tiling of ``OCR_Processer`` on top of a HIP ``CenterNetDetector``."""
 
     def __init__(self, detector, step_ratio: float = 0.6, cut_off: float = 0.4, batch: int = 8, max_boxes: int = 4096,
-                 device: str = "cuda", group=None, shard: bool = True, lanes: int = 2):
+                 device: str = "cuda", group=None, shard: bool = True, lanes: int = 2, variant: str = "production", twopass: bool = False):
+        """variant="demo": the tiling, border margins and page-level selection of the demo script instead of the production class --
+        ``/root/reference/test_image1_torch.py``: step = 3/4 of a tile (``:298-299``), 1/8 margins (``:103-108``), ``eval()``'s selection
+        (``:152-240``; float64 result rows); ``twopass`` (its command-line switch, ``:313-332``): a page of more than 2 steps is first run
+        shrunk onto ONE tile and the boxes found there join the candidates of the full-resolution pass, scaled back."""
+        if variant not in ("production", "demo"):
+            raise ValueError("variant must be 'production' or 'demo'")
+        if twopass and variant != "demo":
+            raise ValueError("twopass is the demo script's mode: variant='demo'")
+        self.variant, self.twopass = variant, bool(twopass)
         self.device = torch.device(device)
         detector.to(device=self.device)
         detector.eval()
@@ -108,6 +146,8 @@ class PageDetector:
         self._lane_streams, self._lane_ws = None, {}
         self._row_hint = None                                  # rows per tile the last page needed (multi-GPU gather of large blocks)
         self.stepx, self.stepy = int(width * step_ratio), int(height * step_ratio)      # process_ocr_base.py:43-45
+        if variant == "demo":
+            self.stepx, self.stepy = width * 3 // 4, height * 3 // 4                     # test_image1_torch.py:298-299
 
     # -- reference signature -----------------------------------------------------------------
     def run_detector(self, ds: Sequence[dict], org_img: np.ndarray):
@@ -141,19 +181,42 @@ class PageDetector:
             full = torch.full((ph, pw, 3), 255.0, dtype=torch.float32, device=self.device)
             full[:h0, :w0] = page_dev.float()
             return full
-        return self._run(gather, origins, (ph, pw), padded_page)
+        seeds = None
+        if self.twopass and (pw / self.stepx > 2 or ph / self.stepy > 2):
+            seeds = self._coarse_pass(im_u8, ph, pw)
+        return self._run(gather, origins, (ph, pw), padded_page, seeds=seeds)
+
+    def _coarse_pass(self, im_u8: np.ndarray, ph: int, pw: int):
+        """The first pass of the demo script's two-pass mode (test_image1_torch.py:313-332): the white-padded page shrunk by
+        s = max(W, H) / 768 with PIL's bilinear filter (the reference's own resampler: host code there as well), padded to one tile, through the
+        same detector and the demo selection (cut_off 0.4).  Returns (locations0 UNSCALED fp32 [K,9] on the GPU, glyphfeatures0 [K,C], s)."""
+        from PIL import Image
+        im0 = np.full((ph, pw, 3), 255, np.uint8)
+        im0[:im_u8.shape[0], :im_u8.shape[1]] = im_u8[:, :, :3]
+        s_ = max(im0.shape[1], im0.shape[0]) / max(width, height)
+        im1 = np.asarray(Image.fromarray(im0).resize((int(im0.shape[1] / s_), int(im0.shape[0] / s_)), resample=Image.BILINEAR))
+        px, py = max(0, width - im1.shape[1]), max(0, height - im1.shape[0])
+        im1 = np.pad(im1, [[0, py], [0, px], [0, 0]], "constant", constant_values=255)
+        x1 = torch.from_numpy((im1.astype(np.float32) / np.float32(255.))[None]).to(self.device)
+        loc0, gf0, _, _ = self._run(lambda lo, hi: x1[lo:hi], [(0, 0)], im1.shape[:2], None, cut_off=0.4, world1=True)
+        if loc0.shape[0] and not np.array_equal(loc0.astype(np.float32).astype(np.float64), loc0):
+            raise RuntimeError("coarse-pass rows are not fp32 values")              # (cannot happen: no seed rows in the coarse pass)
+        return torch.from_numpy(loc0.astype(np.float32)).to(self.device), torch.from_numpy(gf0).to(self.device), float(s_)
 
     # -- shared ------------------------------------------------------------------------------------
-    def _run(self, get_tiles, origins, page_hw, page_f32):
-        """get_tiles(lo, hi) -> [n,768,768,3] fp32 0..1 on the GPU; page_hw = (padded) page size; page_f32() -> the padded fp32 page on the GPU."""
+    def _run(self, get_tiles, origins, page_hw, page_f32, seeds=None, cut_off=None, world1=False):
+        """get_tiles(lo, hi) -> [n,768,768,3] fp32 0..1 on the GPU; page_hw = (padded) page size; page_f32() -> the padded fp32 page on the GPU.
+        seeds (demo variant) = (locations0 fp32 [K,9] unscaled, glyphfeatures0 [K,C], scale) of a coarse pass; world1: no sharding (the coarse pass)."""
         lib = L.load()
+        cut = self.cut_off if cut_off is None else cut_off
+        demo = self.variant == "demo"
         page_h, page_w = page_hw
         mh, mw = page_h // scale, page_w // scale
         canv = torch.zeros((7, mh, mw), dtype=torch.float32, device=self.device)
         parts = []
         import torch.distributed as tdist
         from .dist import all_gather_boxes_static, shard_range
-        world = tdist.get_world_size(self.group) if (self.shard and tdist.is_available() and tdist.is_initialized()) else 1
+        world = tdist.get_world_size(self.group) if (self.shard and not world1 and tdist.is_available() and tdist.is_initialized()) else 1
         first, last = shard_range(len(origins), tdist.get_rank(self.group), world) if world > 1 else (0, len(origins))
         n_batches = (last - first + self.batch - 1) // self.batch if last > first else 0
         n_lanes = min(self.lanes, max(1, n_batches))
@@ -173,7 +236,7 @@ class PageDetector:
                 streams = [main]
             # every tile's geometry record in ONE upload, before any forward is enqueued: a host-to-device copy from pageable memory waits for
             # the stream it is issued on, and inside the loop that was the forward just enqueued (round 4: 2-4 ms of GPU idle per batch)
-            geoms = [TileGeom(ox, oy, page_w, page_h, tile_keep_rect(ox, oy, page_w, page_h, self.step_ratio)) for (oy, ox) in origins[first:last]]
+            geoms = [TileGeom(ox, oy, page_w, page_h, tile_keep_rect(ox, oy, page_w, page_h, None if demo else self.step_ratio)) for (oy, ox) in origins[first:last]]
             tl_all = tiles_to_device(geoms, self.device, height // scale, width // scale) if geoms else None
             if n_lanes > 1:
                 for s_ in streams:
@@ -188,7 +251,7 @@ class PageDetector:
                     stream = torch.cuda.current_stream(self.device).cuda_stream
                     L.check(lib.ftc_paste_maps(heat.data_ptr(), tl.data_ptr(), hi - lo, heat.shape[1], heat.shape[2], scale, canv.data_ptr(),
                                                mh, mw, C.c_void_p(stream)), "ftc_paste_maps")
-                    dec = decode_peaks(heat, feat, tl, cut_off=self.cut_off, max_boxes=self.max_boxes)
+                    dec = decode_peaks(heat, feat, tl, cut_off=cut, max_boxes=self.max_boxes)
                     parts.append((dec.counts, dec.boxes, dec.feats, dec.records))
             if n_lanes > 1:
                 for s_ in streams:
@@ -213,13 +276,20 @@ class PageDetector:
                 counts = torch.cat([c for c, _, _, _ in parts])
                 boxes = torch.cat([b.reshape(-1, 9) for _, b, _, _ in parts])
                 fts = torch.cat([f.reshape(-1, f.shape[-1]) for _, _, f, _ in parts])
-            loc_d, glyph_d = page_merge_gpu(boxes, fts, page_f32(), canv, self.cut_off)
+            if demo:
+                n_tile_rows = boxes.shape[0]
+                if seeds is not None and seeds[0].shape[0]:
+                    boxes, fts = torch.cat([boxes, seeds[0]]), torch.cat([fts, seeds[1]])
+                loc_d, glyph_d = page_merge_gpu(boxes, fts, (page_h, page_w), canv, cut, variant="demo", seed_start=n_tile_rows,
+                                                seed_scale=seeds[2] if seeds is not None else 1.0)
+            else:
+                loc_d, glyph_d = page_merge_gpu(boxes, fts, page_f32(), canv, cut)
             cmax = int(counts.max().item())
             if cmax > self.max_boxes:
                 raise RuntimeError(f"a tile produced {cmax} peaks > max_boxes={self.max_boxes}; raise max_boxes")
             self._row_hint = min(self.max_boxes, (cmax + cmax // 4 + 64) // 64 * 64)      # next page's gather: rows sent when the block is large
             canv_h = canv[1:3].cpu().numpy()
-            return loc_d.cpu().numpy(), glyph_d.cpu().numpy(), canv_h[0], canv_h[1]
+            return (loc_d if demo else loc_d.cpu().numpy()), glyph_d.cpu().numpy(), canv_h[0], canv_h[1]
 
 
 def linedetect_request(locations: np.ndarray, lines: np.ndarray, seps: np.ndarray) -> bytes:

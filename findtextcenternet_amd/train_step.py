@@ -747,9 +747,34 @@ class TrainStep:
         whole accumulated buffer in place, so pass ``sync_grads=False`` on every micro-batch but the LAST before ``optimizer.step()``;
         a second synchronising call without ``zero_grad()`` in between would re-sum already-reduced gradients and raises.
         A caller-supplied ``fmask`` must select exactly the plan's row count (min(1024 * B, B * h * w) pixels, what ``get_fmask`` selects)."""
+        st = self._begin(image, fmask if fmask is not None else self.module.get_fmask(labelmap, None), keep, generator, loss_scale, check_mask=fmask is not None)
+        lib = L.load()
+        dev, plan = st["dev"], st["plan"]
+        with torch.cuda.device(dev):
+            self._set_labels(st, labelmap, idmap)
+            L.check(lib.ftc_plan_run(plan["handle"], st["bases"], st["stream"], 0, plan["n_fwd"] - 1), "ftc_plan_run (train step, forward)")
+            lossv = self._view(plan["lossv"], (16,))
+            raw = {k: lossv[i] for i, k in enumerate(LOSS_KEYS)}
+            if alphas is not None:
+                a = alphas.to(device=dev, dtype=torch.float32)
+                loss = (a * lossv[1:10]).sum()
+            else:
+                if self.cov is None:
+                    from .loss_func import CoVWeightingLoss
+                    self.cov = CoVWeightingLoss(device=dev, losses=COV_KEYS)
+                loss = self.cov(raw)
+                a = self.cov.alphas
+            if backward:
+                self._backward(st, a, sync_grads)
+            self._end(st)
+        return loss, {k: v.clone() for k, v in raw.items()}
+
+    # ---- the phases of a step (forward_backward above = all of them; the train1.py-callable seam below runs them one by one) ----------
+    def _begin(self, image: torch.Tensor, fmask: torch.Tensor, keep, generator, loss_scale: float, check_mask: bool = True) -> dict:
+        """Everything in front of the plan run except the labels: plan + arena, selected-pixel indices, the frozen detector's maps
+        (decoder_only), the StochasticDepth draw, the weight re-pack."""
         if not image.is_cuda:
             raise RuntimeError("findtextcenternet_amd: the train step runs on MI355X (gfx950) only (there is no CPU fallback)")
-        lib = L.load()
         dev = image.device
         x = image.float()
         B, _, H, W = x.shape
@@ -763,12 +788,9 @@ class TrainStep:
             if self.workspace is None or self.workspace.numel() < plan["workspace_bytes"]:
                 self.workspace = torch.empty(plan["workspace_bytes"], dtype=torch.uint8, device=dev)
             mh, mw, n_rows = plan["mh"], plan["mw"], plan["n_rows"]
-            own_mask = fmask is None
-            if own_mask:
-                fmask = self.module.get_fmask(labelmap, None)
             from .loss_func import mask_to_index
             sel, _cnt = mask_to_index(fmask)
-            if not own_mask and int(_cnt.reshape(-1)[0].item()) != n_rows:       # (one host sync, only for masks this step did not compute)
+            if check_mask and int(_cnt.reshape(-1)[0].item()) != n_rows:       # (one host sync, only for masks this step did not compute)
                 raise ValueError(f"forward_backward: fmask selects {int(_cnt.reshape(-1)[0].item())} pixels, the plan gathers {n_rows} rows "
                                  "(rows beyond the count would be read from uninitialised indices)")
             self._view(plan["sel"], (n_rows,), torch.int32).copy_(sel[:n_rows])
@@ -781,8 +803,6 @@ class TrainStep:
                 idx9 = torch.tensor([0, 2, 3, 4, 5, 6, 7, 8, 9], device=dev)
                 self._view(plan["maps"], (B, mh, mw, 9)).copy_(heat.index_select(3, idx9))
                 self._view(plan["feats"], (B, mh, mw, 100)).copy_(feat)
-            self._view(plan["lab"], (B, 5, mh, mw)).copy_(labelmap.to(torch.float32))
-            self._view(plan["idm"], (B, 2, mh, mw), torch.int32).copy_(idmap.to(torch.int32))
             # StochasticDepth draw (torchvision "row" mode)
             n_res = len(plan["res_names"])
             Bp = _align(B, 4)
@@ -805,48 +825,90 @@ class TrainStep:
             self.pack()
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             bases = (C.c_void_p * L.NUM_BASES)(None, self.workspace.data_ptr(), self.blob.data_ptr(), xn.data_ptr(), None, None, self.grads.data_ptr())
-            L.check(lib.ftc_plan_run(plan["handle"], bases, stream, 0, plan["n_fwd"] - 1), "ftc_plan_run (train step, forward)")
-            lossv = self._view(plan["lossv"], (16,))
-            raw = {k: lossv[i] for i, k in enumerate(LOSS_KEYS)}
-            if alphas is not None:
-                a = alphas.to(device=dev, dtype=torch.float32)
-                loss = (a * lossv[1:10]).sum()
-            else:
-                if self.cov is None:
-                    from .loss_func import CoVWeightingLoss
-                    self.cov = CoVWeightingLoss(device=dev, losses=COV_KEYS)
-                loss = self.cov(raw)
-                a = self.cov.alphas
-            self._view(plan["alphas"], (9,)).copy_(a)
-            side = None
-            if self.two_streams:
-                if self.side_stream is None or self.side_stream.device != dev:
-                    self.side_stream = torch.cuda.Stream(device=dev)
-                side = C.c_void_p(self.side_stream.cuda_stream)
-            if backward and (ddp is None or world == 1 or not sync_grads):
-                L.check(lib.ftc_plan_run_streams(plan["handle"], bases, stream, side, plan["n_fwd"], -1), "ftc_plan_run_streams (train step, backward)")
-            elif backward:
-                if getattr(self, "_grads_synced", False):
-                    raise RuntimeError("forward_backward(sync_grads=True) twice without zero_grad(): the gradient buffer already holds the all-reduced "
-                                       "sum; accumulate with sync_grads=False on all but the last micro-batch")
-                self._grads_synced = True
-                key = (B, H, W, float(loss_scale / world))
-                if key not in self._segments:
-                    self._segments[key] = self._bucket_segments(plan)
-                cur = torch.cuda.current_stream(dev)
-                for first, last, bi in self._segments[key]:
-                    if first <= last:
-                        L.check(lib.ftc_plan_run_streams(plan["handle"], bases, stream, side, first, last), "ftc_plan_run_streams (train step, backward segment)")
-                    if bi is not None:
-                        self.comm_stream.wait_stream(cur)                 # the bucket is complete once everything enqueued so far has run
-                        with torch.cuda.stream(self.comm_stream):
-                            ddp.reduce_bucket(bi, async_op=True)
-                ddp.wait()
-                cur.wait_stream(self.comm_stream)
-            torch._foreach_add_(self.counters if not self.decoder_only else self.decoder_counters, 1)
-            from .optim import bump_versions
-            bump_versions(self.stat_buffers)           # the kernels moved the running statistics in place
-        return loss, {k: v.clone() for k, v in raw.items()}
+        return dict(dev=dev, plan=plan, B=B, H=H, W=W, xn=xn, bases=bases, stream=stream, world=world, ddp=ddp, loss_scale=loss_scale)
+
+    def _set_labels(self, st: dict, labelmap: torch.Tensor, idmap: torch.Tensor) -> None:
+        plan, B = st["plan"], st["B"]
+        self._view(plan["lab"], (B, 5, plan["mh"], plan["mw"])).copy_(labelmap.to(torch.float32))
+        self._view(plan["idm"], (B, 2, plan["mh"], plan["mw"]), torch.int32).copy_(idmap.to(torch.int32))
+
+    def _backward(self, st: dict, a: torch.Tensor, sync_grads: bool = True) -> None:
+        """a = the nine loss weights (the detached CoV alphas, or d loss / d loss_i of whatever the caller built): the backward ops of the plan."""
+        lib = L.load()
+        dev, plan, ddp, world = st["dev"], st["plan"], st["ddp"], st["world"]
+        bases, stream = st["bases"], st["stream"]
+        self._view(plan["alphas"], (9,)).copy_(a.to(device=dev, dtype=torch.float32))
+        side = None
+        if self.two_streams:
+            if self.side_stream is None or self.side_stream.device != dev:
+                self.side_stream = torch.cuda.Stream(device=dev)
+            side = C.c_void_p(self.side_stream.cuda_stream)
+        if ddp is None or world == 1 or not sync_grads:
+            L.check(lib.ftc_plan_run_streams(plan["handle"], bases, stream, side, plan["n_fwd"], -1), "ftc_plan_run_streams (train step, backward)")
+            return
+        if getattr(self, "_grads_synced", False):
+            raise RuntimeError("forward_backward(sync_grads=True) twice without zero_grad(): the gradient buffer already holds the all-reduced "
+                               "sum; accumulate with sync_grads=False on all but the last micro-batch")
+        self._grads_synced = True
+        key = (st["B"], st["H"], st["W"], float(st["loss_scale"] / world))
+        if key not in self._segments:
+            self._segments[key] = self._bucket_segments(plan)
+        cur = torch.cuda.current_stream(dev)
+        for first, last, bi in self._segments[key]:
+            if first <= last:
+                L.check(lib.ftc_plan_run_streams(plan["handle"], bases, stream, side, first, last), "ftc_plan_run_streams (train step, backward segment)")
+            if bi is not None:
+                self.comm_stream.wait_stream(cur)                 # the bucket is complete once everything enqueued so far has run
+                with torch.cuda.stream(self.comm_stream):
+                    ddp.reduce_bucket(bi, async_op=True)
+        ddp.wait()
+        cur.wait_stream(self.comm_stream)
+
+    def _end(self, st: dict) -> None:
+        torch._foreach_add_(self.counters if not self.decoder_only else self.decoder_counters, 1)
+        from .optim import bump_versions
+        bump_versions(self.stat_buffers)           # the kernels moved the running statistics in place
+
+    # ---- the reference's own calling sequence ---------------------------------------------------------------------------------------
+    # train1.py:125-131 + :174-179 --   heatmap, decoder_outputs = model(image, fmask);  rawloss = loss_function(fmask, map, idmap, heatmap,
+    # decoder_outputs);  loss = CoWloss(rawloss);  (loss / iters_to_accumulate).backward();  optimizer.step()
+    # -- runs the SAME plan in three pieces: TextDetectorModel.forward (train mode, grad enabled) -> seam_forward (every op but the loss op),
+    # loss_function -> seam_losses (labels in, the loss op; the returned values carry an autograd node), CoVWeightingLoss -> a differentiable
+    # sum with detached alphas, .backward() -> seam_backward with d loss / d loss_i as the nine weights.  Same kernels, same arithmetic as
+    # forward_backward (tests/test_gpu_train_step.py::test_reference_calling_sequence_equals_forward_backward).
+    def seam_forward(self, image: torch.Tensor, fmask: torch.Tensor, keep=None, generator=None):
+        lib = L.load()
+        st = self._begin(image, fmask, keep if keep is not None else self.module.__dict__.get("stochastic_depth_keep"), generator, 1.0)
+        plan, dev, B = st["plan"], st["dev"], st["B"]
+        with torch.cuda.device(dev):
+            L.check(lib.ftc_plan_run(plan["handle"], st["bases"], st["stream"], 0, plan["n_fwd"] - 2), "ftc_plan_run (train step, forward without the loss op)")
+            heat = self._view(plan["maps"], (B, plan["mh"], plan["mw"], 9)).permute(0, 3, 1, 2).clone()
+            decs = [self._view(b, (plan["n_rows"], m)).clone() for b, m in zip(plan["dec_outs"], (1091, 1093, 1097))]
+        st["phase"] = "forward"
+        self._seam = st
+        return heat, decs
+
+    def seam_losses(self, fmask: torch.Tensor, labelmap: torch.Tensor, idmap: torch.Tensor) -> torch.Tensor:
+        st = getattr(self, "_seam", None)
+        if st is None or st.get("phase") not in ("forward", "losses"):
+            raise RuntimeError("loss_function on train-mode outputs needs the model(image, fmask) call of THIS step in front of it")
+        lib = L.load()
+        plan = st["plan"]
+        with torch.cuda.device(st["dev"]):
+            self._set_labels(st, labelmap, idmap)
+            L.check(lib.ftc_plan_run(plan["handle"], st["bases"], st["stream"], plan["n_fwd"] - 1, plan["n_fwd"] - 1), "ftc_plan_run (train step, loss op)")
+            out = self._view(plan["lossv"], (16,)).clone()
+        st["phase"] = "losses"
+        return out
+
+    def seam_backward(self, weights9: torch.Tensor, sync_grads: bool = True) -> None:
+        st = getattr(self, "_seam", None)
+        if st is None or st.get("phase") != "losses":
+            raise RuntimeError("backward of a train-mode loss: the step's activations are gone (one backward per model(image, fmask) call)")
+        with torch.cuda.device(st["dev"]):
+            self._backward(st, weights9, sync_grads)
+            self._end(st)
+        self._seam = None
 
     # ---- data-parallel gradients ----------------------------------------------------------------------------------------------
     def enable_ddp(self, group=None, bucket_bytes: int = 256 << 20) -> None:

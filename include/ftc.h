@@ -38,7 +38,8 @@ extern "C" {
       second stream)
    7: FTC_OP_MBHEAD (expand 1x1 + depthwise 3x3 + SE squeeze of an MBConv block in one launch), FTC_FLAG_SE_HPART
    8: ftc_page_order, page_h / page_w arguments of ftc_page_merge (parallel page-level selection); FTC_FLAG_SE_INLINE
-   9: FTC_FLAG_SE_INLINE removed (flag bit 0x20000000 is free again); FTC_MBHEAD_MAX_SQUEEZE; KBLOCK32 validation on CONV */
+   9: FTC_FLAG_SE_INLINE removed (flag bit 0x20000000 is free again); FTC_MBHEAD_MAX_SQUEEZE; KBLOCK32 validation on CONV;
+      ftc_page_merge_variant (the demo script's selection + two-pass seed rows) */
 #define FTC_ABI_VERSION 9
 
 typedef enum ftc_status {
@@ -452,6 +453,20 @@ int ftc_page_order(const float* locations, int n_boxes, const double* hist0, flo
 int ftc_page_merge(const float* locations, const int32_t* order, int n_boxes, const double* hist1, const double* threshold_dev,
                    float cut_off, const float* seps, const float* codes, int mh, int mw, int scale, int page_h, int page_w,
                    float* out_locations, int32_t* out_index, int32_t* out_count, void* scratch, int64_t scratch_bytes, void* stream);
+/* The same selection in the variant of the reference's demo script (ABI 9): eval() of /root/reference/test_image1_torch.py:152-240 differs from
+ * OCR_Processer.run_detector in three ways -- no contrast filter (hist1 / threshold_dev unused, may be NULL); the coverage image is filled with
+ * the offsets of :196-200 (p2x without the +1, p1y with a +1); and its two-pass mode (:313-332) appends the boxes of a coarse first pass,
+ * multiplied by the shrink factor in float64 (`locations0[:,1:] * s`): rows [seed_start, n_boxes) are such seed rows, given UNSCALED in
+ * fp32, and their columns 1..8 are multiplied by seed_scale in float64 wherever the selection reads them (seed_start < 0 or >= n_boxes: none).
+ * out_locations holds the selected fp32 rows as given (codes updated as in the production variant, from the unscaled values); out_code_max
+ * (optional, [<=N,4] fp32) the 3x3 code-map maxima themselves (-inf where the centre lies outside the page), so that a caller can form
+ * eval()'s float64 result rows: max(code maximum, code column * seed_scale).  variant = FTC_PAGE_MERGE_PRODUCTION: exactly ftc_page_merge. */
+#define FTC_PAGE_MERGE_PRODUCTION 0
+#define FTC_PAGE_MERGE_DEMO 1
+int ftc_page_merge_variant(const float* locations, const int32_t* order, int n_boxes, const double* hist1, const double* threshold_dev,
+                           float cut_off, const float* seps, const float* codes, int mh, int mw, int scale, int page_h, int page_w, int variant,
+                           int seed_start, double seed_scale, float* out_locations, int32_t* out_index, float* out_code_max, int32_t* out_count,
+                           void* scratch, int64_t scratch_bytes, void* stream);
 
 /* Validation / training-step adjuncts (forward only) --------------------------------------------
  * The reference's validation step (train1.py:133-139 test_step, eval mode): fmask = model.get_fmask(labelmap) ->

@@ -132,17 +132,24 @@ def image_hist(im: np.ndarray) -> float:
 
 
 def page_merge(locations: np.ndarray, glyphfeatures: np.ndarray, org_img: np.ndarray, seps_all: np.ndarray,
-               code_all: Sequence[np.ndarray], cut_off: float):
+               code_all: Sequence[np.ndarray], cut_off: float, variant: str = "production"):
     """Page-level selection (``process_ocr_base.py:540-650``).  ``locations`` carries the reference's
-    leading all-zero dummy row (``:478-479``)."""
+    leading all-zero dummy row (``:478-479``).
+
+    ``variant="demo"``: the same block of the demo script's ``eval()`` (``test_image1_torch.py:152-240``), which differs in
+    three places: no ``imageHist`` contrast filter; the coverage image ``fill_map`` is filled with ``p2x`` WITHOUT the ``+1``
+    and ``p1y`` WITH a ``+1`` (``:196-200``); the result stays float64 (no ``astype(np.float32)``).  Its two-pass seed rows
+    (``:150-151``) are the caller's business: ``eval_demo`` appends them."""
+    demo = variant == "demo"
+    assert variant in ("production", "demo")
     page_h, page_w = org_img.shape[:2]
     hists = []
-    for i in range(locations.shape[0]):
+    for i in range(locations.shape[0] if not demo else 0):
         p, cx, cy, w, h = locations[i, :5]
         if p < cut_off:
             continue
         hists.append(image_hist(org_img[int(cy - h / 2) - 1:int(cy + h / 2) + 2, int(cx - w / 2) - 1:int(cx + w / 2) + 2, :]))
-    th_hist = np.median(hists) / 5
+    th_hist = np.median(hists) / 5 if not demo else None
 
     done = np.zeros([0, 4])
     keep: List[int] = []
@@ -150,10 +157,11 @@ def page_merge(locations: np.ndarray, glyphfeatures: np.ndarray, org_img: np.nda
         p, cx, cy, w, h = locations[i, :5]
         if p < cut_off:
             break
-        bx0, bx1 = max(0, int(cx - w / 2)), min(page_w - 1, int(cx + w / 2) + 1)
-        by0, by1 = max(0, int(cy - h / 2)), min(page_h - 1, int(cy + h / 2) + 1)
-        if image_hist(org_img[by0:by1, bx0:bx1, :]) < th_hist:
-            continue
+        if not demo:
+            bx0, bx1 = max(0, int(cx - w / 2)), min(page_w - 1, int(cx + w / 2) + 1)
+            by0, by1 = max(0, int(cy - h / 2)), min(page_h - 1, int(cy + h / 2) + 1)
+            if image_hist(org_img[by0:by1, bx0:bx1, :]) < th_hist:
+                continue
         a0 = w * h
         fill = np.zeros([int(w), int(h)], dtype=bool)
         if done.size > 0:
@@ -172,8 +180,8 @@ def page_merge(locations: np.ndarray, glyphfeatures: np.ndarray, org_img: np.nda
             for j in np.where(iou > 0)[0]:
                 cx1, cy1, w1, h1 = done[j]
                 p1x = int(max(cx1 - w1 / 2, cx - w / 2) - (cx - w / 2))
-                p2x = int(min(cx1 + w1 / 2, cx + w / 2) - (cx - w / 2)) + 1
-                p1y = int(max(cy1 - h1 / 2, cy - h / 2) - (cy - h / 2))
+                p2x = int(min(cx1 + w1 / 2, cx + w / 2) - (cx - w / 2)) + (0 if demo else 1)
+                p1y = int(max(cy1 - h1 / 2, cy - h / 2) - (cy - h / 2)) + (1 if demo else 0)
                 p2y = int(min(cy1 + h1 / 2, cy + h / 2) - (cy - h / 2)) + 1
                 fill[p1x:p2x, p1y:p2y] = True
             if np.mean(fill) > 0.5:
@@ -202,7 +210,7 @@ def page_merge(locations: np.ndarray, glyphfeatures: np.ndarray, org_img: np.nda
             x1, y1 = min(mw, int(cx / scale + 1) + 1), min(mh, int(cy / scale + 1) + 1)
             for k in range(4):
                 locations[i, 5 + k] = max(np.max(code_all[k][y0:y1, x0:x1]), locations[i, 5 + k])
-    return locations.astype(np.float32), glyphfeatures
+    return (locations if demo else locations.astype(np.float32)), glyphfeatures
 
 
 def run_detector(ds: Sequence[dict], org_img: np.ndarray, call_detector: Callable, step_ratio: float = 0.6,
@@ -228,3 +236,44 @@ def run_detector(ds: Sequence[dict], org_img: np.ndarray, call_detector: Callabl
     glyphfeatures = np.concatenate(feats, axis=0)
     locations, glyphfeatures = page_merge(locations, glyphfeatures, org_img, canv[2], canv[3:], cut_off)
     return locations, glyphfeatures, canv[1], canv[2], raw
+
+
+def eval_demo(ds: Sequence[dict], org_img: np.ndarray, call_detector: Callable, cut_off: float = 0.5,
+              locations0: np.ndarray = None, glyphfeatures0: np.ndarray = None, tile: int = width, return_candidates: bool = False):
+    """``eval()`` of the demo script (``/root/reference/test_image1_torch.py:75-240``; the plotting tail ``:242-266`` left out) end
+    to end: per-tile block with the 1/8 border margins (``:103-108``), float64 page canvases (``:81-87``), the seed rows of a coarse
+    first pass appended BEHIND the tile rows (``:147-151``), then the demo variant of the page-level selection.  ``tile`` = the
+    script's ``width`` = ``height`` (768; the golden fixture runs the script's own source with a smaller value to stay small).
+    Returns (locations f64 [M,9], glyphfeatures f32 [M,C], keymap_all, lines_all, seps_all, code_all)."""
+    page_h, page_w = org_img.shape[:2]
+    canv = [np.zeros([page_h // scale, page_w // scale]) for _ in range(7)]            # float64, as np.zeros gives
+    nfeat = None
+    locs = [np.zeros([1, 9])]
+    feats = []
+    x_s = y_s = tile // scale
+    for inputs in ds:
+        x_i, y_i = inputs["offsetx"], inputs["offsety"]
+        heatmap, features = call_detector(inputs["input"])
+        if nfeat is None:
+            nfeat = features.shape[1]
+            feats.append(np.zeros([1, nfeat], dtype=np.float32))
+        x_min = int(x_s * 1 / 8) if x_i > 0 else 0
+        x_max = int(x_s * 7 / 8) + 1 if x_i + tile < page_w else x_s
+        y_min = int(y_s * 1 / 8) if y_i > 0 else 0
+        y_max = int(y_s * 7 / 8) + 1 if y_i + tile < page_h else y_s
+        rect = (x_min, x_max, y_min, y_max)
+        paste_maps(canv, heatmap, x_i, y_i, rect)
+        l, f, _ = decode_tile(heatmap, features, x_i, y_i, page_w, page_h, cut_off, rect)
+        if len(l):
+            locs.append(l)
+            feats.append(f)
+    locations = np.concatenate(locs, axis=0)
+    glyphfeatures = np.concatenate(feats, axis=0) if feats else np.zeros([1, feature_dim], np.float32)
+    if locations0 is not None:
+        locations = np.concatenate([locations, locations0])
+    if glyphfeatures0 is not None:
+        glyphfeatures = np.concatenate([glyphfeatures, glyphfeatures0])
+    if return_candidates:                 # (tests: what the selection sees -- rows in eval()'s concatenation order, seed rows last -- and the canvases)
+        return locations, glyphfeatures, canv
+    locations, glyphfeatures = page_merge(locations, glyphfeatures, org_img, canv[2], canv[3:], cut_off, variant="demo")
+    return locations, glyphfeatures, canv[0], canv[1], canv[2], canv[3:]

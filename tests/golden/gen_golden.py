@@ -675,7 +675,89 @@ def gen_train_trajectory(model):
 
 
 
+def gen_demo_eval():
+    """g13: the demo script's own ``eval()`` -- /root/reference/test_image1_torch.py is not importable (module-level code: argv, model.pt, plotting),
+    so ONLY the source range of ``def eval`` is exec'd here, with the globals it reads supplied by this generator: a REPLAYED detector (stored
+    synthetic maps, one per tile, in call order), the script's ``width = height`` set to 128 (32x32 maps: the fixture stays small; the code is
+    size-agnostic), ``feature_dim`` 4, the reference's own ``util_func.sigmoid`` and a no-op ``plt``.  Two calls, as the script's two-pass mode
+    makes them (:313-345): the coarse pass on one tile, ``locations0[:,1:] * s``, then the page's nine tiles with the seeds appended.  Pins
+    oracle.decode_oracle.eval_demo / page_merge(variant="demo") (tests/test_oracle.py) and through them ftc_page_merge_variant."""
+    src = open(os.path.join(REF, "test_image1_torch.py")).read().split("\n")
+    a = next(i for i, l in enumerate(src) if l.startswith("def eval("))
+    b = next(i for i, l in enumerate(src) if l.startswith("def decode("))
+    code = "\n".join(src[a:b])
+    T, S, C = 128, 4, 4
+    ms = T // S
+    rng = np.random.Generator(np.random.PCG64(1313))
+
+    def page_fields(mh, mw, n_glyph):
+        yy, xx = np.mgrid[0:mh, 0:mw]
+        key = np.full((mh, mw), -6.0) + rng.normal(0, 0.3, (mh, mw))
+        gy, gx = rng.uniform(1, mh - 1, n_glyph), rng.uniform(1, mw - 1, n_glyph)
+        for y0, x0 in zip(gy, gx):
+            key += rng.uniform(6.5, 10.0) * np.exp(-((yy - y0) ** 2 + (xx - x0) ** 2) / (2 * 0.7 ** 2))
+        size = np.log(np.exp(rng.uniform(np.log(14), np.log(64), (2, mh, mw))) / 1024) + 3
+        rest = np.stack([rng.normal(-1.0, 2.0, (mh, mw)), rng.normal(-2.5, 2.5, (mh, mw))] + [rng.normal(-1.0, 2.0, (mh, mw)) for _ in range(4)])
+        return key.astype(np.float32), size.astype(np.float32), rest.astype(np.float32)
+
+    def tile_maps(key, size, rest, y0, x0):
+        k = key[y0:y0 + ms, x0:x0 + ms] + rng.normal(0, 0.05, (ms, ms)).astype(np.float32)      # overlapping tiles see ALMOST the same glyphs
+        pad = np.pad(k, 1, constant_values=-np.inf)
+        lm = np.max(np.stack([pad[dy:dy + ms, dx:dx + ms] for dy in range(3) for dx in range(3)]), axis=0)
+        det = np.where(k < lm, -np.inf, k)                                                       # CenterNetDetector.forward, models/detector.py:291-296
+        hm = np.concatenate([k[None], det[None], size[:, y0:y0 + ms, x0:x0 + ms], rest[:, y0:y0 + ms, x0:x0 + ms]]).astype(np.float32)
+        return hm[None], rng.standard_normal((1, C, ms, ms)).astype(np.float32)
+
+    class Replay:
+        def __init__(self, maps):
+            self.maps, self.k = maps, 0
+
+        def __call__(self, images):
+            hm, ft = self.maps[self.k]
+            self.k += 1
+            return torch.from_numpy(hm), torch.from_numpy(ft)
+
+    class NoPlot:
+        def __getattr__(self, name):
+            return lambda *a_, **k_: None
+
+    def run_eval(ds, img, maps, cut_off, l0=None, g0=None):
+        ns = {"np": np, "torch": torch, "width": T, "height": T, "scale": S, "feature_dim": C, "sigmoid": ref_util.sigmoid, "plt": NoPlot(),
+              "device": "cpu", "detector": Replay(maps)}
+        exec(compile(code, "test_image1_torch.py[eval]", "exec"), ns)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            return ns["eval"](ds, img, cut_off=cut_off, locations0=l0, glyphfeatures0=g0)
+
+    step = T * 3 // 4
+    ph = pw = T + 2 * step                                                     # 3 x 3 tiles
+    img = np.full((ph, pw, 3), 255.0, np.float32)
+    # coarse pass (:313-332): the page shrunk by s onto ONE tile
+    s_f = max(pw, ph) / max(T, T)
+    key, size, rest = page_fields(ms, ms, 24)
+    coarse = [tile_maps(key, size, rest, 0, 0)]
+    ds1 = [{"input": np.zeros((1, T, T, 3), np.float32), "offsetx": 0, "offsety": 0}]
+    l0, g0 = run_eval(ds1, np.zeros((T, T, 3), np.float32), coarse, 0.4)
+    l0_unscaled = l0.copy()
+    l0[:, 1:] = l0[:, 1:] * s_f
+    key, size, rest = page_fields(ph // S, pw // S, 420)
+    offs = [(y, x) for y in range(0, ph - T + 1, step) for x in range(0, pw - T + 1, step)]
+    maps = [tile_maps(key, size, rest, y // S, x // S) for (y, x) in offs]
+    ds0 = [{"input": np.zeros((1, T, T, 3), np.float32), "offsetx": x, "offsety": y} for (y, x) in offs]
+    loc, gf = run_eval(ds0, img, maps, 0.4, l0, g0)
+    loc_noseed, gf_noseed = run_eval(ds0, img, maps, 0.4)
+    print("g13: coarse pass", l0.shape, "page", loc.shape, "without seeds", loc_noseed.shape, "seed rows kept", int((np.isin(loc[:, 1], l0[:, 1])).sum()))
+    save("g13_demo_eval.npz", tile=np.array([T, S, C]), page=np.array([ph, pw]), offsets=np.array(offs), seed_scale=np.array([s_f]),
+         coarse_heat=coarse[0][0], coarse_feat=coarse[0][1], heat=np.concatenate([m[0] for m in maps]), feat=np.concatenate([m[1] for m in maps]),
+         coarse_locations=l0_unscaled, coarse_glyphfeatures=g0, locations=loc, glyphfeatures=gf, locations_noseed=loc_noseed,
+         glyphfeatures_noseed=gf_noseed)
+
+
 def main():
+    if "--demo-only" in sys.argv:
+        gen_demo_eval()
+        return
     if "--train-step-only" in sys.argv:
         torch.manual_seed(0)
         model = ref_detector.TextDetectorModel(pre_weights=False)
@@ -731,6 +813,7 @@ def main():
     gen_train_step_autocast(model)
     gen_train_trajectory(model)
     gen_small_models()
+    gen_demo_eval()
 
 
 if __name__ == "__main__":

@@ -31,17 +31,35 @@ __global__ __launch_bounds__(256) void decode_select_kernel(const float* __restr
     const int rw = tl.x_max - tl.x_min, rh = tl.y_max - tl.y_min;
     const int n = rw * rh;
     const float* hb = heat + (long)b * h * w * 10;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int y = tl.y_min + i / rw, x = tl.x_min + i % rw;
-        const int idx = y * w + x;
-        const float v = hb[(long)idx * 10 + 1];
-        if (!(v >= logit_cut)) continue;                          // -inf (suppressed) and NaN fail
-        const float bw = expf(hb[(long)idx * 10 + 2] - 3.0f) * 1024.0f;   // process_ocr_base.py:523-524
-        const float bh = expf(hb[(long)idx * 10 + 3] - 3.0f) * 1024.0f;
-        if (bw <= 0.f || bh <= 0.f) continue;                     // :525
-        if (bw > (float)tl.page_w || bh > (float)tl.page_h) continue;   // :527
-        const int slot = atomicAdd(&counts[b], 1);
-        cand[(long)b * h * w + slot] = ((unsigned long long)orderable(v) << 32) | (uint32_t)(~(uint32_t)idx);
+    // (round 5) One atomicAdd per WAVE and pass instead of one per candidate: a random-init tile has ~1600 candidates, and their atomics on the
+    // image's one counter serialised at the L2 (50 us for 12 MB of reads).  The slot order is arbitrary either way -- the rank pass below
+    // imposes the total order.  The loop bound is wave-uniform so that the ballot sees every lane.
+    const int lane = threadIdx.x & 63;
+    const int n_up = (n + 63) & ~63;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_up; i += gridDim.x * blockDim.x) {
+        bool keep = false;
+        int idx = 0;
+        float v = 0.f;
+        if (i < n) {
+            const int y = tl.y_min + i / rw, x = tl.x_min + i % rw;
+            idx = y * w + x;
+            v = hb[(long)idx * 10 + 1];
+            if (v >= logit_cut) {                                     // -inf (suppressed) and NaN fail
+                const float bw = expf(hb[(long)idx * 10 + 2] - 3.0f) * 1024.0f;   // process_ocr_base.py:523-524
+                const float bh = expf(hb[(long)idx * 10 + 3] - 3.0f) * 1024.0f;
+                keep = !(bw <= 0.f || bh <= 0.f) &&                   // :525
+                       !(bw > (float)tl.page_w || bh > (float)tl.page_h);   // :527
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (m == 0ull) continue;
+        int base = 0;
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&counts[b], __popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1, 64);
+        if (keep) {
+            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+            cand[(long)b * h * w + slot] = ((unsigned long long)orderable(v) << 32) | (uint32_t)(~(uint32_t)idx);
+        }
     }
 }
 
@@ -51,33 +69,44 @@ __global__ __launch_bounds__(256) void decode_rank_gather_kernel(const float* __
                                                                  const int32_t* __restrict__ counts, int max_boxes,
                                                                  float* __restrict__ boxes, int box_stride, float* __restrict__ feats,
                                                                  int feat_stride, int32_t* __restrict__ index) {
+    // (round 5) A workgroup owns DG = 64 candidates (it was 256: the ~1600 candidates of a tile kept 7 workgroups per image busy and each of their
+    // waves copied 64 feature rows one after the other -- 62 us).  Its 256 threads split the comparison range four ways (thread = candidate x
+    // quarter of the list), the four partial ranks meet in LDS, and every wave then copies 16 rows, four at a time.
+    constexpr int DG = 64;
     __shared__ unsigned long long keys[256];
-    __shared__ int s_rank[256];
-    __shared__ int s_idx[256];
+    __shared__ int s_part[4][DG];
+    __shared__ int s_rank[DG];
+    __shared__ int s_idx[DG];
     const int b = blockIdx.y;
     const int n = counts[b];
-    const int base = blockIdx.x * 256;
+    const int base = blockIdx.x * DG;
     if (base >= n) return;
     const unsigned long long* cb = cand + (long)b * h * w;
     const int t = threadIdx.x;
-    const int me = base + t;
+    const int cl = t & (DG - 1), qd = t >> 6;                       // candidate of the block, quarter of each 256-key chunk
+    const int me = base + cl;
     const unsigned long long mykey = me < n ? cb[me] : 0ull;
-    int rank = 0;
+    int part = 0;
     for (int c0 = 0; c0 < n; c0 += 256) {
         __syncthreads();
         keys[t] = (c0 + t < n) ? cb[c0 + t] : 0ull;
         __syncthreads();
-        const int lim = min(256, n - c0);
-        for (int j = 0; j < lim; ++j) rank += keys[j] > mykey ? 1 : 0;
+        const int lim = min(64, n - c0 - qd * 64);
+        for (int j = 0; j < lim; ++j) part += keys[qd * 64 + j] > mykey ? 1 : 0;
     }
+    s_part[qd][cl] = part;
+    __syncthreads();
+    const int rank = (s_part[0][cl] + s_part[1][cl]) + (s_part[2][cl] + s_part[3][cl]);
     const int idx = (int)(~(uint32_t)(mykey & 0xffffffffull));
-    s_rank[t] = (me < n && rank < max_boxes) ? rank : -1;
-    s_idx[t] = idx;
+    if (t < DG) {
+        s_rank[t] = (me < n && rank < max_boxes) ? rank : -1;
+        s_idx[t] = idx;
+    }
     __syncthreads();
 
     const ftc_tile tl = tiles[b];
     const float* hb = heat + (long)b * h * w * 10;
-    if (s_rank[t] >= 0) {
+    if (t < DG && s_rank[t] >= 0) {
         const float* px = hb + (long)idx * 10;
         const int y = idx / w, x = idx - y * w;
         float* o = boxes + ((long)b * max_boxes + rank) * box_stride;
@@ -96,12 +125,27 @@ __global__ __launch_bounds__(256) void decode_rank_gather_kernel(const float* __
     const int lane = t & 63, wave = t >> 6;
     const int CQ = C >> 2;
     const float* fb = feat + (long)b * h * w * C;
-    for (int k = wave; k < 256; k += 4) {
-        const int r = s_rank[k];
-        if (r < 0) continue;
-        const float* src = fb + (long)s_idx[k] * C;
-        float* dst = feats + ((long)b * max_boxes + r) * feat_stride;
-        for (int q = lane; q < CQ; q += 64) reinterpret_cast<f32x4*>(dst)[q] = reinterpret_cast<const f32x4*>(src)[q];
+    if (CQ <= 64) {                                                   // (C <= 256: one 16-byte access per lane and row -- four rows in flight)
+        for (int k0 = wave * 16; k0 < wave * 16 + 16; k0 += 4) {
+            f32x4 v[4];
+            int r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                r[u] = s_rank[k0 + u];
+                if (r[u] >= 0 && lane < CQ) v[u] = reinterpret_cast<const f32x4*>(fb + (long)s_idx[k0 + u] * C)[lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r[u] >= 0 && lane < CQ) reinterpret_cast<f32x4*>(feats + ((long)b * max_boxes + r[u]) * feat_stride)[lane] = v[u];
+        }
+    } else {
+        for (int k = wave * 16; k < wave * 16 + 16; ++k) {
+            const int r = s_rank[k];
+            if (r < 0) continue;
+            const float* src = fb + (long)s_idx[k] * C;
+            float* dst = feats + ((long)b * max_boxes + r) * feat_stride;
+            for (int q = lane; q < CQ; q += 64) reinterpret_cast<f32x4*>(dst)[q] = reinterpret_cast<const f32x4*>(src)[q];
+        }
     }
 }
 
@@ -119,7 +163,7 @@ hipError_t launch_decode(const float* heat, const float* feat, int B, int h, int
     hipLaunchKernelGGL(decode_select_kernel, dim3(nb < 36 ? nb : 36, B), dim3(256), 0, s, heat, tiles, h, w, logit_cut, cand, counts);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(decode_rank_gather_kernel, dim3(nb, B), dim3(256), 0, s, heat, feat, tiles, h, w, C, scale, cand, counts,
+    hipLaunchKernelGGL(decode_rank_gather_kernel, dim3((h * w + 63) / 64, B), dim3(256), 0, s, heat, feat, tiles, h, w, C, scale, cand, counts,
                        max_boxes, boxes, box_stride, feats, feat_stride, index);
     return hipGetLastError();
 }

@@ -556,7 +556,21 @@ void apply_tuning(std::vector<ftc_op>& ops) {
     if (env_on("FTC_NO_TUNING")) return;
     static std::map<std::string, int> table;
     static std::once_flag once;
-    std::call_once(once, [] { for (const TuneEntry* e = kTuning; e->sig; ++e) table[e->sig] = e->aux0; });
+    std::call_once(once, [] {
+        for (const TuneEntry* e = kTuning; e->sig; ++e) table[e->sig] = e->aux0;
+        // FTC_TUNING_OVERRIDE=<file of "signature aux0" lines>: entries replacing / extending the compiled-in table (tuning experiments without
+        // a rebuild, e.g. tools/lanes_tuning.py: choices measured for the two-lane steady state instead of the kernel alone)
+        if (const char* path = std::getenv("FTC_TUNING_OVERRIDE")) {
+            if (FILE* f = std::fopen(path, "r")) {
+                char sig[192];
+                int v;
+                int n = 0;
+                while (std::fscanf(f, "%191s %d", sig, &v) == 2) { table[sig] = v; ++n; }
+                std::fclose(f);
+                std::fprintf(stderr, "[ftc] FTC_TUNING_OVERRIDE: %d entries from %s\n", n, path);
+            }
+        }
+    });
     for (ftc_op& o : ops) {
         if (o.kind != FTC_OP_CONV) continue;
         auto it = table.find(conv_signature(o));

@@ -400,6 +400,7 @@ class TextDetectorModel(nn.Module):
                     "ftc_decoder_forward")
         return outs
 
+    @torch.compiler.disable
     def forward(self, x, fmask):
         """(heatmap [B,9,h,w], [dec0, dec1, dec2]) -- detector forward, boolean-mask gather of the flattened NHWC feature map
         (``features.permute(0,2,3,1).flatten(0,-2)[fmask]``, models/detector.py:265-266) on the GPU, decoder on the gathered rows."""
@@ -407,8 +408,18 @@ class TextDetectorModel(nn.Module):
             # train() mode: batch-statistics BatchNorm + StochasticDepth, running statistics updated -- forward only (the reference's
             # BN-refresh pass, train1.py:203-211, runs exactly this under torch.no_grad()).  There is no backward pass.
             if torch.is_grad_enabled():
-                raise NotImplementedError("findtextcenternet_amd has no backward pass: the train()-mode forward runs under torch.no_grad() only "
-                                          "(BatchNorm refresh); call .eval() for inference")
+                # The reference's train step exactly as train1.py:125-131 writes it: the SAME static plan TrainStep.forward_backward runs, cut at
+                # the loss op -- loss_function(...) runs the loss op, CoVWeightingLoss weights it, loss.backward() runs the plan's backward half
+                # and ADDS the parameter gradients into .grad (findtextcenternet_amd.train_step: "the reference's own calling sequence").
+                from .train_step import TrainStep
+                ts = self.__dict__.get("_train_step")
+                if ts is None or ts.precision != self.detector.precision:
+                    ts = TrainStep(self, self.detector.precision, decoder_only=not self.detector.training)
+                    self.__dict__["_train_step"] = ts
+                heat, decs = ts.seam_forward(x, fmask)
+                heat.requires_grad_(True)                      # (the anchor of the autograd node loss_function attaches; its own gradient is never formed)
+                heat._ftc_train_step = ts
+                return heat, decs
             from .train_forward import TrainForward
             tf = self.__dict__.get("_train_forward")
             if tf is None or tf.precision != self.detector.precision:

@@ -86,10 +86,49 @@ def heatmap_loss(true: torch.Tensor, logits: torch.Tensor) -> torch.Tensor:
     return out[1] / 10.0                                           # loss_function multiplies the mean by 10 (:114)
 
 
+class _TrainLosses(torch.autograd.Function):
+    """The loss op of the train plan as an autograd node (``TrainStep.seam_losses`` / ``seam_backward``): forward = the 16 values of FTC_OP_LOSSES
+    on the labels given here; backward = the plan's whole backward half with d(objective)/d(loss_i) as the nine loss weights -- the parameter
+    gradients are ADDED to ``.grad`` by the kernels themselves, nothing flows further back through autograd."""
+
+    @staticmethod
+    def forward(ctx, anchor, ts, fmask, labelmap, idmap):
+        ctx.ts = ts
+        return ts.seam_losses(fmask, labelmap, idmap)
+
+    @staticmethod
+    def backward(ctx, g):
+        # 'loss' (entry 0) is the plain sum of the nine (loss_func.py:162-164): its gradient spreads over them; 'correct' / 'total' are counts
+        w = g[1:10] + g[0]
+        ctx.ts.seam_backward(w.detach())
+        return None, None, None, None, None
+
+
+class _WeightedSum(torch.autograd.Function):
+    """value = what ftc_cov_weighting_step computed (sum_i alpha_i loss_i); d value / d loss_i = alpha_i (the alphas are detached weights,
+    loss_func.py:69-71)."""
+
+    @staticmethod
+    def forward(ctx, vals, alphas, value):
+        ctx.save_for_backward(alphas)
+        return value.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (alphas,) = ctx.saved_tensors
+        return g * alphas, None, None
+
+
+@torch.compiler.disable
 def loss_function(fmask: torch.Tensor, labelmap: torch.Tensor, idmap: torch.Tensor, heatmap: torch.Tensor,
                   decoder_outputs: Sequence[torch.Tensor]) -> Dict[str, torch.Tensor]:
     """``loss_func.py:94-177``: dict with the reference's keys; values are 0-d fp32 tensors on the device (``correct`` / ``total``
-    are counts, as in the reference)."""
+    are counts, as in the reference).  On the outputs of a train-mode ``model(image, fmask)`` call with gradients enabled (train1.py:125-131)
+    the values carry the autograd node that runs the backward half of the train plan."""
+    ts = getattr(heatmap, "_ftc_train_step", None)
+    if ts is not None and torch.is_grad_enabled():
+        out = _TrainLosses.apply(heatmap, ts, fmask, labelmap, idmap)
+        return {k: out[i] for i, k in enumerate(_KEYS)}
     sel, cnt = mask_to_index(fmask)
     n_rows = decoder_outputs[0].shape[0]
     out = _run_losses(labelmap, idmap, heatmap, decoder_outputs, sel[:max(1, n_rows)].contiguous(), cnt)
@@ -127,7 +166,13 @@ class CoVWeightingLoss(torch.nn.Module):
     def running_std_l(self) -> Optional[torch.Tensor]:
         return self._state[48:48 + self.num_losses] if self.current_iter >= 0 else None
 
+    @torch.compiler.disable
     def forward(self, losses: Dict[str, torch.Tensor]) -> torch.Tensor:
+        if torch.is_grad_enabled() and any(losses[k].requires_grad for k in self.losses):
+            stacked = torch.stack([losses[k].to(torch.float32).reshape(()) for k in self.losses])
+            with torch.no_grad():
+                value = self.forward({k: losses[k].detach() for k in self.losses})
+            return _WeightedSum.apply(stacked, self.alphas.detach().clone(), value)
         lib = L.load()
         vals = torch.stack([losses[k].detach().to(torch.float32).reshape(()) for k in self.losses]).to(self._state.device).contiguous()
         _check_cuda(vals)

@@ -878,6 +878,17 @@ class TrainStep:
     # forward_backward (tests/test_gpu_train_step.py::test_reference_calling_sequence_equals_forward_backward).
     def seam_forward(self, image: torch.Tensor, fmask: torch.Tensor, keep=None, generator=None):
         lib = L.load()
+        # `optimizer.zero_grad()` (set_to_none=True, torch's default: train1.py:167, 179) drops the .grad views: a dropped gradient restarts at zero
+        missing = [(n, p) for n, p in self.params if p.grad is None]
+        if len(missing) == len(self.params):
+            self.zero_grad()
+        else:
+            for n, p in missing:
+                o = self.ptable[n] // 4
+                self.grads[o: o + p.numel()].zero_()
+                p.grad = self.grads[o: o + p.numel()].view(p.shape)
+            if missing:
+                self._grads_synced = False
         st = self._begin(image, fmask, keep if keep is not None else self.module.__dict__.get("stochastic_depth_keep"), generator, 1.0)
         plan, dev, B = st["plan"], st["dev"], st["B"]
         with torch.cuda.device(dev):

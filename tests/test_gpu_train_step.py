@@ -396,3 +396,72 @@ def test_train_step_fp32_at_the_benchmarked_shape_matches_the_oracle():
     with open("gpurun_out/test_train.log", "a") as f:
         f.write(f"fp32 train step at B=8 768x768 vs the CPU oracle: loss {float(loss):.6f} vs {float(loss_o):.6f}; " + ", ".join(f"{n.split('.')[-3]}.{n.split('.')[-2]} {r:.1e}" for n, r, _, _, _ in rep) + "\n")
     assert len(rep) == len(pick) and not [(n, f"{r:.2e}") for n, r, ok, _, _ in rep if not ok]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_reference_calling_sequence_equals_forward_backward(precision):
+    """train1.py:125-131 + :174-179 verbatim -- ``heatmap, decoder_outputs = model(image, fmask)``; ``rawloss = loss_function(fmask, map, idmap,
+    heatmap, decoder_outputs)``; ``loss = CoWloss(rawloss)``; ``(loss / iters_to_accumulate).backward()``; ``optimizer.step()``;
+    ``optimizer.zero_grad()`` (set_to_none, torch's default) -- under torch.autocast as the reference writes it, against
+    TrainStep.forward_backward on a twin model: same plan, same kernels -> the losses and EVERY gradient are bit-identical over three
+    iterations with accumulation, and so are the parameters after the optimizer steps."""
+    from findtextcenternet_amd import AdamWScheduleFree
+    from findtextcenternet_amd.loss_func import CoVWeightingLoss, loss_function
+    B, H, W, iters = 2, 128, 128, 2
+    batches = []
+    for seed in (61, 63, 65, 67):
+        x = torch.from_numpy(synth.page_images(seed, B, H, W)).permute(0, 3, 1, 2).cuda()
+        label, idmap = synth.train_labels(seed + 1, B, H // 4, W // 4)
+        batches.append((x, torch.from_numpy(label).cuda(), torch.from_numpy(idmap).cuda().long()))
+    probs = None
+    keeps = []
+
+    def run(seam: bool):
+        nonlocal probs
+        model = _model(precision)
+        opt = AdamWScheduleFree([p for p in model.parameters() if p.requires_grad], lr=1e-3)       # (before any TrainStep exists, as train1.py:104)
+        cov = CoVWeightingLoss(device="cuda", losses=COV_KEYS)
+        ts = None if seam else TrainStep(model, cov=cov)
+        if probs is None:
+            probs = (ts or TrainStep(_model(precision))).stochastic_depth_probs()
+            rng = np.random.Generator(np.random.PCG64(9))
+            for _ in batches:
+                keeps.append({n: torch.from_numpy((rng.random(B) < 1 - p).astype(np.float32) / np.float32(1 - p)) for n, p in probs.items()})
+        model.train()
+        cov.train()
+        opt.train()
+        opt.zero_grad()
+        fmask, log = None, []
+        for i, (image, labelmap, idmap) in enumerate(batches):
+            fmask = model.get_fmask(labelmap, fmask)
+            if seam:
+                model.stochastic_depth_keep = keeps[i]                      # (the seeded StochasticDepth draw of this test; None = a fresh draw per step)
+                with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                    heatmap, decoder_outputs = model(image, fmask)
+                    rawloss = loss_function(fmask, labelmap, idmap, heatmap, decoder_outputs)
+                    loss = cov(rawloss)
+                scale_loss = loss / iters
+                scale_loss.backward()
+                ts_ = model.__dict__["_train_step"]
+                grads = ts_.grads.clone()
+            else:
+                if i % iters == 0 and i > 0:
+                    pass
+                loss, rawloss = ts.forward_backward(image, labelmap, idmap, fmask, keep=keeps[i], loss_scale=1.0 / iters)
+                grads = ts.grads.clone()
+            log.append((float(loss), {k: float(v) for k, v in rawloss.items()}, grads))
+            if (i + 1) % iters == 0:
+                opt.step()
+                if seam:
+                    opt.zero_grad()                                        # set_to_none=True: the seam re-attaches the .grad views
+                else:
+                    ts.zero_grad()
+        torch.cuda.synchronize()
+        return log, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    ref_log, ref_params = run(False)
+    got_log, got_params = run(True)
+    for i, ((l0, r0, g0), (l1, r1, g1)) in enumerate(zip(ref_log, got_log)):
+        assert l0 == l1 and r0 == r1, (i, l0, l1)
+        assert torch.equal(g0.view(torch.int32), g1.view(torch.int32)), f"gradients of iteration {i} differ"
+        assert float(g0.abs().max()) > 0
+    assert torch.equal(ref_params.view(torch.int32), got_params.view(torch.int32))

@@ -775,6 +775,17 @@ class TrainStep:
         (decoder_only), the StochasticDepth draw, the weight re-pack."""
         if not image.is_cuda:
             raise RuntimeError("findtextcenternet_amd: the train step runs on MI355X (gfx950) only (there is no CPU fallback)")
+        # `optimizer.zero_grad()` (set_to_none=True, torch's default: train1.py:167, 179) drops the .grad views, and the kernels would go on adding into
+        # a buffer no optimizer sees: a dropped gradient restarts at zero and is re-attached
+        missing = [(n, p) for n, p in self.params if p.grad is None and p.requires_grad]
+        if missing and len(missing) == sum(1 for _, p in self.params if p.requires_grad):
+            self.zero_grad()
+        elif missing:
+            for n, p in missing:
+                o = self.ptable[n] // 4
+                self.grads[o: o + p.numel()].zero_()
+                p.grad = self.grads[o: o + p.numel()].view(p.shape)
+            self._grads_synced = False
         dev = image.device
         x = image.float()
         B, _, H, W = x.shape
@@ -878,17 +889,6 @@ class TrainStep:
     # forward_backward (tests/test_gpu_train_step.py::test_reference_calling_sequence_equals_forward_backward).
     def seam_forward(self, image: torch.Tensor, fmask: torch.Tensor, keep=None, generator=None):
         lib = L.load()
-        # `optimizer.zero_grad()` (set_to_none=True, torch's default: train1.py:167, 179) drops the .grad views: a dropped gradient restarts at zero
-        missing = [(n, p) for n, p in self.params if p.grad is None]
-        if len(missing) == len(self.params):
-            self.zero_grad()
-        else:
-            for n, p in missing:
-                o = self.ptable[n] // 4
-                self.grads[o: o + p.numel()].zero_()
-                p.grad = self.grads[o: o + p.numel()].view(p.shape)
-            if missing:
-                self._grads_synced = False
         st = self._begin(image, fmask, keep if keep is not None else self.module.__dict__.get("stochastic_depth_keep"), generator, 1.0)
         plan, dev, B = st["plan"], st["dev"], st["B"]
         with torch.cuda.device(dev):

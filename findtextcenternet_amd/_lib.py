@@ -22,6 +22,7 @@ FLAG_TOP_FUSE, FLAG_UPCAT_IN, FLAG_GROUP_IN2_SHARED, FLAG_W_FRAG, FLAG_ACCUM, FL
 FLAG_SIDE_STREAM = 0x4000000
 FLAG_SE_HPART = 0x8000000
 FLAG_KBLOCK32 = 0x10000000
+FLAG_PRESPLIT = 0x20000000
 MBHEAD_SLICE = 128
 
 EXPORTS = ["ftc_abi_version", "ftc_last_error", "ftc_device_info", "ftc_plan_create", "ftc_plan_destroy",

@@ -522,7 +522,8 @@ __global__ __launch_bounds__(256) void se_fc2_fold64_kernel(const float* __restr
 // Same prologue as se_fc2_fold64_kernel (64 channels per workgroup); 16 lanes x one chunk = the 64 channels, 16 rows per pass.
 __global__ __launch_bounds__(256) void se_fc2_foldx3_kernel(const float* __restrict__ hidden, const float* __restrict__ w2t,
                                                             const float* __restrict__ b2, float* __restrict__ scale, int C, int S,
-                                                            const u32x4* __restrict__ wp, u32x4* __restrict__ wb, int N) {
+                                                            const u32x4* __restrict__ wp, u32x4* __restrict__ wb, int N,
+                                                            const float* __restrict__ hpart, const float* __restrict__ b1, int NS) {
     extern __shared__ __attribute__((aligned(16))) float lds_f[];      // [S] hidden | [4][64] partial dots | [64] scale
     float* hid = lds_f;
     float* part = lds_f + ((S + 3) & ~3);
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(256) void se_fc2_foldx3_kernel(const float* __restr
     float wreg[SMAX];
 #pragma unroll
     for (int i = 0; i < SMAX; ++i) wreg[i] = (c < C && s_lo + i < s_hi) ? w2t[(long)(s_lo + i) * C + c] : 0.f;
-    for (int s = t; s < S; s += 256) hid[s] = hidden[(long)b * S + s];
+    se_load_hidden(hid, hidden, hpart, b1, b, S, NS, t, 256);          // (round 5: FTC_FLAG_SE_HPART in the fp16x3 plan too -- the fused head's partial products)
     __syncthreads();
     float acc = 0.f;
 #pragma unroll
@@ -660,14 +661,14 @@ hipError_t launch_se(const OpArgs& a, hipStream_t s) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    if (hp && (o.flags & FTC_FLAG_SE_FOLD) && (o.w_dtype == FTC_F32 || (o.flags & 0x100))) return hipErrorInvalidValue;    // (validated: 16-bit fold64 or no fold)
+    if (hp && (o.flags & FTC_FLAG_SE_FOLD) && (o.flags & 0x100)) return hipErrorInvalidValue;    // (validated: fold64 / foldx3 or no fold)
     if ((o.flags & FTC_FLAG_SE_FOLD) && o.w_dtype == FTC_F32) {    // fp16x3 plan: pre-split fp32 chunks in, pre-split per-image copies out
         const int cb = (C + 63) / 64;
         int nz = (768 + cb * o.B - 1) / (cb * o.B);
         const int max_nz = (o.Cout_total + 15) / 16;
         nz = nz < 1 ? 1 : nz > max_nz ? max_nz : nz;
         hipLaunchKernelGGL(se_fc2_foldx3_kernel, dim3(cb, o.B, nz), dim3(256), (size_t)(((S + 3) & ~3) + 256 + 64) * sizeof(float), s, hidden,
-                           (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const u32x4*)a.in, (u32x4*)a.out2, o.Cout_total);
+                           (const float*)a.w2, a.bias2, (float*)a.out, C, S, (const u32x4*)a.in, (u32x4*)a.out2, o.Cout_total, hpart, a.bias, P);
     } else if ((o.flags & FTC_FLAG_SE_FOLD) && !(o.flags & 0x100)) {
         const int cb = (C + 63) / 64;
         int nz = (768 + cb * o.B - 1) / (cb * o.B);                  // ~3 workgroups per CU

@@ -133,7 +133,7 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
     p.w_gs = (long)p.w_bytes;
     p.bias_gs = ((o.flags & FTC_FLAG_BORDER_BIAS) ? 16 : 1) * o.Cout;
     p.out_gs = oslice ? 0 : (long)o.B * o.Ho * o.Wo * o.Cout_total * osz;
-    p.out2_gs = oslice ? 0 : (long)o.B * o.Ho * o.Wo * o.Cout_total * 2;
+    p.out2_gs = oslice ? 0 : (long)o.B * o.Ho * o.Wo * o.Cout_total * (o.w_dtype == FTC_F32 ? 4 : 2);
     p.cout_gs = oslice ? o.Cout : 0;
     p.w2 = nullptr; p.w2_gs = 0; p.Tw = 0;
     p.in2u = nullptr; p.in2u_bytes = 0; p.in2u_gs = 0; p.Cy = 0; p.Hi = p.Wi = 0; p.ry = p.rx = 0.f;

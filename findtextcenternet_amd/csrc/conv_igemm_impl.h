@@ -160,10 +160,11 @@ __device__ __forceinline__ u32x4 bload(__amdgpu_buffer_rsrc_t r, int voff, int s
 
 // One 16-byte LDS chunk worth of K (E elements of WT) of an activation row, read as InT.
 template <typename WT, typename InT>
-__device__ __forceinline__ u32x4 load_act(__amdgpu_buffer_rsrc_t rin, int voff, bool use_se, __amdgpu_buffer_rsrc_t rse, int seoff) {
+__device__ __forceinline__ u32x4 load_act(__amdgpu_buffer_rsrc_t rin, int voff, bool use_se, __amdgpu_buffer_rsrc_t rse, int seoff, bool presplit = false) {
     if constexpr (sizeof(WT) == 4) {
         static_assert(sizeof(InT) == 4, "fp32 compute takes fp32 activations");
         u32x4 raw = bload(rin, voff, 0);
+        if (is_x3<WT> && presplit) return raw;                         // FTC_FLAG_PRESPLIT: the producer stored [hi x4 | lo x4] already (validated: no SE scale)
         if (use_se) {
             f32x4 v = __builtin_bit_cast(f32x4, raw) * __builtin_bit_cast(f32x4, bload(rse, seoff, 0));
             raw = __builtin_bit_cast(u32x4, v);
@@ -208,6 +209,17 @@ __device__ __forceinline__ size_t out2_index(const ConvP& p, int m, int n) {
         return (((size_t)img * (p.Cout >> 5) + (n >> 5)) * hw + r) * 32 + (n & 31);
     }
     return (size_t)m * p.Cout + n;
+}
+
+// The second copy of an fp32 output: the 16-bit trunk copy the 16-bit plans' next GEMM reads, or (fp16x3 plans, FTC_FLAG_SPLIT16) the
+// PRE-SPLIT copy FTC_OP_MBHEAD streams by DMA -- the four fp32 values of a 16-byte chunk as [hi x4 | lo x4] IEEE halves, NHWC.
+template <typename WT>
+__device__ __forceinline__ void store_out2(const ConvP& p, int m, int n, const f32x4& v) {
+    if constexpr (is_x3<WT>) {
+        *reinterpret_cast<u32x4*>(static_cast<char*>(p.out2) + ((size_t)m * p.Cout + n) * 4) = chunk_hl(v);
+    } else {
+        store4<typename Half16<WT>::type>(reinterpret_cast<typename Half16<WT>::type*>(p.out2) + out2_index(p, m, n), v);
+    }
 }
 
 // Epilogue shared by both kernels: lane owns pixel (l31) of each 32-pixel sub-tile and, per register
@@ -260,7 +272,7 @@ __device__ __forceinline__ void conv_epilogue_rows(const ConvP& p, f32x16 (&acc)
                     }
                     store4<OutT>(orow + n, v);
                     if constexpr (sizeof(OutT) == 4) {
-                        if (p.out2) store4<typename Half16<WT>::type>(reinterpret_cast<typename Half16<WT>::type*>(p.out2) + out2_index(p, m, n), v);
+                        if (p.out2) store_out2<WT>(p, m, n, v);
                     }
                 } else {
 #pragma unroll
@@ -358,7 +370,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvP& p, f32x16 (&acc)[
                 else v += load4<typename Half16<WT>::type>(reinterpret_cast<const typename Half16<WT>::type*>(p.res) + (size_t)m * p.Cout + n);
             }
             *reinterpret_cast<f32x4*>(outp + (size_t)m * p.CoutT + p.cout_off + n) = v;
-            if (p.out2) store4<typename Half16<WT>::type>(reinterpret_cast<typename Half16<WT>::type*>(p.out2) + out2_index(p, m, n), v);
+            if (p.out2) store_out2<WT>(p, m, n, v);
         } else {
             if (has_res) {
                 float f[8], r[8];
@@ -517,7 +529,7 @@ __device__ __forceinline__ void conv_epilogue_splitk(const ConvP& p, f32x16 (&ac
             }
             store4<OutT>(outp + (size_t)m * p.CoutT + p.cout_off + n, v);
             if constexpr (sizeof(OutT) == 4) {
-                if (p.out2) store4<typename Half16<WT>::type>(reinterpret_cast<typename Half16<WT>::type*>(p.out2) + out2_index(p, m, n), v);
+                if (p.out2) store_out2<WT>(p, m, n, v);
             }
         } else {
 #pragma unroll
@@ -629,7 +641,7 @@ __global__ __launch_bounds__(256 * KG) void conv_igemm_kernel(const ConvP p_laun
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const bool ok = cok && ((b_mask[i] >> ld_tap) & 1);
-            rb[i] = load_act<WT, InT>(rin, ok ? b_off[i] + in_toff : OOB, use_se, rse, b_se[i] + c0 * 4);
+            rb[i] = load_act<WT, InT>(rin, ok ? b_off[i] + in_toff : OOB, use_se, rse, b_se[i] + c0 * 4, (p.flags & FTC_FLAG_PRESPLIT) != 0);
         }
         if (++ld_cb == p.ncb) {
             ld_cb = 0;
@@ -914,6 +926,7 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p_laun
         offA[g] = (wn * SN * 32 + l31) * ROWB + sl;
         offB[g] = (TN + wm * SM * 32 + l31) * ROWB + sl;
     }
+    const bool presplit = (p.flags & FTC_FLAG_PRESPLIT) != 0;
     auto compute = [&](int bufoff) {
         const unsigned char* base = smem_raw + bufoff;
         if constexpr (is_x3<WT>) {
@@ -927,7 +940,9 @@ __global__ __launch_bounds__(256) void conv_igemm_glds_kernel(const ConvP p_laun
 #pragma unroll
                 for (int j = 0; j < SM; ++j) {
                     f16x8 bh, bl;
-                    split16(*reinterpret_cast<const f32x4*>(base + offB[g] + j * 32 * ROWB), *reinterpret_cast<const f32x4*>(base + offB[g + 1] + j * 32 * ROWB), bh, bl);
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(base + offB[g] + j * 32 * ROWB), b1 = *reinterpret_cast<const f32x4*>(base + offB[g + 1] + j * 32 * ROWB);
+                    if (presplit) frag_hl(b0, b1, bh, bl);             // FTC_FLAG_PRESPLIT: register renaming instead of ~35 VALU instructions per fragment
+                    else split16(b0, b1, bh, bl);
 #pragma unroll
                     for (int i = 0; i < SN; ++i) acc[i][j] = mfma_split(ah[i], al[i], bh, bl, acc[i][j]);
                 }

@@ -110,9 +110,14 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
             !need(o.bias, true, "bias", G * ((o.flags & FTC_FLAG_BORDER_BIAS) ? 16 : 1) * o.Cout * 4)) return why->c_str();
         if (!need(o.in2, (o.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_UPCAT_IN)) != 0, "in2", in2_ext) ||
             !need(o.scale, (o.flags & FTC_FLAG_SE_SCALE) != 0, "scale", (int64_t)o.B * o.Cin * 4)) return why->c_str();
-        if (!need(o.out2, false, "out2", pout * o.Cout * 2)) return why->c_str();
+        const bool x3conv = o.w_dtype == FTC_F32 && (o.flags & FTC_FLAG_SPLIT16);      // out2 = the pre-split copy (4 bytes per element)
+        if (!need(o.out2, false, "out2", pout * o.Cout * (x3conv ? 4 : 2))) return why->c_str();
         if (!need(o.w2, topf, "w2", G * 32 * o.Cout * 2)) return why->c_str();
         if (o.out2.base != FTC_BASE_NULL && (o.out_dtype != FTC_F32 || o.Cout % 4)) return "conv: out2 (bf16 copy) needs an fp32 primary output and Cout % 4 == 0";
+        if ((o.flags & FTC_FLAG_PRESPLIT) && (!x3conv || o.ksize != 1 || (o.flags & (FTC_FLAG_SE_SCALE | FTC_FLAG_UPCAT_IN)) || (o.Cin | o.Cin_total | o.cin_off) % 4))
+            return "conv: FTC_FLAG_PRESPLIT (pre-split input) needs an fp16x3 1x1 convolution without SE scale, channel counts and offsets in whole chunks of 4";
+        if (o.out2.base != FTC_BASE_NULL && o.w_dtype == FTC_F32 && (!x3conv || o.Cout != o.Cout_total || o.cout_off != 0 || G > 1))
+            return "conv: an fp32 convolution writes out2 only as the pre-split copy of an fp16x3 plan (FTC_FLAG_SPLIT16; whole rows, one group)";
         // out2_index (conv_igemm_impl.h) lays the planes out from Cout alone: no channel slice, no groups, a 16-bit compute type
         if ((o.flags & FTC_FLAG_KBLOCK32) && (o.out2.base == FTC_BASE_NULL || !ftc_is16(o.w_dtype) || o.Cout % 32 || o.Cout != o.Cout_total || o.cout_off != 0 || G > 1))
             return "conv: KBLOCK32 describes out2 (the 16-bit copy) and needs a 16-bit w_dtype, Cout % 32 == 0, Cout == Cout_total, cout_off == 0, one group";
@@ -133,11 +138,13 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         return nullptr;
     case FTC_OP_MBHEAD: {
         if (o.Cin <= 0 || o.Cout <= 0) return "mbhead: sizes must be positive";
+        if ((o.flags & FTC_FLAG_PRESPLIT) && o.in_dtype != FTC_F32) return "mbhead: FTC_FLAG_PRESPLIT applies to the fp32-tensor form";
         if (!ftc_mbhead_legal(o))
-            return "mbhead: needs 16-bit in/out/w of one type, stride 1, ksize 3, Ho = H, Wo = W, Cin % 32 == 0, Cout % 128 == 0 and a map (or, with aux1 = "
+            return "mbhead: needs 16-bit in/out/w of one type (Cout % 128 == 0) or fp32 with FTC_FLAG_SPLIT16 (Cout % 64 == 0), stride 1, ksize 3, Ho = H, Wo = W, Cin % 32 == 0 and a map (or, with aux1 = "
                    "output rows per band, a band + 2 halo rows) of <= 576 pixels and < 601 row-separated slots";
-        const int64_t nb = ftc_mbhead_bands(o), ns = o.Cout / FTC_MBHEAD_SLICE;
-        if (!need(o.in, true, "in", pin * o.Cin * 2) || !need(o.out, true, "out", pin * o.Cout * 2) || !need(o.w2, true, "w2", (int64_t)o.Cout * o.Cin * 2) ||
+        const int64_t esz = o.in_dtype == FTC_F32 ? 4 : 2;
+        const int64_t nb = ftc_mbhead_bands(o), ns = o.Cout / (o.in_dtype == FTC_F32 ? FTC_MBHEAD_SLICE_F32 : FTC_MBHEAD_SLICE);
+        if (!need(o.in, true, "in", pin * o.Cin * esz) || !need(o.out, true, "out", pin * o.Cout * esz) || !need(o.w2, true, "w2", (int64_t)o.Cout * o.Cin * esz) ||
             !need(o.bias2, true, "bias2", (int64_t)o.Cout * 4) || !need(o.w, true, "w", (int64_t)9 * o.Cout * 4) ||
             !need(o.bias, true, "bias", (int64_t)o.Cout * 4) || !need(o.aux, true, "aux", (int64_t)o.B * nb * o.Cout * 4)) return why->c_str();
         if ((o.scale.base != FTC_BASE_NULL) != (o.out2.base != FTC_BASE_NULL)) return "mbhead: scale (fc1 weight) and out2 (fc1 partial products) come together";
@@ -514,7 +521,7 @@ int ftc_op_kernel_label(const ftc_op* op, char* buf, int len) {
         break;
     case FTC_OP_SE: std::snprintf(buf, len, (op->flags & FTC_FLAG_SE_HPART) ? "se_gate" : "se_fc1+se_fc2"); break;
     case FTC_OP_MBHEAD:     // two instantiations, as the profiler sees them: the whole 24x24 map (FAST) / the general kernel (bands of rows)
-        std::snprintf(buf, len, "mbconv_slice<%s,128ch,%s>", ftc_dtname(op->in_dtype),
+        std::snprintf(buf, len, "mbconv_slice<%s,%s,%s>", op->in_dtype == FTC_F32 ? "f16x3" : ftc_dtname(op->in_dtype), op->in_dtype == FTC_F32 ? "64ch" : "128ch",
                       op->H == 24 && op->W == 24 && op->aux1 == 0 && !(op->flags & 0x100) ? "24x24" : "bands");
         break;
     case FTC_OP_UPCAT: std::snprintf(buf, len, "upcat_kernel<%s>", ftc_dtname(op->in_dtype)); break;

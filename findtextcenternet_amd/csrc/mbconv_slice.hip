@@ -327,9 +327,10 @@ static int mbhead_rows(const ftc_op& o) { return o.aux1 > 0 ? (o.aux1 + 2 < o.H 
 
 bool ftc_mbhead_legal(const ftc_op& o) {
     const int rows = mbhead_rows(o);
-    return ftc_is16(o.in_dtype) && o.in_dtype == o.out_dtype && o.in_dtype == o.w_dtype && o.stride == 1 && o.ksize == 3 && o.Ho == o.H &&
-           o.Wo == o.W && o.aux1 >= 0 && rows * o.W <= MS_MAXPX && rows * (o.W + 1) + 1 <= MS_MAXSLOT && o.Cout > 0 && o.Cout % MS_CC == 0 &&
-           o.Cin > 0 && o.Cin % 32 == 0;
+    const bool x3 = o.in_dtype == FTC_F32 && (o.flags & FTC_FLAG_SPLIT16);          // the fp32-tensor form (csrc/mbconv_slice_x3.hip): 64-channel slices
+    return (ftc_is16(o.in_dtype) || x3) && o.in_dtype == o.out_dtype && o.in_dtype == o.w_dtype && o.stride == 1 && o.ksize == 3 && o.Ho == o.H &&
+           o.Wo == o.W && o.aux1 >= 0 && rows * o.W <= MS_MAXPX && rows * (o.W + 1) + 1 <= MS_MAXSLOT && o.Cout > 0 &&
+           o.Cout % (x3 ? FTC_MBHEAD_SLICE_F32 : MS_CC) == 0 && o.Cin > 0 && o.Cin % 32 == 0;
 }
 
 int ftc_mbhead_bands(const ftc_op& o) { return o.aux1 > 0 ? (o.H + o.aux1 - 1) / o.aux1 : 1; }
@@ -342,9 +343,12 @@ int ftc_mbhead_band_rows(int H, int W) {
     return r - 2 > 0 ? r - 2 : -1;
 }
 
+hipError_t launch_mbhead_x3(const OpArgs& a, hipStream_t s);
+
 hipError_t launch_mbhead(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
     if (!ftc_mbhead_legal(o)) return hipErrorInvalidValue;
+    if (o.in_dtype == FTC_F32) return launch_mbhead_x3(a, s);
     MbsP p;
     p.x = a.in; p.we = a.w2; p.be = a.bias2; p.wd = static_cast<const float*>(a.w); p.bd = a.bias; p.out = a.out; p.sums = a.aux;
     p.w1 = a.scale; p.hpart = a.scale ? static_cast<float*>(a.out2) : nullptr;

@@ -547,7 +547,7 @@ std::string conv_signature(const ftc_op& o, bool strip_split = false) {
     // fp16 operands run the same kernels at the same rate as bf16: they share the measured table (dtype 2 looks up as 1)
     auto d = [](int dt) { return dt == FTC_F16 ? (int)FTC_BF16 : dt; };
     int n = std::snprintf(buf, sizeof buf, "w%di%do%d_B%d_%dx%d_c%dof%d_n%dof%d_k%ds%d_f%d_a%d", d(o.w_dtype), d(o.in_dtype), d(o.out_dtype), o.B, o.H, o.W,
-                          o.Cin, o.Cin_total, o.Cout, o.Cout_total, o.ksize, o.stride, (strip_split ? (o.flags & ~FTC_FLAG_SPLIT16) : o.flags) & ~FTC_FLAG_KBLOCK32, o.act);      // (KBLOCK32: where the 16-bit copy goes, not which kernel is fastest)
+                          o.Cin, o.Cin_total, o.Cout, o.Cout_total, o.ksize, o.stride, (strip_split ? (o.flags & ~FTC_FLAG_SPLIT16) : o.flags) & ~(FTC_FLAG_KBLOCK32 | FTC_FLAG_PRESPLIT), o.act);      // (KBLOCK32: where the 16-bit copy goes, not which kernel is fastest)
     if (o.groups > 1) std::snprintf(buf + n, sizeof buf - n, "_g%d", o.groups);
     return buf;
 }
@@ -666,7 +666,10 @@ int Builder::build(ModelPlan* out) {
     // the producing epilogue; the next GEMM reads the copy.
     const bool dual = bf_;
     const int G = dual ? A : T;                // dtype the GEMMs read the trunk in
-    auto trunk = [&](int64_t nelem, R* t, R* tb) { *t = buf(nelem, T); *tb = dual ? buf(nelem, A) : R(); };
+    // fp16x3 plan (round 5): a block whose output feeds a fused MBConv head gets a second, PRE-SPLIT copy of its fp32 trunk tensor (hi | lo halves
+    // per 16-byte chunk: what csrc/mbconv_slice_x3.hip streams by DMA) -- `want_copy`
+    const bool x3 = m_->split16 && cdt_ == FTC_F32;
+    auto trunk = [&](int64_t nelem, R* t, R* tb, bool want_copy = false) { *t = buf(nelem, T); *tb = dual ? buf(nelem, A) : (x3 && want_copy) ? buf(nelem, FTC_F32) : R(); };
 
     int h = (H - 1) / 2 + 1, w = (W - 1) / 2 + 1;
     R x, xb;
@@ -688,16 +691,20 @@ int Builder::build(ModelPlan* out) {
     // leaves the CU.  FTC_NO_MBSLICE=1: the three-kernel form; FTC_MBSLICE_MINWG: workgroups below which the three-kernel form is kept
     // (small batches leave most CUs without a slice).  bh, bw = the block's INPUT map.
     // (maps of more than 576 pixels -- the 48x48 stages 4-5 -- run in bands of R output rows: returns R, 0 = the whole map, -1 = not sliced)
+    const int mb_slice = x3 ? FTC_MBHEAD_SLICE_F32 : FTC_MBHEAD_SLICE;
     auto sliced = [&](const BlockSpec& blk, int bh, int bw) -> int {
-        if (blk.fused || !dual || blk.stride != 1 || blk.squeeze > FTC_MBHEAD_MAX_SQUEEZE || env_on("FTC_NO_MBSLICE")) return -1;
+        if (blk.fused || !(dual || x3) || blk.stride != 1 || blk.squeeze > FTC_MBHEAD_MAX_SQUEEZE || env_on("FTC_NO_MBSLICE")) return -1;
+        if (x3 && env_on("FTC_NO_MBSLICE_X3")) return -1;
         const int R = ftc_mbhead_band_rows(bh, bw);
         if (R < 0 || (R > 0 && env_on("FTC_NO_MBBAND"))) return -1;
         ftc_op t{};
         t.in_dtype = t.out_dtype = t.w_dtype = A; t.stride = blk.stride; t.ksize = 3; t.H = t.Ho = bh; t.W = t.Wo = bw;
-        t.Cin = blk.cin; t.Cout = blk.exp; t.aux1 = R;
+        t.Cin = blk.cin; t.Cout = blk.exp; t.aux1 = R; t.flags = x3 ? FTC_FLAG_SPLIT16 : 0;
         const char* mw_env = std::getenv("FTC_MBSLICE_MINWG");
         const int min_wg = mw_env ? std::atoi(mw_env) : 128;
-        return ftc_mbhead_legal(t) && B * ftc_mbhead_bands(t) * (blk.exp / FTC_MBHEAD_SLICE) >= min_wg ? R : -1;
+        // (fp16x3, stage 5 at batch 8 -- 960 workgroups, every 64-channel slice re-streams its image's x: 143 us against 80 + 57 for the two kernels it
+        //  replaces; kept all the same: its pre-split output saves the project convolution 10 us and the pair moves 113 MB less through HBM)
+        return ftc_mbhead_legal(t) && B * ftc_mbhead_bands(t) * (blk.exp / mb_slice) >= min_wg ? R : -1;
     };
     std::vector<const BlockSpec*> flat;
     for (const auto& st : stages)
@@ -711,12 +718,13 @@ int Builder::build(ModelPlan* out) {
             const R res = blk.residual ? x : R();
             const R gin = dual ? xb : x;        // GEMM-side view of the block input
             R y, yb;
-            trunk((int64_t)B * ho * wo * blk.cout, &y, &yb);
+            ++bi;
+            const bool next_sliced = bi < flat.size() && sliced(*flat[bi], ho, wo) >= 0;
+            trunk((int64_t)B * ho * wo * blk.cout, &y, &yb, next_sliced);
             ConvOpt tail;
             tail.residual = res; tail.res_dt = T; tail.out2 = yb;
             // the consumer of this block's 16-bit copy is the next block's expand GEMM: FTC_OP_MBHEAD streams it in 32-channel planes
-            ++bi;
-            const bool out_blocked = bi < flat.size() && sliced(*flat[bi], ho, wo) >= 0 && blk.cout % 32 == 0 && !env_on("FTC_NO_KBLOCK");
+            const bool out_blocked = dual && next_sliced && blk.cout % 32 == 0 && !env_on("FTC_NO_KBLOCK");
             if (out_blocked) tail.extra_flags |= FTC_FLAG_KBLOCK32;
             if (blk.fused && blk.exp == blk.cin) {
                 conv(p + ".0", gin, G, h, w, blk.cin, blk.cin, 0, p + ".0", blk.cout, 3, blk.stride, FTC_ACT_SILU, y, T, tail);
@@ -725,11 +733,11 @@ int Builder::build(ModelPlan* out) {
                 conv(p + ".0", gin, G, h, w, blk.cin, blk.cin, 0, p + ".0", blk.exp, 3, blk.stride, FTC_ACT_SILU, e, A);
                 conv(p + ".1", e, A, ho, wo, blk.exp, blk.exp, 0, p + ".1", blk.cout, 1, 1, FTC_ACT_NONE, y, T, tail);
             } else {
-                const int band_rows = sliced(blk, h, w);
+                const int band_rows = (x3 && !xb) ? -1 : sliced(blk, h, w);      // (fp16x3: the head streams the PRE-SPLIT copy of its input)
                 const bool slice = band_rows >= 0;
                 const int nbands = band_rows > 0 ? (h + band_rows - 1) / band_rows : 1;
                 const int th = blk.stride == 1 ? 8 : 4;
-                const int P = slice ? nbands * (blk.exp / FTC_MBHEAD_SLICE) : ((ho + th - 1) / th) * ((wo + 7) / 8);
+                const int P = slice ? nbands * (blk.exp / mb_slice) : ((ho + th - 1) / th) * ((wo + 7) / 8);
                 const R d = buf((int64_t)B * ho * wo * blk.exp, A);
                 const R part = buf((int64_t)B * P * (slice ? blk.squeeze : blk.exp), FTC_F32);
                 if (slice) {
@@ -737,8 +745,11 @@ int Builder::build(ModelPlan* out) {
                     SymOp s;
                     ftc_op& o = s.o;
                     o.kind = FTC_OP_MBHEAD; o.act = FTC_ACT_SILU; o.in_dtype = A; o.out_dtype = A; o.w_dtype = A; o.B = B; o.H = h; o.W = w; o.Ho = ho; o.Wo = wo;
-                    o.Cin = blk.cin; o.Cout = blk.exp; o.ksize = 3; o.stride = 1; o.aux0 = blk.squeeze; o.aux1 = band_rows; o.flags = in_blocked ? FTC_FLAG_KBLOCK32 : 0;
-                    s.in = gin; s.out = d; s.w2 = wref(p + ".0.w"); s.bias2 = wref(p + ".0.b"); s.w = wref(p + ".1.w"); s.bias = wref(p + ".1.b"); s.aux = sums;
+                    o.Cin = blk.cin; o.Cout = blk.exp; o.ksize = 3; o.stride = 1; o.aux0 = blk.squeeze; o.aux1 = band_rows;
+                    // fp16x3: the head writes d PRE-SPLIT when its only reader, the project convolution, runs on folded weights (no SE scale on the activations)
+                    const bool d_presplit = x3 && !env_on("FTC_NO_X3FOLD") && (ho * wo) % 64 == 0 && blk.exp % 8 == 0 && !env_on("FTC_NO_PRESPLIT");
+                    o.flags = (in_blocked ? FTC_FLAG_KBLOCK32 : 0) | (x3 ? FTC_FLAG_SPLIT16 : 0) | (d_presplit ? FTC_FLAG_PRESPLIT : 0);
+                    s.in = x3 ? xb : gin; s.out = d; s.w2 = wref(p + ".0.w"); s.bias2 = wref(p + ".0.b"); s.w = wref(p + ".1.w"); s.bias = wref(p + ".1.b"); s.aux = sums;
                     s.scale = wref(p + ".2.w1"); s.out2 = part;
                     emit({p + ".0+1", "conv1x1+dw3x3", 2.0 * B * h * w * blk.exp * (blk.cin + 9),
                           (double)B * h * w * (blk.cin + blk.exp) * esize(A) + (double)blk.exp * blk.cin * esize(A) + blk.exp * 44.0 + 4.0 * blk.exp * blk.squeeze}, s);
@@ -777,6 +788,7 @@ int Builder::build(ModelPlan* out) {
                 ConvOpt pj = tail;
                 pj.se = foldse ? R() : sc;
                 pj.wsets = wb;
+                if (x3 && slice && foldse && !env_on("FTC_NO_PRESPLIT")) pj.extra_flags |= FTC_FLAG_PRESPLIT;      // d was written pre-split by the fused head
                 conv(p + ".3", d, A, ho, wo, blk.exp, blk.exp, 0, p + ".3", blk.cout, 1, 1, FTC_ACT_NONE, y, T, pj);
             }
             x = y; xb = yb; h = ho; w = wo;

@@ -30,7 +30,7 @@ def signature(o, merge16: bool = False) -> str:
     """merge16: fp16 operands look up their bf16 twins (same kernels, same rate), as csrc/model.hip does."""
     d = (lambda t: L.BF16 if t == L.F16 else t) if merge16 else (lambda t: t)
     return (f"w{d(o.w_dtype)}i{d(o.in_dtype)}o{d(o.out_dtype)}_B{o.B}_{o.H}x{o.W}_c{o.Cin}of{o.Cin_total}_n{o.Cout}of{o.Cout_total}"
-            f"_k{o.ksize}s{o.stride}_f{o.flags & ~L.FLAG_KBLOCK32}_a{o.act}" + (f"_g{o.groups}" if o.groups > 1 else ""))
+            f"_k{o.ksize}s{o.stride}_f{o.flags & ~(L.FLAG_KBLOCK32 | L.FLAG_PRESPLIT)}_a{o.act}" + (f"_g{o.groups}" if o.groups > 1 else ""))
 
 
 def encode(cfg: int, stage: int, bk: int, halo: bool = False, splitk: int = 1) -> int:

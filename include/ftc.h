@@ -73,6 +73,7 @@ typedef struct ftc_ref {
 } ftc_ref;
 
 #define FTC_MBHEAD_SLICE 128   /* expanded channels one workgroup of FTC_OP_MBHEAD owns */
+#define FTC_MBHEAD_SLICE_F32 64   /* ... in the fp32-tensor form (in_dtype = FTC_F32 with FTC_FLAG_SPLIT16, ABI 9) */
 #define FTC_MBHEAD_MAX_SQUEEZE 160   /* largest SE squeeze width (aux0) for which FTC_OP_MBHEAD forms the fc1 partial products */
 
 typedef enum ftc_op_kind {
@@ -227,6 +228,10 @@ enum {
                                   FTC_OP_MBHEAD streams per stage is whole cache lines (from NHWC it fetched half of every 128-byte line per step and
                                   ran at the L1 fill rate).  On FTC_OP_CONV: the layout of `out2` (the 16-bit trunk copy; Cout % 32 == 0); on
                                   FTC_OP_MBHEAD: the layout of `in` */
+    FTC_FLAG_PRESPLIT = 0x20000000, /* fp16x3 plans (with FTC_FLAG_SPLIT16; ABI 9): an fp32 activation tensor stored PRE-SPLIT -- every 16-byte chunk of four values as
+                                  [hi x4 | lo x4] IEEE halves, what the three-MFMA product consumes, so that the consumer's fragments cost no VALU work and the
+                                  22 bits it would have used are exactly the ones stored.  CONV 1x1 without SE scale: the layout of `in`; MBHEAD: the layout of `out`
+                                  (its `in` always is pre-split); CONV out2 of an fp16x3 convolution always is */
     FTC_FLAG_SE_FOLD = 32      /* SE: besides scale[b,c], write out2[b][n][c] = bf16(in[n][c] * scale[b,c]) for the
                                   bf16 matrix `in` [Cout_total][C] -- the following 1x1 convolution then runs with
                                   FTC_FLAG_W_PER_IMAGE on unscaled activations (both operands by DMA) */

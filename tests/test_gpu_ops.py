@@ -681,6 +681,99 @@ def test_mbconv_slice_head_and_se_from_partial_products(shape, dt, kblock):
     assert float((wb - want).abs().max()) <= float(want.abs().max()) * (2 ** -8 if dt == L.BF16 else 2 ** -11)
 
 
+def _unsplit_f16x3(raw: torch.Tensor, shape) -> torch.Tensor:
+    """inverse of presplit_f16x3: uint8 bytes -> fp32 values hi + lo"""
+    h = raw.view(torch.float16).reshape(-1, 8).float()
+    return (h[:, :4] + h[:, 4:]).reshape(shape)
+
+
+@pytest.mark.parametrize("shape", [(8, 24, 24, 512, 192, 24, 0), (3, 24, 24, 640, 128, 160, 0), (2, 8, 8, 64, 64, 7, 0), (1, 16, 20, 32, 128, 3, 0), (2, 24, 23, 96, 64, 5, 0),
+                                   (2, 48, 48, 256, 128, 64, 10), (3, 48, 48, 192, 64, 48, 10), (2, 24, 24, 64, 128, 9, 7), (1, 40, 30, 32, 64, 4, 17)],
+                         ids=["24x24_512_192", "24x24_640_128_s160", "8x8", "16x20", "24x23", "48x48_band10", "48x48_192_band10", "24x24_band7", "40x30_band17"])
+def test_mbconv_slice_head_fp16x3(shape):
+    """FTC_OP_MBHEAD in the fp32-tensor form (in_dtype = FTC_F32 + FTC_FLAG_SPLIT16, csrc/mbconv_slice_x3.hip; round 5): pre-split input and
+    weights, 64-channel slices, fp32 expanded image in LDS, expf SiLU -- against the chain in float64 on the CPU (torchvision MBConv block[0..2]
+    as instantiated by /root/reference/models/detector.py:17-20), held to the fp32 plans' tolerance; the pre-split copy is produced by an
+    fp16x3 FTC_OP_CONV with out2 (the producer in the plan); then FTC_OP_SE with FTC_FLAG_SE_HPART | SE_FOLD | SPLIT16 on the partial products."""
+    B, H, W, K, Cc, S, R = shape
+    NB = -(-H // R) if R else 1
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cc)
+    Kp = 64                                                           # the producer: a 1x1 fp16x3 convolution Kp -> K whose out2 is the head's input
+    x0 = torch.randn(B, H, W, Kp, generator=g)
+    wprod = torch.randn(K, Kp, generator=g) / Kp ** 0.5
+    bprod = torch.randn(K, generator=g) * 0.1
+    we = torch.randn(Cc, K, generator=g) / K ** 0.5 * 1.5
+    be = torch.randn(Cc, generator=g) * 0.3
+    wd = torch.randn(Cc, 1, 3, 3, generator=g) * 0.4
+    bd = torch.randn(Cc, generator=g) * 0.2
+    w1 = torch.randn(S, Cc, generator=g) / Cc ** 0.5
+    b1 = torch.randn(S, generator=g) * 0.3
+    w2 = torch.randn(Cc, S, generator=g) / S ** 0.5
+    b2 = torch.randn(Cc, generator=g) * 0.3
+    NS = Cc // 64
+    N = 96
+    wp = torch.randn(N, Cc, generator=g) / Cc ** 0.5
+    ar = Arena()
+    o_x0, o_wprod, o_bprod = ar.put(x0), ar.put(presplit_f16x3(wprod)), ar.put(bprod)
+    o_x, o_xs = ar.reserve(B * H * W * K * 4), ar.reserve(B * H * W * K * 4)
+    o_we, o_be = ar.put(presplit_f16x3(we)), ar.put(be)
+    o_wd, o_bd = ar.put(wd.reshape(Cc, 9).t().contiguous()), ar.put(bd)
+    o_w1, o_b1, o_w2t, o_b2 = ar.put(w1), ar.put(b1), ar.put(w2.t().contiguous()), ar.put(b2)
+    o_out = ar.reserve(B * H * W * Cc * 4)
+    o_sums, o_hp = ar.reserve(B * NB * Cc * 4), ar.reserve(B * NB * NS * S * 4)
+    o_scale, o_hid = ar.reserve(B * Cc * 4), ar.reserve(B * S * 4)
+    o_wp, o_wb = ar.put(presplit_f16x3(wp)), ar.reserve(B * N * Cc * 4)
+    o_dps, o_y0, o_y1, o_bp = ar.reserve(B * H * W * Cc * 4), ar.reserve(B * H * W * N * 4), ar.reserve(B * H * W * N * 4), ar.put(torch.zeros(N))
+    ar.materialize()
+    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_SPLIT16, act=L.ACT_NONE, in_dtype=L.F32, out_dtype=L.F32, w_dtype=L.F32, B=B, H=H, W=W, Ho=H, Wo=W, Cin=Kp, Cin_total=Kp,
+                Cout=K, Cout_total=K, ksize=1, stride=1, in_=o_x0, w=o_wprod, bias=o_bprod, out=o_x, out2=o_xs), ar)
+    x = ar.read(o_x, (B, H, W, K), torch.float32)
+    assert _rel(x.reshape(-1, K), x0.reshape(-1, Kp) @ wprod.t() + bprod) < 2e-5
+    xs = _unsplit_f16x3(ar.buf[o_xs:o_xs + B * H * W * K * 4].cpu(), (B, H, W, K))
+    assert float((xs - x).abs().max()) <= float(x.abs().max()) * 2 ** -21           # hi + lo carries 22 significand bits
+    assert torch.equal(ar.buf[o_xs:o_xs + B * H * W * K * 4].cpu(), presplit_f16x3(x))   # ... and is exactly the split of the stored fp32 value
+    run_op(dict(kind=L.OP_MBHEAD, flags=L.FLAG_SPLIT16, act=L.ACT_SILU, in_dtype=L.F32, out_dtype=L.F32, w_dtype=L.F32, B=B, H=H, W=W, Ho=H, Wo=W, Cin=K, Cout=Cc, ksize=3,
+                stride=1, aux0=S, aux1=R, in_=o_xs, w2=o_we, bias2=o_be, w=o_wd, bias=o_bd, out=o_out, aux=o_sums, scale=o_w1, out2=o_hp), ar)
+    xd = x.double()
+    e = F.silu(xd.reshape(-1, K) @ we.double().t() + be.double()).reshape(B, H, W, Cc)
+    ref = F.silu(F.conv2d(e.permute(0, 3, 1, 2), wd.double(), bd.double(), 1, 1, 1, Cc)).permute(0, 2, 3, 1)
+    out = ar.read(o_out, (B, H, W, Cc), torch.float32)
+    err = float((out.double() - ref).abs().max() / ref.abs().max())
+    bsums = ar.read(o_sums, (B, NB, Cc), torch.float32)
+    mean = bsums.sum(1) / (H * W)
+    err_mean = float((mean.double() - ref.mean((1, 2))).abs().max())
+    hp = ar.read(o_hp, (B, NB, NS, S), torch.float32)
+    want_hp = torch.einsum("bnjc,sjc->bnjs", (bsums / (H * W)).reshape(B, NB, NS, 64), w1.reshape(S, NS, 64))
+    err_hp = float((hp - want_hp).abs().max())
+    if R:
+        want_b = torch.stack([ref[:, j * R:(j + 1) * R].sum((1, 2)) for j in range(NB)], 1)
+        assert float((bsums.double() - want_b).abs().max()) < 2e-5 * H * W
+    _log(f"mbhead fp16x3 {shape} rel_err {err:.3e} mean_err {err_mean:.3e} hpart_err {err_hp:.3e}")
+    assert err < 2e-5 and err_mean < 2e-5
+    assert err_hp < 2e-6 * max(1.0, float(want_hp.abs().max()))
+    ref_sc = torch.sigmoid(F.silu(mean @ w1.t() + b1) @ w2.t() + b2)
+    run_op(dict(kind=L.OP_SE, flags=L.FLAG_SE_HPART | L.FLAG_SE_FOLD | L.FLAG_SPLIT16, w_dtype=L.F32, B=B, H=H, W=W, Cin=Cc, Cout=Cc, Cout_total=N, aux0=S, aux1=NB * NS,
+                aux=o_hp, out=o_scale, in2=o_hid, w2=o_w2t, bias=o_b1, bias2=o_b2, in_=o_wp, out2=o_wb), ar)
+    sc = ar.read(o_scale, (B, Cc), torch.float32)
+    assert float((sc - ref_sc).abs().max()) < 3e-6
+    wb = _unsplit_f16x3(ar.buf[o_wb:o_wb + B * N * Cc * 4].cpu(), (B, N, Cc))
+    want = _unsplit_f16x3(presplit_f16x3(wp), (N, Cc))[None] * sc[:, None, :]
+    assert float((wb - want).abs().max()) <= float(want.abs().max()) * 2 ** -20
+    # FTC_FLAG_PRESPLIT: the head writes its output pre-split, and the project convolution (per-image folded weights, FTC_FLAG_W_PER_IMAGE) consumes
+    # it without splitting: the same bits as the fp32 output split on the way, so the two project results are IDENTICAL
+    if (H * W) % 64 == 0:
+        run_op(dict(kind=L.OP_MBHEAD, flags=L.FLAG_SPLIT16 | L.FLAG_PRESPLIT, act=L.ACT_SILU, in_dtype=L.F32, out_dtype=L.F32, w_dtype=L.F32, B=B, H=H, W=W, Ho=H, Wo=W, Cin=K,
+                    Cout=Cc, ksize=3, stride=1, aux0=S, aux1=R, in_=o_xs, w2=o_we, bias2=o_be, w=o_wd, bias=o_bd, out=o_dps, aux=o_sums, scale=o_w1, out2=o_hp), ar)
+        assert torch.equal(ar.buf[o_dps:o_dps + B * H * W * Cc * 4].cpu(), presplit_f16x3(out))
+        for flags, src, dst in ((0, o_out, o_y0), (L.FLAG_PRESPLIT, o_dps, o_y1)):
+            run_op(dict(kind=L.OP_CONV, flags=L.FLAG_SPLIT16 | L.FLAG_W_PER_IMAGE | flags, act=L.ACT_NONE, in_dtype=L.F32, out_dtype=L.F32, w_dtype=L.F32, B=B, H=H, W=W, Ho=H,
+                        Wo=W, Cin=Cc, Cin_total=Cc, Cout=N, Cout_total=N, ksize=1, stride=1, in_=src, w=o_wb, bias=o_bp, out=dst), ar)
+        y0, y1 = ar.read(o_y0, (B, H * W, N), torch.float32), ar.read(o_y1, (B, H * W, N), torch.float32)
+        ref_y = torch.einsum("bpc,bnc->bpn", out.reshape(B, H * W, Cc).double(), wb.double())
+        assert float((y0.double() - ref_y).abs().max() / ref_y.abs().max()) < 2e-5
+        assert torch.equal(y0, y1)
+
+
 def _fbits(v):
     import struct
     return struct.unpack("<i", struct.pack("<f", v))[0]

@@ -11,8 +11,8 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 # --lanes 1: the profiled passes run the steps on ONE stream, so that a kernel's duration is its own (two lanes co-schedule kernels of two
 # batches) and the launch order maps onto the plan's ops (profiles/pmc_kernels.py)
-CMD="python bench.py --steps 3 --warmup 2 --lanes 1 --no-cpu-baseline --no-fp32 --no-profile --no-sustained --no-seam2"
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32 --no-sustained --no-seam2 --dump-ops "$OUT/ops.json" > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
+CMD="python bench.py --steps 3 --warmup 2 --lanes 1 --no-cpu-baseline --no-fp32 --no-profile --no-sustained --no-seam2 --no-configs"
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-fp32 --no-sustained --no-seam2 --no-configs --dump-ops "$OUT/ops.json" > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
 rocprofv3 --kernel-trace --stats -d "$OUT" -o trace -- $CMD > "$OUT/trace.log" 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT" -o fetch -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT" -o write -- $CMD > "$OUT/write.log" 2>&1
@@ -20,7 +20,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_C
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d "$OUT" -o sq2 -- $CMD > "$OUT/sq2.log" 2>&1
 # round 3: the train step (BASELINE configs[4]) and the fp16x3 parity mode, kernel durations only
 rocprofv3 --kernel-trace --stats -d "$OUT" -o train -- python bench.py --train --steps 3 --warmup 1 --no-profile --no-cpu-baseline > "$OUT/train.log" 2>&1
-rocprofv3 --kernel-trace --stats -d "$OUT" -o x3 -- python bench.py --precision fp16x3 --steps 3 --warmup 2 --lanes 1 --no-cpu-baseline --no-fp32 --no-profile --no-sustained --no-seam2 > "$OUT/x3.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT" -o x3 -- python bench.py --precision fp16x3 --steps 3 --warmup 2 --lanes 1 --no-cpu-baseline --no-fp32 --no-profile --no-sustained --no-seam2 --no-configs > "$OUT/x3.log" 2>&1
 ls -la "$OUT" | head -40
 # summaries are made ON the box (gpurun copies back at most 64 MiB of gpurun_out/): the raw counter CSVs stay behind
 mkdir -p "$ROOT/gpurun_out/summ_$TAG"

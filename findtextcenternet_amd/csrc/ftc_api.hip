@@ -140,10 +140,10 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if (o.Cin <= 0 || o.Cout <= 0) return "mbhead: sizes must be positive";
         if ((o.flags & FTC_FLAG_PRESPLIT) && o.in_dtype != FTC_F32) return "mbhead: FTC_FLAG_PRESPLIT applies to the fp32-tensor form";
         if (!ftc_mbhead_legal(o))
-            return "mbhead: needs 16-bit in/out/w of one type (Cout % 128 == 0) or fp32 with FTC_FLAG_SPLIT16 (Cout % 64 == 0), stride 1, ksize 3, Ho = H, Wo = W, Cin % 32 == 0 and a map (or, with aux1 = "
+            return "mbhead: needs 16-bit in/out/w of one type (slice width Cout_total = 0 | 128 | 96 dividing Cout) or fp32 with FTC_FLAG_SPLIT16 (Cout % 64 == 0), stride 1, ksize 3, Ho = H, Wo = W, Cin % 32 == 0 and a map (or, with aux1 = "
                    "output rows per band, a band + 2 halo rows) of <= 576 pixels and < 601 row-separated slots";
         const int64_t esz = o.in_dtype == FTC_F32 ? 4 : 2;
-        const int64_t nb = ftc_mbhead_bands(o), ns = o.Cout / (o.in_dtype == FTC_F32 ? FTC_MBHEAD_SLICE_F32 : FTC_MBHEAD_SLICE);
+        const int64_t nb = ftc_mbhead_bands(o), ns = o.Cout / ftc_mbhead_slice(o);
         if (!need(o.in, true, "in", pin * o.Cin * esz) || !need(o.out, true, "out", pin * o.Cout * esz) || !need(o.w2, true, "w2", (int64_t)o.Cout * o.Cin * esz) ||
             !need(o.bias2, true, "bias2", (int64_t)o.Cout * 4) || !need(o.w, true, "w", (int64_t)9 * o.Cout * 4) ||
             !need(o.bias, true, "bias", (int64_t)o.Cout * 4) || !need(o.aux, true, "aux", (int64_t)o.B * nb * o.Cout * 4)) return why->c_str();
@@ -521,7 +521,7 @@ int ftc_op_kernel_label(const ftc_op* op, char* buf, int len) {
         break;
     case FTC_OP_SE: std::snprintf(buf, len, (op->flags & FTC_FLAG_SE_HPART) ? "se_gate" : "se_fc1+se_fc2"); break;
     case FTC_OP_MBHEAD:     // two instantiations, as the profiler sees them: the whole 24x24 map (FAST) / the general kernel (bands of rows)
-        std::snprintf(buf, len, "mbconv_slice<%s,%s,%s>", op->in_dtype == FTC_F32 ? "f16x3" : ftc_dtname(op->in_dtype), op->in_dtype == FTC_F32 ? "64ch" : "128ch",
+        std::snprintf(buf, len, "mbconv_slice<%s,%dch,%s>", op->in_dtype == FTC_F32 ? "f16x3" : ftc_dtname(op->in_dtype), ftc_mbhead_slice(*op),
                       op->H == 24 && op->W == 24 && op->aux1 == 0 && !(op->flags & 0x100) ? "24x24" : "bands");
         break;
     case FTC_OP_UPCAT: std::snprintf(buf, len, "upcat_kernel<%s>", ftc_dtname(op->in_dtype)); break;

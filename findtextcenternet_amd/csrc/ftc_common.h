@@ -242,6 +242,7 @@ hipError_t launch_se(const OpArgs& a, hipStream_t s);
 bool ftc_mbhead_legal(const ftc_op& o);
 int ftc_mbhead_bands(const ftc_op& o);
 int ftc_mbhead_band_rows(int H, int W);
+int ftc_mbhead_slice(const ftc_op& o);         // expanded channels per workgroup (ftc_op.Cout_total, or the form's default)
 hipError_t launch_mbhead(const OpArgs& a, hipStream_t s);
 hipError_t launch_upcat(const OpArgs& a, hipStream_t s);
 hipError_t launch_nms(const OpArgs& a, hipStream_t s);

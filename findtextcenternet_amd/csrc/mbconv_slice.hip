@@ -49,18 +49,27 @@ struct MbsP {
     unsigned long long* tl;  // flags 0x1000: s_memtime of wave 0 at the phase boundaries and K steps, 32 values per workgroup (tools/mbslice_bench.py)
 };
 
-constexpr int MS_CC = FTC_MBHEAD_SLICE;     // expanded channels per workgroup (128)
 constexpr int MS_NT = 512;                  // threads
 constexpr int MS_MAXPX = 576;               // pixels per image (36 MFMA pixel blocks of 16)
 constexpr int MS_XS = MS_MAXPX * 64;        // bytes of the x part of a stage (64-byte rows: K step 32)
-constexpr int MS_STAGE = MS_XS + MS_CC * 64;
 constexpr int MS_NSTAGE = 3;
 constexpr int MS_MAXSLOT = 601;             // pixel slots of the expanded image (24 x 25 + 1)
-constexpr int MS_PITCH = MS_CC * 2 + 8;     // bytes per slot
-constexpr int MS_CONST = (MS_MAXSLOT * MS_PITCH + 15) / 16 * 16;     // depthwise weights [9][128] + bias [128] fp32, behind the image
-constexpr int MS_LDS = MS_CONST + 10 * MS_CC * 4;
-static_assert(MS_NSTAGE * MS_STAGE <= MS_MAXSLOT * MS_PITCH && MS_LDS <= 160 * 1024, "");
 constexpr int MS_R = 6;                     // outputs per depthwise strip (12: 3.5 instead of 4 reads per output, but 44 registers spilled)
+// Slice width (round 5): NCT channel tiles of 16 per wave = 32 NCT expanded channels per workgroup.  128 (NCT = 4) is the default; 96 (NCT = 3) for
+// blocks whose 128-channel slices leave CUs without a workgroup: stage 6 at batch 8 is 8 x 24 = 192 workgroups on 256 CUs, 8 x 32 = 256 with 96.
+template <int NCT> struct MsGeom {
+    static constexpr int CC = NCT * 32;                  // expanded channels per workgroup
+    static constexpr int CQN = CC / 4;                   // channel quads = lanes per depthwise strip lane group (32 | 24)
+    static constexpr int NPL = MS_NT / CQN;              // depthwise strip lanes (16 | 21; threads beyond NPL * CQN idle through that phase)
+    static constexpr int STAGE = MS_XS + CC * 64;
+    static constexpr int PITCH = CC * 2 + 8;             // bytes per slot
+    static constexpr int IMG = MS_MAXSLOT * PITCH, RING = MS_NSTAGE * STAGE;
+    static constexpr int CONST = ((IMG > RING ? IMG : RING) + 15) / 16 * 16;      // depthwise weights [9][CC] + bias [CC] fp32, behind image and ring
+    static constexpr int LDS = CONST + 10 * CC * 4;
+    static constexpr int NPIECE = 36 + CC / 16;          // DMA pieces of a stage: 36 of x, CC / 16 of weights (44 | 42)
+    static constexpr int NW6 = NPIECE - 40;              // waves that issue six pieces (the others five)
+    static_assert(LDS <= 160 * 1024 && NPIECE > 40 && NPIECE <= 48, "");
+};
 
 __device__ __forceinline__ f32x4 mfma16x16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 mfma16x16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
@@ -70,8 +79,10 @@ __device__ __forceinline__ f32x4 mfma16x16(f16x8 a, f16x8 b, f32x4 c) { return _
 // project GEMM: 60.0 vs 41.7 + 14.9 us -- and round 5's FTC_FLAG_SE_TAIL -- ungated output, the last workgroups of an image fold the project
 // weights: 61.9 vs 42.5 + 14.8 us on one stream and waits that run into their bound under two lanes; profiles/r04_mbhead_se_inline_experiment.txt,
 // profiles/r05_se_tail_experiment.txt, DESIGN.md appendix.)
-template <typename T, bool FAST>
+template <typename T, bool FAST, int NCT = 4>
 __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
+    using GM = MsGeom<NCT>;
+    constexpr int MS_CC = GM::CC, MS_STAGE = GM::STAGE, MS_PITCH = GM::PITCH, MS_CONST = GM::CONST, CQN = GM::CQN, NPL = GM::NPL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
     const int xstep = p.kblock ? Mfull * 64 : 64;                        // bytes between consecutive K steps of x
     auto issue_piece = [&](int i, int step, int bufoff) {
         const int q0 = (i * 8 + wave) * 64;                              // wave-uniform
-        if (i < 5 || wave < 4) {
+        if (i < 5 || wave < GM::NW6) {
             lds_void_t* dst = (lds_void_t*)(smem_raw + bufoff + q0 * 16);
             if (q0 < MS_MAXPX * 4) glds16(rx, dst, s_off[i], step * xstep);
             else glds16(rwe, dst, s_off[i], step * 64);
@@ -131,22 +142,22 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
     // per K step 4 + 9 fragment reads feed 36 MFMAs (the 32x32x16 tiling, 1 x 9 tiles per wave, read 20 per 18 and kept the LDS busy
     // for longer than the matrix pipe).  The accumulators start at the expand bias.
     const int chw = wave & 1, pg = wave >> 1;
-    f32x4 acc[4][9];
+    f32x4 acc[NCT][9];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const f32x4 bi = *reinterpret_cast<const f32x4*>(p.be + c0 + chw * 64 + i * 16 + 4 * lq);
+    for (int i = 0; i < NCT; ++i) {
+        const f32x4 bi = *reinterpret_cast<const f32x4*>(p.be + c0 + chw * (MS_CC / 2) + i * 16 + 4 * lq);
 #pragma unroll
         for (int j = 0; j < 9; ++j) acc[i][j] = bi;
     }
-    if (t < 10 * (MS_CC / 4)) {                                          // depthwise weights [9][128] + bias [128] of this slice -> LDS
-        const int row = t >> 5, ch = (t & 31) * 4;
+    if (t < 10 * CQN) {                                                  // depthwise weights [9][CC] + bias [CC] of this slice -> LDS
+        const int row = t / CQN, ch = (t - row * CQN) * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(row < 9 ? p.wd + (long)row * p.C + c0 + ch : p.bd + c0 + ch);
         *reinterpret_cast<f32x4*>(smem_raw + MS_CONST + t * 16) = v;
     }
 
     using FragT = typename Frag<T>::type;
     const int swz = ((lq ^ (((l15 >> 3) & 1) * 3)) << 4);
-    const int offA = MS_XS + (chw * 64 + l15) * 64 + swz;             // + i * 1024
+    const int offA = MS_XS + (chw * (MS_CC / 2) + l15) * 64 + swz;     // + i * 1024
     const int offB = (pg * 144 + l15) * 64 + swz;                       // + j * 1024
     const int nk = p.K >> 5;
     const bool tl_on = p.tl && t == 0;
@@ -164,15 +175,15 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
         const unsigned long long ta = tl_on ? __builtin_amdgcn_s_memtime() : 0;
         // stage `it` has landed once at most the later-issued stage remains outstanding (per-wave piece counts)
         if (it + 1 >= nk) wait_vmcnt<0>();
-        else if (wave < 4) wait_vmcnt<6>();
+        else if (wave < GM::NW6) wait_vmcnt<6>();
         else wait_vmcnt<5>();
         wg_barrier();
         if (tl_on) { const unsigned long long d = __builtin_amdgcn_s_memtime() - ta; tw += d; if (it == 0) tw0 = d; if (it < 24) tl[8 + it] = ta; }
         const unsigned char* base = smem_raw + cur_off;
         const bool more = it + 2 < nk;                               // stage it + 2 goes to the slot consumed in step it - 1
-        FragT af[4];
+        FragT af[NCT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const FragT*>(base + offA + i * 1024);
+        for (int i = 0; i < NCT; ++i) af[i] = *reinterpret_cast<const FragT*>(base + offA + i * 1024);
         // pixel fragments three groups ahead of their MFMAs (a group of 4 MFMAs lasts 64 cycles, an LDS read takes twice that)
         FragT bq[3];
 #pragma unroll
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
             const FragT bcur = bq[j % 3];
             if (j + 3 < 9) bq[j % 3] = *reinterpret_cast<const FragT*>(base + offB + (j + 3) * 1024);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][j] = mfma16x16(af[i], bcur, acc[i][j]);
+            for (int i = 0; i < NCT; ++i) acc[i][j] = mfma16x16(af[i], bcur, acc[i][j]);
             constexpr int piece_after[9] = {0, 1, -1, 2, 3, -1, 4, 5, -1};
             if (piece_after[j] >= 0 && more) issue_piece(piece_after[j], it + 2, iss_off);
             __builtin_amdgcn_sched_barrier(0);
@@ -196,35 +207,36 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
     if (tl_on) { tl[1] = __builtin_amdgcn_s_memtime(); tl[5] = tw; tl[6] = tw0; }
 
     // ---- expanded image: SiLU, 16-bit, slot(y, x) = y (W+1) + x + 1 ----
-    for (int idx = t; idx < (H + 1) * 32; idx += MS_NT) {       // the zero slots between the rows (and before the first / after the last)
+    for (int idx = t; idx < (H + 1) * CQN; idx += MS_NT) {      // the zero slots between the rows (and before the first / after the last)
         const u32x2 z = {0u, 0u};
-        *reinterpret_cast<u32x2*>(smem_raw + ((idx >> 5) * W1) * MS_PITCH + (idx & 31) * 8) = z;       // (264-byte rows are 8-byte aligned)
+        *reinterpret_cast<u32x2*>(smem_raw + ((idx / CQN) * W1) * MS_PITCH + (idx % CQN) * 8) = z;     // (264- / 200-byte rows are 8-byte aligned)
     }
 #pragma unroll
     for (int j = 0; j < 9; ++j) {
         const int m = pg * 144 + j * 16 + l15;
         if (m < M) {
             const int y = m / W;
-            unsigned char* row = smem_raw + (m + y + 1) * MS_PITCH + (chw * 64 + 4 * lq) * 2;       // slot = y (W+1) + x + 1 = m + y + 1
+            unsigned char* row = smem_raw + (m + y + 1) * MS_PITCH + (chw * (MS_CC / 2) + 4 * lq) * 2;       // slot = y (W+1) + x + 1 = m + y + 1
 #pragma unroll
-            for (int i = 0; i < 4; ++i) store4<T>(reinterpret_cast<T*>(row + i * 32), act_silu_fast4(acc[i][j]));
+            for (int i = 0; i < NCT; ++i) store4<T>(reinterpret_cast<T*>(row + i * 32), act_silu_fast4(acc[i][j]));
         }
     }
     __syncthreads();
     if (tl_on) tl[2] = __builtin_amdgcn_s_memtime();
 
     // ---- depthwise 3x3 + bias + SiLU + channel sums ----
-    const int cq = t & 31, pl = t >> 5;                        // 4 channels cq*4.., strip lane 0..15
+    const int pl = t / CQN, cq = t - pl * CQN;                 // 4 channels cq*4.., strip lane 0..NPL-1 (96-channel slices: threads 504.. have no lane)
+    const bool dw_on = pl < NPL;
     const int c = c0 + cq * 4;
     // this slice's columns of the SE fc1 matrix, requested now: they arrive under the depthwise phase (behind its stores they would
     // wait for every store to drain: vmcnt is in order).  Lane = 4 channels, 16 units s apart per pass.
-    constexpr int NU = FTC_MBHEAD_MAX_SQUEEZE / 16;             // S <= 160 (validated: ftc_api.hip)
+    constexpr int NU = (FTC_MBHEAD_MAX_SQUEEZE + NPL - 1) / NPL;      // S <= 160 (validated: ftc_api.hip)
     f32x4 w1r[NU];
     auto load_w1 = [&]() {
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
-            const int su = pl + 16 * i;
-            w1r[i] = su < p.S ? *reinterpret_cast<const f32x4*>(p.w1 + (size_t)su * p.C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int su = pl + NPL * i;
+            w1r[i] = (dw_on && su < p.S) ? *reinterpret_cast<const f32x4*>(p.w1 + (size_t)su * p.C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     if (p.hpart) load_w1();
@@ -238,7 +250,7 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     T* outp = reinterpret_cast<T*>(p.out) + ((size_t)b * Mfull + (size_t)ylo * W) * p.C + c;
     const unsigned char* zslot = smem_raw + cq * 8;             // slot 0: zeros
-    for (int s = pl; s < nstrips; s += 16) {
+    for (int s = dw_on ? pl : nstrips; s < nstrips; s += NPL) {
         const int sr = s / W, x = s - sr * W;
         const int oy0 = yo + sr * MS_R;
         // window rows 0..6 from base0, 7.. from base1: the immediate offset of a DS instruction is 16 bits
@@ -281,38 +293,41 @@ __global__ __launch_bounds__(MS_NT, 2) void mbconv_slice_kernel(const MbsP p) {
 
     // ---- squeeze: the image's channel sums, complete in this workgroup (the expanded image is dead: its memory holds the scratch) ----
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem_raw);           // [8 waves][128]
-    float* lmean = red + 8 * MS_CC;
-    {
+    constexpr int NRED = NCT == 4 ? 8 : NPL;                   // partial sums per channel: one per wave (128 channels: two strip lanes per wave) | per strip lane
+    float* red = reinterpret_cast<float*>(smem_raw);           // [NRED][CC]
+    float* lmean = red + NRED * MS_CC;
+    if constexpr (NCT == 4) {
         f32x4 v = sum;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += __shfl_xor(v[e], 32, 64);
         if (lane < 32) *reinterpret_cast<f32x4*>(red + wave * MS_CC + lane * 4) = v;
+    } else {
+        if (dw_on) *reinterpret_cast<f32x4*>(red + pl * MS_CC + cq * 4) = sum;
     }
     __syncthreads();
     if (t < MS_CC) {
         float tot = 0.f;
 #pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) tot += red[w8 * MS_CC + t];
+        for (int w8 = 0; w8 < NRED; ++w8) tot += red[w8 * MS_CC + t];
         p.sums[((size_t)b * p.nb + band) * p.C + c0 + t] = tot;
         lmean[t] = tot * p.inv_hw;
     }
     if (p.hpart) {
         __syncthreads();
-        // lane (4 channels) x unit products -> LDS [unit][32 + 1], then one thread per unit adds the 32 channel quads in order
+        // lane (4 channels) x unit products -> LDS [unit][CQN + 1], then one thread per unit adds the channel quads in order
         float* fcb = lmean + MS_CC;
-        const f32x4 m4 = *reinterpret_cast<const f32x4*>(lmean + cq * 4);
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(lmean + (dw_on ? cq : 0) * 4);
 #pragma unroll
         for (int i = 0; i < NU; ++i) {
             const f32x4 pr = w1r[i] * m4;
-            const int su = pl + 16 * i;
-            if (su < p.S) fcb[su * 33 + cq] = (pr[0] + pr[1]) + (pr[2] + pr[3]);
+            const int su = pl + NPL * i;
+            if (dw_on && su < p.S) fcb[su * (CQN + 1) + cq] = (pr[0] + pr[1]) + (pr[2] + pr[3]);
         }
         __syncthreads();
         if (t < p.S) {
             float d = 0.f;
 #pragma unroll
-            for (int q = 0; q < 32; ++q) d += fcb[t * 33 + q];
+            for (int q = 0; q < CQN; ++q) d += fcb[t * (CQN + 1) + q];
             float* dst = p.hpart + (((size_t)b * p.nb + band) * (p.C / MS_CC) + sl) * p.S + t;
             *dst = d;
         }
@@ -328,10 +343,15 @@ static int mbhead_rows(const ftc_op& o) { return o.aux1 > 0 ? (o.aux1 + 2 < o.H 
 bool ftc_mbhead_legal(const ftc_op& o) {
     const int rows = mbhead_rows(o);
     const bool x3 = o.in_dtype == FTC_F32 && (o.flags & FTC_FLAG_SPLIT16);          // the fp32-tensor form (csrc/mbconv_slice_x3.hip): 64-channel slices
+    const int slice = ftc_mbhead_slice(o);
+    if (x3 ? slice != FTC_MBHEAD_SLICE_F32 : (slice != 128 && slice != 96)) return false;
     return (ftc_is16(o.in_dtype) || x3) && o.in_dtype == o.out_dtype && o.in_dtype == o.w_dtype && o.stride == 1 && o.ksize == 3 && o.Ho == o.H &&
            o.Wo == o.W && o.aux1 >= 0 && rows * o.W <= MS_MAXPX && rows * (o.W + 1) + 1 <= MS_MAXSLOT && o.Cout > 0 &&
-           o.Cout % (x3 ? FTC_MBHEAD_SLICE_F32 : MS_CC) == 0 && o.Cin > 0 && o.Cin % 32 == 0;
+           o.Cout % slice == 0 && o.Cin > 0 && o.Cin % 32 == 0;
 }
+
+// expanded channels per workgroup: ftc_op.Cout_total when given (128 | 96; 64 in the fp32-tensor form), else the default of the form
+int ftc_mbhead_slice(const ftc_op& o) { return o.Cout_total > 0 ? o.Cout_total : (o.in_dtype == FTC_F32 ? FTC_MBHEAD_SLICE_F32 : FTC_MBHEAD_SLICE); }
 
 int ftc_mbhead_bands(const ftc_op& o) { return o.aux1 > 0 ? (o.H + o.aux1 - 1) / o.aux1 : 1; }
 
@@ -358,20 +378,26 @@ hipError_t launch_mbhead(const OpArgs& a, hipStream_t s) {
     p.img_bytes = (unsigned)((long)o.H * o.W * o.Cin * 2);
     p.inv_hw = 1.0f / (float)(o.H * o.W);
     p.tl = (o.flags & 0x1000) ? reinterpret_cast<unsigned long long*>(const_cast<void*>(a.in2)) : nullptr;      // phase timeline (tools/mbslice_bench.py)
+    const int slice = ftc_mbhead_slice(o);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipSuccess;
-        for (const void* f : {reinterpret_cast<const void*>(mbconv_slice_kernel<__bf16, true>), reinterpret_cast<const void*>(mbconv_slice_kernel<__bf16, false>),
-                              reinterpret_cast<const void*>(mbconv_slice_kernel<_Float16, true>), reinterpret_cast<const void*>(mbconv_slice_kernel<_Float16, false>)})
-            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MS_LDS);
+        for (const void* f : {reinterpret_cast<const void*>(mbconv_slice_kernel<__bf16, true, 4>), reinterpret_cast<const void*>(mbconv_slice_kernel<__bf16, false, 4>),
+                              reinterpret_cast<const void*>(mbconv_slice_kernel<_Float16, true, 4>), reinterpret_cast<const void*>(mbconv_slice_kernel<_Float16, false, 4>)})
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MsGeom<4>::LDS);
+        for (const void* f : {reinterpret_cast<const void*>(mbconv_slice_kernel<__bf16, true, 3>), reinterpret_cast<const void*>(mbconv_slice_kernel<__bf16, false, 3>),
+                              reinterpret_cast<const void*>(mbconv_slice_kernel<_Float16, true, 3>), reinterpret_cast<const void*>(mbconv_slice_kernel<_Float16, false, 3>)})
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, MsGeom<3>::LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int nblk = o.B * p.nb * (o.Cout / MS_CC);
+    const int nblk = o.B * p.nb * (o.Cout / slice);
     const bool fast = o.H == 24 && o.W == 24 && p.nb == 1 && !(o.flags & 0x100);          // 0x100: the general kernel (tests)
-#define MBS_LAUNCH(T, F) hipLaunchKernelGGL((mbconv_slice_kernel<T, F>), dim3(nblk), dim3(MS_NT), MS_LDS, s, p)
-    if (o.in_dtype == FTC_F16) { if (fast) MBS_LAUNCH(_Float16, true); else MBS_LAUNCH(_Float16, false); }
-    else { if (fast) MBS_LAUNCH(__bf16, true); else MBS_LAUNCH(__bf16, false); }
+#define MBS_LAUNCH(T, F, N) hipLaunchKernelGGL((mbconv_slice_kernel<T, F, N>), dim3(nblk), dim3(MS_NT), MsGeom<N>::LDS, s, p)
+#define MBS_PICK(T, N) do { if (fast) MBS_LAUNCH(T, true, N); else MBS_LAUNCH(T, false, N); } while (0)
+    if (o.in_dtype == FTC_F16) { if (slice == 96) MBS_PICK(_Float16, 3); else MBS_PICK(_Float16, 4); }
+    else { if (slice == 96) MBS_PICK(__bf16, 3); else MBS_PICK(__bf16, 4); }
+#undef MBS_PICK
 #undef MBS_LAUNCH
     return hipGetLastError();
 }

@@ -691,7 +691,16 @@ int Builder::build(ModelPlan* out) {
     // leaves the CU.  FTC_NO_MBSLICE=1: the three-kernel form; FTC_MBSLICE_MINWG: workgroups below which the three-kernel form is kept
     // (small batches leave most CUs without a slice).  bh, bw = the block's INPUT map.
     // (maps of more than 576 pixels -- the 48x48 stages 4-5 -- run in bands of R output rows: returns R, 0 = the whole map, -1 = not sliced)
-    const int mb_slice = x3 ? FTC_MBHEAD_SLICE_F32 : FTC_MBHEAD_SLICE;
+    // Slice width of a block's fused head: 64 (fp32 tensors), 128, or -- whole-map blocks whose 128-channel slices leave more than a fifth of the 256
+    // CUs without a workgroup while 96-channel slices still fit one round (stage 6 at batch 8: 192 -> 256 workgroups) -- 96.  FTC_MBSLICE_96=0: never.
+    auto mb_slice_of = [&](const BlockSpec& blk, int bh, int bw) -> int {
+        if (x3) return FTC_MBHEAD_SLICE_F32;
+        if (ftc_mbhead_band_rows(bh, bw) != 0 || blk.exp % 96 != 0) return FTC_MBHEAD_SLICE;
+        const char* e96 = std::getenv("FTC_MBSLICE_96");
+        if (e96 && e96[0] == '0') return FTC_MBHEAD_SLICE;
+        const int w128 = B * (blk.exp / 128), w96 = B * (blk.exp / 96);
+        return (w128 <= 204 && w96 <= 256) ? 96 : FTC_MBHEAD_SLICE;
+    };
     auto sliced = [&](const BlockSpec& blk, int bh, int bw) -> int {
         if (blk.fused || !(dual || x3) || blk.stride != 1 || blk.squeeze > FTC_MBHEAD_MAX_SQUEEZE || env_on("FTC_NO_MBSLICE")) return -1;
         if (x3 && env_on("FTC_NO_MBSLICE_X3")) return -1;
@@ -700,6 +709,8 @@ int Builder::build(ModelPlan* out) {
         ftc_op t{};
         t.in_dtype = t.out_dtype = t.w_dtype = A; t.stride = blk.stride; t.ksize = 3; t.H = t.Ho = bh; t.W = t.Wo = bw;
         t.Cin = blk.cin; t.Cout = blk.exp; t.aux1 = R; t.flags = x3 ? FTC_FLAG_SPLIT16 : 0;
+        const int mb_slice = mb_slice_of(blk, bh, bw);
+        t.Cout_total = mb_slice;
         const char* mw_env = std::getenv("FTC_MBSLICE_MINWG");
         const int min_wg = mw_env ? std::atoi(mw_env) : 128;
         // (fp16x3, stage 5 at batch 8 -- 960 workgroups, every 64-channel slice re-streams its image's x: 143 us against 80 + 57 for the two kernels it
@@ -737,6 +748,7 @@ int Builder::build(ModelPlan* out) {
                 const bool slice = band_rows >= 0;
                 const int nbands = band_rows > 0 ? (h + band_rows - 1) / band_rows : 1;
                 const int th = blk.stride == 1 ? 8 : 4;
+                const int mb_slice = mb_slice_of(blk, h, w);
                 const int P = slice ? nbands * (blk.exp / mb_slice) : ((ho + th - 1) / th) * ((wo + 7) / 8);
                 const R d = buf((int64_t)B * ho * wo * blk.exp, A);
                 const R part = buf((int64_t)B * P * (slice ? blk.squeeze : blk.exp), FTC_F32);
@@ -745,7 +757,7 @@ int Builder::build(ModelPlan* out) {
                     SymOp s;
                     ftc_op& o = s.o;
                     o.kind = FTC_OP_MBHEAD; o.act = FTC_ACT_SILU; o.in_dtype = A; o.out_dtype = A; o.w_dtype = A; o.B = B; o.H = h; o.W = w; o.Ho = ho; o.Wo = wo;
-                    o.Cin = blk.cin; o.Cout = blk.exp; o.ksize = 3; o.stride = 1; o.aux0 = blk.squeeze; o.aux1 = band_rows;
+                    o.Cin = blk.cin; o.Cout = blk.exp; o.Cout_total = mb_slice; o.ksize = 3; o.stride = 1; o.aux0 = blk.squeeze; o.aux1 = band_rows;
                     // fp16x3: the head writes d PRE-SPLIT when its only reader, the project convolution, runs on folded weights (no SE scale on the activations)
                     const bool d_presplit = x3 && !env_on("FTC_NO_X3FOLD") && (ho * wo) % 64 == 0 && blk.exp % 8 == 0 && !env_on("FTC_NO_PRESPLIT");
                     o.flags = (in_blocked ? FTC_FLAG_KBLOCK32 : 0) | (x3 ? FTC_FLAG_SPLIT16 : 0) | (d_presplit ? FTC_FLAG_PRESPLIT : 0);

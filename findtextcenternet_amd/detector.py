@@ -411,6 +411,9 @@ class TextDetectorModel(nn.Module):
                 # The reference's train step exactly as train1.py:125-131 writes it: the SAME static plan TrainStep.forward_backward runs, cut at
                 # the loss op -- loss_function(...) runs the loss op, CoVWeightingLoss weights it, loss.backward() runs the plan's backward half
                 # and ADDS the parameter gradients into .grad (findtextcenternet_amd.train_step: "the reference's own calling sequence").
+                if fmask is None:
+                    raise ValueError("train-mode forward with gradients enabled is the train step's forward (train1.py:125-131): pass fmask = "
+                                     "model.get_fmask(labelmap, fmask); for the BatchNorm-refresh pass wrap the call in torch.no_grad()")
                 from .train_step import TrainStep
                 ts = self.__dict__.get("_train_step")
                 if ts is None or ts.precision != self.detector.precision:

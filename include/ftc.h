@@ -173,7 +173,10 @@ typedef enum ftc_op_kind {
        channels c of slice j of scale[s][c] * mean_hw(out[b,:,:,c]) -- FTC_OP_SE with FTC_FLAG_SE_HPART adds the slices' vectors.
        Band mode for larger maps (the 48x48 stages), aux1 = R > 0: a workgroup owns R output rows of an image (nb = ceil(H / R) bands) and
        recomputes one expanded halo row above and below; (R + 2) * W <= 576 and (R + 2) * (W + 1) < 601 then replace the whole-map limits,
-       aux = [B][nb][Cout] per-band channel sums (FTC_OP_SE: aux1 = nb) and out2 = [B][nb * Cout/FTC_MBHEAD_SLICE][aux0] */
+       aux = [B][nb][Cout] per-band channel sums (FTC_OP_SE: aux1 = nb) and out2 = [B][nb * Cout/FTC_MBHEAD_SLICE][aux0].
+       Round 5 (ABI 9): Cout_total = the slice width (0 = the default: 128; 96 where 128-channel slices leave CUs idle), Cout % slice == 0, out2 and
+       FTC_OP_SE's aux1 count Cout / slice slices; the fp32-tensor form (in_dtype = out_dtype = w_dtype = FTC_F32 with FTC_FLAG_SPLIT16, csrc/mbconv_slice_x3.hip):
+       `in` and w2 PRE-SPLIT (see FTC_FLAG_PRESPLIT), 64-channel slices, fp32 `out` (pre-split with FTC_FLAG_PRESPLIT) */
     FTC_OP_MBHEAD = 25,
     FTC_OP_TAPSUM = 7          /* second half of a 3x3 convolution split as per-pixel taps + 9-point sum (FTC_FLAG_TOP_FUSE):
                                   out[b,y,x,ch_j] = bias[j] + sum_{r,s} in[g_j][b,y+r-1,x+s-1][(3r+s)*co_j + o_j] (zero outside),

@@ -620,6 +620,21 @@ def test_mbconv_slice_head_and_se_from_partial_products(shape, dt, kblock):
     products in one launch, against the same chain in fp32 on the CPU (expanded tensor rounded to the 16-bit type, as the three-kernel
     path stores it); then FTC_OP_SE with FTC_FLAG_SE_HPART (with and without the per-image weight fold) against the SE MLP on those
     means.  torchvision MBConv block[0..2] as instantiated by /root/reference/models/detector.py:17-20."""
+    _mbhead_case(shape, dt, kblock, L.MBHEAD_SLICE)
+
+
+@pytest.mark.parametrize("dt", [L.BF16, L.F16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(8, 24, 24, 512, 384, 24, 0), (3, 24, 24, 640, 192, 160, 0), (2, 8, 8, 64, 96, 7, 0), (1, 16, 20, 32, 288, 3, 0),
+                                   (2, 48, 48, 256, 288, 64, 10), (2, 24, 24, 64, 96, 9, 7)],
+                         ids=["24x24_512_384", "24x24_640_192_s160", "8x8", "16x20", "48x48_band10", "24x24_band7"])
+def test_mbconv_slice_head_96_channel_slices(shape, dt):
+    """FTC_OP_MBHEAD with 96-channel slices (ftc_op.Cout_total = 96; round 5: stage 6 at batch 8 then launches 256 workgroups instead of 192 on the
+    256 CUs): same checks as the 128-channel form, NHWC and 32-channel-plane input."""
+    _mbhead_case(shape, dt, False, 96)
+    _mbhead_case(shape, dt, True, 96)
+
+
+def _mbhead_case(shape, dt, kblock, slice_w):
     B, H, W, K, Cc, S, R = shape
     NB = -(-H // R) if R else 1
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cc)
@@ -635,7 +650,7 @@ def test_mbconv_slice_head_and_se_from_partial_products(shape, dt, kblock):
     b2 = torch.randn(Cc, generator=g) * 0.3
     e = r16(F.silu(x.reshape(-1, K) @ we.t() + be)).reshape(B, H, W, Cc)
     ref = F.silu(F.conv2d(e.permute(0, 3, 1, 2), wd, bd, 1, 1, 1, Cc)).permute(0, 2, 3, 1)
-    NS = Cc // L.MBHEAD_SLICE
+    NS = Cc // slice_w
     ar = Arena()
     xdev = x.reshape(B, H * W, K // 32, 32).permute(0, 2, 1, 3) if kblock else x      # FTC_FLAG_KBLOCK32: [B][K/32][H*W][32]
     o_x, o_we, o_be = ar.put(to_dev_bytes(xdev, dt)), ar.put(to_dev_bytes(we, dt)), ar.put(be)
@@ -648,7 +663,7 @@ def test_mbconv_slice_head_and_se_from_partial_products(shape, dt, kblock):
     wp = r16(torch.randn(N, Cc, generator=g) / Cc ** 0.5)
     o_wp, o_wb = ar.put(to_dev_bytes(wp, dt)), ar.reserve(B * N * Cc * 2)
     ar.materialize()
-    run_op(dict(kind=L.OP_MBHEAD, flags=L.FLAG_KBLOCK32 if kblock else 0, act=L.ACT_SILU, in_dtype=dt, out_dtype=dt, w_dtype=dt, B=B, H=H, W=W, Ho=H, Wo=W, Cin=K, Cout=Cc, ksize=3, stride=1,
+    run_op(dict(kind=L.OP_MBHEAD, flags=L.FLAG_KBLOCK32 if kblock else 0, act=L.ACT_SILU, in_dtype=dt, out_dtype=dt, w_dtype=dt, B=B, H=H, W=W, Ho=H, Wo=W, Cin=K, Cout=Cc, Cout_total=0 if slice_w == L.MBHEAD_SLICE else slice_w, ksize=3, stride=1,
                 aux0=S, aux1=R, in_=o_x, w2=o_we, bias2=o_be, w=o_wd, bias=o_bd, out=o_out, aux=o_sums, scale=o_w1, out2=o_hp), ar)
     out = ar.read(o_out, (B, H, W, Cc), tdtype(dt)).float()
     err = _rel(out, ref)
@@ -656,7 +671,7 @@ def test_mbconv_slice_head_and_se_from_partial_products(shape, dt, kblock):
     mean = bsums.sum(1) / (H * W)
     err_mean = float((mean - ref.mean((1, 2))).abs().max())
     hp = ar.read(o_hp, (B, NB, NS, S), torch.float32)
-    want_hp = torch.einsum("bnjc,sjc->bnjs", (bsums / (H * W)).reshape(B, NB, NS, L.MBHEAD_SLICE), w1.reshape(S, NS, L.MBHEAD_SLICE))
+    want_hp = torch.einsum("bnjc,sjc->bnjs", (bsums / (H * W)).reshape(B, NB, NS, slice_w), w1.reshape(S, NS, slice_w))
     err_hp = float((hp - want_hp).abs().max())
     if R:
         want_b = torch.stack([ref[:, j * R:(j + 1) * R].sum((1, 2)) for j in range(NB)], 1)

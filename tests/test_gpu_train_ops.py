@@ -180,8 +180,8 @@ def test_train_mode_forward_matches_oracle_and_reference(precision, tol_maps, to
     label, _ = synth.train_labels(930, B, H // 4, W // 4)
     keep = {str(n): torch.from_numpy(k) for n, k in zip(g["keep_names"], g["keep"])}
     m.train()
-    with pytest.raises(NotImplementedError):
-        m(x, None)                                           # gradients enabled: there is no backward pass
+    with pytest.raises(ValueError):
+        m(x, None)                                           # gradients enabled = the train step's forward (round 5): it needs the pixel mask
     m.stochastic_depth_keep = keep
     with torch.no_grad():
         fmask = m.get_fmask(torch.from_numpy(label).cuda(), None)

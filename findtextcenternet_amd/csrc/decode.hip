@@ -160,7 +160,7 @@ hipError_t launch_decode(const float* heat, const float* feat, int B, int h, int
     if (e != hipSuccess) return e;
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(scratch);
     const int nb = (h * w + 255) / 256;
-    hipLaunchKernelGGL(decode_select_kernel, dim3(nb < 36 ? nb : 36, B), dim3(256), 0, s, heat, tiles, h, w, logit_cut, cand, counts);
+    hipLaunchKernelGGL(decode_select_kernel, dim3(nb, B), dim3(256), 0, s, heat, tiles, h, w, logit_cut, cand, counts);      // one pixel per thread: a single round of loads (36 workgroups per image walked four dependent rounds: 50 us)
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(decode_rank_gather_kernel, dim3((h * w + 63) / 64, B), dim3(256), 0, s, heat, feat, tiles, h, w, C, scale, cand, counts,

@@ -263,7 +263,7 @@ def test_oracle_reproduces_the_first_iterations_of_the_reference_training_loop()
             assert abs(float(raw[k]) - float(g["raw"][it][j])) < 2e-5 * max(1e-3, abs(float(g["raw"][it][j]))), (it, k)
 
 
-class _Replay:
+class _ReplayMaps:
     def __init__(self, heat, feat):
         self.h, self.f, self.k = heat, feat, 0
 
@@ -283,17 +283,17 @@ def test_demo_script_eval_matches_reference():
     img = np.full((ph, pw, 3), 255.0, np.float32)
     ds = [{"input": None, "offsetx": int(x), "offsety": int(y)} for y, x in g["offsets"]]
     l0, g0, *_ = decode_oracle.eval_demo([{"input": None, "offsetx": 0, "offsety": 0}], np.zeros((T, T, 3), np.float32),
-                                         _Replay(g["coarse_heat"], g["coarse_feat"]), 0.4, tile=T)
+                                         _ReplayMaps(g["coarse_heat"], g["coarse_feat"]), 0.4, tile=T)
     assert np.array_equal(l0, g["coarse_locations"]) and np.array_equal(g0, g["coarse_glyphfeatures"]) and l0.dtype == np.float64
     l0s = l0.copy()
     l0s[:, 1:] = l0s[:, 1:] * float(g["seed_scale"][0])
-    loc, gf, *_ = decode_oracle.eval_demo(ds, img, _Replay(g["heat"], g["feat"]), 0.4, l0s, g0, tile=T)
+    loc, gf, *_ = decode_oracle.eval_demo(ds, img, _ReplayMaps(g["heat"], g["feat"]), 0.4, l0s, g0, tile=T)
     assert np.array_equal(loc, g["locations"]) and np.array_equal(gf, g["glyphfeatures"])
-    loc2, gf2, *_ = decode_oracle.eval_demo(ds, img, _Replay(g["heat"], g["feat"]), 0.4, tile=T)
+    loc2, gf2, *_ = decode_oracle.eval_demo(ds, img, _ReplayMaps(g["heat"], g["feat"]), 0.4, tile=T)
     assert np.array_equal(loc2, g["locations_noseed"]) and np.array_equal(gf2, g["glyphfeatures_noseed"])
     assert len(loc) != len(loc2) and len(loc) > 30
     # the same candidates through the production rules (white page: the contrast filter of a uniform crop is 0 < NaN-free threshold 0 -> keeps all):
-    cand, cfe, canv = decode_oracle.eval_demo(ds, img, _Replay(g["heat"], g["feat"]), 0.4, tile=T, return_candidates=True)
+    cand, cfe, canv = decode_oracle.eval_demo(ds, img, _ReplayMaps(g["heat"], g["feat"]), 0.4, tile=T, return_candidates=True)
     prod, _ = decode_oracle.page_merge(cand.copy(), cfe.copy(), img, canv[2], canv[3:], 0.4)
     demo, _ = decode_oracle.page_merge(cand.copy(), cfe.copy(), img, canv[2], canv[3:], 0.4, variant="demo")
     assert np.array_equal(demo, loc2) and prod.shape != demo.shape or not np.array_equal(prod, demo.astype(np.float32))

@@ -10,6 +10,7 @@ hipError_t launch_conv_f32(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_x3(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_bf16_bb(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_bf16_fb(const ConvP& p, const ftc_op& o, hipStream_t s);
+hipError_t launch_conv1x1_px144(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_bf16_bf(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_bf16_ff(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_f16_hh(const ConvP& p, const ftc_op& o, hipStream_t s);
@@ -32,6 +33,10 @@ void conv_kernel_label(const ftc_op& op, char* buf, int len) {
         snprintf(buf, len, (op.flags & FTC_FLAG_TOP_FUSE) ? "conv3x3_halo+top<%s,out=%s,tile=%dx16x16,bk=%d>" : "conv3x3_halo<%s,out=%s,tile=%dx16x16,bk=%d>", dt[op.w_dtype & 3],
                  dt[op.out_dtype & 3], halo_sn(op) * 64, halo_cpr(op) * (ftc_is16(op.w_dtype) ? 8 : 4));
         if (op.groups > 1) snprintf(buf + strlen(buf) - 1, len - strlen(buf) + 1, ",groups=%d>", op.groups);
+        return;
+    }
+    if (cfg_px144(select_cfg(op))) {
+        snprintf(buf, len, "conv1x1_px144<%s,tile=%s,bk=64,nbuf=4>", dt[op.w_dtype & 3], kCfgName[select_cfg(op)]);
         return;
     }
     const bool dma = uses_glds(op);
@@ -90,6 +95,8 @@ const char* conv_validate(const ftc_op& op) {
     if (op.groups > 1 && (op.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_SE_SCALE | FTC_FLAG_W_PER_IMAGE))) return "conv: grouped launches exclude RESIDUAL / SE_SCALE / W_PER_IMAGE";
     if ((op.flags & FTC_FLAG_GROUP_OUT_SLICE) && (op.groups <= 1 || op.cout_off + op.groups * op.Cout > op.Cout_total)) return "conv: GROUP_OUT_SLICE channel slices out of range";
     if (op.groups > 1 && (long)op.groups * op.B * op.Ho * op.Wo > 0x7fffffffL / 4) return "conv: too many output pixels over all groups";
+    if (cfg_px144(hint_cfg(op)) && (!px144_legal(op, hint_cfg(op)) || hint_halo(op) || hint_splitk(op) > 1))
+        return "conv: the x144 tiles are the 1x1 kernel for 16-bit operands, fp32 output, Cin % 64 == 0, Cout % (64 | 80 | 128) == 0, Ho*Wo % 144 == 0";
     if (hint_halo(op) && !halo_legal(op)) return "conv: LDS-halo kernel is not legal for this op/tile";
     if (hint_splitk(op) > 1 && !splitk_legal(op, hint_splitk(op))) return "conv: split-K variant is not legal for this op/tile";
     if (op.aux0 < 0 || op.aux0 > 0xfff || hint_cfg(op) >= CFG_COUNT) return "conv: aux0 (tuned kernel choice) out of range";
@@ -154,6 +161,10 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
         p.w2 = a.w2; p.w2_gs = (long)32 * o.Cout * 2; p.Tw = o.aux1;
         p.out_gs = (long)o.B * o.Ho * o.Wo * o.aux1 * 4;       // `out` holds T [G][B,Ho,Wo][aux1] fp32
         p.out2 = nullptr;
+    }
+    if (cfg_px144(select_cfg(o))) {
+        if (o.flags & 0x1000) p.w2 = a.w2;                                  // phase timeline (tools/px144_bench.py)
+        return launch_conv1x1_px144(p, o, s);
     }
     if (o.w_dtype == FTC_F32) return (o.flags & FTC_FLAG_SPLIT16) ? launch_conv_x3(p, o, s) : launch_conv_f32(p, o, s);
     if (o.w_dtype == FTC_F16) {

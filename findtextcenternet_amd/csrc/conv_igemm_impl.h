@@ -1849,15 +1849,18 @@ hipError_t launch_cfg(const ConvP& p, hipStream_t s) {
 // Tile configurations (output channels x output pixels per workgroup), in order of preference.
 // (tried in round 2 and removed: a 256x64 tile (4 waves side by side over N) for the wide MBConv expand GEMMs -- 0.6x the L2->LDS bytes
 //  per FLOP of the 64x64 tile -- never won in the tuner: gpurun_out/tuning_r2_1x1.log)
-enum { CFG_192x128 = 0, CFG_128x128, CFG_96x128, CFG_64x128, CFG_128x64, CFG_32x256, CFG_64x64, CFG_COUNT };
-static const char* const kCfgName[] = {"192x128", "128x128", "96x128", "64x128", "128x64", "32x256", "64x64"};
-static const int kCfgTN[] = {192, 128, 96, 64, 128, 32, 64};
-static const int kCfgTM[] = {128, 128, 128, 128, 64, 256, 64};
+// The x144 configs are a kernel of their own (conv1x1_px144.hip: 1x1, 16-bit operands, fp32 output), chosen only by hint.
+enum { CFG_192x128 = 0, CFG_128x128, CFG_96x128, CFG_64x128, CFG_128x64, CFG_32x256, CFG_64x64, CFG_64x144, CFG_80x144, CFG_128x144, CFG_COUNT };
+static const char* const kCfgName[] = {"192x128", "128x128", "96x128", "64x128", "128x64", "32x256", "64x64", "64x144", "80x144", "128x144"};
+static const int kCfgTN[] = {192, 128, 96, 64, 128, 32, 64, 64, 80, 128};
+static const int kCfgTM[] = {128, 128, 128, 128, 64, 256, 64, 144, 144, 144};
+inline bool cfg_px144(int cfg) { return cfg >= CFG_64x144 && cfg <= CFG_128x144; }
 
 // ftc_op.aux0 carries the tuned kernel choice (0 = heuristics below): bits 0-3 tile config + 1,
 // bits 4-5 staging (1 = register-staged, 2 = direct-to-LDS 2-slot ring, 3 = 3-slot ring), bits 8-9 K step
 // (1 = 32, 2 = 64, 3 = 128).  The Python side fills it from a table measured on MI355X
-// (findtextcenternet_amd/tuning.py); every choice gives bit-identical results (same K order).
+// (findtextcenternet_amd/tuning.py); the choices compute the same convolution -- bit-identical among the tile configs and stagings (same K
+// order), in another fp32 summation order with split-K and on the 144-pixel tiles.
 inline int hint_cfg(const ftc_op& o) { return (o.aux0 & 15) - 1; }
 inline bool hint_halo(const ftc_op& o) { return (o.aux0 & 64) != 0; }         // bit 6: LDS-halo 3x3 kernel
 inline bool hint_wl1(const ftc_op& o) { return (o.aux0 & 192) == 192; }       // bits 6+7: its weights-through-L1 successor (needs FTC_FLAG_W_FRAG weights)
@@ -1883,6 +1886,11 @@ inline int select_cfg(const ftc_op& o) {
     if ((o.flags & FTC_FLAG_W_PER_IMAGE) && (o.Ho * o.Wo) % kCfgTM[d]) return o.Cout > 64 ? CFG_128x64 : CFG_64x64;
     return d;
 }
+inline bool px144_legal(const ftc_op& o, int cfg) {
+    return o.ksize == 1 && o.stride == 1 && ftc_is16(o.w_dtype) && o.in_dtype == o.w_dtype && o.out_dtype == FTC_F32 && o.Cin >= 64 && o.Cin % 64 == 0 &&
+           o.Cout % kCfgTN[cfg] == 0 && ((o.Cout_total | o.cout_off | o.Cin_total | o.cin_off) & 7) == 0 && (o.Ho * o.Wo) % 144 == 0 && o.groups <= 1 &&
+           !(o.flags & (FTC_FLAG_SE_SCALE | FTC_FLAG_BORDER_BIAS | FTC_FLAG_UPCAT_IN | FTC_FLAG_TOP_FUSE | FTC_FLAG_GROUP_OUT_SLICE | FTC_FLAG_PRESPLIT));
+}
 inline bool wset_legal(const ftc_op& o) {
     if (!(o.flags & FTC_FLAG_W_PER_IMAGE)) return true;
     if (hint_halo(o)) return true;                                   // the halo kernel tiles each image separately
@@ -1898,6 +1906,7 @@ inline int select_bk(const ftc_op& o) {
 }
 inline bool glds_legal(const ftc_op& o) {
     if (o.in_dtype != o.w_dtype) return false;
+    if (cfg_px144(select_cfg(o))) return false;
     const int bk = select_bk(o);
     if (bk == 128) return false;
     const int cpr = bk / (ftc_is16(o.w_dtype) ? 8 : 4);

@@ -22,7 +22,8 @@ from typing import Dict, List, Optional
 from . import _lib as L
 
 TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_gfx950.json")
-CFG_NAMES = ["192x128", "128x128", "96x128", "64x128", "128x64", "32x256", "64x64"]
+CFG_NAMES = ["192x128", "128x128", "96x128", "64x128", "128x64", "32x256", "64x64", "64x144", "80x144", "128x144"]
+N_GENERIC_CFGS = 7           # the last three are the 144-pixel 1x1 kernel (csrc/conv1x1_px144.hip), chosen by aux0 = 8 | 9 | 10 alone
 _table: Optional[Dict[str, int]] = None
 
 
@@ -43,6 +44,8 @@ def describe(aux0: int) -> str:
     if aux0 & 64:
         return f"halo,channels={CFG_NAMES[(aux0 & 15) - 1].split('x')[0]}" + (",bk=32" if (aux0 >> 8) & 3 == 1 else "")
     sk = [1, 2, 4, 1][(aux0 >> 10) & 3]
+    if (aux0 & 15) - 1 >= N_GENERIC_CFGS:
+        return f"px144,tile={CFG_NAMES[(aux0 & 15) - 1]}"
     return (f"tile={CFG_NAMES[(aux0 & 15) - 1]},stage={['auto', 'reg', 'dma2', 'dma3'][(aux0 >> 4) & 3]},bk={[0, 32, 64, 128][(aux0 >> 8) & 3]}"
             + (f",splitk={sk}" if sk > 1 else ""))
 
@@ -125,7 +128,7 @@ def candidates(o) -> List[int]:
     if o.w_dtype == L.BF16 and o.Cin % 64 == 0:
         bks = [b for b in bks if b != 32]                 # 32 never wins when 64 is legal
     out = []
-    for cfg in range(len(CFG_NAMES)):
+    for cfg in range(N_GENERIC_CFGS):
         tn = int(CFG_NAMES[cfg].split("x")[0])
         if tn > 2 * max(32, o.Cout):                      # more than half the tile rows would be padding
             continue
@@ -137,6 +140,8 @@ def candidates(o) -> List[int]:
             for bk in [b for b in bks if b >= 64]:
                 for sk in (2, 4):
                     out.append(encode(cfg, 1, bk, splitk=sk))
+    if o.ksize == 1 and o.w_dtype != L.F32 and o.in_dtype == o.w_dtype and o.out_dtype == L.F32 and (o.Ho * o.Wo) % 144 == 0:
+        out += [8, 9, 10]                                 # 144-pixel tiles (the illegal ones are refused at plan creation)
     if o.ksize == 3 and o.stride == 1:
         for cfg in (0, 1, 3):                             # LDS-halo kernel with 192 / 128 / 64 channel tiles
             out.append(encode(cfg, 0, 0, halo=True))

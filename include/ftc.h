@@ -260,7 +260,12 @@ typedef struct ftc_op {
     int32_t ksize;             /* 1 or 3 */
     int32_t stride;            /* 1 or 2 */
     int32_t aux0;              /* DWCONV: number of row-strips P;  SE: squeeze channels;
-                                  UPCAT: channels of the upsampled part (0 = none) */
+                                  UPCAT: channels of the upsampled part (0 = none);
+                                  CONV: tuned kernel choice, 0 = the library's heuristics (bits 0-3 tile config + 1 -- 8 | 9 | 10 = the
+                                  64 | 80 | 128-channel x 144-pixel 1x1 kernel for 16-bit operands and fp32 output, Cin % 64 == 0,
+                                  Cout % tile == 0, Ho*Wo % 144 == 0 --, bits 4-5 staging, 6-7 LDS-halo kernels, 8-9 K step, 10-11 split-K:
+                                  csrc/conv_igemm_impl.h; every choice computes the same convolution, the 144-pixel tiles and
+                                  split-K in another summation order) */
     int32_t aux1;              /* SE: number of partial sums P;  UPCAT: tap channels;  CONV+TOP_FUSE: floats per pixel of T;
                                   TAPSUM: number of outputs (aux0 = floats per pixel of T) */
     int32_t res_dtype;         /* ftc_dtype of in2 (CONV residual / UPCAT tap) */

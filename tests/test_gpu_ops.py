@@ -207,6 +207,64 @@ def test_se_fold_then_per_image_weight_conv(odt, dt, aux0):
     assert err < TOL16[dt]
 
 
+@pytest.mark.parametrize("variant", ["plain", "res_copy", "res_kblock", "per_image", "slices"])
+@pytest.mark.parametrize("dt", [L.BF16, L.F16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(3, 12, 12, 256, 192, 8), (8, 24, 24, 1536, 256, 8), (2, 24, 24, 3072, 512, 8), (1, 12, 24, 64, 64, 8), (5, 24, 24, 320, 640, 8),
+                                   (5, 24, 24, 320, 640, 9), (3, 12, 12, 192, 80, 9), (2, 48, 48, 1536, 256, 10), (3, 12, 12, 64, 384, 10)],
+                         ids=lambda s: "x".join(map(str, s[:5])) + "-" + {8: "64x144", 9: "80x144", 10: "128x144"}[s[5]])
+def test_conv1x1_px144_tile(shape, dt, variant):
+    """The (64 | 80 | 128)-channel x 144-pixel 1x1 kernel (aux0 low nibble 8 | 9 | 10: csrc/conv1x1_px144.hip -- the MBConv project convolutions) against the fp32
+    convolution of the rounded operands, and against the 64x64 tile config within fp32 summation-order noise: residual, the 16-bit trunk copy
+    (NHWC / 32-channel planes), per-image weight sets, channel slices of wider tensors."""
+    B, H, W, Cin, Cout, px_aux0 = shape
+    if variant == "res_kblock" and Cout % 32:
+        pytest.skip("32-channel planes need Cout % 32 == 0")
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout)
+    r16 = lambda t: round16(t, dt)
+    sl = variant == "slices"
+    CinT, cin_off = (Cin + 64, 32) if sl else (Cin, 0)
+    CoutT, cout_off = (Cout + 24, 16) if sl else (Cout, 0)
+    per = variant == "per_image"
+    res_on = variant in ("res_copy", "res_kblock", "per_image")
+    copy = variant in ("res_copy", "res_kblock")
+    xw = r16(torch.randn(B, H, W, CinT, generator=g))
+    x = xw[..., cin_off:cin_off + Cin]
+    w = r16(torch.randn(B if per else 1, Cout, Cin, generator=g) / Cin ** 0.5)
+    bias = torch.randn(Cout, generator=g) * 0.3
+    res = torch.randn(B, H, W, Cout, generator=g)
+    ref = torch.einsum("bhwk,bnk->bhwn", x.double(), w.expand(B, -1, -1).double()).float() + bias
+    if res_on:
+        ref = ref + res
+    outs = []
+    for aux0 in (px_aux0, 7 + 48 + 512) if not (per and H * W % 64) else (px_aux0, px_aux0):      # (per-image sets: the 64-pixel tiles must divide the image)
+        ar = Arena()
+        o_in, o_w, o_b, o_res = ar.put(to_dev_bytes(xw, dt)), ar.put(to_dev_bytes(w, dt)), ar.put(bias), ar.put(res)
+        o_out, o_out2 = ar.reserve(B * H * W * CoutT * 4), ar.reserve(B * H * W * Cout * 2)
+        ar.materialize()
+        ar.buf[o_out:o_out + B * H * W * CoutT * 4] = 0xCD
+        flags = (L.FLAG_RESIDUAL if res_on else 0) | (L.FLAG_W_PER_IMAGE if per else 0) | (L.FLAG_KBLOCK32 if variant == "res_kblock" else 0)
+        run_op(dict(kind=L.OP_CONV, flags=flags, act=L.ACT_NONE, in_dtype=dt, out_dtype=L.F32, w_dtype=dt, B=B, H=H, W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=CinT,
+                    cin_off=cin_off, Cout=Cout, Cout_total=CoutT, cout_off=cout_off, ksize=1, stride=1, res_dtype=L.F32, aux0=aux0,
+                    in_=o_in, in2=o_res if res_on else None, out=o_out, out2=o_out2 if copy else None, w=o_w, bias=o_b), ar)
+        full = ar.read(o_out, (B, H, W, CoutT), torch.float32)
+        out = full[..., cout_off:cout_off + Cout]
+        if sl:
+            raw = ar.buf[o_out:o_out + B * H * W * CoutT * 4].cpu().view(B * H * W, CoutT * 4)
+            keep = torch.ones(CoutT * 4, dtype=torch.bool)
+            keep[cout_off * 4:(cout_off + Cout) * 4] = False
+            assert (raw[:, keep] == 0xCD).all()
+        if copy:
+            if variant == "res_kblock":
+                out2 = ar.read(o_out2, (B, Cout // 32, H * W, 32), tdtype(dt)).permute(0, 2, 1, 3).reshape(B, H, W, Cout)
+            else:
+                out2 = ar.read(o_out2, (B, H, W, Cout), tdtype(dt))
+            assert torch.equal(out2, out.to(tdtype(dt)))
+        outs.append(out)
+    e0, e1, d = _rel(outs[0], ref), _rel(outs[1], ref), _rel(outs[0], outs[1])
+    _log(f"conv1x1_px144 {shape} dt={dt} {variant}: rel_err {e0:.2e} (64x64: {e1:.2e}), between the two {d:.2e}")
+    assert e0 < 1e-5 and d < 1e-5          # operands are exactly representable: only the fp32 summation order differs
+
+
 @pytest.mark.parametrize("aux0", [0, 4 + 32 + 512, 2 + 16 + 512, 65, 68], ids=["default", "64x128_dma2", "128x128_reg", "halo192", "halo64"])
 @pytest.mark.parametrize("mode", [CONV_MODES[0], CONV_MODES[1]], ids=["f32", "bf16"])
 @pytest.mark.parametrize("out_slice", [False, True], ids=["stacked", "out_slice"])

@@ -41,6 +41,12 @@ template <int NCT> struct PxGeom {
 __device__ __forceinline__ f32x4 px_mfma(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 px_mfma(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <typename F, int... Is>
+__device__ __forceinline__ void px_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void px_for(F&& f) { px_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
 // vmcnt wait of a loader wave: n = outstanding DMA pieces allowed (0, one or two stages of 6..9 pieces)
 __device__ __forceinline__ void px_wait(int n) {
     switch (n) {
@@ -201,48 +207,62 @@ __global__ __launch_bounds__(PxGeom<NCT>::NT, 1) void conv1x1_px144_kernel(const
     // use, the first RD before the waves meet (one load per tile behind its own s_waitcnt -- first version -- put ten HBM latencies end
     // to end at the tail of every workgroup: 29.6 -> 26.5 us on stage 6).  The barrier between sending and receiving waits for LDS only
     // (__syncthreads would also wait for those loads).
-    float* __restrict__ outp = reinterpret_cast<float*>(p.out);
     constexpr int RD = GM::NPG == 1 ? 6 : 4;
     f32x4 rv[RD];
-    auto tile_m = [&](int jl) { return m0 + (j0 + jl) * 16 + l15; };
-    auto tile_n = [&](int i) { return n0 + (ct0 + i) * 16 + 4 * lq; };
-    auto load_res = [&](int i, int jl) -> f32x4 {
+    auto load_res = [&](int i, int jl) __attribute__((always_inline)) -> f32x4 {           // (the slow path: 16-bit residuals, or an fp32 residual beside a 128-channel tile)
         if (!has_res || res_lds || i >= na || jl >= jn) return f32x4{0.f, 0.f, 0.f, 0.f};
-        const size_t off = (size_t)tile_m(jl) * p.Cout + tile_n(i);
+        const size_t off = (size_t)(m0 + (j0 + jl) * 16 + l15) * p.Cout + n0 + (ct0 + i) * 16 + 4 * lq;
         if (p.res_dtype == FTC_F32) return load4<float>(reinterpret_cast<const float*>(p.res) + off);
         return load4<typename Half16<T>::type>(reinterpret_cast<const typename Half16<T>::type*>(p.res) + off);
     };
     // tiles of a finishing range [J0, J1) in order idx -> (jl = J0 + idx / NA, i = idx % NA)
-    auto prefetch = [&](auto J0c, auto J1c) {
+    auto prefetch = [&](auto J0c, auto J1c) __attribute__((always_inline)) {
         constexpr int J0 = decltype(J0c)::value, NTL = (decltype(J1c)::value - J0) * NA;
 #pragma unroll
         for (int idx = 0; idx < RD && idx < NTL; ++idx) rv[idx] = load_res(idx % NA, J0 + idx / NA);
     };
+    // Output addressing without a branch per tile (every decision that depends on a flag is taken once, outside the unrolled loops: with
+    // flags tested per tile -- first version -- each tile was its own basic block, LDS read -> wait -> store, 9.1 k cycles for ten tiles):
+    // fp32 out[m][cout_off + n]; the 16-bit copy at ibase + r SR + (n >> 5) SP + (n & 31), which is NHWC with (SR, SP) = (Cout, 32) and the
+    // 32-channel planes of FTC_FLAG_KBLOCK32 with (SR, SP) = (32, 32 Ho Wo).
+    using H16 = typename Half16<T>::type;
+    float* __restrict__ out_base = reinterpret_cast<float*>(p.out) + (size_t)m0 * p.CoutT + p.cout_off + n0;
+    const int hw = p.Ho * p.Wo;
+    const bool kb = (p.flags & FTC_FLAG_KBLOCK32) != 0;
+    const int img = m0 / hw;
+    const int SR = kb ? 32 : p.Cout, SP = kb ? hw * 32 : 32;
+    H16* __restrict__ out2_base = reinterpret_cast<H16*>(p.out2) + (kb ? (size_t)img * p.Cout * hw + (size_t)(m0 - img * hw) * 32 : (size_t)m0 * p.Cout);
     const unsigned char* xin = smem_raw + (pg * 2 + cw) * (JN * NA * 1024) + lane * 16;
-    auto finish_range = [&](auto J0c, auto J1c, auto K0c) {
-        constexpr int J0 = decltype(J0c)::value, NTL = (decltype(J1c)::value - J0) * NA;
-        constexpr bool mine_k0 = decltype(K0c)::value;
-#pragma unroll
-        for (int idx = 0; idx < NTL; ++idx) {
-            const int i = idx % NA, jl = J0 + idx / NA;
-            f32x4 r = rv[idx % RD];
-            if (idx + RD < NTL) rv[idx % RD] = load_res((idx + RD) % NA, J0 + (idx + RD) / NA);
-            if (i < na && jl < jn) {
-                const f32x4 other = *reinterpret_cast<const f32x4*>(xin + (jl * NA + i) * 1024);
-                if constexpr (GM::RES_LDS) {
-                    if (res_lds) {
-                        const int row = (j0 + jl) * 16 + l15;
-                        r = *reinterpret_cast<const f32x4*>(smem_raw + GM::RING + row * (TN * 4) + px_res_slot((ct0 + i) * 4 + lq, row) * 16);
-                    }
-                }
-                f32x4 v = mine_k0 ? acc[i][jl] + other : other + acc[i][jl];
-                v = apply_act4<true>(v, p.act);
-                v += r;
-                const int m = tile_m(jl), n = tile_n(i);
-                store4<float>(outp + (size_t)m * p.CoutT + p.cout_off + n, v);
-                if (p.out2) store_out2<T>(p, m, n, v);
+    // RM: where the residual comes from (0 none, 1 the LDS tile, 2 the rv ring); COPY: the 16-bit copy is written
+    auto finish_range = [&](auto J0c, auto J1c, auto K0c, auto RMc, auto COPYc) __attribute__((always_inline)) {
+        constexpr int J0 = decltype(J0c)::value, NTL = (decltype(J1c)::value - J0) * NA, RM = decltype(RMc)::value;
+        constexpr bool mine_k0 = decltype(K0c)::value, COPY = decltype(COPYc)::value;
+        px_for<NTL>([&](auto IDXc) __attribute__((always_inline)) {
+            constexpr int idx = decltype(IDXc)::value, i = idx % NA, jl = J0 + idx / NA;
+            // a tile this wave does not have (the fifth pixel block of the second pixel group, the third channel tile of the second channel
+            // half of an 80-channel tile) repeats its neighbour: the same values to the same addresses instead of a branch
+            const bool jok = GM::NPG == 1 || jl < JN - 1 || jl < jn, iok = !(NCT & 1) || i < NA - 1 || i < na;
+            const int jv = jok ? jl : jl - 1, iv = iok ? i : i - 1;
+            f32x4 a = acc[i][jl];
+            if constexpr (GM::NPG == 2) { if (jl == JN - 1) a = jok ? a : acc[i][jl > 0 ? jl - 1 : 0]; }
+            if constexpr ((NCT & 1) != 0) { if (i == NA - 1) a = iok ? a : acc[i > 0 ? i - 1 : 0][jl]; }
+            f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (RM == 2) {
+                r = rv[idx % RD];
+                if (idx + RD < NTL) rv[idx % RD] = load_res((idx + RD) % NA, J0 + (idx + RD) / NA);
+                if (!(jok && iok)) r = load_res(iv, jv);
             }
-        }
+            const int row = (j0 + jv) * 16 + l15, ch = (ct0 + iv) * 16 + 4 * lq;
+            const f32x4 other = *reinterpret_cast<const f32x4*>(xin + (jv * NA + iv) * 1024);
+            if constexpr (RM == 1 && GM::RES_LDS) r = *reinterpret_cast<const f32x4*>(smem_raw + GM::RING + row * (TN * 4) + px_res_slot((ct0 + iv) * 4 + lq, row) * 16);
+            f32x4 v = mine_k0 ? a + other : other + a;
+            v += r;
+            store4<float>(out_base + (size_t)row * p.CoutT + ch, v);
+            if constexpr (COPY) {
+                const int nn = n0 + ch;
+                store4<H16>(out2_base + (size_t)row * SR + (size_t)(nn >> 5) * SP + (nn & 31), v);
+            }
+        });
     };
     using I0 = std::integral_constant<int, 0>;
     using IH = std::integral_constant<int, JH>;
@@ -265,8 +285,16 @@ __global__ __launch_bounds__(PxGeom<NCT>::NT, 1) void conv1x1_px144_kernel(const
     wg_barrier();
     if (loader) return;
     if (tl) tl[3] = __builtin_amdgcn_s_memtime();
-    if (kh == 0) finish_range(I0{}, IH{}, std::true_type{});
-    else finish_range(IH{}, IN{}, std::false_type{});
+    using R0 = std::integral_constant<int, 0>;
+    using R1 = std::integral_constant<int, 1>;
+    using R2 = std::integral_constant<int, 2>;
+    auto finish = [&](auto RMc, auto COPYc) __attribute__((always_inline)) {
+        if (kh == 0) finish_range(I0{}, IH{}, std::true_type{}, RMc, COPYc);
+        else finish_range(IH{}, IN{}, std::false_type{}, RMc, COPYc);
+    };
+    const int rm = !has_res ? 0 : res_lds ? 1 : 2;
+    if (p.out2) { if (rm == 0) finish(R0{}, std::true_type{}); else if (rm == 1) finish(R1{}, std::true_type{}); else finish(R2{}, std::true_type{}); }
+    else { if (rm == 0) finish(R0{}, std::false_type{}); else if (rm == 1) finish(R1{}, std::false_type{}); else finish(R2{}, std::false_type{}); }
     if (tl) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tl[4] = __builtin_amdgcn_s_memtime(); }
 }
 

@@ -1887,7 +1887,7 @@ inline int select_cfg(const ftc_op& o) {
     return d;
 }
 inline bool px144_legal(const ftc_op& o, int cfg) {
-    return o.ksize == 1 && o.stride == 1 && ftc_is16(o.w_dtype) && o.in_dtype == o.w_dtype && o.out_dtype == FTC_F32 && o.Cin >= 64 && o.Cin % 64 == 0 &&
+    return o.ksize == 1 && o.stride == 1 && o.act == FTC_ACT_NONE && ftc_is16(o.w_dtype) && o.in_dtype == o.w_dtype && o.out_dtype == FTC_F32 && o.Cin >= 64 && o.Cin % 64 == 0 &&
            o.Cout % kCfgTN[cfg] == 0 && ((o.Cout_total | o.cout_off | o.Cin_total | o.cin_off) & 7) == 0 && (o.Ho * o.Wo) % 144 == 0 && o.groups <= 1 &&
            !(o.flags & (FTC_FLAG_SE_SCALE | FTC_FLAG_BORDER_BIAS | FTC_FLAG_UPCAT_IN | FTC_FLAG_TOP_FUSE | FTC_FLAG_GROUP_OUT_SLICE | FTC_FLAG_PRESPLIT));
 }

@@ -18,8 +18,8 @@
 
 namespace convimpl {
 
-constexpr int PX_TM = 144, PX_NST = 4;
-template <int NCT> struct PxGeom {
+constexpr int PX_TM = 144;
+template <int NCT, bool X3 = false> struct PxGeom {
     static constexpr int TN = NCT * 16;                // output channels per workgroup
     static constexpr int NA = (NCT + 1) / 2;           // channel tiles of the first channel half (the second has NCT - NA)
     static constexpr int NPG = NCT > 5 ? 2 : 1;        // pixel groups of the multiplying waves (2: blocks 0..4 / 5..8 -- 80 accumulator registers instead of 144)
@@ -28,11 +28,13 @@ template <int NCT> struct PxGeom {
     static constexpr int JN = NPG == 1 ? 9 : 5;        // pixel blocks per multiplying wave (the second group has 4)
     static constexpr int JH = (JN + 1) / 2;            // of which the kh = 0 wave finishes the first JH, its partner the rest
     static constexpr int ROWS = TN + PX_TM;
-    static constexpr int STAGE = ROWS * 128;
-    static constexpr int PIECES = STAGE / 1024;        // DMA pieces (64 lanes x 16 B = 8 rows) per stage: 26 | 28 | 34
+    static constexpr int ROWB = X3 ? 256 : 128;        // bytes of K per operand row and stage: 64 K values (16-bit: 128 B; pre-split fp32: 256 B)
+    static constexpr int NST = X3 ? 3 : 4;             // ring depth (NST - 1 stages in flight)
+    static constexpr int STAGE = ROWS * ROWB;
+    static constexpr int PIECES = STAGE / 1024;        // DMA pieces (64 lanes x 16 B = 8 | 4 rows) per stage: 26 | 28 | 34; fp16x3: 52
     static constexpr int NPW = (PIECES + 3) / 4;       // pieces per loader wave (the last ones may have one less)
-    static constexpr int RING = PX_NST * STAGE;        // 106,496 | 114,688 | 139,264 B
-    static constexpr bool RES_LDS = RING + TN * PX_TM * 4 <= 160 * 1024;    // the residual tile travels by DMA too (64 and 80 channels)
+    static constexpr int RING = NST * STAGE;           // 106,496 | 114,688 | 139,264 B; fp16x3 64x144: 159,744 B
+    static constexpr bool RES_LDS = !X3 && RING + TN * PX_TM * 4 <= 160 * 1024;    // the residual tile travels by DMA too (64 and 80 channels)
     static constexpr int RES_PIECES = TN * PX_TM * 4 / 1024;                // 36 | 45
     static constexpr int LDS = RING + (RES_LDS ? TN * PX_TM * 4 : 0);
     static_assert(STAGE % 1024 == 0 && NPG * 2 * JN * NA * 1024 <= RING && LDS <= 160 * 1024, "");
@@ -56,6 +58,7 @@ __device__ __forceinline__ void px_wait(int n) {
     case 8: wait_vmcnt<8>(); break;
     case 9: wait_vmcnt<9>(); break;
     case 12: wait_vmcnt<12>(); break;
+    case 13: wait_vmcnt<13>(); break;
     case 14: wait_vmcnt<14>(); break;
     case 16: wait_vmcnt<16>(); break;
     case 18: wait_vmcnt<18>(); break;
@@ -67,9 +70,22 @@ __device__ __forceinline__ void px_wait(int n) {
 // chunk index land in different bank quads (chunks 16..19 of the 80-channel tile only four ways)
 __device__ __forceinline__ int px_res_slot(int c, int r) { return c < 16 ? c ^ (r & 15) : 16 + ((c - 16) ^ (r & 3)); }
 
+// K chunk swizzle of operand row r: chunk slot s of row r holds K chunk s ^ px_g(r).  16-bit operands (128-byte rows, 8 chunks): a lane reads
+// chunk 4 kh + lq of its row.  fp16x3 (pre-split fp32: a 16-byte chunk = 4 K values as [hi x4 | lo x4]; 256-byte rows, 16 chunks -- every row
+// starts in the same bank quad): a lane reads the chunks 8 kh + 2 lq and + 1.  Both maps put the 16 lanes the LDS serves together
+// ({0-3, 12-15, 20-27}, ..) into 16 different bank quads (checked by enumeration: tools/px144_bench.py --swizzle).
+template <bool X3> __device__ __forceinline__ int px_g(int r) { return X3 ? (r & 15) : ((r >> 1) & 7); }
+
+// T = __bf16 | _Float16: 16-bit operands, a stage = 64 K values, the K halves of a pair of waves = the halves of a stage.
+// T = x3f32 (FTC_FLAG_SPLIT16 + FTC_FLAG_PRESPLIT): both operands pre-split fp32, 256-byte rows, a three-stage ring, a product = three fp16
+// MFMAs (64x144 tiles only: the wider tiles do not fit the LDS).  (First version: 32 K values per stage, the two K groups taking the even /
+// odd stages -- with a barrier per stage they alternated instead of overlapping: 1574 cycles per stage against 842 of DMA time.)
 template <typename T, int NCT>
 __global__ __launch_bounds__(PxGeom<NCT>::NT, 1) void conv1x1_px144_kernel(const ConvP p) {
-    using GM = PxGeom<NCT>;
+    constexpr bool X3 = is_x3<T>;
+    using GM = PxGeom<NCT, X3>;
+    constexpr int ROWB = GM::ROWB, CPR = ROWB / 16, TSTR = 16 * ROWB, NST = GM::NST;
+    constexpr int ES = X3 ? 4 : 2;
     constexpr int TN = GM::TN, NA = GM::NA, STAGE = GM::STAGE, PIECES = GM::PIECES, NPW = GM::NPW, JN = GM::JN, JH = GM::JH, NWC = GM::NWC;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int t = threadIdx.x;
@@ -102,9 +118,9 @@ __global__ __launch_bounds__(PxGeom<NCT>::NT, 1) void conv1x1_px144_kernel(const
 #pragma unroll
     for (int j = 0; j < NPW; ++j) {
         const int q = (lw + 4 * j) * 64 + lane;
-        const int row = q >> 3;
-        const int kc = (q & 7) ^ ((row >> 1) & 7);
-        s_off[j] = row < TN ? ((n0 + row) * p.Cin) * 2 + kc * 16 : ((m0 + row - TN) * p.CinT + p.cin_off) * 2 + kc * 16;
+        const int row = q / CPR;
+        const int kc = (q & (CPR - 1)) ^ px_g<X3>(row);
+        s_off[j] = row < TN ? ((n0 + row) * p.Cin) * ES + kc * 16 : ((m0 + row - TN) * p.CinT + p.cin_off) * ES + kc * 16;
     }
     auto issue_stage = [&](int step, int bufoff) {
 #pragma unroll
@@ -112,8 +128,8 @@ __global__ __launch_bounds__(PxGeom<NCT>::NT, 1) void conv1x1_px144_kernel(const
             const int i = lw + 4 * j;                                   // wave-uniform
             if (i < PIECES) {
                 lds_void_t* dst = (lds_void_t*)(smem_raw + bufoff + i * 1024);
-                if (i < TN / 8) glds16(rw, dst, s_off[j], step * 128);
-                else glds16(rin, dst, s_off[j], step * 128);
+                if (i < TN * ROWB / 1024) glds16(rw, dst, s_off[j], step * ROWB);
+                else glds16(rin, dst, s_off[j], step * ROWB);
             }
         }
     };
@@ -151,16 +167,17 @@ __global__ __launch_bounds__(PxGeom<NCT>::NT, 1) void conv1x1_px144_kernel(const
     }
 
     using FragT = typename Frag<T>::type;
-    const int swz = (((kh * 4 + lq) ^ ((l15 >> 1) & 7)) << 4);
-    const int offA = (ct0 * 16 + l15) * 128 + swz;                      // + i * 2048
-    const int offB = (TN + j0 * 16 + l15) * 128 + swz;                  // + j * 2048
+    const int swz = (((X3 ? 8 * kh + 2 * lq : kh * 4 + lq) ^ px_g<X3>(l15)) << 4);
+    const int swz1 = (((8 * kh + 2 * lq + 1) ^ px_g<X3>(l15)) << 4);   // fp16x3: the second chunk of a fragment
+    const int offA = (ct0 * 16 + l15) * ROWB + swz;                     // + i * TSTR
+    const int offB = (TN + j0 * 16 + l15) * ROWB + swz;                 // + j * TSTR
     const int nk = p.Cin >> 6;
     if (loader) {
 #pragma unroll
-        for (int s = 0; s < PX_NST - 1; ++s)
+        for (int s = 0; s < NST - 1; ++s)
             if (s < nk) issue_stage(s, s * STAGE);
     }
-    int cur_off = 0, iss_off = (PX_NST - 1) * STAGE;
+    int cur_off = 0, iss_off = (NST - 1) * STAGE;
     // phase timeline of wave 0 (flag 0x1000, tools/px144_bench.py): start, first stage landed, K loop done, exchange done, end, barrier wait cycles
     unsigned long long* tl = (p.w2 && t == 0) ? reinterpret_cast<unsigned long long*>(const_cast<void*>(p.w2)) + (size_t)blockIdx.x * 8 : nullptr;
     unsigned long long tw = 0;
@@ -170,30 +187,67 @@ __global__ __launch_bounds__(PxGeom<NCT>::NT, 1) void conv1x1_px144_kernel(const
         if (loader) {
             // stage `it` has landed once at most the later-issued stages remain outstanding (per-wave piece counts; vmcnt is in order)
             const int ahead = nk - 1 - it;
-            px_wait(ahead >= 2 ? 2 * npw : ahead == 1 ? npw : 0);
+            px_wait((ahead < NST - 2 ? ahead : NST - 2) * npw);
         }
         wg_barrier();
         if (tl) { const unsigned long long tb = __builtin_amdgcn_s_memtime(); tw += tb - ta; if (it == 0) tl[1] = tb; }
         if (loader) {
             // stage it + 3 goes to the slot consumed in step it - 1: every multiplying wave has passed this barrier behind its reads
-            if (it + PX_NST - 1 < nk) issue_stage(it + PX_NST - 1, iss_off);
+            if (it + NST - 1 < nk) issue_stage(it + NST - 1, iss_off);
             iss_off = iss_off + STAGE == GM::RING ? 0 : iss_off + STAGE;
         } else {
             const unsigned char* base = smem_raw + cur_off;
-            FragT af[NA];
+            if constexpr (X3) {
+                {
+                    const int d1 = swz1 - swz;
+                    f16x8 ah[NA], al[NA];
 #pragma unroll
-            for (int i = 0; i < NA; ++i) af[i] = *reinterpret_cast<const FragT*>(base + offA + (i < na ? i : 0) * 2048);
-            FragT bq[3];
+                    for (int i = 0; i < NA; ++i) {
+                        const unsigned char* a = base + offA + (i < na ? i : 0) * TSTR;
+                        frag_hl(*reinterpret_cast<const f32x4*>(a), *reinterpret_cast<const f32x4*>(a + d1), ah[i], al[i]);
+                    }
+                    f32x4 bq[2][2];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) bq[j] = *reinterpret_cast<const FragT*>(base + offB + j * 2048);
+                    for (int j = 0; j < 2; ++j) {
+                        bq[j][0] = *reinterpret_cast<const f32x4*>(base + offB + j * TSTR);
+                        bq[j][1] = *reinterpret_cast<const f32x4*>(base + offB + j * TSTR + d1);
+                    }
 #pragma unroll
-            for (int j = 0; j < JN; ++j) {
-                const FragT bcur = bq[j % 3];
-                if (j + 3 < JN) bq[j % 3] = *reinterpret_cast<const FragT*>(base + offB + (j + 3 < jn ? j + 3 : 0) * 2048);
-                if (j < jn) {
+                    for (int j = 0; j < JN; ++j) {
+                        f16x8 bh, bl;
+                        frag_hl(bq[j % 2][0], bq[j % 2][1], bh, bl);
+                        if (j + 2 < JN) {
+                            const unsigned char* b = base + offB + (j + 2 < jn ? j + 2 : 0) * TSTR;
+                            bq[j % 2][0] = *reinterpret_cast<const f32x4*>(b);
+                            bq[j % 2][1] = *reinterpret_cast<const f32x4*>(b + d1);
+                        }
+                        if (j < jn) {
 #pragma unroll
-                    for (int i = 0; i < NA; ++i)
-                        if (i < na) acc[i][j] = px_mfma(af[i], bcur, acc[i][j]);
+                            for (int i = 0; i < NA; ++i)
+                                if (i < na) {
+                                    acc[i][j] = px_mfma(ah[i], bl, acc[i][j]);
+                                    acc[i][j] = px_mfma(al[i], bh, acc[i][j]);
+                                    acc[i][j] = px_mfma(ah[i], bh, acc[i][j]);
+                                }
+                        }
+                    }
+                }
+            } else {
+                FragT af[NA];
+#pragma unroll
+                for (int i = 0; i < NA; ++i) af[i] = *reinterpret_cast<const FragT*>(base + offA + (i < na ? i : 0) * TSTR);
+                FragT bq[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) bq[j] = *reinterpret_cast<const FragT*>(base + offB + j * TSTR);
+#pragma unroll
+                for (int j = 0; j < JN; ++j) {
+                    const FragT bcur = bq[j % 3];
+                    if (j + 3 < JN) bq[j % 3] = *reinterpret_cast<const FragT*>(base + offB + (j + 3 < jn ? j + 3 : 0) * TSTR);
+                    if (j < jn) {
+#pragma unroll
+                        for (int i = 0; i < NA; ++i)
+                            if (i < na) acc[i][j] = px_mfma(af[i], bcur, acc[i][j]);
+                    }
                 }
             }
             cur_off = cur_off + STAGE == GM::RING ? 0 : cur_off + STAGE;
@@ -225,7 +279,7 @@ __global__ __launch_bounds__(PxGeom<NCT>::NT, 1) void conv1x1_px144_kernel(const
     // flags tested per tile -- first version -- each tile was its own basic block, LDS read -> wait -> store, 9.1 k cycles for ten tiles):
     // fp32 out[m][cout_off + n]; the 16-bit copy at ibase + r SR + (n >> 5) SP + (n & 31), which is NHWC with (SR, SP) = (Cout, 32) and the
     // 32-channel planes of FTC_FLAG_KBLOCK32 with (SR, SP) = (32, 32 Ho Wo).
-    using H16 = typename Half16<T>::type;
+    using H16 = typename Half16<typename std::conditional<X3, _Float16, T>::type>::type;      // (fp16x3: the copy is the pre-split fp32 chunk, NHWC)
     float* __restrict__ out_base = reinterpret_cast<float*>(p.out) + (size_t)m0 * p.CoutT + p.cout_off + n0;
     const int hw = p.Ho * p.Wo;
     const bool kb = (p.flags & FTC_FLAG_KBLOCK32) != 0;
@@ -258,7 +312,9 @@ __global__ __launch_bounds__(PxGeom<NCT>::NT, 1) void conv1x1_px144_kernel(const
             f32x4 v = mine_k0 ? a + other : other + a;
             v += r;
             store4<float>(out_base + (size_t)row * p.CoutT + ch, v);
-            if constexpr (COPY) {
+            if constexpr (COPY && X3) {
+                *reinterpret_cast<u32x4*>(static_cast<char*>(p.out2) + ((size_t)(m0 + row) * p.Cout + n0 + ch) * 4) = chunk_hl(v);
+            } else if constexpr (COPY) {
                 const int nn = n0 + ch;
                 store4<H16>(out2_base + (size_t)row * SR + (size_t)(nn >> 5) * SP + (nn & 31), v);
             }
@@ -304,21 +360,23 @@ using namespace convimpl;
 
 template <typename T, int NCT>
 static hipError_t launch_px(ConvP& p, hipStream_t s) {
+    using GM = PxGeom<NCT, is_x3<T>>;
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_px144_kernel<T, NCT>), hipFuncAttributeMaxDynamicSharedMemorySize, PxGeom<NCT>::LDS);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_px144_kernel<T, NCT>), hipFuncAttributeMaxDynamicSharedMemorySize, GM::LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    p.nN = p.Cout / PxGeom<NCT>::TN;
+    p.nN = p.Cout / GM::TN;
     p.nblk = p.nN * (p.M / PX_TM);
-    hipLaunchKernelGGL((conv1x1_px144_kernel<T, NCT>), dim3(p.nblk), dim3(PxGeom<NCT>::NT), PxGeom<NCT>::LDS, s, p);
+    hipLaunchKernelGGL((conv1x1_px144_kernel<T, NCT>), dim3(p.nblk), dim3(GM::NT), GM::LDS, s, p);
     return hipGetLastError();
 }
 
 hipError_t launch_conv1x1_px144(const ConvP& p0, const ftc_op& o, hipStream_t s) {
     ConvP p = p0;
     const int tn = kCfgTN[select_cfg(o)];
+    if (o.w_dtype == FTC_F32) return launch_px<x3f32, 4>(p, s);            // (validated: 64x144 only)
     if (o.w_dtype == FTC_BF16) return tn == 64 ? launch_px<__bf16, 4>(p, s) : tn == 80 ? launch_px<__bf16, 5>(p, s) : launch_px<__bf16, 8>(p, s);
     return tn == 64 ? launch_px<_Float16, 4>(p, s) : tn == 80 ? launch_px<_Float16, 5>(p, s) : launch_px<_Float16, 8>(p, s);
 }

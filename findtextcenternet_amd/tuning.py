@@ -140,7 +140,7 @@ def candidates(o) -> List[int]:
             for bk in [b for b in bks if b >= 64]:
                 for sk in (2, 4):
                     out.append(encode(cfg, 1, bk, splitk=sk))
-    if o.ksize == 1 and o.w_dtype != L.F32 and o.in_dtype == o.w_dtype and o.out_dtype == L.F32 and (o.Ho * o.Wo) % 144 == 0:
+    if o.ksize == 1 and o.in_dtype == o.w_dtype and o.out_dtype == L.F32 and (o.Ho * o.Wo) % 144 == 0 and (o.w_dtype != L.F32 or o.flags & L.FLAG_PRESPLIT):
         out += [8, 9, 10]                                 # 144-pixel tiles (the illegal ones are refused at plan creation)
     if o.ksize == 3 and o.stride == 1:
         for cfg in (0, 1, 3):                             # LDS-halo kernel with 192 / 128 / 64 channel tiles

@@ -265,6 +265,45 @@ def test_conv1x1_px144_tile(shape, dt, variant):
     assert e0 < 1e-5 and d < 1e-5          # operands are exactly representable: only the fp32 summation order differs
 
 
+@pytest.mark.parametrize("variant", ["plain", "res_copy", "per_image"])
+@pytest.mark.parametrize("shape", [(3, 12, 12, 256, 192, 8), (2, 24, 24, 3072, 512, 8), (1, 12, 24, 64, 64, 8), (5, 24, 24, 192, 640, 8), (2, 48, 48, 1536, 256, 8), (3, 12, 12, 128, 384, 8)],
+                         ids=lambda s: "x".join(map(str, s[:5])))
+def test_conv1x1_px144_tile_fp16x3(shape, variant):
+    """The 144-pixel 1x1 kernel in the fp16x3 plan's form: fp32 tensors, BOTH operands stored pre-split (FTC_FLAG_SPLIT16 | FTC_FLAG_PRESPLIT), 256-byte operand rows,
+    three fp16 MFMAs per product (64x144 tiles only); the trunk copy (out2) is the pre-split form of the fp32 output.  Held to the fp32 tolerance of the other fp16x3 kernels
+    and compared with the 64x64 tile config of the generic kernel."""
+    B, H, W, Cin, Cout, px_aux0 = shape
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + 1)
+    per = variant == "per_image"
+    res_on = variant in ("res_copy", "per_image")
+    copy = variant == "res_copy"
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(B if per else 1, Cout, Cin, generator=g) / Cin ** 0.5
+    bias = torch.randn(Cout, generator=g) * 0.3
+    res = torch.randn(B, H, W, Cout, generator=g)
+    ref = torch.einsum("bhwk,bnk->bhwn", x.double(), w.expand(B, -1, -1).double()).float() + bias
+    if res_on:
+        ref = ref + res
+    outs = []
+    for aux0 in (px_aux0, 7 + 48 + 256) if not (per and H * W % 64) else (px_aux0, px_aux0):
+        ar = Arena()
+        o_in, o_w, o_b, o_res = ar.put(presplit_f16x3(x)), ar.put(presplit_f16x3(w)), ar.put(bias), ar.put(res)
+        o_out, o_out2 = ar.reserve(B * H * W * Cout * 4), ar.reserve(B * H * W * Cout * 4)
+        ar.materialize()
+        flags = L.FLAG_SPLIT16 | L.FLAG_PRESPLIT | (L.FLAG_RESIDUAL if res_on else 0) | (L.FLAG_W_PER_IMAGE if per else 0)
+        run_op(dict(kind=L.OP_CONV, flags=flags, act=L.ACT_NONE, in_dtype=L.F32, out_dtype=L.F32, w_dtype=L.F32, B=B, H=H, W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cin,
+                    Cout=Cout, Cout_total=Cout, ksize=1, stride=1, res_dtype=L.F32, aux0=aux0,
+                    in_=o_in, in2=o_res if res_on else None, out=o_out, out2=o_out2 if copy else None, w=o_w, bias=o_b), ar)
+        out = ar.read(o_out, (B, H, W, Cout), torch.float32)
+        if copy:
+            raw = ar.buf[o_out2:o_out2 + B * H * W * Cout * 4].cpu()
+            assert torch.equal(raw, presplit_f16x3(out).cpu())               # the copy is exactly the pre-split form of the fp32 value
+        outs.append(out)
+    e0, e1, d = _rel(outs[0], ref), _rel(outs[1], ref), _rel(outs[0], outs[1])
+    _log(f"conv1x1_px144 fp16x3 {shape} {variant}: rel_err {e0:.2e} (64x64: {e1:.2e}), between the two {d:.2e}")
+    assert e0 < 1e-5 and d < 1e-5
+
+
 @pytest.mark.parametrize("aux0", [0, 4 + 32 + 512, 2 + 16 + 512, 65, 68], ids=["default", "64x128_dma2", "128x128_reg", "halo192", "halo64"])
 @pytest.mark.parametrize("mode", [CONV_MODES[0], CONV_MODES[1]], ids=["f32", "bf16"])
 @pytest.mark.parametrize("out_slice", [False, True], ids=["stacked", "out_slice"])

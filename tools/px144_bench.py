@@ -6,10 +6,14 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 from findtextcenternet_amd import _lib as L
-from gpu_harness import Arena, to_dev_bytes
+from gpu_harness import Arena, to_dev_bytes, presplit_f16x3
+
+X3 = "--x3" in sys.argv            # the fp16x3 form: fp32 tensors, both operands pre-split
 
 SHAPES = [("stage5", 8, 48, 48, 1536, 256), ("stage6", 8, 24, 24, 3072, 512), ("stage7", 8, 24, 24, 3840, 640), ("stage6_b32", 32, 24, 24, 3072, 512)]
 CFGS = [("64x64_dma3", 7 + 48 + 512), ("128x64_dma3", 5 + 48 + 512), ("96x128_dma2", 3 + 32 + 512), ("64x144", 8), ("80x144", 9), ("128x144", 10)]
+if X3:
+    CFGS = [("64x64_dma2", 7 + 32 + 256), ("128x64_dma2", 5 + 32 + 256), ("64x144", 8), ("80x144", 9), ("128x144", 10)]
 
 
 def main():
@@ -17,16 +21,18 @@ def main():
     for name, B, H, W, Cin, Cout in SHAPES:
         g = torch.Generator().manual_seed(1)
         ar = Arena()
-        o_in = ar.put(to_dev_bytes(torch.randn(B * H * W, Cin, generator=g), L.BF16))
-        o_w = ar.put(to_dev_bytes(torch.randn(B, Cout, Cin, generator=g) / Cin ** 0.5, L.BF16))
+        conv = presplit_f16x3 if X3 else (lambda t: to_dev_bytes(t, L.BF16))
+        o_in = ar.put(conv(torch.randn(B * H * W, Cin, generator=g)))
+        o_w = ar.put(conv(torch.randn(B, Cout, Cin, generator=g) / Cin ** 0.5))
         o_b, o_res = ar.put(torch.randn(Cout, generator=g)), ar.put(torch.randn(B * H * W, Cout, generator=g))
-        o_out, o_out2 = ar.reserve(B * H * W * Cout * 4), ar.reserve(B * H * W * Cout * 2)
+        o_out, o_out2 = ar.reserve(B * H * W * Cout * 4), ar.reserve(B * H * W * Cout * 4)
         o_tl = ar.reserve(2048 * 64)
         ar.materialize()
         line = [f"{name:11s}"]
         for cname, aux0 in CFGS:
             op = (L.Op * 1)()
-            f = dict(kind=L.OP_CONV, flags=L.FLAG_RESIDUAL | L.FLAG_W_PER_IMAGE | L.FLAG_KBLOCK32, act=L.ACT_NONE, in_dtype=L.BF16, out_dtype=L.F32, w_dtype=L.BF16,
+            dt = L.F32 if X3 else L.BF16
+            f = dict(kind=L.OP_CONV, flags=L.FLAG_RESIDUAL | L.FLAG_W_PER_IMAGE | ((L.FLAG_SPLIT16 | L.FLAG_PRESPLIT) if X3 else L.FLAG_KBLOCK32), act=L.ACT_NONE, in_dtype=dt, out_dtype=L.F32, w_dtype=dt,
                      B=B, H=H, W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cin, Cout=Cout, Cout_total=Cout, ksize=1, stride=1, res_dtype=L.F32, aux0=aux0)
             for k, v in f.items():
                 setattr(op[0], k, int(v))
@@ -49,7 +55,7 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1000 / 200
-            tf = 2.0 * B * H * W * Cin * Cout / us * 1e-6
+            tf = (3 if X3 else 1) * 2.0 * B * H * W * Cin * Cout / us * 1e-6
             line.append(f"{cname}: {us:6.1f} us {tf:5.0f} TF")
             lib.ftc_plan_destroy(h)
             if aux0 in (8, 9, 10) and "--timeline" in sys.argv:

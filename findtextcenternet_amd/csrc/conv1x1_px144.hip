@@ -1,4 +1,4 @@
-// 1x1 convolution on (64 | 80 | 128)-channel x 144-pixel tiles (tile configs "64x144", "80x144", "128x144": ftc_op.aux0 low nibble 8, 9, 10):
+// 1x1 convolution on (64 | 80 | 96 | 128)-channel x 144-pixel tiles (tile configs "64x144", "80x144", "128x144", "96x144": ftc_op.aux0 low nibble 8..11):
 // the project convolutions of the MBConv blocks of the low-resolution stages (M = B x 576 or B x 2304 pixels, N = 256..640, K = 1536..3840).
 //
 // Why this shape.  Those GEMMs are small (4608 x 512 x 3072 at batch 8) and their time on the 64x64 / 128x64 tiles follows the bytes a CU
@@ -6,7 +6,7 @@
 // A3/A5).  With one workgroup per CU the tile AREA is given (M N / 256); the operand bytes per output are (TN + TM) / (TN TM): 64x64 = 1/32,
 // 64x144 = 1/44, 80x144 = 1/51, 128x144 = 1/68.  576 = 4 x 144: a tile lies in one image (per-image weight sets, FTC_FLAG_W_PER_IMAGE), and
 // the tile order gives each XCD whole images -- an image's d and its folded weights cross the fabric once.  The channel width is chosen so
-// that the launch has 256 workgroups: 64 for N = 512 at batch 8, 80 for N = 640, 128 for N = 256 on the 48x48 maps.
+// that the launch has 256 workgroups: 64 for N = 512 at batch 8, 80 for N = 640, 128 for N = 256 and 96 for N = 192 on the 48x48 maps.
 //
 // One workgroup = 8 waves, one per CU.  A stage = 64 K values of the TN weight rows and the 144 pixel rows (128-byte rows = whole cache
 // lines), DMA'd straight to LDS, four stages in a ring (three in flight).  Waves 0..3 multiply: 2 channel halves x 2 K halves of a stage
@@ -377,6 +377,6 @@ hipError_t launch_conv1x1_px144(const ConvP& p0, const ftc_op& o, hipStream_t s)
     ConvP p = p0;
     const int tn = kCfgTN[select_cfg(o)];
     if (o.w_dtype == FTC_F32) return launch_px<x3f32, 4>(p, s);            // (validated: 64x144 only)
-    if (o.w_dtype == FTC_BF16) return tn == 64 ? launch_px<__bf16, 4>(p, s) : tn == 80 ? launch_px<__bf16, 5>(p, s) : launch_px<__bf16, 8>(p, s);
-    return tn == 64 ? launch_px<_Float16, 4>(p, s) : tn == 80 ? launch_px<_Float16, 5>(p, s) : launch_px<_Float16, 8>(p, s);
+    if (o.w_dtype == FTC_BF16) return tn == 64 ? launch_px<__bf16, 4>(p, s) : tn == 80 ? launch_px<__bf16, 5>(p, s) : tn == 96 ? launch_px<__bf16, 6>(p, s) : launch_px<__bf16, 8>(p, s);
+    return tn == 64 ? launch_px<_Float16, 4>(p, s) : tn == 80 ? launch_px<_Float16, 5>(p, s) : tn == 96 ? launch_px<_Float16, 6>(p, s) : launch_px<_Float16, 8>(p, s);
 }

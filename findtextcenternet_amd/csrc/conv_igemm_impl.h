@@ -1850,11 +1850,11 @@ hipError_t launch_cfg(const ConvP& p, hipStream_t s) {
 // (tried in round 2 and removed: a 256x64 tile (4 waves side by side over N) for the wide MBConv expand GEMMs -- 0.6x the L2->LDS bytes
 //  per FLOP of the 64x64 tile -- never won in the tuner: gpurun_out/tuning_r2_1x1.log)
 // The x144 configs are a kernel of their own (conv1x1_px144.hip: 1x1, 16-bit operands, fp32 output), chosen only by hint.
-enum { CFG_192x128 = 0, CFG_128x128, CFG_96x128, CFG_64x128, CFG_128x64, CFG_32x256, CFG_64x64, CFG_64x144, CFG_80x144, CFG_128x144, CFG_COUNT };
-static const char* const kCfgName[] = {"192x128", "128x128", "96x128", "64x128", "128x64", "32x256", "64x64", "64x144", "80x144", "128x144"};
-static const int kCfgTN[] = {192, 128, 96, 64, 128, 32, 64, 64, 80, 128};
-static const int kCfgTM[] = {128, 128, 128, 128, 64, 256, 64, 144, 144, 144};
-inline bool cfg_px144(int cfg) { return cfg >= CFG_64x144 && cfg <= CFG_128x144; }
+enum { CFG_192x128 = 0, CFG_128x128, CFG_96x128, CFG_64x128, CFG_128x64, CFG_32x256, CFG_64x64, CFG_64x144, CFG_80x144, CFG_128x144, CFG_96x144, CFG_COUNT };
+static const char* const kCfgName[] = {"192x128", "128x128", "96x128", "64x128", "128x64", "32x256", "64x64", "64x144", "80x144", "128x144", "96x144"};
+static const int kCfgTN[] = {192, 128, 96, 64, 128, 32, 64, 64, 80, 128, 96};
+static const int kCfgTM[] = {128, 128, 128, 128, 64, 256, 64, 144, 144, 144, 144};
+inline bool cfg_px144(int cfg) { return cfg >= CFG_64x144 && cfg <= CFG_96x144; }
 
 // ftc_op.aux0 carries the tuned kernel choice (0 = heuristics below): bits 0-3 tile config + 1,
 // bits 4-5 staging (1 = register-staged, 2 = direct-to-LDS 2-slot ring, 3 = 3-slot ring), bits 8-9 K step

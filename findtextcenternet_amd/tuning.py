@@ -22,8 +22,8 @@ from typing import Dict, List, Optional
 from . import _lib as L
 
 TABLE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning_gfx950.json")
-CFG_NAMES = ["192x128", "128x128", "96x128", "64x128", "128x64", "32x256", "64x64", "64x144", "80x144", "128x144"]
-N_GENERIC_CFGS = 7           # the last three are the 144-pixel 1x1 kernel (csrc/conv1x1_px144.hip), chosen by aux0 = 8 | 9 | 10 alone
+CFG_NAMES = ["192x128", "128x128", "96x128", "64x128", "128x64", "32x256", "64x64", "64x144", "80x144", "128x144", "96x144"]
+N_GENERIC_CFGS = 7           # the others are the 144-pixel 1x1 kernel (csrc/conv1x1_px144.hip), chosen by aux0 = 8 .. 11 alone
 _table: Optional[Dict[str, int]] = None
 
 
@@ -141,7 +141,7 @@ def candidates(o) -> List[int]:
                 for sk in (2, 4):
                     out.append(encode(cfg, 1, bk, splitk=sk))
     if o.ksize == 1 and o.in_dtype == o.w_dtype and o.out_dtype == L.F32 and (o.Ho * o.Wo) % 144 == 0 and (o.w_dtype != L.F32 or o.flags & L.FLAG_PRESPLIT):
-        out += [8, 9, 10]                                 # 144-pixel tiles (the illegal ones are refused at plan creation)
+        out += [8, 9, 10, 11]                              # 144-pixel tiles (the illegal ones are refused at plan creation)
     if o.ksize == 3 and o.stride == 1:
         for cfg in (0, 1, 3):                             # LDS-halo kernel with 192 / 128 / 64 channel tiles
             out.append(encode(cfg, 0, 0, halo=True))

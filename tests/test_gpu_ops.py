@@ -210,8 +210,9 @@ def test_se_fold_then_per_image_weight_conv(odt, dt, aux0):
 @pytest.mark.parametrize("variant", ["plain", "res_copy", "res_kblock", "per_image", "slices"])
 @pytest.mark.parametrize("dt", [L.BF16, L.F16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("shape", [(3, 12, 12, 256, 192, 8), (8, 24, 24, 1536, 256, 8), (2, 24, 24, 3072, 512, 8), (1, 12, 24, 64, 64, 8), (5, 24, 24, 320, 640, 8),
-                                   (5, 24, 24, 320, 640, 9), (3, 12, 12, 192, 80, 9), (2, 48, 48, 1536, 256, 10), (3, 12, 12, 64, 384, 10)],
-                         ids=lambda s: "x".join(map(str, s[:5])) + "-" + {8: "64x144", 9: "80x144", 10: "128x144"}[s[5]])
+                                   (5, 24, 24, 320, 640, 9), (3, 12, 12, 192, 80, 9), (2, 48, 48, 1536, 256, 10), (3, 12, 12, 64, 384, 10),
+                                   (2, 48, 48, 768, 192, 11), (3, 12, 12, 128, 96, 11)],
+                         ids=lambda s: "x".join(map(str, s[:5])) + "-" + {8: "64x144", 9: "80x144", 10: "128x144", 11: "96x144"}[s[5]])
 def test_conv1x1_px144_tile(shape, dt, variant):
     """The (64 | 80 | 128)-channel x 144-pixel 1x1 kernel (aux0 low nibble 8 | 9 | 10: csrc/conv1x1_px144.hip -- the MBConv project convolutions) against the fp32
     convolution of the rounded operands, and against the 64x64 tile config within fp32 summation-order noise: residual, the 16-bit trunk copy

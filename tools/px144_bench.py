@@ -10,8 +10,8 @@ from gpu_harness import Arena, to_dev_bytes, presplit_f16x3
 
 X3 = "--x3" in sys.argv            # the fp16x3 form: fp32 tensors, both operands pre-split
 
-SHAPES = [("stage5", 8, 48, 48, 1536, 256), ("stage6", 8, 24, 24, 3072, 512), ("stage7", 8, 24, 24, 3840, 640), ("stage6_b32", 32, 24, 24, 3072, 512)]
-CFGS = [("64x64_dma3", 7 + 48 + 512), ("128x64_dma3", 5 + 48 + 512), ("96x128_dma2", 3 + 32 + 512), ("64x144", 8), ("80x144", 9), ("128x144", 10)]
+SHAPES = [("stage4", 8, 48, 48, 768, 192), ("stage5", 8, 48, 48, 1536, 256), ("stage6", 8, 24, 24, 3072, 512), ("stage7", 8, 24, 24, 3840, 640), ("stage6_b32", 32, 24, 24, 3072, 512)]
+CFGS = [("64x64_dma3", 7 + 48 + 512), ("128x64_dma3", 5 + 48 + 512), ("96x128_dma2", 3 + 32 + 512), ("64x144", 8), ("80x144", 9), ("128x144", 10), ("96x144", 11)]
 if X3:
     CFGS = [("64x64_dma2", 7 + 32 + 256), ("128x64_dma2", 5 + 32 + 256), ("64x144", 8), ("80x144", 9), ("128x144", 10)]
 
@@ -58,8 +58,8 @@ def main():
             tf = (3 if X3 else 1) * 2.0 * B * H * W * Cin * Cout / us * 1e-6
             line.append(f"{cname}: {us:6.1f} us {tf:5.0f} TF")
             lib.ftc_plan_destroy(h)
-            if aux0 in (8, 9, 10) and "--timeline" in sys.argv:
-                nblk = (Cout // {8: 64, 9: 80, 10: 128}[aux0]) * (B * H * W // 144)
+            if aux0 in (8, 9, 10, 11) and "--timeline" in sys.argv:
+                nblk = (Cout // {8: 64, 9: 80, 10: 128, 11: 96}[aux0]) * (B * H * W // 144)
                 op[0].flags |= 0x1000
                 r = op[0].w2
                 r.base, r.offset = L.BASE_WORKSPACE, int(o_tl)

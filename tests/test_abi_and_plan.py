@@ -311,3 +311,31 @@ def test_mbconv_slice_rejects_shapes_it_cannot_hold():
             r.base, r.offset = L.BASE_WORKSPACE, 0
         h = C.c_void_p()
         assert lib.ftc_plan_create(op, 1, 1 << 30, 0, C.byref(h)) != 0 and b"mbhead" in lib.ftc_last_error()
+
+
+def test_px144_tile_configs_are_validated_and_planned(models):
+    """The 144-pixel 1x1 kernel (aux0 low nibble 8..11, csrc/conv1x1_px144.hip) is refused where its tiles do not divide the op, and the bf16 batch-8
+    plan runs the MBConv project convolutions of stages 4-7 on it (the tuning table's choice)."""
+    lib = L.load()
+    h = C.c_void_p()
+    ok = dict(kind=L.OP_CONV, flags=L.FLAG_RESIDUAL, in_dtype=L.BF16, out_dtype=L.F32, w_dtype=L.BF16, res_dtype=L.F32, B=2, H=24, W=24, Ho=24, Wo=24,
+              Cin=512, Cin_total=512, Cout=640, Cout_total=640, ksize=1, stride=1, in_=0, in2=1 << 22, out=1 << 23, w=1 << 21, bias=1 << 20)
+    for aux0 in (8, 9, 10):                     # 640 = 10 x 64 = 8 x 80 = 5 x 128
+        assert lib.ftc_plan_create(_op(**dict(ok, aux0=aux0)), 1, 1 << 25, 0, C.byref(h)) == 0, lib.ftc_last_error()
+        lib.ftc_plan_destroy(h)
+    for bad in (dict(ok, aux0=11),                               # 640 % 96
+                dict(ok, aux0=8, H=16, W=16, Ho=16, Wo=16),      # 256 pixels per image: 144 does not divide
+                dict(ok, aux0=8, Cin=480, Cin_total=480),        # K step 64
+                dict(ok, aux0=8, out_dtype=L.BF16),              # fp32 output only
+                dict(ok, aux0=8, act=L.ACT_SILU),
+                dict(ok, aux0=8, ksize=3),
+                dict(ok, aux0=8, in_dtype=L.F32, w_dtype=L.F32, flags=L.FLAG_RESIDUAL | L.FLAG_SPLIT16)):      # fp16x3 needs BOTH operands pre-split
+        assert lib.ftc_plan_create(_op(**bad), 1, 1 << 26, 0, C.byref(h)) == -1, bad
+        assert b"x144" in lib.ftc_last_error() or b"conv" in lib.ftc_last_error()
+    x3 = dict(ok, in_dtype=L.F32, w_dtype=L.F32, flags=L.FLAG_RESIDUAL | L.FLAG_SPLIT16 | L.FLAG_PRESPLIT, w=1 << 24, in_=1 << 22, in2=0)
+    assert lib.ftc_plan_create(_op(**dict(x3, aux0=8)), 1, 1 << 26, 0, C.byref(h)) == 0, lib.ftc_last_error()
+    lib.ftc_plan_destroy(h)
+    assert lib.ftc_plan_create(_op(**dict(x3, aux0=10)), 1, 1 << 26, 0, C.byref(h)) == -1      # 256-byte rows: only the 64-channel tile fits the LDS
+    pl = models["bf16"].plan(8, 768, 768)
+    px = [pl.meta[i].name for i in range(len(pl.ops)) if pl.ops[i].kind == L.OP_CONV and 8 <= (pl.ops[i].aux0 & 15) <= 11 and not pl.ops[i].aux0 & 64]
+    assert len(px) >= 70 and all(".block.3" in n or ".block.2" in n for n in px), (len(px), px[:4])

@@ -29,7 +29,7 @@ template <int NCT, bool X3 = false> struct PxGeom {
     static constexpr int JH = (JN + 1) / 2;            // of which the kh = 0 wave finishes the first JH, its partner the rest
     static constexpr int ROWS = TN + PX_TM;
     static constexpr int ROWB = X3 ? 256 : 128;        // bytes of K per operand row and stage: 64 K values (16-bit: 128 B; pre-split fp32: 256 B)
-    static constexpr int NST = X3 ? 3 : 4;             // ring depth (NST - 1 stages in flight)
+    static constexpr int NST = X3 ? (NCT > 4 ? 2 : 3) : 4;    // ring depth (NST - 1 stages in flight; the wide fp16x3 tiles: a double buffer is what fits)
     static constexpr int STAGE = ROWS * ROWB;
     static constexpr int PIECES = STAGE / 1024;        // DMA pieces (64 lanes x 16 B = 8 | 4 rows) per stage: 26 | 28 | 34; fp16x3: 52
     static constexpr int NPW = (PIECES + 3) / 4;       // pieces per loader wave (the last ones may have one less)
@@ -78,7 +78,7 @@ template <bool X3> __device__ __forceinline__ int px_g(int r) { return X3 ? (r &
 
 // T = __bf16 | _Float16: 16-bit operands, a stage = 64 K values, the K halves of a pair of waves = the halves of a stage.
 // T = x3f32 (FTC_FLAG_SPLIT16 + FTC_FLAG_PRESPLIT): both operands pre-split fp32, 256-byte rows, a three-stage ring, a product = three fp16
-// MFMAs (64x144 tiles only: the wider tiles do not fit the LDS).  (First version: 32 K values per stage, the two K groups taking the even /
+// MFMAs (the wider tiles: a two-stage ring).  (First version: 32 K values per stage, the two K groups taking the even /
 // odd stages -- with a barrier per stage they alternated instead of overlapping: 1574 cycles per stage against 842 of DMA time.)
 template <typename T, int NCT>
 __global__ __launch_bounds__(PxGeom<NCT>::NT, 1) void conv1x1_px144_kernel(const ConvP p) {
@@ -376,7 +376,7 @@ static hipError_t launch_px(ConvP& p, hipStream_t s) {
 hipError_t launch_conv1x1_px144(const ConvP& p0, const ftc_op& o, hipStream_t s) {
     ConvP p = p0;
     const int tn = kCfgTN[select_cfg(o)];
-    if (o.w_dtype == FTC_F32) return launch_px<x3f32, 4>(p, s);            // (validated: 64x144 only)
+    if (o.w_dtype == FTC_F32) return tn == 64 ? launch_px<x3f32, 4>(p, s) : tn == 80 ? launch_px<x3f32, 5>(p, s) : tn == 96 ? launch_px<x3f32, 6>(p, s) : launch_px<x3f32, 8>(p, s);
     if (o.w_dtype == FTC_BF16) return tn == 64 ? launch_px<__bf16, 4>(p, s) : tn == 80 ? launch_px<__bf16, 5>(p, s) : tn == 96 ? launch_px<__bf16, 6>(p, s) : launch_px<__bf16, 8>(p, s);
     return tn == 64 ? launch_px<_Float16, 4>(p, s) : tn == 80 ? launch_px<_Float16, 5>(p, s) : tn == 96 ? launch_px<_Float16, 6>(p, s) : launch_px<_Float16, 8>(p, s);
 }

@@ -96,7 +96,7 @@ const char* conv_validate(const ftc_op& op) {
     if ((op.flags & FTC_FLAG_GROUP_OUT_SLICE) && (op.groups <= 1 || op.cout_off + op.groups * op.Cout > op.Cout_total)) return "conv: GROUP_OUT_SLICE channel slices out of range";
     if (op.groups > 1 && (long)op.groups * op.B * op.Ho * op.Wo > 0x7fffffffL / 4) return "conv: too many output pixels over all groups";
     if (cfg_px144(hint_cfg(op)) && (!px144_legal(op, hint_cfg(op)) || hint_halo(op) || hint_splitk(op) > 1))
-        return "conv: the x144 tiles are the 1x1 kernel for 16-bit operands or pre-split fp16x3 operands (64x144 only), Cin % 64 == 0, fp32 output, no activation, Cout % (64 | 80 | 128) == 0, Ho*Wo % 144 == 0";
+        return "conv: the x144 tiles are the 1x1 kernel for 16-bit operands or pre-split fp16x3 operands, Cin % 64 == 0, fp32 output, no activation, Cout % (64 | 80 | 128) == 0, Ho*Wo % 144 == 0";
     if (hint_halo(op) && !halo_legal(op)) return "conv: LDS-halo kernel is not legal for this op/tile";
     if (hint_splitk(op) > 1 && !splitk_legal(op, hint_splitk(op))) return "conv: split-K variant is not legal for this op/tile";
     if (op.aux0 < 0 || op.aux0 > 0xfff || hint_cfg(op) >= CFG_COUNT) return "conv: aux0 (tuned kernel choice) out of range";

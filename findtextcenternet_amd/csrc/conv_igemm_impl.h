@@ -1891,7 +1891,6 @@ inline bool px144_legal(const ftc_op& o, int cfg) {
     const bool x3 = o.w_dtype == FTC_F32 && (o.flags & FTC_FLAG_SPLIT16) && (o.flags & FTC_FLAG_PRESPLIT) && !(o.flags & FTC_FLAG_KBLOCK32);
     const bool h16 = ftc_is16(o.w_dtype) && !(o.flags & FTC_FLAG_PRESPLIT);
     const int ks = 64;
-    if (x3 && cfg != CFG_64x144) return false;                     // (256-byte rows: only the 64-channel tile fits the LDS)
     return o.ksize == 1 && o.stride == 1 && o.act == FTC_ACT_NONE && (x3 || h16) && o.in_dtype == o.w_dtype && o.out_dtype == FTC_F32 && o.Cin >= ks && o.Cin % ks == 0 &&
            o.Cout % kCfgTN[cfg] == 0 && ((o.Cout_total | o.cout_off | o.Cin_total | o.cin_off) & 7) == 0 && (o.Ho * o.Wo) % 144 == 0 && o.groups <= 1 &&
            !(o.flags & (FTC_FLAG_SE_SCALE | FTC_FLAG_BORDER_BIAS | FTC_FLAG_UPCAT_IN | FTC_FLAG_TOP_FUSE | FTC_FLAG_GROUP_OUT_SLICE));

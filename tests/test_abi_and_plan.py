@@ -335,7 +335,6 @@ def test_px144_tile_configs_are_validated_and_planned(models):
     x3 = dict(ok, in_dtype=L.F32, w_dtype=L.F32, flags=L.FLAG_RESIDUAL | L.FLAG_SPLIT16 | L.FLAG_PRESPLIT, w=1 << 24, in_=1 << 22, in2=0)
     assert lib.ftc_plan_create(_op(**dict(x3, aux0=8)), 1, 1 << 26, 0, C.byref(h)) == 0, lib.ftc_last_error()
     lib.ftc_plan_destroy(h)
-    assert lib.ftc_plan_create(_op(**dict(x3, aux0=10)), 1, 1 << 26, 0, C.byref(h)) == -1      # 256-byte rows: only the 64-channel tile fits the LDS
     pl = models["bf16"].plan(8, 768, 768)
     px = [pl.meta[i].name for i in range(len(pl.ops)) if pl.ops[i].kind == L.OP_CONV and 8 <= (pl.ops[i].aux0 & 15) <= 11 and not pl.ops[i].aux0 & 64]
     assert len(px) >= 70 and all(".block.3" in n or ".block.2" in n for n in px), (len(px), px[:4])

@@ -267,11 +267,11 @@ def test_conv1x1_px144_tile(shape, dt, variant):
 
 
 @pytest.mark.parametrize("variant", ["plain", "res_copy", "per_image"])
-@pytest.mark.parametrize("shape", [(3, 12, 12, 256, 192, 8), (2, 24, 24, 3072, 512, 8), (1, 12, 24, 64, 64, 8), (5, 24, 24, 192, 640, 8), (2, 48, 48, 1536, 256, 8), (3, 12, 12, 128, 384, 8)],
-                         ids=lambda s: "x".join(map(str, s[:5])))
+@pytest.mark.parametrize("shape", [(3, 12, 12, 256, 192, 8), (2, 24, 24, 3072, 512, 8), (1, 12, 24, 64, 64, 8), (5, 24, 24, 192, 640, 9), (2, 48, 48, 1536, 256, 10), (3, 12, 12, 128, 384, 11)],
+                         ids=lambda s: "x".join(map(str, s[:5])) + "-" + {8: "64x144", 9: "80x144", 10: "128x144", 11: "96x144"}[s[5]])
 def test_conv1x1_px144_tile_fp16x3(shape, variant):
     """The 144-pixel 1x1 kernel in the fp16x3 plan's form: fp32 tensors, BOTH operands stored pre-split (FTC_FLAG_SPLIT16 | FTC_FLAG_PRESPLIT), 256-byte operand rows,
-    three fp16 MFMAs per product (64x144 tiles only); the trunk copy (out2) is the pre-split form of the fp32 output.  Held to the fp32 tolerance of the other fp16x3 kernels
+    three fp16 MFMAs per product; the trunk copy (out2) is the pre-split form of the fp32 output.  Held to the fp32 tolerance of the other fp16x3 kernels
     and compared with the 64x64 tile config of the generic kernel."""
     B, H, W, Cin, Cout, px_aux0 = shape
     g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + 1)

@@ -13,7 +13,7 @@ X3 = "--x3" in sys.argv            # the fp16x3 form: fp32 tensors, both operand
 SHAPES = [("stage4", 8, 48, 48, 768, 192), ("stage5", 8, 48, 48, 1536, 256), ("stage6", 8, 24, 24, 3072, 512), ("stage7", 8, 24, 24, 3840, 640), ("stage6_b32", 32, 24, 24, 3072, 512)]
 CFGS = [("64x64_dma3", 7 + 48 + 512), ("128x64_dma3", 5 + 48 + 512), ("96x128_dma2", 3 + 32 + 512), ("64x144", 8), ("80x144", 9), ("128x144", 10), ("96x144", 11)]
 if X3:
-    CFGS = [("64x64_dma2", 7 + 32 + 256), ("128x64_dma2", 5 + 32 + 256), ("64x144", 8), ("80x144", 9), ("128x144", 10)]
+    CFGS = [("64x64_dma2", 7 + 32 + 256), ("128x64_dma2", 5 + 32 + 256), ("64x144", 8), ("80x144", 9), ("128x144", 10), ("96x144", 11)]
 
 
 def main():

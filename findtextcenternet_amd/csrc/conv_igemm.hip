@@ -86,8 +86,9 @@ const char* conv_validate(const ftc_op& op) {
     }
     if (op.flags & FTC_FLAG_TOP_FUSE) {
         if (!uses_halo(op) || halo_sn(op) != 3 || halo_cpr(op) != 8 || op.Cout != 192 || op.Cout_total != 192 || op.cout_off != 0 ||
-            !ftc_is16(op.w_dtype) || op.in_dtype != op.w_dtype || op.out_dtype != op.w_dtype)
-            return "conv: TOP_FUSE needs the 16-bit LDS-halo kernel with one 192-channel tile (aux0 = 65, Cin % 64 == 0, Cout = 192)";
+            op.in_dtype != op.w_dtype || op.out_dtype != op.w_dtype)
+            return "conv: TOP_FUSE needs the LDS-halo kernel with one 192-channel tile (aux0 = 65, Cin % 64 == 0 in 16 bits / % 32 in fp32, Cout = 192), tensors in the compute type";
+        if (op.w_dtype == FTC_F32 && op.aux1 > 20) return "conv: TOP_FUSE in fp32 holds at most 20 outputs per pixel";
         if (op.flags & (FTC_FLAG_RESIDUAL | FTC_FLAG_GROUP_OUT_SLICE)) return "conv: TOP_FUSE excludes RESIDUAL / GROUP_OUT_SLICE";
         if (op.aux1 < 4 || op.aux1 > 32 || op.aux1 % 4) return "conv: TOP_FUSE output row width (aux1) must be a multiple of 4 in 4..32";
     }
@@ -158,7 +159,7 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
         p.res = nullptr;
     }
     if (o.flags & FTC_FLAG_TOP_FUSE) {
-        p.w2 = a.w2; p.w2_gs = (long)32 * o.Cout * 2; p.Tw = o.aux1;
+        p.w2 = a.w2; p.w2_gs = (long)32 * o.Cout * (o.w_dtype == FTC_F32 ? 4 : 2); p.Tw = o.aux1;      // (fp32 plans: an fp32 tap matrix)
         p.out_gs = (long)o.B * o.Ho * o.Wo * o.aux1 * 4;       // `out` holds T [G][B,Ho,Wo][aux1] fp32
         p.out2 = nullptr;
     }

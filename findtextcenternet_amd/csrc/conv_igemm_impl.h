@@ -479,6 +479,93 @@ __device__ __forceinline__ void conv_epilogue_topfuse(const ConvP& p, f32x16 (&a
     }
 }
 
+// FTC_FLAG_TOP_FUSE for the fp32-tensor plans (fp32 and fp16x3; round 5).  The same decomposition as above -- T[p][tap*Co+o] = sum_c y[p][c]
+// Wtop[o][tap][c], FTC_OP_TAPSUM does the 9-point sum -- but the per-pixel map is done in fp32 FMA straight from the accumulators: a lane
+// holds 48 of its pixels' 192 activated channels (the 32x32 C layout: 4 consecutive channels per register quad), multiplies them by the tap
+// matrix rows in LDS (wave-wide broadcast reads: only `half` differs between the lanes of a read) and the four partial sums of a pixel
+// (2 channel halves of the tile x 2 lane halves) meet in LDS in a fixed order.  Per tile 2 x 960 FMA per lane -- ~1.5 % of the tile's K loop
+// in the three-MFMA plan -- and the 192-channel fp32 tensor of the eight map heads (1.8 GB at batch 8) is neither written nor read back by
+// thin_conv3x3_kernel.  `w2` = fp32 [32][TN] per group (rows >= Tw unused), T fp32 [pixels][Tw].
+template <int SN, int SM, int NTHREADS, int TN, int TM, typename RowFn>
+__device__ __forceinline__ void conv_epilogue_topfuse_f32(const ConvP& p, f32x16 (&acc)[SN][SM], unsigned char* smem, int nw0, int pw0,
+                                                          int half, int lpix, RowFn row_to_m) {
+    constexpr int TWMAX = 20;                               // floats per pixel of T (9 taps x 2 outputs, padded)
+    __syncthreads();                                        // every wave is done with the operand buffers
+    const int nrows = (p.flags & FTC_FLAG_BORDER_BIAS) ? 16 : 1;
+    float* lw = reinterpret_cast<float*>(smem);                             // [TWMAX][TN] tap matrix
+    float* lbias = lw + TWMAX * TN;                                         // [nrows][TN]
+    float* part = lbias + 16 * TN;                                          // [4][TM][TWMAX] partial sums
+    const int Tw = p.Tw < TWMAX ? p.Tw : TWMAX;
+    for (int c = threadIdx.x; c < TWMAX * (TN / 4); c += NTHREADS) {
+        const int r = c / (TN / 4);
+        *reinterpret_cast<f32x4*>(lw + 4 * c) = r < Tw ? *reinterpret_cast<const f32x4*>(static_cast<const float*>(p.w2) + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int c = threadIdx.x; c < nrows * (TN / 4); c += NTHREADS)
+        *reinterpret_cast<f32x4*>(lbias + 4 * c) = *reinterpret_cast<const f32x4*>(p.bias + 4 * c);
+    __syncthreads();
+    const float* brow[SM];
+#pragma unroll
+    for (int j = 0; j < SM; ++j) {
+        brow[j] = lbias;
+        if (p.flags & FTC_FLAG_BORDER_BIAS) {
+            const int m = row_to_m(pw0 + j * 32 + lpix);
+            if (m >= 0) {
+                const int rem = m % (p.Ho * p.Wo);
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                brow[j] += ((oy == 0 ? 1 : 0) | (oy == p.Ho - 1 ? 2 : 0) | (ox == 0 ? 4 : 0) | (ox == p.Wo - 1 ? 8 : 0)) * TN;
+            }
+        }
+    }
+    // bias + activation in place (the accumulators become y), then one pass per output row of the tap matrix: 12 broadcast reads of 16 bytes,
+    // 48 FMA per pixel, one partial sum per pixel stored -- a loop over o that is NOT unrolled (unrolled, 240 bodies x 2 pixels, the
+    // register allocator gave up: 3.4 KB of scratch)
+#pragma unroll
+    for (int i = 0; i < SN; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int nl = nw0 + i * 32 + 8 * q + 4 * half;
+#pragma unroll
+            for (int j = 0; j < SM; ++j) {
+                f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                v += *reinterpret_cast<const f32x4*>(brow[j] + nl);
+                v = apply_act4<false>(v, p.act);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = v[e];
+            }
+        }
+    const int pidx = (nw0 ? 2 : 0) + half;                  // which of the pixel's four partial sums (nw0 = 0 | TN / 2)
+    float* pdst = part + ((size_t)pidx * TM + pw0 + lpix) * TWMAX;
+#pragma unroll 1
+    for (int o = 0; o < TWMAX; ++o) {
+        float sj[SM];
+#pragma unroll
+        for (int j = 0; j < SM; ++j) sj[j] = 0.f;
+        if (o < Tw) {
+#pragma unroll
+            for (int i = 0; i < SN; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(lw + o * TN + nw0 + i * 32 + 8 * q + 4 * half);
+#pragma unroll
+                    for (int j = 0; j < SM; ++j)
+                        sj[j] += (acc[i][j][4 * q] * w[0] + acc[i][j][4 * q + 1] * w[1]) + (acc[i][j][4 * q + 2] * w[2] + acc[i][j][4 * q + 3] * w[3]);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < SM; ++j) pdst[(size_t)j * 32 * TWMAX + o] = sj[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < TM * (TWMAX / 4); c += NTHREADS) {
+        const int prow = c / (TWMAX / 4), o4 = (c - prow * (TWMAX / 4)) * 4;
+        const int m = row_to_m(prow);
+        if (m < 0 || o4 >= p.Tw) continue;
+        const float* s0 = part + (size_t)prow * TWMAX + o4;
+        const f32x4 v = (*reinterpret_cast<const f32x4*>(s0) + *reinterpret_cast<const f32x4*>(s0 + TM * TWMAX)) +
+                        (*reinterpret_cast<const f32x4*>(s0 + 2 * TM * TWMAX) + *reinterpret_cast<const f32x4*>(s0 + 3 * TM * TWMAX));
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.Tw + o4) = v;
+    }
+}
+
 // Epilogue of the intra-workgroup split-K variant: every K group parks its raw fp32 partial tile in its own
 // LDS image, then all 256*KG threads sum the KG images chunk by chunk (group 0 first: fixed order) and
 // apply bias / activation / residual / bf16 copy on the way out.
@@ -1371,7 +1458,13 @@ __global__ __launch_bounds__(128 * WMQ, (WMQ == 2) ? 2 : (CPR == 4 && !UPIN && !
         const int oy = ty0 + wm * 4 + j * 2 + (lpix >> 4), ox = tx0 + (lpix & 15);
         mrow[j] = (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
     }
-    if constexpr (TOPF) {
+    if constexpr (TOPF && sizeof(WT) == 4) {
+        static_assert(sizeof(OutT) == 4 && SN == 3 && WMQ == 4, "one 192-channel tile, 2 channel halves x 4 pixel quarters");
+        conv_epilogue_topfuse_f32<SN, SM, NT, TN, TY * TX>(p, acc, smem_raw, wn * SN * 32, wm * SM * 32, half, lpix, [&](int row) {
+            const int oy = ty0 + (row >> 4), ox = tx0 + (row & 15);
+            return (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
+        });
+    } else if constexpr (TOPF) {
         static_assert(sizeof(WT) == 2 && sizeof(OutT) == 2, "");
         conv_epilogue_topfuse<WT, SN, SM, NT, TN, TY * TX>(p, acc, smem_raw, wn * SN * 32, wm * SM * 32, half, l31, lpix, wave, [&](int row) {
             const int oy = ty0 + (row >> 4), ox = tx0 + (row & 15);
@@ -1983,6 +2076,9 @@ hipError_t launch_halo_dispatch(const ConvP& p, const ftc_op& o, hipStream_t s) 
     }
     if (o.flags & FTC_FLAG_TOP_FUSE) {
         if constexpr (sizeof(WT) == 2 && sizeof(OutT) == 2) {
+            if (cpr == 8 && sn == 3) return (o.flags & FTC_FLAG_UPCAT_IN) ? launch_halo<WT, OutT, 8, 3, true, true>(p, s) : launch_halo<WT, OutT, 8, 3, true>(p, s);
+        }
+        if constexpr (sizeof(WT) == 4 && sizeof(OutT) == 4) {                  // fp32 / fp16x3: the FMA epilogue (conv_epilogue_topfuse_f32)
             if (cpr == 8 && sn == 3) return (o.flags & FTC_FLAG_UPCAT_IN) ? launch_halo<WT, OutT, 8, 3, true, true>(p, s) : launch_halo<WT, OutT, 8, 3, true>(p, s);
         }
         return hipErrorInvalidValue;

@@ -112,7 +112,7 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
             !need(o.scale, (o.flags & FTC_FLAG_SE_SCALE) != 0, "scale", (int64_t)o.B * o.Cin * 4)) return why->c_str();
         const bool x3conv = o.w_dtype == FTC_F32 && (o.flags & FTC_FLAG_SPLIT16);      // out2 = the pre-split copy (4 bytes per element)
         if (!need(o.out2, false, "out2", pout * o.Cout * (x3conv ? 4 : 2))) return why->c_str();
-        if (!need(o.w2, topf, "w2", G * 32 * o.Cout * 2)) return why->c_str();
+        if (!need(o.w2, topf, "w2", G * 32 * o.Cout * (o.w_dtype == FTC_F32 ? 4 : 2))) return why->c_str();
         if (o.out2.base != FTC_BASE_NULL && (o.out_dtype != FTC_F32 || o.Cout % 4)) return "conv: out2 (bf16 copy) needs an fp32 primary output and Cout % 4 == 0";
         if ((o.flags & FTC_FLAG_PRESPLIT) && (!x3conv || o.ksize != 1 || (o.flags & (FTC_FLAG_SE_SCALE | FTC_FLAG_UPCAT_IN)) || (o.Cin | o.Cin_total | o.cin_off) % 4))
             return "conv: FTC_FLAG_PRESPLIT (pre-split input) needs an fp16x3 1x1 convolution without SE scale, channel counts and offsets in whole chunks of 4";

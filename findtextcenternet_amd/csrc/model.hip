@@ -483,7 +483,7 @@ int pack_weights(ftc_model* m, Weights& w) {
             bl.add_f32("heads.top6.b", b6.data(), (int64_t)b6.size());
         }
     }
-    if (bf && ok) {
+    if (ok) {
         // The eight map heads' top convolutions as per-pixel tap matrices for the fused last-level epilogue (FTC_FLAG_TOP_FUSE +
         // FTC_OP_TAPSUM): row tap*Co + o of head g = top_conv weight [o, :, r, s], 32 rows zero padded.
         std::vector<double> wt((size_t)(NHEADS - 1) * 32 * FPN_DIM, 0.0);
@@ -500,7 +500,12 @@ int pack_weights(ftc_model* m, Weights& w) {
             }
         }
         if (ok) {
-            bl.add_compute("heads.top8.wt", wt.data(), (int64_t)wt.size(), cdt);
+            if (!bf) {                           // fp32 / fp16x3 plans: the epilogue multiplies in fp32 FMA (conv_epilogue_topfuse_f32): a plain fp32 matrix
+                std::vector<float> wf(wt.begin(), wt.end());
+                bl.add_f32("heads.top8.wt", wf.data(), (int64_t)wf.size());
+            } else {
+                bl.add_compute("heads.top8.wt", wt.data(), (int64_t)wt.size(), cdt);
+            }
             bl.add_f32("heads.top8.b", bias.data(), (int64_t)bias.size());
             std::memcpy(bl.add("heads.top8.map", (int64_t)omap.size() * 4), omap.data(), omap.size() * 4);
         }
@@ -831,7 +836,8 @@ int Builder::build(ModelPlan* out) {
     R y = y0;
     int yh = t4.h, yw = t4.w;
     const int nmap = nh - 1;                   // the map heads (all but `feature`)
-    const bool fuse_top = dual && taps[0].c + FPN_DIM == 256 && !env_on("FTC_NO_TOPFUSE");
+    // (round 5: in the fp32 / fp16x3 plans too -- fp32 FMA epilogue, conv_epilogue_topfuse_f32; FTC_NO_TOPFUSE32=1: the two-kernel form)
+    const bool fuse_top = (dual || (cdt_ == FTC_F32 && !env_on("FTC_NO_TOPFUSE32"))) && taps[0].c + FPN_DIM == 256 && !env_on("FTC_NO_TOPFUSE");
     const int TW = 20;                         // floats per pixel of the tap tensor T (9 * 2 outputs, padded)
     // (round 3: also in the fp32 / fp16x3 plans, whose last-level concatenated input is 2.7 GB: FTC_NO_UPFUSE32=1 materialises it)
     const bool fuse_up = (dual || (cdt_ == FTC_F32 && !env_on("FTC_NO_UPFUSE32"))) && !env_on("FTC_NO_UPFUSE");

@@ -141,8 +141,8 @@ def test_plan_structure_flops_and_arena(models, mode):
     # (bf16 mode: the last level forms its input in the convolution's loader and reads the shared tap, no upcat launch)
     n_up = 2 if mode == "bf16" else 3
     assert sum(n for k, n in zip(kinds, inst) if k == "upcat") == 9 * n_up and kinds.count("upcat") == n_up
-    # bf16 mode: the eight map heads' top convolutions live in the epilogue of the last FPN level (+ one TAPSUM)
-    fused_top = 8 if mode == "bf16" else 0
+    # the eight map heads' top convolutions live in the epilogue of the last FPN level (+ one TAPSUM); round 5: in the fp32 / fp16x3 plans too
+    fused_top = 8
     assert sum(n for k, n in zip(kinds, inst) if k.startswith("conv")) == 20 + 16 + 160 + 1 + 1 + 27 + 9 - fused_top
     assert kinds.count("tapsum") == (1 if fused_top else 0)
     # arena: no two simultaneously-live buffers overlap

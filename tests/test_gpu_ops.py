@@ -372,25 +372,29 @@ def test_grouped_upcat(in_slice, dt):
     assert err < (1e-5 if dt == L.F32 else 6e-3)
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f32", "f32x3"])
 @pytest.mark.parametrize("shape", [(2, 32, 48), (1, 21, 19)], ids=["32x48", "21x19_ragged"])
-def test_top_fuse_epilogue_plus_tapsum_equals_two_convolutions(shape):
+def test_top_fuse_epilogue_plus_tapsum_equals_two_convolutions(shape, mode):
     """FTC_FLAG_TOP_FUSE + FTC_OP_TAPSUM: conv3x3+GELU (192 ch, never stored) followed by a 3x3 top convolution with bias,
-    for G heads with 1 / 2 / 1 output channels, against the two convolutions in fp32 (intermediate rounded to bf16 as the
-    kernel's LDS image is)."""
+    for G heads with 1 / 2 / 1 output channels, against the two convolutions in fp32 (bf16: intermediate rounded to bf16 as the
+    kernel's LDS image is; fp32 / fp16x3 plans, round 5: the tap matrix is applied in fp32 FMA straight from the accumulators)."""
     B, H, W = shape
     G, Cin, Cm, TW = 3, 64, 192, 20
     cos = [1, 2, 1]
     chs = [[0], [2, 3], [5]]
     g = torch.Generator().manual_seed(47)
-    x = bf16_round(torch.randn(G, B, H, W, Cin, generator=g))
-    w = bf16_round(torch.randn(G, Cm, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    bf = mode == "bf16"
+    rnd = bf16_round if bf else (lambda t: t)
+    dt = L.BF16 if bf else L.F32
+    x = rnd(torch.randn(G, B, H, W, Cin, generator=g))
+    w = rnd(torch.randn(G, Cm, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
     bias = torch.randn(G, Cm, generator=g) * 0.3
-    wt = [bf16_round(torch.randn(co, Cm, 3, 3, generator=g) / (Cm * 9) ** 0.5) for co in cos]
+    wt = [rnd(torch.randn(co, Cm, 3, 3, generator=g) / (Cm * 9) ** 0.5) for co in cos]
     bt = [torch.randn(co, generator=g) * 0.2 for co in cos]
     ref = torch.full((B, H, W, 10), float("nan"))
     for i in range(G):
-        y = bf16_round(F.gelu(F.conv2d(x[i].permute(0, 3, 1, 2), w[i], bias[i], 1, 1)))
-        o = F.conv2d(y, wt[i], bt[i], 1, 1).permute(0, 2, 3, 1)
+        y = rnd(F.gelu(F.conv2d(x[i].permute(0, 3, 1, 2).double(), w[i].double(), bias[i].double(), 1, 1)).float())
+        o = F.conv2d(y.double(), wt[i].double(), bt[i].double(), 1, 1).float().permute(0, 2, 3, 1)
         for k, ch in enumerate(chs[i]):
             ref[..., ch] = o[..., k]
     wt_mat = torch.zeros(G, 32, Cm)
@@ -402,16 +406,17 @@ def test_top_fuse_epilogue_plus_tapsum_equals_two_convolutions(shape):
             omap.append((i, o, cos[i], chs[i][o]))
             ob.append(float(bt[i][o]))
     ar = Arena()
-    o_in = ar.put(to_dev_bytes(x, L.BF16))
-    o_w = ar.put(to_dev_bytes(w.permute(0, 1, 3, 4, 2).reshape(G, Cm, 9, Cin), L.BF16))
+    wk = w.permute(0, 1, 3, 4, 2).reshape(G, Cm, 9, Cin)
+    o_in = ar.put(to_dev_bytes(x, dt))
+    o_w = ar.put(presplit_f16x3(wk) if mode == "f32x3" else to_dev_bytes(wk, dt))
     o_b = ar.put(bias)
-    o_wt = ar.put(to_dev_bytes(wt_mat, L.BF16))
+    o_wt = ar.put(to_dev_bytes(wt_mat, dt))                 # (fp32 plans: a plain fp32 tap matrix)
     o_map = ar.put(torch.tensor(omap, dtype=torch.int32))
     o_ob = ar.put(torch.tensor(ob))
     o_T = ar.reserve(G * B * H * W * TW * 4)
     o_out = ar.reserve(B * H * W * 10 * 4)
     ar.materialize()
-    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_TOP_FUSE, act=L.ACT_GELU, in_dtype=L.BF16, out_dtype=L.BF16, w_dtype=L.BF16, B=B, H=H, W=W, Ho=H,
+    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_TOP_FUSE | (L.FLAG_SPLIT16 if mode == "f32x3" else 0), act=L.ACT_GELU, in_dtype=dt, out_dtype=dt, w_dtype=dt, B=B, H=H, W=W, Ho=H,
                 Wo=W, Cin=Cin, Cin_total=Cin, Cout=Cm, Cout_total=Cm, ksize=3, stride=1, aux0=65, aux1=TW, groups=G, in_=o_in, out=o_T, w=o_w,
                 bias=o_b, w2=o_wt), ar)
     run_op(dict(kind=L.OP_TAPSUM, B=B, H=H, W=W, Ho=H, Wo=W, Cout_total=10, aux0=TW, aux1=len(omap), groups=G, in_=o_T, out=o_out, w=o_map,
@@ -419,8 +424,8 @@ def test_top_fuse_epilogue_plus_tapsum_equals_two_convolutions(shape):
     out = ar.read(o_out, (B, H, W, 10), torch.float32)
     used = [c for cc in chs for c in cc]
     err = _rel(out[..., used], ref[..., used])
-    _log(f"top_fuse+tapsum {shape} rel_err {err:.3e}")
-    assert err < 1.5e-2
+    _log(f"top_fuse+tapsum {shape} {mode} rel_err {err:.3e}")
+    assert err < (1.5e-2 if bf else 2e-5 if mode == "f32x3" else 1e-5)
     raw = ar.buf[o_out:o_out + B * H * W * 40].cpu().view(B * H * W, 40)
     untouched = [c for c in range(10) if c not in used]
     for c in untouched:                                  # channels not listed in the map keep the 0xCD fill
@@ -1045,11 +1050,13 @@ def test_thin_top_convolution(G, B, H, W, Cin, Cout, x3):
     assert float((full[..., 0] - 7.0).abs().max()) == 0.0 and float((full[..., coff + G * Cout:] - 7.0).abs().max()) == 0.0      # other channels untouched
 
 
+@pytest.mark.parametrize("top", [False, True], ids=["plain", "top_fuse"])
 @pytest.mark.parametrize("x3", [False, True], ids=["f32", "f32x3"])
-@pytest.mark.parametrize("shape", [(2, 2, 16, 24, 192, 64), (1, 1, 22, 10, 64, 32), (9, 1, 32, 32, 192, 64)], ids=lambda s: "x".join(map(str, s)))
-def test_upcat_in_conv_fp32_and_fp16x3(shape, x3):
+@pytest.mark.parametrize("shape", [(2, 2, 16, 24, 192, 64), (1, 1, 22, 10, 64, 32), (9, 1, 32, 32, 192, 64), (8, 2, 32, 32, 192, 64)], ids=lambda s: "x".join(map(str, s)))
+def test_upcat_in_conv_fp32_and_fp16x3(shape, x3, top):
     """FTC_FLAG_UPCAT_IN on fp32 tensors (round 3: the fp32 / fp16x3 plans' last FPN level): four fp32 channels per halo chunk, the
-    fp16x3 halo written pre-split; against F.interpolate(align_corners=True) + cat + conv2d."""
+    fp16x3 halo written pre-split; against F.interpolate(align_corners=True) + cat + conv2d.  top_fuse (round 5): the same launch with the
+    fp32 FMA form of FTC_FLAG_TOP_FUSE -- T = y . tap matrix instead of y -- followed by FTC_OP_TAPSUM, against a 3x3 top convolution of y."""
     G, B, H, W, Cy, Ct = shape
     g = torch.Generator().manual_seed(59)
     prev = torch.randn(G, B, H // 2, W // 2, Cy, generator=g)
@@ -1066,12 +1073,36 @@ def test_upcat_in_conv_fp32_and_fp16x3(shape, x3):
     ar = Arena()
     o_prev, o_tap, o_b = ar.put(prev), ar.put(tap), ar.put(bias)
     o_w = ar.put(presplit_f16x3(wk) if x3 else wk)
-    o_out = ar.reserve(G * B * H * W * Cout * 4)
+    flags = L.FLAG_UPCAT_IN | (L.FLAG_SPLIT16 if x3 else 0)
+    common = dict(kind=L.OP_CONV, act=L.ACT_GELU, in_dtype=L.F32, out_dtype=L.F32, w_dtype=L.F32, B=B, H=H, W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cy, Cout=Cout,
+                  Cout_total=Cout, ksize=3, stride=1, aux0=65, groups=G if G > 1 else 0)
+    if not top:
+        o_out = ar.reserve(G * B * H * W * Cout * 4)
+        ar.materialize()
+        run_op(dict(common, flags=flags, in_=o_prev, in2=o_tap, out=o_out, w=o_w, bias=o_b), ar)
+        out = ar.read(o_out, (G, B, H, W, Cout), torch.float32)
+        err = _rel(out, ref)
+        _log(f"upcat_in fp32 conv {shape} x3={x3} rel_err {err:.3e}")
+        assert err < 2e-5
+        return
+    if Cy % 64 or G > 10:
+        pytest.skip("TOP_FUSE: one 192-channel tile per head, at most 10 one-channel heads in this test")
+    TW = 12                                                  # one output channel per head: 9 taps, padded to 12 floats per pixel
+    wt = torch.randn(G, 1, Cout, 3, 3, generator=g) / (Cout * 9) ** 0.5
+    bt = torch.randn(G, generator=g) * 0.2
+    want = torch.stack([F.conv2d(ref[i].permute(0, 3, 1, 2).double(), wt[i].double(), bt[i:i + 1].double(), 1, 1)[:, 0] for i in range(G)], -1).float()    # [B,H,W,G]
+    wt_mat = torch.zeros(G, 32, Cout)
+    for i in range(G):
+        for t9 in range(9):
+            wt_mat[i, t9] = wt[i, 0, :, t9 // 3, t9 % 3]
+    omap = torch.tensor([(i, 0, 1, i) for i in range(G)], dtype=torch.int32)
+    o_wt, o_map, o_ob = ar.put(wt_mat), ar.put(omap), ar.put(bt)
+    o_T = ar.reserve(G * B * H * W * TW * 4)
+    o_out = ar.reserve(B * H * W * 10 * 4)
     ar.materialize()
-    run_op(dict(kind=L.OP_CONV, flags=L.FLAG_UPCAT_IN | (L.FLAG_SPLIT16 if x3 else 0), act=L.ACT_GELU, in_dtype=L.F32, out_dtype=L.F32, w_dtype=L.F32, B=B, H=H,
-                W=W, Ho=H, Wo=W, Cin=Cin, Cin_total=Cy, Cout=Cout, Cout_total=Cout, ksize=3, stride=1, aux0=65, groups=G if G > 1 else 0,
-                in_=o_prev, in2=o_tap, out=o_out, w=o_w, bias=o_b), ar)
-    out = ar.read(o_out, (G, B, H, W, Cout), torch.float32)
-    err = _rel(out, ref)
-    _log(f"upcat_in fp32 conv {shape} x3={x3} rel_err {err:.3e}")
+    run_op(dict(common, flags=flags | L.FLAG_TOP_FUSE, aux1=TW, in_=o_prev, in2=o_tap, out=o_T, w=o_w, bias=o_b, w2=o_wt), ar)
+    run_op(dict(kind=L.OP_TAPSUM, B=B, H=H, W=W, Ho=H, Wo=W, Cout_total=10, aux0=TW, aux1=G, groups=G, in_=o_T, out=o_out, w=o_map, bias=o_ob), ar)
+    out = ar.read(o_out, (B, H, W, 10), torch.float32)[..., :G]
+    err = _rel(out, want)
+    _log(f"upcat_in + top_fuse fp32 conv {shape} x3={x3} rel_err {err:.3e}")
     assert err < 2e-5

@@ -202,9 +202,11 @@ enum {
                                   tensor (group g reads channels cin_off + g*aux0 ..) instead of stacked tensors */
     FTC_FLAG_GROUP_OUT_SLICE = 128, /* CONV with groups > 1: the groups write channel slices of ONE tensor (group g writes
                                   channels cout_off + g*Cout ..) instead of stacked tensors */
-    FTC_FLAG_TOP_FUSE = 0x10000, /* CONV 3x3 (bf16 LDS-halo kernel, one 192-channel tile): the activated output tile is not
+    FTC_FLAG_TOP_FUSE = 0x10000, /* CONV 3x3 (LDS-halo kernel, one 192-channel tile): the activated output tile is not
                                   stored; instead T[p][0..32) = tile[p][:] . w2[0..32)[:] is computed on it and its first
-                                  aux1 values per pixel go to `out` = T [groups][B,Ho,Wo][aux1] fp32 (w2 = bf16 [groups][32][Cout]);
+                                  aux1 values per pixel go to `out` = T [groups][B,Ho,Wo][aux1] fp32 (w2 = [groups][32][Cout] in
+                                  the compute type: bf16 / fp16 -- one more MFMA GEMM on the tile's 16-bit LDS image -- or, with
+                                  fp32 tensors (fp32 and fp16x3 plans; aux1 <= 20), plain fp32 applied in fp32 FMA);
                                   FTC_OP_TAPSUM finishes the following top convolution */
     FTC_FLAG_UPCAT_IN = 0x20000, /* CONV 3x3 stride 1 (bf16 LDS-halo kernel, 192-channel tiles): the input is the concatenation the
                                   reference builds with UpsamplingBilinear2d + cat (models/detector.py:192-201), formed while the

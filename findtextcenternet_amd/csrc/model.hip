@@ -404,7 +404,7 @@ int pack_weights(ftc_model* m, Weights& w) {
         bl.add_compute("heads.L" + std::to_string(i) + ".w", wall.data(), (int64_t)wall.size(), cdt);
         bl.add_f32("heads.L" + std::to_string(i) + ".b", ball.data(), (int64_t)ball.size());
     }
-    if (bf && ntap >= 2 && ok) {
+    if (ntap >= 2 && ok) {                  // (round 5: in the fp32 / fp16x3 plans too; the convolution then reads the fp32 tap itself)
         // Last level with the input BatchNorm of the backbone tap folded in exactly (as level 0 above): scale into the tap columns
         // of the weights, shift into a 16-case border bias table -- the convolution then reads the shared bf16 trunk copy of the
         // tap instead of nine batch-normed copies (FTC_FLAG_GROUP_IN2_SHARED + FTC_FLAG_BORDER_BIAS).
@@ -430,7 +430,7 @@ int pack_weights(ftc_model* m, Weights& w) {
         if (ok) {
             bl.add_compute("heads.L" + std::to_string(i) + "f.w", wall.data(), (int64_t)wall.size(), cdt);
             bl.add_f32("heads.L" + std::to_string(i) + "f.b", ball.data(), (int64_t)ball.size());         // [9][16][192]
-            if (cin % 64 == 0) {
+            if (bf && cin % 64 == 0) {
                 // the same weights FRAGMENT-MAJOR for the weights-through-L1 kernel (FTC_FLAG_W_FRAG): per head
                 // [6 row blocks][9 taps][cin/64][4 K groups][64 lanes][8]: lane L, element e = W[32 rb + (L & 31)][tap][64 cb + 16 g + 8 (L >> 5) + e]
                 const int ncb = cin / 64;
@@ -857,14 +857,15 @@ int Builder::build(ModelPlan* out) {
         const bool up_in = fuse_up && i >= 2 && th_ == 2 * yh && tw_ == 2 * yw && cy % 64 == 0 && tc % 64 == 0;
         // ... and on the last level the tap's BatchNorm is folded into the weights + a border bias table, so that all heads read the ONE
         // bf16 trunk copy of the tap
-        const R tap_copy = (ntap - 1 - i) < (int)tap_copies.size() ? tap_copies[ntap - 1 - i] : R();
+        // (fp32 / fp16x3 plans: the tap itself -- fp32 NHWC, what the halo loader reads)
+        const R tap_copy = !dual ? ((tdt == A && !env_on("FTC_NO_BNFOLD32")) ? tp.buf : R()) : (ntap - 1 - i) < (int)tap_copies.size() ? tap_copies[ntap - 1 - i] : R();
         const std::string lf = "heads.L" + std::to_string(i) + "f";
         const bool bn_fold = up_in && last && tap_copy && has_w(lf + ".w") && !env_on("FTC_NO_BNFOLD");
         R tapbn, cat;
         double src_bytes;
         if (bn_fold) {
             tapbn = tap_copy;
-            src_bytes = (double)B * yh * yw * cy * 2 + (double)M * tc * 2 / nh;
+            src_bytes = (double)B * yh * yw * cy * esize(A) + (double)M * tc * esize(A) / nh;
         } else if (up_in) {
             tapbn = buf((int64_t)nh * M * tc, A);
             SymOp s;
@@ -903,7 +904,7 @@ int Builder::build(ModelPlan* out) {
             if (bn_fold) {
                 flags |= FTC_FLAG_UPCAT_IN | FTC_FLAG_BORDER_BIAS | FTC_FLAG_GROUP_IN2_SHARED;
                 o.Cin_total = cy; o.aux0 = 65;
-                s.in = sub(y, (int64_t)g0 * B * yh * yw * cy * 2); s.in2 = tapbn;
+                s.in = sub(y, (int64_t)g0 * B * yh * yw * cy * esize(A)); s.in2 = tapbn;
                 if (wl1) { flags |= FTC_FLAG_W_FRAG; s.w = wref(lf + ".wfrag", (int64_t)g0 * wsz); }
             } else if (up_in) {
                 flags |= FTC_FLAG_UPCAT_IN;

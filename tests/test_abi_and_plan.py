@@ -138,8 +138,8 @@ def test_plan_structure_flops_and_arena(models, mode):
     assert kinds.count("dwconv3x3") == 80 and kinds.count("se") == 80 and kinds.count("stem") == 1 and kinds[-1] == "nms"
     # nine heads x three levels of upsample+concat and conv, nine top convs: grouped launches count once per instance
     inst = [max(1, pl.ops[i].groups) for i in range(len(kinds))]
-    # (bf16 mode: the last level forms its input in the convolution's loader and reads the shared tap, no upcat launch)
-    n_up = 2 if mode == "bf16" else 3
+    # (the last level forms its input in the convolution's loader and reads the shared tap, no upcat launch; round 5: in the fp32 / fp16x3 plans too)
+    n_up = 2
     assert sum(n for k, n in zip(kinds, inst) if k == "upcat") == 9 * n_up and kinds.count("upcat") == n_up
     # the eight map heads' top convolutions live in the epilogue of the last FPN level (+ one TAPSUM); round 5: in the fp32 / fp16x3 plans too
     fused_top = 8

@@ -854,7 +854,10 @@ int Builder::build(ModelPlan* out) {
         // bf16 mode, levels whose upsampled source is a stacked tensor (2..): the concatenated input is never materialised -- the
         // convolution upsamples while it stages its halo (FTC_FLAG_UPCAT_IN).  (measured: with 32-channel K blocks the per-block
         // upsampling work outweighs the saved pass, so Cin 288 keeps the two-kernel form)
-        const bool up_in = fuse_up && i >= 2 && th_ == 2 * yh && tw_ == 2 * yw && cy % 64 == 0 && tc % 64 == 0;
+        // (fp32 / fp16x3 plans: the halo kernel's K block is 32 channels of 4 bytes, and the three-MFMA product makes the upsampling work per block
+        // a smaller share: level 2 -- 192 + 96 channels -- goes too; FTC_NO_UPFUSE32_L2=1: as before)
+        const int kblk = (dual || env_on("FTC_NO_UPFUSE32_L2")) ? 64 : 32;
+        const bool up_in = fuse_up && i >= 2 && th_ == 2 * yh && tw_ == 2 * yw && cy % kblk == 0 && tc % kblk == 0;
         // ... and on the last level the tap's BatchNorm is folded into the weights + a border bias table, so that all heads read the ONE
         // bf16 trunk copy of the tap
         // (fp32 / fp16x3 plans: the tap itself -- fp32 NHWC, what the halo loader reads)

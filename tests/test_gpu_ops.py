@@ -1052,7 +1052,7 @@ def test_thin_top_convolution(G, B, H, W, Cin, Cout, x3):
 
 @pytest.mark.parametrize("top", [False, True], ids=["plain", "top_fuse"])
 @pytest.mark.parametrize("x3", [False, True], ids=["f32", "f32x3"])
-@pytest.mark.parametrize("shape", [(2, 2, 16, 24, 192, 64), (1, 1, 22, 10, 64, 32), (9, 1, 32, 32, 192, 64), (8, 2, 32, 32, 192, 64)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("shape", [(2, 2, 16, 24, 192, 64), (1, 1, 22, 10, 64, 32), (9, 1, 32, 32, 192, 64), (8, 2, 32, 32, 192, 64), (3, 2, 24, 16, 192, 96)], ids=lambda s: "x".join(map(str, s)))
 def test_upcat_in_conv_fp32_and_fp16x3(shape, x3, top):
     """FTC_FLAG_UPCAT_IN on fp32 tensors (round 3: the fp32 / fp16x3 plans' last FPN level): four fp32 channels per halo chunk, the
     fp16x3 halo written pre-split; against F.interpolate(align_corners=True) + cat + conv2d.  top_fuse (round 5): the same launch with the

@@ -580,7 +580,14 @@ void apply_tuning(std::vector<ftc_op>& ops) {
         if (o.kind != FTC_OP_CONV) continue;
         auto it = table.find(conv_signature(o));
         if (it == table.end() && (o.flags & FTC_FLAG_SPLIT16)) it = table.find(conv_signature(o, true));     // fp16x3 without its own measurement: the fp32 choice
-        if (it != table.end() && it->second) o.aux0 = it->second;
+        if (it == table.end() || !it->second) continue;
+        // A table entry is a HINT measured for one flag combination; the signature drops flags that do not change which kernel is fastest
+        // (KBLOCK32, PRESPLIT) and fp16x3 falls back to the fp32 entry, so an entry can name a kernel that is not legal for THIS op
+        // (e.g. a 144-pixel fp16x3 tile without pre-split operands under FTC_NO_PRESPLIT / FTC_NO_MBSLICE_X3).  Adopt it only if the op
+        // validates with it; otherwise the default selection stands.
+        const int keep = o.aux0;
+        o.aux0 = it->second;
+        if (conv_validate(o) != nullptr) o.aux0 = keep;
     }
 }
 

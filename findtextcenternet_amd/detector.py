@@ -416,7 +416,7 @@ class TextDetectorModel(nn.Module):
                                      "model.get_fmask(labelmap, fmask); for the BatchNorm-refresh pass wrap the call in torch.no_grad()")
                 from .train_step import TrainStep
                 ts = self.__dict__.get("_train_step")
-                if ts is None or ts.precision != self.detector.precision:
+                if ts is None or ts.precision != self.detector.precision or ts.decoder_only != (not self.detector.training):
                     ts = TrainStep(self, self.detector.precision, decoder_only=not self.detector.training)
                     self.__dict__["_train_step"] = ts
                 heat, decs = ts.seam_forward(x, fmask)

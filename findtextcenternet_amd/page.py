@@ -287,7 +287,11 @@ class PageDetector:
             cmax = int(counts.max().item())
             if cmax > self.max_boxes:
                 raise RuntimeError(f"a tile produced {cmax} peaks > max_boxes={self.max_boxes}; raise max_boxes")
-            self._row_hint = min(self.max_boxes, (cmax + cmax // 4 + 64) // 64 * 64)      # next page's gather: rows sent when the block is large
+            if world > 1 or not world1:
+                # next page's gather: rows sent when the block is large.  Every rank must hold the SAME value (it sizes an RCCL message): only
+                # counts that came out of a gather -- or a run in which every rank saw every tile -- may set it, never the unsharded coarse
+                # pass of the two-pass mode, whose per-rank results are only equal if the GPUs agree bit for bit.
+                self._row_hint = min(self.max_boxes, (cmax + cmax // 4 + 64) // 64 * 64)
             canv_h = canv[1:3].cpu().numpy()
             return (loc_d if demo else loc_d.cpu().numpy()), glyph_d.cpu().numpy(), canv_h[0], canv_h[1]
 

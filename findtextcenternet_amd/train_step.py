@@ -895,7 +895,9 @@ class TrainStep:
             L.check(lib.ftc_plan_run(plan["handle"], st["bases"], st["stream"], 0, plan["n_fwd"] - 2), "ftc_plan_run (train step, forward without the loss op)")
             heat = self._view(plan["maps"], (B, plan["mh"], plan["mw"], 9)).permute(0, 3, 1, 2).clone()
             decs = [self._view(b, (plan["n_rows"], m)).clone() for b, m in zip(plan["dec_outs"], (1091, 1093, 1097))]
-        st["phase"] = "forward"
+        from .optim import bump_versions
+        bump_versions(self.stat_buffers)           # the forward ops moved the running statistics in place -- visible to the inference engine's
+        st["phase"] = "forward"                     # fingerprint even if this forward is never backpropagated (_end() bumps again: harmless)
         self._seam = st
         return heat, decs
 
@@ -917,9 +919,25 @@ class TrainStep:
         if st is None or st.get("phase") != "losses":
             raise RuntimeError("backward of a train-mode loss: the step's activations are gone (one backward per model(image, fmask) call)")
         with torch.cuda.device(st["dev"]):
-            self._backward(st, weights9, sync_grads)
+            self._backward(st, weights9, sync_grads and not getattr(self, "_no_sync", False))
             self._end(st)
         self._seam = None
+
+    def no_sync(self):
+        """Context manager for gradient accumulation under enable_ddp() with the reference's calling sequence (train1.py:125-140,
+        `iters_to_accumulate` > 1): inside it `loss.backward()` adds this rank's gradients without the all-reduce; run the LAST micro-batch
+        outside so the accumulated buffer is reduced once (what torch's DistributedDataParallel.no_sync() does)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            prev = getattr(self, "_no_sync", False)
+            self._no_sync = True
+            try:
+                yield self
+            finally:
+                self._no_sync = prev
+        return cm()
 
     # ---- data-parallel gradients ----------------------------------------------------------------------------------------------
     def enable_ddp(self, group=None, bucket_bytes: int = 256 << 20) -> None:

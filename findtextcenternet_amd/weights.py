@@ -76,6 +76,9 @@ def fill_tensor(seed: int, name: str, shape: Tuple[int, ...], kind: str) -> torc
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
+_FILLED: Dict[Tuple[int, str], Dict[str, torch.Tensor]] = {}
+
+
 def deterministic_state_dict(seed: int = 0, model_size: str = "xl", with_decoder: bool = True,
                              prefix_detector: bool = True) -> "OrderedDict[str, torch.Tensor]":
     """Seeded ``state_dict`` with the reference's key set.
@@ -85,15 +88,22 @@ def deterministic_state_dict(seed: int = 0, model_size: str = "xl", with_decoder
     Tensor values depend only on (seed, un-prefixed detector key), so both forms agree.
     """
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    memo = _FILLED.setdefault((seed, model_size), {})          # generated once per process (~9 s for "xl"); callers get their own copies
+
+    def filled(base, shape, kind):
+        t = memo.get(base)
+        if t is None:
+            t = memo[base] = fill_tensor(seed, base, shape, kind)
+        return t.clone()
     if prefix_detector:
         for k, (shape, kind) in text_detector_schema(model_size).items():
             if k.startswith("decoder.") and not with_decoder:
                 continue
             base = k[len("detector."):] if k.startswith("detector.") else k
-            out[k] = fill_tensor(seed, base, shape, kind)
+            out[k] = filled(base, shape, kind)
     else:
         for k, (shape, kind) in detector_schema(model_size).items():
-            out[k] = fill_tensor(seed, k, shape, kind)
+            out[k] = filled(k, shape, kind)
     return out
 
 

@@ -97,3 +97,45 @@ def presplit_f16x3(w: torch.Tensor) -> torch.Tensor:
     hi = f.clamp(-65504.0, 65504.0).to(torch.float16)
     lo = (f - hi.float()).to(torch.float16)
     return torch.cat([hi, lo], dim=1).contiguous().view(torch.uint8).reshape(-1)
+
+
+# ---- shared models (the -m gpu suite) --------------------------------------------------------------------------------------------
+# Building one XL model costs ~25 s of HOST time (seeded state_dict 9 s, random init of 262 M parameters 7 s, load 3 s, ftc_create's
+# float64 fold + pack 5-9 s); round 5's suite built ~30 of them = 40 % of its 1021 s.  Tests that only READ a model share one per
+# (precision, size) for the whole session; tests that edit parameters build their own through `fresh_model` (random init skipped:
+# every tensor is overwritten by load_state_dict anyway).
+_SHARED = {}
+
+
+def fresh_model(precision, model_size="xl", seed=0, load=True):
+    """A private TextDetectorModel holding deterministic_state_dict(seed); the constructor's random init is replaced by zeros."""
+    import torch
+    import findtextcenternet_amd.detector as D
+    from findtextcenternet_amd import TextDetectorModel, deterministic_state_dict
+    orig = D._init_like_reference
+
+    def no_random(shape, kind):
+        return torch.zeros(shape) if kind in ("conv", "conv_proj", "conv_dw", "se_w1", "se_w2", "conv_top", "linear") else orig(shape, kind)
+    D._init_like_reference = no_random if load else orig
+    try:
+        m = TextDetectorModel(pre_weights=False, precision=precision, model_size=model_size)
+    finally:
+        D._init_like_reference = orig
+    if load:
+        m.load_state_dict(deterministic_state_dict(seed, model_size=model_size))
+    return m
+
+
+def shared_detector(precision, model_size="xl"):
+    """(CenterNetDetector on cuda in eval mode, its TextDetectorModel) shared by every test of the session that does not edit it."""
+    from findtextcenternet_amd import CenterNetDetector
+    key = (precision, model_size)
+    if key not in _SHARED:
+        m = fresh_model(precision, model_size)
+        d = CenterNetDetector(m.detector)
+        d.to(device="cuda")
+        d.eval()
+        _SHARED[key] = (d, m)
+    d, m = _SHARED[key]
+    assert not d.training
+    return d, m

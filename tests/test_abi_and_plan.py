@@ -338,3 +338,27 @@ def test_px144_tile_configs_are_validated_and_planned(models):
     pl = models["bf16"].plan(8, 768, 768)
     px = [pl.meta[i].name for i in range(len(pl.ops)) if pl.ops[i].kind == L.OP_CONV and 8 <= (pl.ops[i].aux0 & 15) <= 11 and not pl.ops[i].aux0 & 64]
     assert len(px) >= 70 and all(".block.3" in n or ".block.2" in n for n in px), (len(px), px[:4])
+
+
+def test_fp16x3_plans_build_with_every_documented_switch(sd, monkeypatch):
+    """Round-5 advisor (medium): the tuning table's signature drops FTC_FLAG_PRESPLIT, so an fp16x3 project convolution built WITHOUT
+    pre-split operands (any of the switches below) used to inherit a 144-pixel-tile hint that is only legal with them, and
+    ftc_plan_create refused the whole batch-8 / batch-32 plan.  apply_tuning now adopts a hint only if the op validates with it."""
+    m = FtcModel(sd, "fp16x3")
+    cases = [({"FTC_NO_PRESPLIT": "1"}, 8, False), ({"FTC_NO_MBSLICE_X3": "1"}, 8, True), ({"FTC_NO_MBSLICE": "1"}, 32, False),
+             ({"FTC_MBSLICE_MINWG": "1000000"}, 32, True)]
+    for env, B, nchw in cases:                   # (plans are cached per (B, H, W, layout): one key per switch)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pl = m.plan(B, 768, 768, nchw=nchw)
+        for k in env:
+            monkeypatch.delenv(k)
+        px = [i for i in range(len(pl.ops)) if pl.ops[i].kind == L.OP_CONV and 8 <= (pl.ops[i].aux0 & 15) <= 11 and not pl.ops[i].aux0 & 64]
+        assert all(pl.ops[i].flags & L.FLAG_PRESPLIT for i in px), env
+        if "FTC_NO_PRESPLIT" in env:
+            assert not px
+    # and the default plan does run the fused heads and the 144-pixel tiles
+    pl = m.plan(16, 768, 768)
+    n_head = sum(pl.ops[i].kind == L.OP_MBHEAD for i in range(len(pl.ops)))
+    px = [i for i in range(len(pl.ops)) if pl.ops[i].kind == L.OP_CONV and 8 <= (pl.ops[i].aux0 & 15) <= 11 and not pl.ops[i].aux0 & 64]
+    assert n_head >= 70, n_head

@@ -15,6 +15,7 @@ import torch
 import synth
 from findtextcenternet_amd import (CenterNetDetector, HipDetectorBackend, TextDetectorModel, TileGeom, decode_peaks,
                                    deterministic_state_dict, tile_keep_rect)
+from gpu_harness import fresh_model, shared_detector
 from oracle import decode_oracle
 
 pytestmark = pytest.mark.gpu
@@ -46,33 +47,18 @@ def sd():
 # fp16 MFMAs of hi / lo split operands): ONE program that has to meet the reference's 1e-3 tolerance, the exact NMS mask and the
 # exact peak set AND run above 125 images/s per GPU (the fp32-MFMA mode: 117).
 @pytest.fixture(scope="module", params=["fp32", "fp16x3"])
-def det_fp32(sd, request):
-    m = TextDetectorModel(pre_weights=False, precision=request.param)
-    m.load_state_dict(sd)
-    d = CenterNetDetector(m.detector)
-    d.to(device="cuda")
-    d.eval()
-    return d
+def det_fp32(request):
+    return shared_detector(request.param)[0]
 
 
 @pytest.fixture(scope="module")
-def det_bf16(sd):
-    m = TextDetectorModel(pre_weights=False, precision="bf16")
-    m.load_state_dict(sd)
-    d = CenterNetDetector(m.detector)
-    d.to(device="cuda")
-    d.eval()
-    return d
+def det_bf16():
+    return shared_detector("bf16")[0]
 
 
 @pytest.fixture(scope="module")
-def det_fp16(sd):
-    m = TextDetectorModel(pre_weights=False, precision="fp16")
-    m.load_state_dict(sd)
-    d = CenterNetDetector(m.detector)
-    d.to(device="cuda")
-    d.eval()
-    return d
+def det_fp16():
+    return shared_detector("fp16")[0]
 
 
 def _load_unstable(golden_dir, tag):
@@ -347,16 +333,90 @@ def test_bench_plans_b8_b32_16bit_match_their_b1_results_and_the_golden(det_bf16
         assert np.array_equal(dec.feats[b, :k].cpu().numpy(), ft[b].reshape(100, -1)[:, idx].T)
 
 
+def _plan_labels(m, B, H, W):
+    """Kernel labels (ftc_op_kernel_label) of the plan the library runs for this shape -- the plan ftc_forward itself selects."""
+    import ctypes as C
+    from findtextcenternet_amd import _lib as L
+    lib = L.load()
+    pl = m.detector._engine.model.plan(B, H, W)
+    buf = C.create_string_buffer(160)
+    out = []
+    for i in range(len(pl.ops)):
+        L.check(lib.ftc_op_kernel_label(C.byref(pl.ops[i]), buf, 160), "ftc_op_kernel_label")
+        out.append(buf.value.decode())
+    return out
+
+
+@pytest.mark.parametrize("prec,B", [("fp16x3", 8), ("fp16x3", 32), ("fp32", 8)])
+def test_bench_plans_b8_b32_contract_grade_modes_meet_the_reference_tolerance(golden_dir, prec, B):
+    """The plans that produce bench.py's contract-grade figure (`config.contract_mode` / `north_star_value`: fp16x3 at batch 8 and 32; fp32 beside
+    it) checked at FULL size against the reference's golden -- round 5's full-model golden tests only reached these modes at B <= 3, where
+    model.hip selects no fused MBConv head (fewer than 128 workgroups) and the 144-pixel project tiles are not the batch-8 choices.
+    BASELINE.json north_star: maps within 1e-3, peak indices bit-exact.  Image 0 is golden g2 `page`: heat-map within TOL with the NMS mask
+    identical outside the reference-derived instability mask, features at the 1024 stored positions within TOL, peak index set identical
+    to the oracle decode of the REFERENCE's map; every image (a sample at B = 32) against the same image run alone within 1e-4 and with the
+    same NMS mask (tiles are independent units); GPU decode + gather of the batch == oracle decode of the same maps."""
+    det, m = shared_detector(prec)
+    g = np.load(os.path.join(golden_dir, "g2_fwd768_page.npz"))
+    imgs = np.concatenate([synth.page_images(4242, 1, 768, 768)] + [synth.noise_images(900 + i, 1, 768, 768) if i % 2 else
+                                                                     synth.page_images(900 + i, 1, 768, 768) for i in range(1, B)])
+    x = torch.from_numpy(imgs).permute(0, 3, 1, 2).to("cuda")
+    with torch.no_grad():
+        heat, feat = det.forward_nhwc(x)
+        rect = tile_keep_rect(0, 0, 768, 768, 0.6)
+        dec = decode_peaks(heat, feat, [TileGeom(0, 0, 768, 768, rect)] * B, cut_off=0.4, max_boxes=4096)
+        hm = heat.permute(0, 3, 1, 2).cpu().numpy()
+        ft = feat.permute(0, 3, 1, 2).cpu().numpy()
+    labels = _plan_labels(m, B, 768, 768)
+    if prec == "fp16x3":                                     # the kernels round 5's fp16x3 gain came from must be IN the plan under test
+        n_head = sum(l.startswith("mbconv_slice<f16x3") for l in labels)
+        n_px = sum(l.startswith("conv1x1_px144<f16x3") for l in labels)
+        _log(f"{prec} B={B} plan: {len(labels)} ops, {n_head} mbconv_slice<f16x3>, {n_px} conv1x1_px144<f16x3>")
+        assert n_head >= 70 and n_px >= 60, (n_head, n_px)
+    # (a) image 0 against the reference's golden
+    un = _load_unstable(golden_dir, "fwd768_page")
+    _compare_maps(f"{prec} B={B} image 0 vs golden g2 page", hm[:1], None, g["heatmap"], unstable=un)
+    e_ft = float(np.abs(ft[0].reshape(100, -1)[:, g["feat_pos"]] - g["feat_at"]).max())
+    sets_b = _peak_sets(hm)
+    ref = _peak_sets(g["heatmap"])[0]
+    _log(f"{prec} B={B} image 0: features@1024 Linf {e_ft:.3e}; peaks {len(sets_b[0])} vs reference {len(ref)}, identical: {sets_b[0] == ref}")
+    assert e_ft < TOL and sets_b[0] == ref and len(ref) > 20
+    # (b) every image against the same image run alone.  The two plans sum in different orders (other tiles, fused heads): a keep /
+    # suppress or cut-off decision may differ only where its margin is below twice the difference measured between the two runs
+    worst, worst_f, n_flip = 0.0, 0.0, 0
+    with torch.no_grad():
+        for b in ([0, 1, 2, B // 2, B - 1] if B > 8 else range(B)):
+            h1, f1 = det.forward_nhwc(x[b:b + 1])
+            h1, f1 = h1.permute(0, 3, 1, 2).cpu().numpy(), f1.permute(0, 3, 1, 2).cpu().numpy()
+            fin = np.isfinite(h1) & np.isfinite(hm[b:b + 1])
+            e_b = float(np.abs(h1[fin] - hm[b:b + 1][fin]).max())
+            env = _oracle_unstable(h1)
+            near = (env["margin64"] <= 2 * e_b)[0] | (np.abs(env["key64"][0] - np.float32(np.log(0.4 / 0.6))) <= 2 * e_b)
+            flips = np.isfinite(h1[0, 1]) != np.isfinite(hm[b, 1])
+            assert not (flips & ~near).any(), f"image {b}: NMS mask differs between the batch-{B} and batch-1 plans outside near-ties"
+            diff = _peak_sets(h1)[0] ^ sets_b[b]
+            assert all(near.reshape(-1)[i] for i in diff), f"image {b}: peak sets differ outside near-ties: {sorted(diff)[:8]}"
+            n_flip += int(flips.sum()) + len(diff)
+            worst, worst_f = max(worst, e_b), max(worst_f, float(np.abs(f1 - ft[b:b + 1]).max()))
+    _log(f"{prec} B={B} vs B=1 plans: heatmap Linf {worst:.2e}, features Linf {worst_f:.2e}, {n_flip} near-tie decisions differ")
+    assert worst < 1e-4 and worst_f < 1e-4 and n_flip <= 4
+    # (c) GPU decode + gather of the whole batch == oracle decode of the same maps
+    for b in range(B):
+        n = int(dec.counts[b])
+        assert n == len(sets_b[b]) and set(dec.index[b, :n].cpu().tolist()) == sets_b[b]
+        k = min(n, 16)
+        idx = dec.index[b, :k].cpu().numpy()
+        assert np.array_equal(dec.feats[b, :k].cpu().numpy(), ft[b].reshape(100, -1)[:, idx].T)
+
+
 @pytest.mark.parametrize("prec", ["bf16", "fp16x3"])
-def test_forward_stays_inside_its_buffers(sd, prec):
+def test_forward_stays_inside_its_buffers(prec):
     """Device-side bounds check of the whole forward (the ASan build of the shim only sees host code): workspace, both
     outputs and the input sit between 1 MiB guard bands of a known pattern inside ONE allocation; after forwards at several shapes -- the
     benchmarked batch 8, an odd batch whose plan takes other kernels (no FTC_OP_MBHEAD below 128 workgroups), a non-square tile -- every
     guard byte is unchanged, and a forward into a NaN-poisoned workspace gives the same result as into a zeroed one (nothing reads what
     the plan did not write first)."""
-    m = TextDetectorModel(pre_weights=False, precision=prec)
-    m.load_state_dict(sd)
-    det = CenterNetDetector(m.detector).to("cuda").eval()
+    det, m = shared_detector(prec)
     eng = m.detector._engine
     G = 1 << 20
     for (B, H, W) in [(8, 768, 768), (3, 768, 768), (2, 512, 640)]:
@@ -403,8 +463,7 @@ def test_parameter_edits_are_noticed(sd):
     raw-pointer AdamWScheduleFree), re-allocations, load_state_dict (also assign=True) all change the next forward; a deep copy gets
     its own engine.  Writes through `p.data` are not detectable (separate version counter): they need engine.invalidate()."""
     import copy
-    m = TextDetectorModel(pre_weights=False, precision="bf16")
-    m.load_state_dict(sd)
+    m = fresh_model("bf16")
     d = CenterNetDetector(m.detector).to("cuda").eval()
     x = torch.from_numpy(synth.page_images(3, 1, 128, 128)).permute(0, 3, 1, 2).to("cuda")
     with torch.no_grad():
@@ -442,13 +501,11 @@ def test_parameter_edits_are_noticed(sd):
         assert float((h7[:, 0] - h6[:, 0]).abs().max()) > 1e-3
 
 
-def test_fp16_mode_same_plan_much_closer_to_the_reference(sd, golden_dir):
+def test_fp16_mode_same_plan_much_closer_to_the_reference(golden_dir):
     """precision='fp16': the speed-mode plan with IEEE-half MFMA operands (same matrix rate as bf16, 11-bit significands).
     Against the reference golden it must beat the bf16 mode by a wide margin: heat-map / features within 0.15 % of range (bf16:
     ~0.5 %), peak-set Jaccard >= 0.97."""
-    m = TextDetectorModel(pre_weights=False, precision="fp16")
-    m.load_state_dict(sd)
-    d = CenterNetDetector(m.detector).to("cuda").eval()
+    d = shared_detector("fp16")[0]
     g = np.load(os.path.join(golden_dir, "g2_fwd768_page.npz"))
     x = torch.from_numpy(synth.page_images(4242, 1, 768, 768)).permute(0, 3, 1, 2).to("cuda")
     with torch.no_grad():
@@ -467,9 +524,7 @@ def test_fp16_mode_same_plan_much_closer_to_the_reference(sd, golden_dir):
     assert e / rng < 0.0015 and e_ft / frng < 0.0015 and jac >= FP16_JACCARD_GATE and recall >= FP16_RECALL_GATE
     # other geometries / batch sizes run the same code paths as bf16 (shared tuning table): quick agreement check with fp32
     x2 = torch.from_numpy(synth.page_images(778, 3, 256, 192)).permute(0, 3, 1, 2).to("cuda")
-    m32 = TextDetectorModel(pre_weights=False, precision="fp32")
-    m32.load_state_dict(sd)
-    d32 = CenterNetDetector(m32.detector).to("cuda").eval()
+    d32 = shared_detector("fp32")[0]
     with torch.no_grad():
         h16, f16 = d(x2)
         h32, f32_ = d32(x2)
@@ -481,13 +536,10 @@ def test_fp16_mode_same_plan_much_closer_to_the_reference(sd, golden_dir):
 def test_other_model_sizes_match_the_reference(golden_dir, size):
     """TextDetectorModel(model_size='s' | 'm' | 'l') on the GPU against the reference's own outputs for those sizes (g8)."""
     g = np.load(os.path.join(golden_dir, f"g8_fwd128_{size}.npz"))
-    sd_ = deterministic_state_dict(0, model_size=size)
     x = torch.from_numpy(synth.page_images(int(g["seed"]), 1, 128, 128)).permute(0, 3, 1, 2).to("cuda")
     outs = {}
     for prec in ("fp32", "fp16", "bf16"):
-        m = TextDetectorModel(pre_weights=False, model_size=size, precision=prec)
-        m.load_state_dict(sd_)
-        d = CenterNetDetector(m.detector).to("cuda").eval()
+        d = shared_detector(prec, size)[0]
         with torch.no_grad():
             hm, ft = d(x)
         outs[prec] = (hm.cpu().numpy(), ft.cpu().numpy())
@@ -510,8 +562,7 @@ def test_small_module_calls_replay_a_graph_bit_identical_and_follow_weight_edits
     """One-tile module calls (the reference's loops; HipDetectorBackend.call_detector) replay the forward from a HIP graph captured on the
     second call: same bits as the eager path on every call, fresh output tensors per call, and an edited parameter re-packs and
     re-captures instead of replaying the old weights."""
-    m = TextDetectorModel(pre_weights=False, precision="bf16")
-    m.load_state_dict(sd)
+    m = fresh_model("bf16")
     det = CenterNetDetector(m.detector)
     be = HipDetectorBackend(det)
     eng = m.detector._engine

@@ -5,8 +5,8 @@ import pytest
 import torch
 
 import synth
-from findtextcenternet_amd import (CenterNetDetector, DetectorLanes, TextDetectorModel, TileGeom, decode_peaks, deterministic_state_dict,
-                                   exact_logit_cut, tile_keep_rect, tiles_to_device)
+from findtextcenternet_amd import DetectorLanes, TileGeom, decode_peaks, exact_logit_cut, tile_keep_rect, tiles_to_device
+from gpu_harness import shared_detector
 
 pytestmark = pytest.mark.gpu
 
@@ -14,11 +14,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("precision,lanes", [("bf16", 2), ("bf16", 3), ("fp16x3", 2)])
 def test_lanes_are_bit_identical_to_one_stream(precision, lanes):
     dev = torch.device("cuda")
-    m = TextDetectorModel(pre_weights=False, precision=precision)
-    m.load_state_dict(deterministic_state_dict(0))
-    det = CenterNetDetector(m.detector)
-    det.to(device=dev)
-    det.eval()
+    det, _ = shared_detector(precision)
     B, S, n_batches = 2, 256, 7
     h = S // 4
     rect = tile_keep_rect(0, 0, S, S, 0.6, tile_w=S, tile_h=S)
@@ -66,11 +62,7 @@ def test_lanes_are_bit_identical_to_one_stream(precision, lanes):
 
 def test_lane_workspace_is_checked():
     dev = torch.device("cuda")
-    m = TextDetectorModel(pre_weights=False, precision="bf16")
-    m.load_state_dict(deterministic_state_dict(0))
-    det = CenterNetDetector(m.detector)
-    det.to(device=dev)
-    det.eval()
+    det, _ = shared_detector("bf16")
     x = torch.zeros((1, 3, 128, 128), device=dev)
     with pytest.raises(ValueError):
         det.forward_nhwc(x, workspace=torch.empty(1024, dtype=torch.uint8, device=dev))

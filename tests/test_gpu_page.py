@@ -9,7 +9,8 @@ import pytest
 import torch
 
 import synth
-from findtextcenternet_amd import CenterNetDetector, TextDetectorModel, TileGeom, deterministic_state_dict, tile_keep_rect, tiles_to_device
+from findtextcenternet_amd import TileGeom, deterministic_state_dict, tile_keep_rect, tiles_to_device
+from gpu_harness import shared_detector
 from findtextcenternet_amd import _lib as L
 from findtextcenternet_amd import page
 from oracle import decode_oracle, detector_oracle
@@ -248,9 +249,7 @@ def test_page_merge_gpu_no_boxes_and_nan_threshold():
 
 @pytest.fixture(scope="module")
 def detector():
-    m = TextDetectorModel(pre_weights=False, precision="fp32")
-    m.load_state_dict(deterministic_state_dict(0))
-    return CenterNetDetector(m.detector).to("cuda").eval()
+    return shared_detector("fp32")[0]
 
 
 def test_run_detector_two_tiles_vs_oracle(detector):

@@ -12,7 +12,8 @@ import pytest
 import torch
 
 import synth
-from findtextcenternet_amd import TextDetectorModel, deterministic_state_dict
+from findtextcenternet_amd import deterministic_state_dict
+from gpu_harness import fresh_model
 from findtextcenternet_amd import loss_func as LF
 from oracle import loss_oracle
 
@@ -27,9 +28,7 @@ def g7(golden_dir):
 
 @pytest.fixture(scope="module")
 def model_fp32():
-    m = TextDetectorModel(pre_weights=False, precision="fp32")
-    m.load_state_dict(deterministic_state_dict(0))
-    return m.to("cuda").eval()
+    return fresh_model("fp32").to("cuda").eval()
 
 
 def _labels(B=2, hw=64, seed=616):
@@ -146,9 +145,7 @@ def test_cov_weighting_matches_reference(g7):
 
 def test_validation_step_bf16_mode_tracks_fp32(model_fp32):
     """The speed mode runs the decoder GEMMs in bf16: same decisions on clear rows, losses within bf16 noise."""
-    m = TextDetectorModel(pre_weights=False, precision="bf16")
-    m.load_state_dict(deterministic_state_dict(0))
-    m.to("cuda").eval()
+    m = fresh_model("bf16").to("cuda").eval()
     lab, ids = _labels()
     x = torch.from_numpy(synth.page_images(515, 2, 256, 256)).permute(0, 3, 1, 2).cuda()
     fm = m.get_fmask(lab, None)
@@ -173,8 +170,7 @@ def test_train_mode_forward_matches_oracle_and_reference(precision, tol_maps, to
     g = np.load(os.path.join(golden_dir, "g9_train_forward.npz"))
     B, H, W = 3, 128, 128
     sd = deterministic_state_dict(0)
-    m = TextDetectorModel(pre_weights=False, precision=precision)
-    m.load_state_dict(sd)
+    m = fresh_model(precision)
     m = m.to("cuda")
     x = torch.from_numpy(synth.page_images(929, B, H, W)).cuda().permute(0, 3, 1, 2)
     label, _ = synth.train_labels(930, B, H // 4, W // 4)
@@ -226,8 +222,7 @@ def test_train_mode_forward_small_models_vs_oracle(size):
     from oracle import detector_oracle
     B, H, W = 2, 128, 128
     sd = deterministic_state_dict(0, model_size=size)
-    m = TextDetectorModel(pre_weights=False, precision="fp32", model_size=size)
-    m.load_state_dict(sd)
+    m = fresh_model("fp32", model_size=size)
     m = m.to("cuda").train()
     x_cpu = torch.from_numpy(synth.page_images(31, B, H, W)).permute(0, 3, 1, 2)
     label, _ = synth.train_labels(32, B, H // 4, W // 4)

@@ -15,7 +15,8 @@ import pytest
 import torch
 
 import synth
-from findtextcenternet_amd import TextDetectorModel, deterministic_state_dict
+from findtextcenternet_amd import deterministic_state_dict
+from gpu_harness import fresh_model
 from findtextcenternet_amd.train_step import COV_KEYS, TrainStep
 from oracle import train_oracle
 
@@ -28,9 +29,7 @@ def g10(golden_dir):
 
 
 def _model(precision):
-    m = TextDetectorModel(pre_weights=False, precision=precision)
-    m.load_state_dict(deterministic_state_dict(0))
-    return m.to("cuda").train()
+    return fresh_model(precision).to("cuda").train()
 
 
 def grad_report(ts, ref_grads, tol_rel=1e-3, tol_abs=1e-7, sibling_scale=None):

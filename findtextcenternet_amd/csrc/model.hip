@@ -146,6 +146,22 @@ inline uint16_t f32_to_f16_rne(float f) {           // IEEE half, round-to-neare
     return u;
 }
 
+// The fold / re-layout / conversion loops below touch every one of the 262 M weights in float64: on one thread ftc_create took 5-9 s.
+// par_for splits an index range over a few threads when it is large (results do not depend on the split: every index is independent).
+template <typename F>
+void par_for(int64_t n, int64_t grain, F&& f) {          // f(begin, end); begin is a multiple of `grain`
+    const int64_t chunks = (n + grain - 1) / grain;
+    int nt = (int)std::min<int64_t>(std::min<unsigned>(8, std::max(1u, std::thread::hardware_concurrency())), chunks);
+    if (n < (int64_t)1 << 18 || nt <= 1) { f(0, n); return; }
+    std::vector<std::thread> th;
+    const int64_t per = (chunks + nt - 1) / nt * grain;
+    for (int t = 0; t < nt; ++t) {
+        const int64_t b = t * per, e = std::min(n, b + per);
+        if (b < e) th.emplace_back([&f, b, e] { f(b, e); });
+    }
+    for (auto& x : th) x.join();
+}
+
 struct Blob {
     std::vector<uint8_t> bytes;
     std::map<std::string, int64_t> table;
@@ -157,7 +173,7 @@ struct Blob {
     }
     void add_f32(const std::string& name, const double* v, int64_t n) {
         float* d = reinterpret_cast<float*>(add(name, n * 4));
-        for (int64_t i = 0; i < n; ++i) d[i] = (float)v[i];
+        par_for(n, 1024, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) d[i] = (float)v[i]; });
     }
     void add_f32(const std::string& name, const float* v, int64_t n) { std::memcpy(add(name, n * 4), v, (size_t)n * 4); }
     // MFMA compute type: fp32, or bf16 / fp16 (double -> float -> 16 bit, both steps round-to-nearest-even)
@@ -165,19 +181,21 @@ struct Blob {
         if (dt == FTC_F32) { add_f32(name, v, n); return; }
         if (dt == FTC_PRECISION_F16X3) {                    // fp16x3: every 16-byte chunk of four fp32 weights becomes [hi x4 | lo x4] IEEE halves
             uint16_t* d = reinterpret_cast<uint16_t*>(add(name, n * 4));
-            for (int64_t i = 0; i + 3 < n; i += 4)
-                for (int e = 0; e < 4; ++e) {
-                    float x = (float)v[i + e];
-                    const float xs = x > 65504.0f ? 65504.0f : x < -65504.0f ? -65504.0f : x;
-                    const uint16_t h = f32_to_f16_rne(xs);
-                    d[2 * i + e] = h;
-                    d[2 * i + 4 + e] = f32_to_f16_rne(x - f16_to_f32(h));
-                }
+            par_for(n, 1024, [&](int64_t b, int64_t en) {
+                for (int64_t i = b; i + 3 < en; i += 4)
+                    for (int e = 0; e < 4; ++e) {
+                        float x = (float)v[i + e];
+                        const float xs = x > 65504.0f ? 65504.0f : x < -65504.0f ? -65504.0f : x;
+                        const uint16_t h = f32_to_f16_rne(xs);
+                        d[2 * i + e] = h;
+                        d[2 * i + 4 + e] = f32_to_f16_rne(x - f16_to_f32(h));
+                    }
+            });
             return;
         }
         uint16_t* d = reinterpret_cast<uint16_t*>(add(name, n * 2));
-        if (dt == FTC_BF16) for (int64_t i = 0; i < n; ++i) d[i] = f32_to_bf16_rne((float)v[i]);
-        else for (int64_t i = 0; i < n; ++i) d[i] = f32_to_f16_rne((float)v[i]);
+        if (dt == FTC_BF16) par_for(n, 1024, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) d[i] = f32_to_bf16_rne((float)v[i]); });
+        else par_for(n, 1024, [&](int64_t b, int64_t e) { for (int64_t i = b; i < e; ++i) d[i] = f32_to_f16_rne((float)v[i]); });
     }
 };
 
@@ -205,12 +223,14 @@ bool fold(Weights& w, const std::string& conv_key, const std::string& bn_prefix,
     if (!cw || !bn_affine(w, bn_prefix, O, eps, &a)) return false;
     const int64_t per = (int64_t)I * k * k;
     wf->resize((size_t)O * per);
-    for (int o = 0; o < O; ++o) {
-        const double s = a.s[o];
-        const float* src = cw->data + o * per;
-        double* dst = wf->data() + o * per;
-        for (int64_t i = 0; i < per; ++i) dst[i] = (double)src[i] * s;
-    }
+    par_for((int64_t)O * per, per, [&](int64_t b, int64_t e) {
+        for (int64_t o = b / per; o * per < e; ++o) {
+            const double s = a.s[o];
+            const float* src = cw->data + o * per;
+            double* dst = wf->data() + o * per;
+            for (int64_t i = 0; i < per; ++i) dst[i] = (double)src[i] * s;
+        }
+    });
     *bias = a.t;
     return true;
 }
@@ -219,9 +239,12 @@ bool fold(Weights& w, const std::string& conv_key, const std::string& bn_prefix,
 std::vector<double> kmajor(const std::vector<double>& w, int O, int I, int k) {
     std::vector<double> out(w.size());
     const int kk = k * k;
-    for (int o = 0; o < O; ++o)
-        for (int i = 0; i < I; ++i)
-            for (int t = 0; t < kk; ++t) out[((size_t)o * kk + t) * I + i] = w[((size_t)o * I + i) * kk + t];
+    const int64_t per = (int64_t)I * kk;
+    par_for((int64_t)O * per, per, [&](int64_t b, int64_t e) {
+        for (int64_t o = b / per; o * per < e; ++o)
+            for (int i = 0; i < I; ++i)
+                for (int t = 0; t < kk; ++t) out[((size_t)o * kk + t) * I + i] = w[((size_t)o * I + i) * kk + t];
+    });
     return out;
 }
 

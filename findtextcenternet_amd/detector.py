@@ -69,9 +69,34 @@ def _init_like_reference(shape, kind: str) -> torch.Tensor:
     return torch.zeros(shape)
 
 
+_INIT_LIKE_REFERENCE = _init_like_reference
+
+
+def _init_normal_np(shape, kind: str, seed: int) -> torch.Tensor:
+    """The conv kinds of _init_like_reference from a per-tensor numpy generator (fills release the GIL: _populate runs them on threads)."""
+    fan_out = shape[0] * shape[2] * shape[3]
+    a = np.random.Generator(np.random.SFC64(seed)).standard_normal(shape, dtype=np.float32)
+    a *= np.float32(math.sqrt(2.0 / fan_out))
+    return torch.from_numpy(a)
+
+
 def _populate(root: nn.Module, schema) -> None:
-    for name, (shape, kind) in schema.items():
-        _attach(root, name, _init_like_reference(shape, kind), kind in ("bn_mean", "bn_var", "bn_count"))
+    # 262 M parameters for "xl": torch.randn on one thread takes ~7 s.  The large tensors (the conv kinds) are drawn by per-tensor numpy
+    # generators on a few threads instead, seeded from ONE draw of torch's global generator (torch.manual_seed still fixes the init).
+    from concurrent.futures import ThreadPoolExecutor
+    if _init_like_reference is not _INIT_LIKE_REFERENCE:              # (tests replace the initialiser: keep the plain path)
+        for name, (shape, kind) in schema.items():
+            _attach(root, name, _init_like_reference(shape, kind), kind in ("bn_mean", "bn_var", "bn_count"))
+        return
+    base = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    items = list(schema.items())
+    big = [(i, shape, kind) for i, (_, (shape, kind)) in enumerate(items) if kind in ("conv", "conv_proj", "conv_dw", "se_w1", "se_w2")]
+    drawn = {}
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        for (i, _, _), t in zip(big, ex.map(lambda a: _init_normal_np(a[1], a[2], base + a[0]), big)):
+            drawn[i] = t
+    for i, (name, (shape, kind)) in enumerate(items):
+        _attach(root, name, drawn[i] if i in drawn else _init_like_reference(shape, kind), kind in ("bn_mean", "bn_var", "bn_count"))
 
 
 class _HipEngine:

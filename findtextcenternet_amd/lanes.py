@@ -21,18 +21,24 @@ from .decode import DecodeWorkspace, decode_peaks
 
 
 class DetectorLanes:
-    def __init__(self, detector, B: int, H: int = 768, W: int = 768, lanes: int = 2, max_boxes: int = 2048, device="cuda"):
+    def __init__(self, detector, B: int, H: int = 768, W: int = 768, lanes: int = 2, max_boxes: int = 2048, device="cuda", decode=None):
         """detector: a findtextcenternet_amd.CenterNetDetector in eval mode on `device`.  Its weights must not change while batches are in
-        flight (a parameter edit re-packs the weight blob every lane reads): call synchronize-then-edit, as with any stream of work."""
+        flight (a parameter edit re-packs the weight blob every lane reads): call synchronize-then-edit, as with any stream of work.
+
+        `decode` (default `decode_peaks`) and a CPU `device` exist for ONE purpose: the world-size-2 gloo test of the control flow
+        (lane rotation, per-lane buffers, `then=` collectives issued lane after lane -- tests/test_dist.py) with a stub detector and a stub
+        decode.  On a CPU device there are no streams: a submission runs inline, in order.  The product path is `device="cuda"`."""
         self.det, self.B, self.H, self.W, self.n = detector, B, H, W, lanes
         dev = torch.device(device)
         self.dev = dev
+        self._decode = decode if decode is not None else decode_peaks
         h, w = H // 4, W // 4
         eng = detector.detector._engine
-        with torch.cuda.device(dev):
+        import contextlib
+        with (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):
             eng.ensure_model(dev)
             nbytes = eng.model.workspace_bytes(B, H, W)
-            self.streams = [torch.cuda.Stream(device=dev) for _ in range(lanes)]
+            self.streams = [torch.cuda.Stream(device=dev) if dev.type == "cuda" else None for _ in range(lanes)]
             self.ws = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(lanes)]
             self.heat = [torch.empty((B, h, w, 10), dtype=torch.float32, device=dev) for _ in range(lanes)]
             self.feat = [torch.empty((B, h, w, 100), dtype=torch.float32, device=dev) for _ in range(lanes)]
@@ -51,6 +57,11 @@ class DetectorLanes:
         caller's stream before `wait(lane)` is still a race, as with any asynchronous consumer."""
         i = self.k % self.n
         self.k += 1
+        if self.dev.type != "cuda":                          # (the gloo test of the control flow: inline, in submission order)
+            with torch.no_grad():
+                self.det.forward_nhwc(x, out=(self.heat[i], self.feat[i]), workspace=self.ws[i])
+                dec = self._decode(self.heat[i], self.feat[i], tiles, cut_off=cut_off, max_boxes=self.max_boxes, logit_cut=logit_cut, workspace=self.dws[i])
+                return i, (then(dec) if then is not None else dec)
         cur = torch.cuda.current_stream(self.dev)
         s = self.streams[i]
         s.wait_stream(cur)                                   # whatever produced x (and the caller's earlier work) comes first
@@ -59,12 +70,14 @@ class DetectorLanes:
                 t.record_stream(s)
         with torch.cuda.stream(s), torch.no_grad():
             self.det.forward_nhwc(x, out=(self.heat[i], self.feat[i]), workspace=self.ws[i])
-            dec = decode_peaks(self.heat[i], self.feat[i], tiles, cut_off=cut_off, max_boxes=self.max_boxes, logit_cut=logit_cut, workspace=self.dws[i])
+            dec = self._decode(self.heat[i], self.feat[i], tiles, cut_off=cut_off, max_boxes=self.max_boxes, logit_cut=logit_cut, workspace=self.dws[i])
             out = then(dec) if then is not None else dec
         return i, out
 
     def wait(self, lane: Optional[int] = None) -> None:
         """Makes the CURRENT stream wait for one lane (or all): after it, that lane's outputs may be read on the current stream."""
+        if self.dev.type != "cuda":
+            return
         cur = torch.cuda.current_stream(self.dev)
         for j in ([lane] if lane is not None else range(self.n)):
             cur.wait_stream(self.streams[j])

@@ -88,7 +88,16 @@ def deterministic_state_dict(seed: int = 0, model_size: str = "xl", with_decoder
     Tensor values depend only on (seed, un-prefixed detector key), so both forms agree.
     """
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
-    memo = _FILLED.setdefault((seed, model_size), {})          # generated once per process (~9 s for "xl"); callers get their own copies
+    memo = _FILLED.setdefault((seed, model_size), {})          # generated once per process; callers get their own copies
+    if not memo:
+        # every tensor has its own counter-based generator (keyed by its name): fill them on a few threads (numpy's generators release the
+        # GIL while they fill) -- ~9 s -> ~2 s for "xl"; the values do not depend on the order
+        from concurrent.futures import ThreadPoolExecutor
+        import os
+        todo = [(k[len("detector."):] if k.startswith("detector.") else k, shape, kind) for k, (shape, kind) in text_detector_schema(model_size).items()]
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+            for (base, _, _), t in zip(todo, ex.map(lambda a: fill_tensor(seed, *a), todo)):
+                memo[base] = t
 
     def filled(base, shape, kind):
         t = memo.get(base)

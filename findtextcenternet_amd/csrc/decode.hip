@@ -23,43 +23,74 @@ __device__ __forceinline__ uint32_t orderable(float v) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// Round 6.  The select pass used to take 50 us for 12 MB of reads (profiles/r05e_bf16_b8_kernel_stats.txt): one pixel per thread, and even with
+// one atomicAdd per WAVE (round 5) an image's counter saw ~540 same-address atomics, which the L2 serialises at ~90 ns each.  Now a workgroup
+// owns a contiguous 1/SEL_WG of the trusted rectangle: every thread has all its SEL_PT key logits in flight at once (one round of loads), the
+// candidates' w/h checks are a second, sparse round, the slots inside the workgroup come from ballots + an LDS scan over the waves, and the
+// image's counter sees ONE atomicAdd per workgroup (16 per image).  Slot order is arbitrary as before -- the rank pass imposes the total order.
+constexpr int SEL_WG = 16;            // workgroups per image
+constexpr int SEL_PT = 12;            // positions per thread and pass (256 x 12 x 16 = 49,152 >= 192 x 192; larger maps take more passes)
+
 __global__ __launch_bounds__(256) void decode_select_kernel(const float* __restrict__ heat, const ftc_tile* __restrict__ tiles,
                                                             int h, int w, float logit_cut, unsigned long long* __restrict__ cand,
                                                             int32_t* __restrict__ counts) {
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
     const int b = blockIdx.y;
     const ftc_tile tl = tiles[b];
     const int rw = tl.x_max - tl.x_min, rh = tl.y_max - tl.y_min;
     const int n = rw * rh;
     const float* hb = heat + (long)b * h * w * 10;
-    // (round 5) One atomicAdd per WAVE and pass instead of one per candidate: a random-init tile has ~1600 candidates, and their atomics on the
-    // image's one counter serialised at the L2 (50 us for 12 MB of reads).  The slot order is arbitrary either way -- the rank pass below
-    // imposes the total order.  The loop bound is wave-uniform so that the ballot sees every lane.
-    const int lane = threadIdx.x & 63;
-    const int n_up = (n + 63) & ~63;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_up; i += gridDim.x * blockDim.x) {
-        bool keep = false;
-        int idx = 0;
-        float v = 0.f;
-        if (i < n) {
-            const int y = tl.y_min + i / rw, x = tl.x_min + i % rw;
-            idx = y * w + x;
-            v = hb[(long)idx * 10 + 1];
-            if (v >= logit_cut) {                                     // -inf (suppressed) and NaN fail
-                const float bw = expf(hb[(long)idx * 10 + 2] - 3.0f) * 1024.0f;   // process_ocr_base.py:523-524
-                const float bh = expf(hb[(long)idx * 10 + 3] - 3.0f) * 1024.0f;
-                keep = !(bw <= 0.f || bh <= 0.f) &&                   // :525
-                       !(bw > (float)tl.page_w || bh > (float)tl.page_h);   // :527
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per_wg = (n + SEL_WG - 1) / SEL_WG;
+    const int lo = blockIdx.x * per_wg, hi = min(n, lo + per_wg);
+    for (int p0 = lo; p0 < hi; p0 += 256 * SEL_PT) {              // (one pass for maps up to 192 x 192)
+        float v[SEL_PT];
+        int idx[SEL_PT];
+#pragma unroll
+        for (int u = 0; u < SEL_PT; ++u) {                         // position = p0 + u * 256 + t: a wave reads 64 consecutive pixels
+            const int i = p0 + u * 256 + t;
+            idx[u] = -1;
+            v[u] = -__builtin_huge_valf();
+            if (i < hi) {
+                const int y = tl.y_min + i / rw, x = tl.x_min + i % rw;
+                idx[u] = y * w + x;
+                v[u] = hb[(long)idx[u] * 10 + 1];
             }
         }
-        const unsigned long long m = __ballot(keep);
-        if (m == 0ull) continue;
-        int base = 0;
-        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&counts[b], __popcll(m));
-        base = __shfl(base, __ffsll((long long)m) - 1, 64);
-        if (keep) {
-            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-            cand[(long)b * h * w + slot] = ((unsigned long long)orderable(v) << 32) | (uint32_t)(~(uint32_t)idx);
+        unsigned keepm = 0;
+        int mine = 0;
+#pragma unroll
+        for (int u = 0; u < SEL_PT; ++u) {
+            if (idx[u] >= 0 && v[u] >= logit_cut) {                // -inf (suppressed) and NaN fail
+                const float bw = expf(hb[(long)idx[u] * 10 + 2] - 3.0f) * 1024.0f;   // process_ocr_base.py:523-524
+                const float bh = expf(hb[(long)idx[u] * 10 + 3] - 3.0f) * 1024.0f;
+                if (!(bw <= 0.f || bh <= 0.f) &&                   // :525
+                    !(bw > (float)tl.page_w || bh > (float)tl.page_h)) {   // :527
+                    keepm |= 1u << u;
+                    ++mine;
+                }
+            }
         }
+        // exclusive prefix of `mine` over the workgroup: lanes by shuffles, waves through LDS
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        const int w0 = s_wave[0], w1 = s_wave[1], w2 = s_wave[2], w3 = s_wave[3];
+        const int total = w0 + w1 + w2 + w3;
+        if (t == 0) s_base = total ? atomicAdd(&counts[b], total) : 0;
+        __syncthreads();
+        int slot = s_base + (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0) + incl - mine;
+#pragma unroll
+        for (int u = 0; u < SEL_PT; ++u)
+            if (keepm & (1u << u))
+                cand[(long)b * h * w + slot++] = ((unsigned long long)orderable(v[u]) << 32) | (uint32_t)(~(uint32_t)idx[u]);
+        __syncthreads();                                             // s_wave / s_base are reused by the next pass
     }
 }
 
@@ -159,8 +190,7 @@ hipError_t launch_decode(const float* heat, const float* feat, int B, int h, int
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * B, s);
     if (e != hipSuccess) return e;
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(scratch);
-    const int nb = (h * w + 255) / 256;
-    hipLaunchKernelGGL(decode_select_kernel, dim3(nb, B), dim3(256), 0, s, heat, tiles, h, w, logit_cut, cand, counts);      // one pixel per thread: a single round of loads (36 workgroups per image walked four dependent rounds: 50 us)
+    hipLaunchKernelGGL(decode_select_kernel, dim3(SEL_WG, B), dim3(256), 0, s, heat, tiles, h, w, logit_cut, cand, counts);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(decode_rank_gather_kernel, dim3((h * w + 63) / 64, B), dim3(256), 0, s, heat, feat, tiles, h, w, C, scale, cand, counts,

@@ -157,18 +157,18 @@ __global__ __launch_bounds__(256) void decode_rank_gather_kernel(const float* __
     const int CQ = C >> 2;
     const float* fb = feat + (long)b * h * w * C;
     if (CQ <= 64) {                                                   // (C <= 256: one 16-byte access per lane and row -- four rows in flight)
-        for (int k0 = wave * 16; k0 < wave * 16 + 16; k0 += 4) {
-            f32x4 v[4];
-            int r[4];
+        // (round 6) all 16 rows of the wave in flight at once: the four dependent rounds of four rows cost ~1.5 us each
+        const int k0 = wave * 16;
+        f32x4 v[16];
+        int r[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                r[u] = s_rank[k0 + u];
-                if (r[u] >= 0 && lane < CQ) v[u] = reinterpret_cast<const f32x4*>(fb + (long)s_idx[k0 + u] * C)[lane];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (r[u] >= 0 && lane < CQ) reinterpret_cast<f32x4*>(feats + ((long)b * max_boxes + r[u]) * feat_stride)[lane] = v[u];
+        for (int u = 0; u < 16; ++u) {
+            r[u] = s_rank[k0 + u];
+            if (r[u] >= 0 && lane < CQ) v[u] = reinterpret_cast<const f32x4*>(fb + (long)s_idx[k0 + u] * C)[lane];
         }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (r[u] >= 0 && lane < CQ) reinterpret_cast<f32x4*>(feats + ((long)b * max_boxes + r[u]) * feat_stride)[lane] = v[u];
     } else {
         for (int k = wave * 16; k < wave * 16 + 16; ++k) {
             const int r = s_rank[k];

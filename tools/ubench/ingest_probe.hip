@@ -118,6 +118,51 @@ __device__ __forceinline__ void ingest_body(const Args& p) {
 }
 
 
+// The same slab stream by plain `buffer_load_dwordx4` into registers (no LDS): is ~36 B/clk the LDS-DMA path's ceiling or the CU's?
+// NW waves, each thread keeps DEPTH x 7 16-byte loads in flight (a "stage" = the same 26 pieces), values folded into one word.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <int NW, int NST>
+__device__ __forceinline__ void ingest_regs_body(const Args& p) {
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr int NPW = (PIECES + NW - 1) / NW;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.a), 0, p.a_bytes, 0x00020000);
+    int voff[NPW];
+#pragma unroll
+    for (int j = 0; j < NPW; ++j) voff[j] = blockIdx.x * (int)p.slab_bytes + (wave + NW * j) * 1024 + lane * 16;
+    u32x4_t acc = {0u, 0u, 0u, 0u};
+    u32x4_t buf[NST - 1][NPW];
+    __syncthreads();
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    const int total = p.ksteps * p.passes;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s) {
+        const int soff = (int)(((unsigned)(s % p.ksteps) * STAGE) % p.slab_bytes);
+#pragma unroll
+        for (int j = 0; j < NPW; ++j)
+            if (wave + NW * j < PIECES) buf[s][j] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff[j], soff, 0);
+    }
+    for (int k0 = 0; k0 < total; k0 += NST - 1) {
+#pragma unroll
+        for (int s = 0; s < NST - 1; ++s) {
+            const int k = k0 + s;
+#pragma unroll
+            for (int j = 0; j < NPW; ++j)
+                if (wave + NW * j < PIECES) acc ^= buf[s][j];                   // consume stage k (waits for exactly its loads)
+            const int kn = k + NST - 1;
+            if (kn < total) {
+                const int soff = (int)(((unsigned)(kn % p.ksteps) * STAGE) % p.slab_bytes);
+#pragma unroll
+                for (int j = 0; j < NPW; ++j)
+                    if (wave + NW * j < PIECES) buf[s][j] = __builtin_amdgcn_raw_buffer_load_b128(ra, voff[j], soff, 0);
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (t == 0) p.cyc[blockIdx.x] = t1 - t0;
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345678u) p.cyc[1] = 1;       // (keeps the loads observable)
+}
+
 template <int PATTERN, int NW, int NST> struct Kern;
 #define FTC_INGEST_KERNEL(PATTERN, NW, NST)                                                                    \
     __global__ __launch_bounds__(NW * 64, 1) void ingest_p##PATTERN##_w##NW##_s##NST(const Args p) { ingest_body<PATTERN, NW, NST>(p); } \
@@ -125,6 +170,10 @@ template <int PATTERN, int NW, int NST> struct Kern;
 FTC_INGEST_KERNEL(0, 4, 4) FTC_INGEST_KERNEL(0, 8, 4) FTC_INGEST_KERNEL(0, 4, 5)
 FTC_INGEST_KERNEL(1, 4, 4) FTC_INGEST_KERNEL(1, 8, 4) FTC_INGEST_KERNEL(1, 4, 5)
 FTC_INGEST_KERNEL(2, 4, 4) FTC_INGEST_KERNEL(2, 8, 4) FTC_INGEST_KERNEL(2, 4, 5)
+#define FTC_INGEST_REGS(NW, NST)                                                                                 \
+    __global__ __launch_bounds__(NW * 64, 1) void ingest_regs_w##NW##_s##NST(const Args p) { ingest_regs_body<NW, NST>(p); } \
+    template <> struct Kern<3, NW, NST> { static constexpr auto fn = ingest_regs_w##NW##_s##NST; };
+FTC_INGEST_REGS(4, 4) FTC_INGEST_REGS(8, 4) FTC_INGEST_REGS(16, 3)
 
 template <int PATTERN, int NW, int NST>
 static void run(const char* name, Args p, int reps, double ghz_hint) {
@@ -203,6 +252,10 @@ int main(int argc, char** argv) {
             run<0, 4, 4>(nm, p, 9, ghz);
             run<0, 8, 4>(nm, p, 9, ghz);
             run<0, 4, 5>(nm, p, 9, ghz);
+            std::snprintf(nm, sizeof nm, "slab   %u KB, loads to REGISTERS", slab / 1024);
+            run<3, 4, 4>(nm, p, 9, ghz);
+            run<3, 8, 4>(nm, p, 9, ghz);
+            run<3, 16, 3>(nm, p, 9, ghz);
             CHECK(hipFree(a));
         }
     }

@@ -625,7 +625,7 @@ def main():
                 f_[q] += v[q]
             f_["labels"].append(k)
         name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
-        if name.startswith("conv") or name.startswith("mbconv"):
+        if name.startswith(("conv", "mbconv", "fmbconv")):
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             pk = "fp32" if ("<f32" in name and "x3" not in name and precision == "fp32") else precision
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[pk], "unit": "TFLOP/s"}
@@ -660,12 +660,12 @@ def main():
         roof["share_of_forward_time"] = round(d["ms"] / total_ms, 3)
         # ... and the largest SINGLE launch, as rounds 1-4 reported it
         n1, d1 = max(by.items(), key=lambda kv: kv[1]["ms"] / kv[1]["launches"])
-        if n1.startswith(("conv", "mbconv")):
+        if n1.startswith(("conv", "mbconv", "fmbconv")):
             roof["largest_launch"] = {"kernel": n1, "avg_launch_ms": round(d1["ms"] / d1["launches"], 4),
                                       "achieved": round(d1["flops"] / (d1["ms"] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
                                       "frac": round(d1["flops"] / (d1["ms"] * 1e-3) / 1e12 / PEAK[precision], 4)}
-        conv_ms = sum(v["ms"] for k, v in by.items() if k.startswith(("conv", "mbconv")))
-        conv_fl = sum(v["flops"] for k, v in by.items() if k.startswith(("conv", "mbconv")))
+        conv_ms = sum(v["ms"] for k, v in by.items() if k.startswith(("conv", "mbconv", "fmbconv")))
+        conv_fl = sum(v["flops"] for k, v in by.items() if k.startswith(("conv", "mbconv", "fmbconv")))
         allconv = {"ms_per_step": round(conv_ms, 3), "tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                    "share_of_forward_time": round(conv_ms / total_ms, 3)}        # (incl. the fused MBConv heads)
         if dump:

@@ -9,12 +9,12 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libftc_hip.so")
 
-FTC_ABI_VERSION = 9
+FTC_ABI_VERSION = 10
 F32, BF16, F16 = 0, 1, 2
 (BASE_NULL, BASE_WORKSPACE, BASE_WEIGHTS, BASE_INPUT, BASE_HEATMAP, BASE_FEATURES, BASE_GRADS, NUM_BASES) = range(8)
 OP_STEM, OP_CONV, OP_DWCONV, OP_SE, OP_UPCAT, OP_NMS, OP_TAPSUM, OP_BNSTAT, OP_BNACT = 1, 2, 3, 4, 5, 6, 7, 8, 9
 (OP_GATHER_ROWS, OP_LOSSES, OP_LOSS_BWD, OP_SCATTER_ROWS, OP_BNBWD, OP_WGRAD, OP_DWBWD, OP_SEBWD, OP_UPCATBWD, OP_DILATE, OP_TOPDGRAD, OP_COLSUM,
- OP_STEMWGRAD, OP_FILL, OP_JOIN, OP_MBHEAD) = range(10, 26)
+ OP_STEMWGRAD, OP_FILL, OP_JOIN, OP_MBHEAD, OP_FMBCONV) = range(10, 27)
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 FLAG_RESIDUAL, FLAG_SE_SCALE, FLAG_IN_NCHW, FLAG_BORDER_BIAS, FLAG_W_PER_IMAGE, FLAG_SE_FOLD = 1, 2, 4, 8, 16, 32
 FLAG_GROUP_IN_SLICE, FLAG_GROUP_OUT_SLICE = 64, 128

@@ -156,6 +156,16 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
         if (o.flags & 0x1000) { if (!need(o.in2, true, "in2", (int64_t)o.B * nb * ns * 256)) return why->c_str(); }      // phase timeline (tools/mbslice_bench.py)
         return nullptr;
     }
+    case FTC_OP_FMBCONV: {
+        if (!ftc_fmbconv_legal(o))
+            return "fmbconv: needs 16-bit in / w of one type, fp32 out, 3x3 stride 1 (Ho = H, Wo = W), Cin % 32 == 0, aux1 (expanded channels) 256 or 384, Cout % 32 == 0 and "
+                   "<= 128, whole tensors (no channel slices, no groups), act = SiLU, flags = RESIDUAL or none";
+        const int64_t E = o.aux1;
+        if (!need(o.in, true, "in", pin * o.Cin * 2) || !need(o.out, true, "out", pin * o.Cout * 4) || !need(o.w2, true, "w2", E * 9 * o.Cin * 2) ||
+            !need(o.bias2, true, "bias2", E * 4) || !need(o.w, true, "w", (int64_t)o.Cout * E * 2) || !need(o.bias, true, "bias", (int64_t)o.Cout * 4) ||
+            !need(o.in2, (o.flags & FTC_FLAG_RESIDUAL) != 0, "in2", pin * o.Cout * 4) || !need(o.out2, false, "out2", pin * o.Cout * 2)) return why->c_str();
+        return nullptr;
+    }
     case FTC_OP_SE:
         if (o.aux0 <= 0 || o.aux1 <= 0 || o.Cin <= 0) return "se: C, S, P must be positive";
         if (!need(o.aux, true, "aux", (int64_t)o.B * o.aux1 * ((o.flags & FTC_FLAG_SE_HPART) ? o.aux0 : o.Cin) * 4) || !need(o.out, true, "out", (int64_t)o.B * o.Cin * 4) ||
@@ -353,6 +363,7 @@ hipError_t run_one(const ftc_op& o, void* const bases[FTC_NUM_BASES], hipStream_
     case FTC_OP_DWCONV: return launch_dwconv(a, s);
     case FTC_OP_SE: return launch_se(a, s);
     case FTC_OP_MBHEAD: return launch_mbhead(a, s);
+    case FTC_OP_FMBCONV: return launch_fmbconv(a, s);
     case FTC_OP_UPCAT: return launch_upcat(a, s);
     case FTC_OP_NMS: return launch_nms(a, s);
     case FTC_OP_TAPSUM: return launch_tapsum(a, s);
@@ -524,6 +535,7 @@ int ftc_op_kernel_label(const ftc_op* op, char* buf, int len) {
         std::snprintf(buf, len, "mbconv_slice<%s,%dch,%s>", op->in_dtype == FTC_F32 ? "f16x3" : ftc_dtname(op->in_dtype), ftc_mbhead_slice(*op),
                       op->H == 24 && op->W == 24 && op->aux1 == 0 && !(op->flags & 0x100) ? "24x24" : "bands");
         break;
+    case FTC_OP_FMBCONV: ftc_fmbconv_label(*op, buf, len); break;
     case FTC_OP_UPCAT: std::snprintf(buf, len, "upcat_kernel<%s>", ftc_dtname(op->in_dtype)); break;
     case FTC_OP_NMS: std::snprintf(buf, len, "nms_kernel"); break;
     case FTC_OP_TAPSUM: std::snprintf(buf, len, "tapsum_kernel"); break;

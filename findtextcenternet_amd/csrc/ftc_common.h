@@ -244,6 +244,8 @@ int ftc_mbhead_bands(const ftc_op& o);
 int ftc_mbhead_band_rows(int H, int W);
 int ftc_mbhead_slice(const ftc_op& o);         // expanded channels per workgroup (ftc_op.Cout_total, or the form's default)
 hipError_t launch_mbhead(const OpArgs& a, hipStream_t s);
+hipError_t launch_fmbconv(const OpArgs& a, hipStream_t s);      // fused_mbconv.hip (FTC_OP_FMBCONV)
+const char* ftc_fmbconv_label(const ftc_op& o, char* buf, int len);
 hipError_t launch_upcat(const OpArgs& a, hipStream_t s);
 hipError_t launch_nms(const OpArgs& a, hipStream_t s);
 hipError_t launch_tapsum(const OpArgs& a, hipStream_t s);

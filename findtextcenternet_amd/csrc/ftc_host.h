@@ -21,5 +21,8 @@ int ftc_mbhead_bands(const ftc_op& o);          // workgroup bands per image (1 
 int ftc_mbhead_band_rows(int H, int W);         // ftc_op.aux1 for an H x W map: 0 = whole map, > 0 = output rows per band, -1 = does not fit
 int ftc_mbhead_slice(const ftc_op& o);          // expanded channels per workgroup (ftc_op.Cout_total, or the form's default)
 
+// fused_mbconv.hip: shapes FTC_OP_FMBCONV accepts (the plan builder asks before it emits one)
+bool ftc_fmbconv_legal(const ftc_op& o);
+
 // conv_igemm.hip: NULL if the convolution op (incl. its tuned kernel choice ftc_op.aux0) is supported, else the reason
 const char* conv_validate(const ftc_op& op);

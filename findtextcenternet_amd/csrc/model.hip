@@ -752,6 +752,18 @@ int Builder::build(ModelPlan* out) {
         //  replaces; kept all the same: its pre-split output saves the project convolution 10 us and the pair moves 113 MB less through HBM)
         return ftc_mbhead_legal(t) && B * ftc_mbhead_bands(t) * (blk.exp / mb_slice) >= min_wg ? R : -1;
     };
+    // Fused-MBConv blocks with expansion, 16-bit plans, stride 1: one launch (FTC_OP_FMBCONV) where the shape is one the kernel holds
+    auto fmb_fused = [&](const BlockSpec& blk, int bh, int bw) -> bool {
+        if (!blk.fused || blk.exp == blk.cin || !dual || blk.stride != 1 || env_on("FTC_NO_FMBFUSE")) return false;
+        // Measured (tools/fmbconv_bench.py, batch 8): the one-launch form wins where the 3x3 runs K steps of 64 (Cin % 64 == 0: stage 2, 174-182 us
+        // against 126 + 65) and loses on stage 3 (Cin = 96: K steps of 32, twice the barriers per FLOP: 116-135 us against 75 + 28.5).
+        // FTC_FMBFUSE_ALL=1: every shape the kernel holds.
+        if (blk.cin % 64 != 0 && !env_on("FTC_FMBFUSE_ALL")) return false;
+        ftc_op t{};
+        t.in_dtype = t.w_dtype = A; t.out_dtype = T; t.res_dtype = T; t.ksize = 3; t.stride = 1; t.H = t.Ho = bh; t.W = t.Wo = bw; t.B = B;
+        t.Cin = t.Cin_total = blk.cin; t.Cout = t.Cout_total = blk.cout; t.aux1 = blk.exp; t.act = FTC_ACT_SILU; t.flags = blk.residual ? FTC_FLAG_RESIDUAL : 0;
+        return ftc_fmbconv_legal(t);
+    };
     std::vector<const BlockSpec*> flat;
     for (const auto& st : stages)
         for (const BlockSpec& blk : st) flat.push_back(&blk);
@@ -774,6 +786,19 @@ int Builder::build(ModelPlan* out) {
             if (out_blocked) tail.extra_flags |= FTC_FLAG_KBLOCK32;
             if (blk.fused && blk.exp == blk.cin) {
                 conv(p + ".0", gin, G, h, w, blk.cin, blk.cin, 0, p + ".0", blk.cout, 3, blk.stride, FTC_ACT_SILU, y, T, tail);
+            } else if (blk.fused && fmb_fused(blk, h, w)) {
+                // Round 6: the whole block in one launch (csrc/fused_mbconv.hip): the expanded tensor (151 MB per stage-2 block at batch 8) is
+                // neither written nor read back.  FTC_NO_FMBFUSE=1: the two-launch form below.
+                SymOp s;
+                ftc_op& o = s.o;
+                o.kind = FTC_OP_FMBCONV; o.act = FTC_ACT_SILU; o.in_dtype = G; o.out_dtype = T; o.w_dtype = cdt_; o.res_dtype = T;
+                o.flags = res ? FTC_FLAG_RESIDUAL : 0;
+                o.B = B; o.H = h; o.W = w; o.Ho = ho; o.Wo = wo; o.Cin = blk.cin; o.Cin_total = blk.cin; o.Cout = blk.cout; o.Cout_total = blk.cout;
+                o.ksize = 3; o.stride = 1; o.aux1 = blk.exp;
+                s.in = gin; s.in2 = res; s.out = y; s.out2 = yb; s.w2 = wref(p + ".0.w"); s.bias2 = wref(p + ".0.b"); s.w = wref(p + ".1.w"); s.bias = wref(p + ".1.b");
+                const double px = (double)B * h * w;
+                emit({p + ".0+1", "conv3x3+conv1x1", 2.0 * px * blk.exp * (9.0 * blk.cin + blk.cout),
+                      px * blk.cin * esize(G) + px * blk.cout * (esize(T) * (res ? 2 : 1) + (yb ? 2 : 0)) + (double)blk.exp * (9.0 * blk.cin + blk.cout) * esize(cdt_)}, s);
             } else if (blk.fused) {
                 const R e = buf((int64_t)B * ho * wo * blk.exp, A);
                 conv(p + ".0", gin, G, h, w, blk.cin, blk.cin, 0, p + ".0", blk.exp, 3, blk.stride, FTC_ACT_SILU, e, A);

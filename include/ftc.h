@@ -39,8 +39,9 @@ extern "C" {
    7: FTC_OP_MBHEAD (expand 1x1 + depthwise 3x3 + SE squeeze of an MBConv block in one launch), FTC_FLAG_SE_HPART
    8: ftc_page_order, page_h / page_w arguments of ftc_page_merge (parallel page-level selection); FTC_FLAG_SE_INLINE
    9: FTC_FLAG_SE_INLINE removed (flag bit 0x20000000 is free again); FTC_MBHEAD_MAX_SQUEEZE; KBLOCK32 validation on CONV;
-      ftc_page_merge_variant (the demo script's selection + two-pass seed rows) */
-#define FTC_ABI_VERSION 9
+      ftc_page_merge_variant (the demo script's selection + two-pass seed rows)
+   10: FTC_OP_FMBCONV (Fused-MBConv block with expansion in one launch: 3x3 expand + SiLU + 1x1 project + residual) */
+#define FTC_ABI_VERSION 10
 
 typedef enum ftc_status {
     FTC_OK = 0,
@@ -178,6 +179,12 @@ typedef enum ftc_op_kind {
        FTC_OP_SE's aux1 count Cout / slice slices; the fp32-tensor form (in_dtype = out_dtype = w_dtype = FTC_F32 with FTC_FLAG_SPLIT16, csrc/mbconv_slice_x3.hip):
        `in` and w2 PRE-SPLIT (see FTC_FLAG_PRESPLIT), 64-channel slices, fp32 `out` (pre-split with FTC_FLAG_PRESPLIT) */
     FTC_OP_MBHEAD = 25,
+    /* Fused-MBConv block with expansion (torchvision FusedMBConv, expand_ratio != 1; /root/reference/models/detector.py:14-16) in one launch
+       (csrc/fused_mbconv.hip):  e = act(conv3x3(in) + bias2)  [Cin -> E = aux1, 3x3 stride 1 "same"],  out = conv1x1(e) + bias (+ in2)  [E -> Cout].
+       in [B,H,W,Cin] 16-bit, w2 [E][9][Cin] (K-major, same type), bias2 fp32 [E], w [Cout][E] (same type), bias fp32 [Cout], in2 fp32 [B,H,W,Cout]
+       with FTC_FLAG_RESIDUAL, out fp32 [B,H,W,Cout], out2 = optional 16-bit copy of out (NHWC).  e is rounded to the 16-bit type exactly as
+       the two-launch form stores it, but never leaves the CU.  Cin % 32 == 0, aux1 in {256, 384}, Cout % 32 == 0, Cout <= 128, act = FTC_ACT_SILU. */
+    FTC_OP_FMBCONV = 26,
     FTC_OP_TAPSUM = 7          /* second half of a 3x3 convolution split as per-pixel taps + 9-point sum (FTC_FLAG_TOP_FUSE):
                                   out[b,y,x,ch_j] = bias[j] + sum_{r,s} in[g_j][b,y+r-1,x+s-1][(3r+s)*co_j + o_j] (zero outside),
                                   for the aux1 outputs j listed in `w` as int32 quadruples (g_j, o_j, co_j, ch_j);

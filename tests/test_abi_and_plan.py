@@ -143,7 +143,11 @@ def test_plan_structure_flops_and_arena(models, mode):
     assert sum(n for k, n in zip(kinds, inst) if k == "upcat") == 9 * n_up and kinds.count("upcat") == n_up
     # the eight map heads' top convolutions live in the epilogue of the last FPN level (+ one TAPSUM); round 5: in the fp32 / fp16x3 plans too
     fused_top = 8
-    assert sum(n for k, n in zip(kinds, inst) if k.startswith("conv")) == 20 + 16 + 160 + 1 + 1 + 27 + 9 - fused_top
+    # round 6, 16-bit plans: the 7 stride-1 Fused-MBConv blocks of stage 2 are ONE launch each (FTC_OP_FMBCONV: 3x3 expand + 1x1 project; stage 3's
+    # Cin = 96 runs K steps of 32 and measured slower fused: FTC_FMBFUSE_ALL=1)
+    fmb = kinds.count("conv3x3+conv1x1")
+    assert fmb == (7 if mode == "bf16" else 0) and sum(pl.ops[i].kind == L.OP_FMBCONV for i in range(len(kinds))) == fmb
+    assert sum(n for k, n in zip(kinds, inst) if k.startswith("conv")) == 20 + 16 + 160 + 1 + 1 + 27 + 9 - fused_top - fmb
     assert kinds.count("tapsum") == (1 if fused_top else 0)
     # arena: no two simultaneously-live buffers overlap
     live = {}
@@ -215,7 +219,7 @@ def test_tuning_table_entries_are_legal(models):
             if want:
                 hits += 1
                 assert pl.ops[i].aux0 == want, (pl.meta[i].name, pl.ops[i].aux0, want)
-    assert hits > 100
+    assert hits > 80                     # (round 6: the 28 convolutions of the stride-1 Fused-MBConv blocks became 14 FTC_OP_FMBCONV launches: 122 -> 94)
 
 
 def test_drop_in_module_schema_and_loud_failures():

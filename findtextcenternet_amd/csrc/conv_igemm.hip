@@ -17,11 +17,19 @@ hipError_t launch_conv_f16_hh(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_f16_fh(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_f16_hf(const ConvP& p, const ftc_op& o, hipStream_t s);
 hipError_t launch_conv_f16_ff(const ConvP& p, const ftc_op& o, hipStream_t s);
+namespace convimpl {
+bool conv3x3_c32_legal(const ftc_op& o);                               // conv3x3_c32.hip: the resident 32 -> 32 kernel (stage 1)
+hipError_t launch_conv3x3_c32(const ConvP& p, const ftc_op& o, hipStream_t s);
+}
 
 void conv_kernel_label(const ftc_op& op, char* buf, int len) {
     const char* dt[] = {"f32", "bf16", "f16", "?"};
     if (ftc_thin_conv_legal(op)) {
         snprintf(buf, len, op.groups > 1 ? "thin_conv3x3<%s,co=%d,groups=%d>" : "thin_conv3x3<%s,co=%d>", (op.flags & FTC_FLAG_SPLIT16) ? "f16x3" : "f32", op.Cout, op.groups);
+        return;
+    }
+    if (conv3x3_c32_legal(op)) {
+        snprintf(buf, len, "conv3x3_c32<%s,tile=32x16x16,resident>", dt[op.w_dtype & 3]);
         return;
     }
     if (uses_halo(op) && hint_wl1(op) && (op.flags & FTC_FLAG_W_FRAG)) {
@@ -163,6 +171,7 @@ hipError_t launch_conv(const OpArgs& a, hipStream_t s) {
         p.out_gs = (long)o.B * o.Ho * o.Wo * o.aux1 * 4;       // `out` holds T [G][B,Ho,Wo][aux1] fp32
         p.out2 = nullptr;
     }
+    if (conv3x3_c32_legal(o)) return launch_conv3x3_c32(p, o, s);
     if (cfg_px144(select_cfg(o))) {
         if (o.flags & 0x1000) p.w2 = a.w2;                                  // phase timeline (tools/px144_bench.py)
         return launch_conv1x1_px144(p, o, s);

@@ -15,11 +15,22 @@
 
 namespace convimpl {
 
-constexpr int C32_NT = 256, C32_HALO = 324, C32_HB = C32_HALO * 64, C32_WB = 9 * 32 * 64;      // threads; halo pixels; bytes of the two images
-constexpr int C32_LDS = C32_HB + C32_WB;                                                         // 39,168 B (the epilogue image + bias rows alias it: 34.8 KB)
+//
+// fp16x3 form (T = x3f32: fp32 tensors, FTC_FLAG_SPLIT16 -- the contract-grade plan, where the implicit-GEMM kernel splits every activation chunk into hi / lo
+// halves once per TAP while staging it: 257 us per block, VALU per MFMA 39.5, profiles/r06a_fp16x3_b8_pmc_kernels.txt): 128-byte rows (8 chunks of four fp32
+// channels, XOR-swizzled by (row >> 1) & 7 like the halo kernel's), the weights arrive pre-split from the blob, the halo is split IN PLACE once by the thread
+// that DMA'd the chunk; three fp16 MFMAs per product.  78 KB of LDS: two workgroups per CU.
+constexpr int C32_NT = 256, C32_HALO = 324;                                                      // threads; halo pixels
+template <typename T> struct C32Geom {
+    static constexpr int ROWB = is_x3<T> ? 128 : 64, CPR = ROWB / 16;                            // bytes / 16-byte chunks per pixel (and weight) row
+    static constexpr int HB = C32_HALO * ROWB, WB = 9 * 32 * ROWB, LDS = HB + WB;                // 39,168 B | 78,336 B (the epilogue image + bias rows alias it: 34.8 KB)
+};
 
 template <typename T>
-__global__ __launch_bounds__(C32_NT, 4) void conv3x3_c32_kernel(const ConvP p) {
+__global__ __launch_bounds__(C32_NT, is_x3<T> ? 2 : 4) void conv3x3_c32_kernel(const ConvP p) {
+    using GM = C32Geom<T>;
+    constexpr bool X3 = is_x3<T>;
+    constexpr int ROWB = GM::ROWB, CPR = GM::CPR, ES = X3 ? 4 : 2, EPC = 16 / ES, C32_HB = GM::HB;   // element size; elements per chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -37,15 +48,16 @@ __global__ __launch_bounds__(C32_NT, 4) void conv3x3_c32_kernel(const ConvP p) {
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
 
     // ---- one round of DMA: 1296 halo chunks + 1152 weight chunks of 16 bytes, 64 per wave-instruction ----
-    constexpr int HCH = C32_HALO * 4, WCH = 9 * 32 * 4;
+    constexpr int HCH = C32_HALO * CPR, WCH = 9 * 32 * CPR, NHP = (HCH + C32_NT - 1) / C32_NT;
+    auto swz = [](int row) { return X3 ? (row >> 1) & 7 : (row >> 2) & 3; };
 #pragma unroll
-    for (int i = 0; i < (HCH + C32_NT - 1) / C32_NT; ++i) {
+    for (int i = 0; i < NHP; ++i) {
         const int q = i * C32_NT + t;
         if (i * C32_NT + wave * 64 < HCH) {                                         // wave-uniform
-            const int hr = q >> 2, kc = (q & 3) ^ ((hr >> 2) & 3);
+            const int hr = q / CPR, kc = (q % CPR) ^ swz(hr);
             const int iy = ty0 - 1 + hr / 18, ix = tx0 - 1 + hr % 18;
             const bool ok = q < HCH && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const int off = ok ? (((img * p.H + iy) * p.W + ix) * 32 + kc * 8) * 2 : OOB;
+            const int off = ok ? (((img * p.H + iy) * p.W + ix) * 32 + kc * EPC) * ES : OOB;
             if (q < HCH) glds16(rin, (lds_void_t*)(smem_raw + (i * C32_NT + wave * 64) * 16), off, 0);
         }
     }
@@ -53,9 +65,9 @@ __global__ __launch_bounds__(C32_NT, 4) void conv3x3_c32_kernel(const ConvP p) {
     for (int i = 0; i < (WCH + C32_NT - 1) / C32_NT; ++i) {
         const int q = i * C32_NT + t;
         if (i * C32_NT + wave * 64 < WCH) {
-            const int row = q >> 2, kc = (q & 3) ^ ((row >> 2) & 3);                // row = tap * 32 + n
+            const int row = q / CPR, kc = (q % CPR) ^ swz(row);                     // row = tap * 32 + n
             const int tap = row >> 5, n = row & 31;
-            const int off = ((n * 9 + tap) * 32 + kc * 8) * 2;                      // weights [Cout][9][Cin]
+            const int off = ((n * 9 + tap) * 32 + kc * EPC) * ES;                   // weights [Cout][9][Cin] (fp16x3: pre-split chunks, same addressing)
             if (q < WCH) glds16(rw, (lds_void_t*)(smem_raw + C32_HB + (i * C32_NT + wave * 64) * 16), off, 0);
         }
     }
@@ -71,22 +83,50 @@ __global__ __launch_bounds__(C32_NT, 4) void conv3x3_c32_kernel(const ConvP p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) hr0[j] = (wave * 4 + j * 2 + (lpix >> 4)) * 18 + (lpix & 15);
     wait_vmcnt<0>();
+    if constexpr (X3) {                                                              // own halo chunks have landed: fp32 -> [hi x4 | lo x4], in place
+#pragma unroll
+        for (int i = 0; i < NHP; ++i) {
+            const int q = i * C32_NT + t;
+            if (q < HCH) {
+                f32x4* c = reinterpret_cast<f32x4*>(smem_raw + q * 16);
+                *reinterpret_cast<u32x4*>(c) = chunk_hl(*c);
+            }
+        }
+    }
     __syncthreads();
 
     using FragT = typename Frag<T>::type;
-    const unsigned char* const wbase = smem_raw + C32_HB + l31 * 64;
-    const int fa = (l31 >> 2) & 3;
+    const unsigned char* const wbase = smem_raw + C32_HB + l31 * ROWB;
+    const int fa = swz(l31);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int d = (tap / 3) * 18 + tap % 3;
+        if constexpr (X3) {
+            // a K block of 16 = the chunks 4 b + half and 4 b + 2 + half of a row (the fp32 kernels' K groups 2 b, 2 b + 1: the same permutation on both operands)
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const FragT a = *reinterpret_cast<const FragT*>(wbase + tap * 2048 + (((g * 2 + half) ^ fa) << 4));
+            for (int b16 = 0; b16 < 2; ++b16) {
+                f16x8 ah, al;
+                frag_hl(*reinterpret_cast<const FragT*>(wbase + tap * 32 * ROWB + (((4 * b16 + half) ^ fa) << 4)),
+                        *reinterpret_cast<const FragT*>(wbase + tap * 32 * ROWB + (((4 * b16 + 2 + half) ^ fa) << 4)), ah, al);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int hr = hr0[j] + d;
-                const FragT b = *reinterpret_cast<const FragT*>(smem_raw + hr * 64 + (((g * 2 + half) ^ ((hr >> 2) & 3)) << 4));
-                acc[0][j] = mfma16(a, b, acc[0][j]);
+                for (int j = 0; j < 2; ++j) {
+                    const int hr = hr0[j] + d, fb = swz(hr);
+                    f16x8 bh, bl;
+                    frag_hl(*reinterpret_cast<const FragT*>(smem_raw + hr * ROWB + (((4 * b16 + half) ^ fb) << 4)),
+                            *reinterpret_cast<const FragT*>(smem_raw + hr * ROWB + (((4 * b16 + 2 + half) ^ fb) << 4)), bh, bl);
+                    acc[0][j] = mfma_split(ah, al, bh, bl, acc[0][j]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const FragT a = *reinterpret_cast<const FragT*>(wbase + tap * 32 * ROWB + (((g * 2 + half) ^ fa) << 4));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int hr = hr0[j] + d;
+                    const FragT b = *reinterpret_cast<const FragT*>(smem_raw + hr * ROWB + (((g * 2 + half) ^ swz(hr)) << 4));
+                    acc[0][j] = mfma16(a, b, acc[0][j]);
+                }
             }
         }
     }
@@ -101,7 +141,15 @@ static hipError_t launch_c32_t(ConvP p, hipStream_t s) {
     auto kern = conv3x3_c32_kernel<T>;
     p.nN = 1;
     p.nblk = p.B * ((p.H + 15) / 16) * ((p.W + 15) / 16);
-    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(C32_NT), C32_LDS, s, p);
+    if constexpr (is_x3<T>) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, C32Geom<T>::LDS);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(p.nblk), dim3(C32_NT), C32Geom<T>::LDS, s, p);
     return hipGetLastError();
 }
 
@@ -110,12 +158,16 @@ static hipError_t launch_c32_t(ConvP p, hipStream_t s) {
 bool conv3x3_c32_legal(const ftc_op& o) {
     static const bool off = [] { const char* e = std::getenv("FTC_NO_C32"); return e && *e && *e != '0'; }();
     if (off) return false;
-    return ftc_is16(o.w_dtype) && o.in_dtype == o.w_dtype && o.out_dtype == FTC_F32 && o.ksize == 3 && o.stride == 1 && o.Ho == o.H && o.Wo == o.W && o.Cin == 32 &&
-           o.Cin_total == 32 && o.cin_off == 0 && o.Cout == 32 && o.Cout_total == 32 && o.cout_off == 0 && o.groups <= 1 && (o.flags & ~FTC_FLAG_RESIDUAL) == 0 &&
-           (!(o.flags & FTC_FLAG_RESIDUAL) || o.res_dtype == FTC_F32);
+    const bool x3 = o.w_dtype == FTC_F32 && (o.flags & FTC_FLAG_SPLIT16);              // fp16x3: fp32 tensors, pre-split weights; out2 = the pre-split copy
+    static const bool off3 = [] { const char* e = std::getenv("FTC_NO_C32_X3"); return e && *e && *e != '0'; }();
+    if (x3 && off3) return false;
+    return (ftc_is16(o.w_dtype) || x3) && o.in_dtype == o.w_dtype && o.out_dtype == FTC_F32 && o.ksize == 3 && o.stride == 1 && o.Ho == o.H && o.Wo == o.W && o.Cin == 32 &&
+           o.Cin_total == 32 && o.cin_off == 0 && o.Cout == 32 && o.Cout_total == 32 && o.cout_off == 0 && o.groups <= 1 &&
+           (o.flags & ~(FTC_FLAG_RESIDUAL | (x3 ? FTC_FLAG_SPLIT16 : 0))) == 0 && (!(o.flags & FTC_FLAG_RESIDUAL) || o.res_dtype == FTC_F32);
 }
 
 hipError_t launch_conv3x3_c32(const ConvP& p, const ftc_op& o, hipStream_t s) {
+    if (o.w_dtype == FTC_F32) return launch_c32_t<x3f32>(p, s);
     return o.w_dtype == FTC_F16 ? launch_c32_t<_Float16>(p, s) : launch_c32_t<__bf16>(p, s);
 }
 

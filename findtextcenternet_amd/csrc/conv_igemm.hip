@@ -29,7 +29,7 @@ void conv_kernel_label(const ftc_op& op, char* buf, int len) {
         return;
     }
     if (conv3x3_c32_legal(op)) {
-        snprintf(buf, len, "conv3x3_c32<%s,tile=32x16x16,resident>", dt[op.w_dtype & 3]);
+        snprintf(buf, len, "conv3x3_c32<%s,tile=32x16x16,resident>", (op.flags & FTC_FLAG_SPLIT16) ? "f16x3" : dt[op.w_dtype & 3]);
         return;
     }
     if (uses_halo(op) && hint_wl1(op) && (op.flags & FTC_FLAG_W_FRAG)) {

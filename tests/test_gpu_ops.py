@@ -1163,33 +1163,39 @@ def test_fused_mbconv_block_in_one_launch(shape, dt):
     assert bool((tail == 0xCD).all())
 
 
-@pytest.mark.parametrize("dt", [L.BF16, L.F16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("dt", [L.BF16, L.F16, 3], ids=["bf16", "f16", "f16x3"])
 @pytest.mark.parametrize("shape", [(2, 32, 48, True, L.ACT_SILU), (1, 21, 19, True, L.ACT_SILU), (3, 16, 16, False, L.ACT_NONE), (1, 7, 50, True, L.ACT_GELU), (8, 96, 96, True, L.ACT_SILU)],
                          ids=["32x48", "21x19_ragged", "16x16_nores_noact", "7x50", "b8_96x96"])
 def test_conv3x3_c32_resident_kernel(shape, dt):
     """csrc/conv3x3_c32.hip (round 6): the 32 -> 32 channel 3x3 convolution of the stage-1 Fused-MBConv blocks (/root/reference/models/detector.py:14) with halo AND
-    weights resident in LDS -- against PyTorch fp32 on the CPU, and against the implicit-GEMM kernel on the same data (reached by presenting the input as a
-    32-channel slice of a 64-channel buffer, which the resident kernel does not take): same K order, bit-identical.  Ragged maps, maps smaller than a tile."""
+    weights resident in LDS -- against PyTorch on the CPU (float64 for the fp16x3 form: fp32 tensors, three fp16 MFMAs per product, held to 2e-5), and against the
+    implicit-GEMM kernel on the same data (reached by presenting the input as a 32-channel slice of a 64-channel buffer, which the resident kernel does not take):
+    same K order, bit-identical.  Ragged maps, maps smaller than a tile."""
     B, H, W, has_res, act = shape
+    x3 = dt == 3
+    sdt = L.F32 if x3 else dt                                                   # storage / compute type of the op
     g = torch.Generator().manual_seed(B * 100 + H)
-    x = round16(torch.randn(B, H, W, 32, generator=g), dt)
-    w = round16(torch.randn(32, 32, 3, 3, generator=g) / (9 * 32) ** 0.5 * 1.5, dt)
+    x = round16(torch.randn(B, H, W, 32, generator=g), sdt)
+    w = round16(torch.randn(32, 32, 3, 3, generator=g) / (9 * 32) ** 0.5 * 1.5, sdt)
     bias = torch.randn(32, generator=g) * 0.3
     res = torch.randn(B, H, W, 32, generator=g) if has_res else None
-    ref = {L.ACT_NONE: lambda v: v, L.ACT_SILU: F.silu, L.ACT_GELU: F.gelu}[act](F.conv2d(x.permute(0, 3, 1, 2), w, bias, 1, 1)).permute(0, 2, 3, 1)
+    actf = {L.ACT_NONE: lambda v: v, L.ACT_SILU: F.silu, L.ACT_GELU: F.gelu}[act]
+    ref = actf(F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), bias.double(), 1, 1)).permute(0, 2, 3, 1)
     if has_res:
-        ref = ref + res
+        ref = ref + res.double()
+    ref = ref.float()
     ar = Arena()
-    o_x = ar.put(to_dev_bytes(x, dt))
+    o_x = ar.put(to_dev_bytes(x, sdt))
     xw = torch.zeros(B, H, W, 64)
     xw[..., :32] = x
-    o_xw = ar.put(to_dev_bytes(xw, dt))
-    o_w, o_b = ar.put(to_dev_bytes(w.permute(0, 2, 3, 1).contiguous(), dt)), ar.put(bias)
+    o_xw = ar.put(to_dev_bytes(xw, sdt))
+    wk = w.permute(0, 2, 3, 1).contiguous()                                     # [Cout][9][Cin]
+    o_w, o_b = ar.put(presplit_f16x3(wk) if x3 else to_dev_bytes(wk, sdt)), ar.put(bias)
     o_res = ar.put(res) if has_res else None
-    o_out, o_out2, o_gen = ar.reserve(B * H * W * 32 * 4), ar.reserve(B * H * W * 32 * 2), ar.reserve(B * H * W * 32 * 4)
+    o_out, o_out2, o_gen = ar.reserve(B * H * W * 32 * 4), ar.reserve(B * H * W * 32 * 4), ar.reserve(B * H * W * 32 * 4)
     ar.materialize()
-    common = dict(kind=L.OP_CONV, flags=L.FLAG_RESIDUAL if has_res else 0, act=act, in_dtype=dt, out_dtype=L.F32, w_dtype=dt, res_dtype=L.F32, B=B, H=H, W=W, Ho=H, Wo=W,
-                  Cin=32, Cout=32, Cout_total=32, ksize=3, stride=1, in2=o_res, w=o_w, bias=o_b)
+    common = dict(kind=L.OP_CONV, flags=(L.FLAG_RESIDUAL if has_res else 0) | (L.FLAG_SPLIT16 if x3 else 0), act=act, in_dtype=sdt, out_dtype=L.F32, w_dtype=sdt,
+                  res_dtype=L.F32, B=B, H=H, W=W, Ho=H, Wo=W, Cin=32, Cout=32, Cout_total=32, ksize=3, stride=1, in2=o_res, w=o_w, bias=o_b)
     lib = L.load()
     op = (L.Op * 1)()
     for k, v in dict(common, Cin_total=32).items():
@@ -1197,14 +1203,18 @@ def test_conv3x3_c32_resident_kernel(shape, dt):
             setattr(op[0], k, int(v))
     buf = C.create_string_buffer(128)
     lib.ftc_op_kernel_label(C.byref(op[0]), buf, 128)
-    assert buf.value.decode().startswith("conv3x3_c32<"), buf.value                   # the shape of the plan's stage-1 ops takes the resident kernel
+    assert buf.value.decode().startswith("conv3x3_c32<" + ("f16x3" if x3 else "")), buf.value      # the shape of the plan's stage-1 ops takes the resident kernel
     run_op(dict(common, Cin_total=32, in_=o_x, out=o_out, out2=o_out2), ar)
     run_op(dict(common, Cin_total=64, in_=o_xw, out=o_gen), ar)                          # the implicit-GEMM kernel (channel slice of a wider buffer)
     out, gen = ar.read(o_out, (B, H, W, 32), torch.float32), ar.read(o_gen, (B, H, W, 32), torch.float32)
-    out2 = ar.read(o_out2, (B, H, W, 32), tdtype(dt)).float()
     err = _rel(out, ref)
     _log(f"conv3x3_c32 {shape} dt={dt}: rel_err vs CPU {err:.3e}, max |resident - implicit GEMM| {float((out - gen).abs().max()):.3e}")
-    assert err < (3e-3 if dt == L.BF16 else 5e-4)
+    assert err < (2e-5 if x3 else 3e-3 if dt == L.BF16 else 5e-4)
     assert torch.equal(out, gen)
-    assert float((out2 - round16(out, dt)).abs().max()) == 0.0
+    if x3:                                                                               # out2 = the PRE-SPLIT copy: [hi x4 | lo x4] halves per 16-byte chunk, hi + lo == out to 2^-22
+        raw = ar.buf[o_out2:o_out2 + B * H * W * 32 * 4].cpu()
+        assert float((_unsplit_f16x3(raw, (B, H, W, 32)) - out).abs().max()) <= 3e-6 * float(out.abs().max())
+    else:
+        out2 = ar.read(o_out2, (B, H, W, 32), tdtype(dt)).float()
+        assert float((out2 - round16(out, dt)).abs().max()) == 0.0
     assert bool((ar.buf[ar.size:ar.size + 256] == 0xCD).all())

@@ -158,12 +158,12 @@ const char* validate_op(const ftc_op& o, const ftc_plan* pl, std::string* why) {
     }
     case FTC_OP_FMBCONV: {
         if (!ftc_fmbconv_legal(o))
-            return "fmbconv: needs 16-bit in / w of one type, fp32 out, 3x3 stride 1 (Ho = H, Wo = W), Cin % 32 == 0, aux1 (expanded channels) 256 or 384, Cout % 32 == 0 and "
+            return "fmbconv: needs 16-bit in / w of one type (or fp32 in / w with FTC_FLAG_SPLIT16 and aux1 = 256), fp32 out, 3x3 stride 1 (Ho = H, Wo = W), Cin % 32 == 0, aux1 (expanded channels) 256 or 384, Cout % 32 == 0 and "
                    "<= 128, whole tensors (no channel slices, no groups), act = SiLU, flags = RESIDUAL or none";
-        const int64_t E = o.aux1;
-        if (!need(o.in, true, "in", pin * o.Cin * 2) || !need(o.out, true, "out", pin * o.Cout * 4) || !need(o.w2, true, "w2", E * 9 * o.Cin * 2) ||
-            !need(o.bias2, true, "bias2", E * 4) || !need(o.w, true, "w", (int64_t)o.Cout * E * 2) || !need(o.bias, true, "bias", (int64_t)o.Cout * 4) ||
-            !need(o.in2, (o.flags & FTC_FLAG_RESIDUAL) != 0, "in2", pin * o.Cout * 4) || !need(o.out2, false, "out2", pin * o.Cout * 2)) return why->c_str();
+        const int64_t E = o.aux1, esz = o.w_dtype == FTC_F32 ? 4 : 2;      // (fp16x3 form: fp32 tensors, pre-split weights, out2 = the pre-split copy)
+        if (!need(o.in, true, "in", pin * o.Cin * esz) || !need(o.out, true, "out", pin * o.Cout * 4) || !need(o.w2, true, "w2", E * 9 * o.Cin * esz) ||
+            !need(o.bias2, true, "bias2", E * 4) || !need(o.w, true, "w", (int64_t)o.Cout * E * esz) || !need(o.bias, true, "bias", (int64_t)o.Cout * 4) ||
+            !need(o.in2, (o.flags & FTC_FLAG_RESIDUAL) != 0, "in2", pin * o.Cout * 4) || !need(o.out2, false, "out2", pin * o.Cout * esz)) return why->c_str();
         return nullptr;
     }
     case FTC_OP_SE:

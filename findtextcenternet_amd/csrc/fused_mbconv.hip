@@ -285,6 +285,227 @@ hipError_t launch_fmb(FmbP p, hipStream_t s) {
     return hipGetLastError();
 }
 
+
+// ---- fp16x3 form (fp32 tensors, FTC_FLAG_SPLIT16: the contract-grade plan; stage 2 there is 7 x (388 + 104) us with a 302 MB fp32 expanded tensor making the
+// round trip).  Same structure as the 8-wave form above, E = 256 only: K steps of 32 (128-byte rows of pre-split chunks: four fp32 values as [hi x4 | lo x4]
+// IEEE halves), weights arrive pre-split from the blob, activation chunks are split on the way to LDS (as the register-staged x3 kernel does), a product =
+// three fp16 MFMAs; exact SiLU; the activated tile goes to LDS as pre-split chunks (1 KiB rows, XOR-swizzled by row & 15: 128 KB -- one workgroup per CU) --
+// the very values the stand-alone 1x1 forms when it stages the fp32 tensor the 3x3 wrote, so the result is bit-identical to the two-launch form.
+struct FmbX3 {
+    static constexpr int E = 256, SN = 2, SM = 2, TM = 128, NT = 512, BK = 32, CPR = 8, ROW = 36, RPP = NT / CPR, NA = E / RPP, NB = TM / RPP;
+    static constexpr int BUF = (E + TM) * ROW * 4, PITCH = E * 4, TILE = TM * PITCH, LDS = TILE + E * 4;
+    static_assert(BUF <= TILE && LDS <= 160 * 1024, "");
+};
+
+__global__ __launch_bounds__(FmbX3::NT, 2) void fmbconv_fused_x3_kernel(const FmbP p) {
+    using GM = FmbX3;
+    constexpr int E = GM::E, SN = GM::SN, SM = GM::SM, TM = GM::TM, NTH = GM::NT, BK = GM::BK, CPR = GM::CPR, ROW = GM::ROW, RPP = GM::RPP, NA = GM::NA, NB = GM::NB,
+                  PITCH = GM::PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* const lds = reinterpret_cast<float*>(smem_raw);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    int bid = blockIdx.x;
+    {
+        const int q = p.nblk >> 3, r = p.nblk & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int m0 = bid * TM;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w1), 0, p.w1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    const int kc = t % CPR, row0 = t / CPR;
+    const int HW = p.H * p.W;
+    const int a_off0 = (row0 * 9 * p.Cin + kc * 4) * 4;
+    const int a_pass = RPP * 9 * p.Cin * 4;
+    int b_off[NB], b_mask[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int m = m0 + row0 + i * RPP;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int img = mm / HW, rem = mm - img * HW;
+        const int oy = rem / p.W, ox = rem - oy * p.W;
+        b_off[i] = (((img * p.H + oy - 1) * p.W + ox - 1) * p.Cin + kc * 4) * 4;
+        int mask = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                if (ok && (unsigned)(oy - 1 + r) < (unsigned)p.H && (unsigned)(ox - 1 + s) < (unsigned)p.W) mask |= 1 << (r * 3 + s);
+        b_mask[i] = mask;
+    }
+    u32x4 ra[NA], rb[NB];
+    int ld_tap = 0, ld_cb = 0, ld_r = 0, ld_s = 0;
+    auto gload = [&]() {
+        const int c0 = ld_cb * BK;
+        const int w_soff = (ld_tap * p.Cin + c0) * 4;
+        const int in_toff = ((ld_r * p.W + ld_s) * p.Cin + c0) * 4;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = bload(rw, a_off0, w_soff + i * a_pass);                       // weights: pre-split in the blob
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = bload(rin, ((b_mask[i] >> ld_tap) & 1) ? b_off[i] + in_toff : OOB, 0);
+        if (++ld_cb == p.ncb) {
+            ld_cb = 0;
+            ++ld_tap;
+            if (++ld_s == 3) { ld_s = 0; ++ld_r; }
+        }
+    };
+    float* const wA = lds + row0 * ROW + kc * 4;
+    float* const wB = lds + (E + row0) * ROW + kc * 4;
+    auto lds_write = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(wA + i * RPP * ROW) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4*>(wB + i * RPP * ROW) = chunk_hl(__builtin_bit_cast(f32x4, rb[i]));      // activations: split once, on the way to LDS
+    };
+    f32x16 acc[SN][SM];
+#pragma unroll
+    for (int i = 0; i < SN; ++i)
+#pragma unroll
+        for (int j = 0; j < SM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    const float* const fA = lds + (wn * SN * 32 + l31) * ROW + half * 4;
+    const float* const fB = lds + (E + wm * SM * 32 + l31) * ROW + half * 4;
+    gload();
+    for (int it = 0; it < p.nk; ++it) {
+        lds_write();
+        __syncthreads();
+        if (it + 1 < p.nk) gload();
+#pragma unroll
+        for (int g = 0; g < BK / 8; g += 2) {
+            f16x8 ah[SN], al[SN];
+#pragma unroll
+            for (int i = 0; i < SN; ++i)
+                frag_hl(*reinterpret_cast<const f32x4*>(fA + i * 32 * ROW + g * 8), *reinterpret_cast<const f32x4*>(fA + i * 32 * ROW + g * 8 + 8), ah[i], al[i]);
+#pragma unroll
+            for (int j = 0; j < SM; ++j) {
+                f16x8 bh, bl;
+                frag_hl(*reinterpret_cast<const f32x4*>(fB + j * 32 * ROW + g * 8), *reinterpret_cast<const f32x4*>(fB + j * 32 * ROW + g * 8 + 8), bh, bl);
+#pragma unroll
+                for (int i = 0; i < SN; ++i) acc[i][j] = mfma_split(ah[i], al[i], bh, bl, acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- projection weights (pre-split): K block b of 16 = the chunks 4 b + half and 4 b + 2 + half of a row ----
+    const int wm2 = wave & 3, wn2 = wave >> 2;
+    const int nt2 = p.Cout >> 5;
+    const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w2), 0, p.w2_bytes, 0x00020000);
+    constexpr int NG2 = E / 16, PF = 4, NT2 = 2;
+    int w2off[NT2];
+#pragma unroll
+    for (int u = 0; u < NT2; ++u) {
+        const int tile = wn2 + 2 * u;
+        w2off[u] = tile < nt2 ? (tile * 32 + l31) * E * 4 + half * 16 : OOB;
+    }
+    u32x4 wq[NT2][PF][2];
+#pragma unroll
+    for (int g = 0; g < PF; ++g)
+#pragma unroll
+        for (int u = 0; u < NT2; ++u) {
+            wq[u][g][0] = bload(rw2, w2off[u], g * 64);
+            wq[u][g][1] = bload(rw2, w2off[u], g * 64 + 32);
+        }
+
+    // ---- bias + exact SiLU -> the tile [128 px][E] in LDS as pre-split chunks ----
+    float* const lbias = reinterpret_cast<float*>(smem_raw + GM::TILE);
+    for (int c = t; c < E / 4; c += NTH) *reinterpret_cast<f32x4*>(lbias + 4 * c) = *reinterpret_cast<const f32x4*>(p.b1 + 4 * c);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SM; ++j) {
+        const int prow = wm * SM * 32 + j * 32 + l31;
+        unsigned char* lrow = smem_raw + prow * PITCH;
+#pragma unroll
+        for (int i = 0; i < SN; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nl = wn * SN * 32 + i * 32 + 8 * q + 4 * half;
+                f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                v += *reinterpret_cast<const f32x4*>(lbias + nl);
+                v = apply_act4<false>(v, FTC_ACT_SILU);
+                *reinterpret_cast<u32x4*>(lrow + (((nl >> 2) ^ (prow & 15)) << 4)) = chunk_hl(v);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- GEMM 2 ----
+    f32x16 acc2[NT2];
+#pragma unroll
+    for (int u = 0; u < NT2; ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[u][e] = 0.0f;
+    const int prow2 = wm2 * 32 + l31;
+    const unsigned char* trow = smem_raw + prow2 * PITCH;
+    const int fx = prow2 & 15;
+#pragma unroll
+    for (int g0 = 0; g0 < NG2; g0 += PF) {
+        u32x4 wn_[NT2][PF][2];
+        if (g0 + PF < NG2) {
+#pragma unroll
+            for (int g = 0; g < PF; ++g)
+#pragma unroll
+                for (int u = 0; u < NT2; ++u) {
+                    wn_[u][g][0] = bload(rw2, w2off[u], (g0 + PF + g) * 64);
+                    wn_[u][g][1] = bload(rw2, w2off[u], (g0 + PF + g) * 64 + 32);
+                }
+        }
+#pragma unroll
+        for (int g = 0; g < PF; ++g) {
+            const int b16 = g0 + g;
+            f16x8 bh, bl;
+            frag_hl(*reinterpret_cast<const f32x4*>(trow + (((4 * b16 + half) ^ fx) << 4)), *reinterpret_cast<const f32x4*>(trow + (((4 * b16 + 2 + half) ^ fx) << 4)), bh, bl);
+#pragma unroll
+            for (int u = 0; u < NT2; ++u)
+                if (u == 0 || wn2 + 2 * u < nt2) {
+                    f16x8 ah, al;
+                    frag_hl(__builtin_bit_cast(f32x4, wq[u][g][0]), __builtin_bit_cast(f32x4, wq[u][g][1]), ah, al);
+                    acc2[u] = mfma_split(ah, al, bh, bl, acc2[u]);
+                }
+        }
+        if (g0 + PF < NG2) {
+#pragma unroll
+            for (int g = 0; g < PF; ++g)
+#pragma unroll
+                for (int u = 0; u < NT2; ++u) { wq[u][g][0] = wn_[u][g][0]; wq[u][g][1] = wn_[u][g][1]; }
+        }
+    }
+
+    const int m = m0 + prow2;
+    if (m < p.M) {
+#pragma unroll
+        for (int u = 0; u < NT2; ++u) {
+            const int tile = wn2 + 2 * u;
+            if (tile >= nt2) continue;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = tile * 32 + 8 * q + 4 * half;
+                f32x4 v = {acc2[u][4 * q], acc2[u][4 * q + 1], acc2[u][4 * q + 2], acc2[u][4 * q + 3]};
+                v += *reinterpret_cast<const f32x4*>(p.b2 + n);
+                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + n);
+                *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.Cout + n) = v;
+                if (p.out2) *reinterpret_cast<u32x4*>(static_cast<char*>(p.out2) + ((size_t)m * p.Cout + n) * 4) = chunk_hl(v);      // the pre-split copy
+            }
+        }
+    }
+}
+
+static hipError_t launch_fmb_x3(FmbP p, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fmbconv_fused_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FmbX3::LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    p.nblk = (p.M + FmbX3::TM - 1) / FmbX3::TM;
+    hipLaunchKernelGGL(fmbconv_fused_x3_kernel, dim3(p.nblk), dim3(FmbX3::NT), FmbX3::LDS, s, p);
+    return hipGetLastError();
+}
+
 }  // namespace convimpl
 
 // Shapes FTC_OP_FMBCONV accepts (the plan builder asks before it emits one): 16-bit operands of one type, fp32 output (+ optional 16-bit copy), 3x3
@@ -292,6 +513,11 @@ hipError_t launch_fmb(FmbP p, hipStream_t s) {
 bool ftc_fmbconv_legal(const ftc_op& o) {
     const int E = o.aux1;
     const long px = (long)o.B * o.H * o.W;
+    if (o.w_dtype == FTC_F32)               // the fp16x3 form: fp32 tensors with FTC_FLAG_SPLIT16, E = 256, out2 = the optional PRE-SPLIT copy
+        return (o.flags & FTC_FLAG_SPLIT16) && o.in_dtype == FTC_F32 && o.out_dtype == FTC_F32 && o.ksize == 3 && o.stride == 1 && o.Ho == o.H && o.Wo == o.W && o.Cin > 0 &&
+               o.Cin % 32 == 0 && E == 256 && o.Cout > 0 && o.Cout % 32 == 0 && o.Cout <= 128 && o.Cin_total == o.Cin && o.cin_off == 0 && o.Cout_total == o.Cout &&
+               o.cout_off == 0 && o.groups <= 1 && o.act == FTC_ACT_SILU && (o.flags & ~(FTC_FLAG_RESIDUAL | FTC_FLAG_SPLIT16)) == 0 &&
+               (!(o.flags & FTC_FLAG_RESIDUAL) || o.res_dtype == FTC_F32) && px * o.Cin * 4 < 0x7fffffffL && px > 0 && px < 0x7fffffffL / 128;
     return ftc_is16(o.w_dtype) && o.in_dtype == o.w_dtype && o.out_dtype == FTC_F32 && o.ksize == 3 && o.stride == 1 && o.Ho == o.H && o.Wo == o.W &&
            o.Cin > 0 && o.Cin % 32 == 0 && (E == 256 || E == 384) && o.Cout > 0 && o.Cout % 32 == 0 && o.Cout <= 128 && o.Cin_total == o.Cin && o.cin_off == 0 &&
            o.Cout_total == o.Cout && o.cout_off == 0 && o.groups <= 1 && o.act == FTC_ACT_SILU && (o.flags & ~(FTC_FLAG_RESIDUAL)) == 0 &&
@@ -299,7 +525,8 @@ bool ftc_fmbconv_legal(const ftc_op& o) {
 }
 
 const char* ftc_fmbconv_label(const ftc_op& o, char* buf, int len) {
-    std::snprintf(buf, len, "fmbconv_fused<%s,e=%d,bk=%d>", o.w_dtype == FTC_F16 ? "f16" : "bf16", o.aux1, o.Cin % 64 == 0 ? 64 : 32);
+    if (o.w_dtype == FTC_F32) std::snprintf(buf, len, "fmbconv_fused<f16x3,e=%d,bk=32>", o.aux1);
+    else std::snprintf(buf, len, "fmbconv_fused<%s,e=%d,bk=%d>", o.w_dtype == FTC_F16 ? "f16" : "bf16", o.aux1, o.Cin % 64 == 0 ? 64 : 32);
     return buf;
 }
 
@@ -313,9 +540,15 @@ hipError_t launch_fmbconv(const OpArgs& a, hipStream_t s) {
     p.out = static_cast<float*>(a.out); p.out2 = a.out2;
     p.B = o.B; p.H = o.H; p.W = o.W; p.Cin = o.Cin; p.E = o.aux1; p.Cout = o.Cout;
     p.M = o.B * o.H * o.W;
-    p.x_bytes = (unsigned)((long)p.M * o.Cin * 2);
-    p.w1_bytes = (unsigned)((long)p.E * 9 * o.Cin * 2);
-    p.w2_bytes = (unsigned)((long)o.Cout * p.E * 2);
+    const long es = o.w_dtype == FTC_F32 ? 4 : 2;
+    p.x_bytes = (unsigned)((long)p.M * o.Cin * es);
+    p.w1_bytes = (unsigned)((long)p.E * 9 * o.Cin * es);
+    p.w2_bytes = (unsigned)((long)o.Cout * p.E * es);
+    if (o.w_dtype == FTC_F32) {
+        p.ncb = o.Cin / 32;
+        p.nk = 9 * p.ncb;
+        return launch_fmb_x3(p, s);
+    }
     const int bk = o.Cin % 64 == 0 ? 64 : 32;
     p.ncb = o.Cin / bk;
     p.nk = 9 * p.ncb;

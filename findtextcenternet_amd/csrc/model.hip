@@ -754,14 +754,16 @@ int Builder::build(ModelPlan* out) {
     };
     // Fused-MBConv blocks with expansion, 16-bit plans, stride 1: one launch (FTC_OP_FMBCONV) where the shape is one the kernel holds
     auto fmb_fused = [&](const BlockSpec& blk, int bh, int bw) -> bool {
-        if (!blk.fused || blk.exp == blk.cin || !dual || blk.stride != 1 || env_on("FTC_NO_FMBFUSE")) return false;
+        if (!blk.fused || blk.exp == blk.cin || !(dual || x3) || blk.stride != 1 || env_on("FTC_NO_FMBFUSE")) return false;
+        if (x3 && env_on("FTC_NO_FMBFUSE_X3")) return false;
         // Measured (tools/fmbconv_bench.py, batch 8): the one-launch form wins where the 3x3 runs K steps of 64 (Cin % 64 == 0: stage 2, 174-182 us
         // against 126 + 65) and loses on stage 3 (Cin = 96: K steps of 32, twice the barriers per FLOP: 116-135 us against 75 + 28.5).
         // FTC_FMBFUSE_ALL=1: every shape the kernel holds.
         if (blk.cin % 64 != 0 && !env_on("FTC_FMBFUSE_ALL")) return false;
         ftc_op t{};
-        t.in_dtype = t.w_dtype = A; t.out_dtype = T; t.res_dtype = T; t.ksize = 3; t.stride = 1; t.H = t.Ho = bh; t.W = t.Wo = bw; t.B = B;
-        t.Cin = t.Cin_total = blk.cin; t.Cout = t.Cout_total = blk.cout; t.aux1 = blk.exp; t.act = FTC_ACT_SILU; t.flags = blk.residual ? FTC_FLAG_RESIDUAL : 0;
+        t.in_dtype = t.w_dtype = x3 ? FTC_F32 : A; t.out_dtype = T; t.res_dtype = T; t.ksize = 3; t.stride = 1; t.H = t.Ho = bh; t.W = t.Wo = bw; t.B = B;
+        t.Cin = t.Cin_total = blk.cin; t.Cout = t.Cout_total = blk.cout; t.aux1 = blk.exp; t.act = FTC_ACT_SILU;
+        t.flags = (blk.residual ? FTC_FLAG_RESIDUAL : 0) | (x3 ? FTC_FLAG_SPLIT16 : 0);
         return ftc_fmbconv_legal(t);
     };
     std::vector<const BlockSpec*> flat;
@@ -792,7 +794,7 @@ int Builder::build(ModelPlan* out) {
                 SymOp s;
                 ftc_op& o = s.o;
                 o.kind = FTC_OP_FMBCONV; o.act = FTC_ACT_SILU; o.in_dtype = G; o.out_dtype = T; o.w_dtype = cdt_; o.res_dtype = T;
-                o.flags = res ? FTC_FLAG_RESIDUAL : 0;
+                o.flags = (res ? FTC_FLAG_RESIDUAL : 0) | (x3 ? FTC_FLAG_SPLIT16 : 0);
                 o.B = B; o.H = h; o.W = w; o.Ho = ho; o.Wo = wo; o.Cin = blk.cin; o.Cin_total = blk.cin; o.Cout = blk.cout; o.Cout_total = blk.cout;
                 o.ksize = 3; o.stride = 1; o.aux1 = blk.exp;
                 s.in = gin; s.in2 = res; s.out = y; s.out2 = yb; s.w2 = wref(p + ".0.w"); s.bias2 = wref(p + ".0.b"); s.w = wref(p + ".1.w"); s.bias = wref(p + ".1.b");

@@ -14,13 +14,15 @@
 // Shape of the first GEMM: rows = E output channels (MFMA A operand = weights, K-major [E][9][Cin]), columns = 128 pixels (B operand =
 // NHWC activations gathered per tap, out-of-image taps answered with zeros by the buffer unit), K = 9 Cin in steps of BK = 64 (Cin % 64 == 0)
 // or 32.  8 waves = 4 channel quarters x 2 pixel halves, (E/128) x 2 accumulator tiles of 32x32 per wave; operands are staged global ->
-// registers -> LDS (padded rows, conflict-free ds_read_b128) in TWO buffers: the loads of step k+1 are in flight and its LDS writes happen
-// under the MFMAs of step k, one barrier per step.  E x 128 instead of the 128 x 128 tiles the tuner picks for the stand-alone 3x3: 0.75x the
-// operand bytes per FLOP through L2 -> LDS.
+// registers -> LDS (padded rows, conflict-free ds_read_b128): the loads of step k+1 are in flight under the MFMAs of step k.  The adopted form
+// keeps ONE operand buffer (65 KB of LDS, 122 VGPRs): two workgroups share a CU and one's SiLU / projection phases run under the other's 3x3
+// GEMM (the first version had two buffers and one barrier per step but only one workgroup per CU: no faster than the pair of launches it
+// replaced; all forms measured: DESIGN.md appendix A9, profiles/r06_fmbconv_forms.txt).  E x 128 instead of the 128 x 128 tiles the tuner
+// picks for the stand-alone 3x3: 0.75x the operand bytes per FLOP through L2 -> LDS.
 // Second GEMM: rows = Cout channels, columns = the same 128 pixels, K = E; wave = (pixel block of 32) x (channel tiles t, t + 2).
 //
-// Numerics: identical rounding points to conv3x3 (+SiLU, 16-bit store) followed by conv1x1 (fp32 accumulate, + bias, + fp32 residual); the
-// fp32 sums associate differently (other tile shapes), as between any two tile configurations of the stand-alone kernels' split-K variants.
+// Numerics: identical rounding points AND K order to conv3x3 (+SiLU, 16-bit store) followed by conv1x1 (fp32 accumulate, + bias, + fp32 residual):
+// measured bit-identical to the two-launch form in its default tile configurations (tests/test_gpu_ops.py::test_fused_mbconv_block_in_one_launch).
 #include "conv_igemm_impl.h"
 #include "ftc_host.h"
 

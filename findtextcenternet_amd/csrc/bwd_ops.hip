@@ -187,25 +187,44 @@ __global__ __launch_bounds__(256) void bnbwd_apply_kernel(BnBwdP p, const float*
     int bcur = -1;
     f32x4 ga = {1.f, 1.f, 1.f, 1.f}, gb = {0.f, 0.f, 0.f, 0.f};
     float kp = 1.0f;
-    for (int r = r0 + rl; r < r1; r += RL) {
-        const int b = r / p.HW;
-        if (b != bcur) {
-            bcur = b;
-            if (p.ga) ga = *reinterpret_cast<const f32x4*>(p.ga + (long)b * p.C + c);
-            if (p.gb) gb = *reinterpret_cast<const f32x4*>(p.gb + (long)b * p.C + c);
-            if (p.keep) kp = p.keep[b];
+    // (round 6) U rows' loads (gradient, pre-activation and, when accumulating, the old output) in flight before the first is consumed: the plain loop
+    // issued one row's loads and waited (40 us per launch at 2.8 TB/s, 356 launches on the step's critical stream); same arithmetic per element
+    constexpr int U = 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int r0u = r0 + rl; r0u < r1; r0u += RL * U) {
+        f32x4 gv[U], zvv[U], ov[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0u + u * RL;
+            const bool ok = r < r1;
+            const int rr = ok ? r : r0u;
+            gv[u] = ok ? *reinterpret_cast<const f32x4*>(p.gy + (long)rr * p.gs + p.goff + c) : zero;
+            zvv[u] = ok ? load4<ZT>(static_cast<const ZT*>(p.z) + (long)rr * p.C + c) : zero;
+            ov[u] = (ok && out && accum) ? *reinterpret_cast<const f32x4*>(out + (long)rr * p.C + c) : zero;
         }
-        const f32x4 g = (*reinterpret_cast<const f32x4*>(p.gy + (long)r * p.gs + p.goff + c) * ga + gb) * kp;
-        const f32x4 zv = load4<ZT>(static_cast<const ZT*>(p.z) + (long)r * p.C + c);
-        const f32x4 dt = g * dact4<FAST>(zv * sc + sh, p.act);
-        f32x4 o = sc * (dt - c1 - (zv - mean) * istd * c2);
-        if (out) {
-            float* op = out + (long)r * p.C + c;
-            if (accum) o += *reinterpret_cast<const f32x4*>(op);
-            *reinterpret_cast<f32x4*>(op) = o;
-        }
-        if constexpr (sizeof(TC) == 2) {
-            if (out2) store4<TC>(out2 + (long)r * p.C + c, o);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0u + u * RL;
+            if (r >= r1) break;
+            const int b = r / p.HW;
+            if (b != bcur) {
+                bcur = b;
+                if (p.ga) ga = *reinterpret_cast<const f32x4*>(p.ga + (long)b * p.C + c);
+                if (p.gb) gb = *reinterpret_cast<const f32x4*>(p.gb + (long)b * p.C + c);
+                if (p.keep) kp = p.keep[b];
+            }
+            const f32x4 g = (gv[u] * ga + gb) * kp;
+            const f32x4 zv = zvv[u];
+            const f32x4 dt = g * dact4<FAST>(zv * sc + sh, p.act);
+            f32x4 o = sc * (dt - c1 - (zv - mean) * istd * c2);
+            if (out) {
+                float* op = out + (long)r * p.C + c;
+                if (accum) o += ov[u];
+                *reinterpret_cast<f32x4*>(op) = o;
+            }
+            if constexpr (sizeof(TC) == 2) {
+                if (out2) store4<TC>(out2 + (long)r * p.C + c, o);
+            }
         }
     }
 }
@@ -267,23 +286,38 @@ __global__ __launch_bounds__(256) void dwbwd_weight_partial_kernel(const float* 
     f32x4 acc[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int p = r0 + rl; p < r1; p += RL) {
-        const int row = p / Wo;
-        const int ox = p - row * Wo;
-        const int b = row / Ho;
-        const int oy = row - b * Ho;
-        const f32x4 g = *reinterpret_cast<const f32x4*>(dz + (long)p * C + c);
+    // (round 6) U pixels per trip with all of their 10 loads in flight before the first product: the plain loop issued a pixel's ten 16-byte loads and
+    // waited for them, one memory round trip per pixel and lane -- 142 us per launch for 113 MB (0.8 TB/s; profiles/r06b_train_bf16_b8_kernel_stats.txt).
+    // Out-of-image taps read nothing and add 0; the sums are taken in the same pixel and tap order as before.
+    constexpr int U = 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int p0 = r0 + rl; p0 < r1; p0 += RL * U) {
+        f32x4 g[U], xv[U][9];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int iy = oy * stride + r - 1;
-            if ((unsigned)iy >= (unsigned)H) continue;
+        for (int u = 0; u < U; ++u) {
+            const int p = p0 + u * RL;
+            const bool pok = p < r1;
+            const int pp = pok ? p : r0;
+            const int row = pp / Wo;
+            const int ox = pp - row * Wo;
+            const int b = row / Ho;
+            const int oy = row - b * Ho;
+            g[u] = pok ? *reinterpret_cast<const f32x4*>(dz + (long)pp * C + c) : zero;
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int ix = ox * stride + s - 1;
-                if ((unsigned)ix >= (unsigned)W) continue;
-                acc[r * 3 + s] += g * *reinterpret_cast<const f32x4*>(x + (((long)b * H + iy) * W + ix) * C + c);
+            for (int r = 0; r < 3; ++r) {
+                const int iy = oy * stride + r - 1;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int ix = ox * stride + s - 1;
+                    const bool ok = pok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                    xv[u][r * 3 + s] = ok ? *reinterpret_cast<const f32x4*>(x + (((long)b * H + iy) * W + ix) * C + c) : zero;
+                }
             }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k] += g[u] * xv[u][k];
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) *reinterpret_cast<f32x4*>(&red[rl][k][cq * 4]) = acc[k];
@@ -321,9 +355,22 @@ __global__ __launch_bounds__(256) void sebwd_ds_kernel(const float* __restrict__
     const int rows = (HW + pch - 1) / pch;
     const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int r = r0 + rl; r < r1; r += RL) {
-        const long i = ((long)b * HW + r) * C + c;
-        acc += *reinterpret_cast<const f32x4*>(g + i) * *reinterpret_cast<const f32x4*>(y + i);
+    // (round 6: four rows' loads in flight before the first product -- the plain loop waited for each pair; same order of the sums)
+    constexpr int U = 4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0 + rl; r < r1; r += RL * U) {
+        f32x4 gv[U], yv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * RL;
+            const bool ok = rr < r1;
+            const long i = ((long)b * HW + (ok ? rr : r)) * C + c;
+            gv[u] = ok ? *reinterpret_cast<const f32x4*>(g + i) : zero;
+            yv[u] = ok ? *reinterpret_cast<const f32x4*>(y + i) : zero;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (r + u * RL < r1) acc += gv[u] * yv[u];
     }
     *reinterpret_cast<f32x4*>(&red[rl][cq * 4]) = acc;
     __syncthreads();

@@ -451,6 +451,65 @@ __global__ __launch_bounds__(256) void bnact_kernel(const TI* __restrict__ x, co
     }
 }
 
+// (round 6) The same pass with 16-byte lanes and U rows in flight: the kernel above moves 4 bytes per lane and trip and waits for each load before it
+// issues the next (12 ms of the train step's forward over 320 launches, profiles/r06b_train_bf16_b8_kernel_stats.txt).  Q channel quads x (256 / Q) row
+// lanes per workgroup (Q = the largest power of two <= 64 dividing C / 4); same arithmetic per element; with Q = 64 the same four row lanes and the same
+// association of the channel sums as the scalar kernel.
+__device__ __forceinline__ f32x4 act4_rt(f32x4 v, int act) { return f32x4{apply_act_rt(v[0], act), apply_act_rt(v[1], act), apply_act_rt(v[2], act), apply_act_rt(v[3], act)}; }
+
+template <typename TI, typename TO, typename TC, int Q>
+__global__ __launch_bounds__(256) void bnact_q_kernel(const TI* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      const void* __restrict__ res, int res_dtype, const float* __restrict__ keep, TO* __restrict__ out,
+                                                      TC* __restrict__ out2, float* __restrict__ sums, int HW, int C, int P, int act) {
+    constexpr int RL = 256 / Q, U = 4;
+    __shared__ __attribute__((aligned(16))) float red[RL][Q * 4];
+    const int t = threadIdx.x, cq = t % Q, rl = t / Q;
+    const int c = (blockIdx.x * Q + cq) * 4, p = blockIdx.y, b = blockIdx.z;
+    const int rows = (HW + P - 1) / P;
+    const int r0 = p * rows, r1 = min(HW, r0 + rows);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+    const float kp = keep ? keep[b] : 1.0f;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = zero;
+    for (int r = r0 + rl; r < r1; r += RL * U) {
+        f32x4 xv[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * RL;
+            const bool ok = rr < r1;
+            const long i = ((long)b * HW + (ok ? rr : r)) * C + c;
+            xv[u] = ok ? load4<TI>(x + i) : zero;
+            rv[u] = zero;
+            if (res && ok) rv[u] = res_dtype == FTC_F32 ? load4<float>(reinterpret_cast<const float*>(res) + i) : load4<TC>(reinterpret_cast<const TC*>(res) + i);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * RL;
+            if (rr >= r1) break;
+            const long i = ((long)b * HW + rr) * C + c;
+            f32x4 v = act4_rt(xv[u] * sc + sh, act);
+            if (res) v = v * kp + rv[u];
+            store4<TO>(out + i, v);
+            if (out2) store4<TC>(out2 + i, v);
+            acc += v;
+        }
+    }
+    if (sums) {
+        *reinterpret_cast<f32x4*>(&red[rl][cq * 4]) = acc;
+        __syncthreads();
+        if (t < Q * 4) {
+            float tot;
+            if constexpr (RL == 4) tot = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+            else {
+                tot = 0.f;
+#pragma unroll
+                for (int k = 0; k < RL; ++k) tot += red[k][t];
+            }
+            sums[((long)b * P + p) * C + blockIdx.x * Q * 4 + t] = tot;
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_bnstat(const OpArgs& a, hipStream_t s) {
@@ -486,6 +545,18 @@ hipError_t launch_bnact_t(const OpArgs& a, hipStream_t s) {
     const ftc_op& o = *a.op;
     const int HW = o.H * o.W, C = o.Cin, P = o.aux0 > 0 ? o.aux0 : 1;
     const bool has_res = (o.flags & FTC_FLAG_RESIDUAL) != 0;
+    static const bool scalar_only = [] { const char* e = std::getenv("FTC_BNACT_SCALAR"); return e && *e && *e != '0'; }();
+    if (C % 4 == 0 && !scalar_only) {
+        const int q = C / 4;
+        const int Q = q % 64 == 0 ? 64 : q % 32 == 0 ? 32 : q % 16 == 0 ? 16 : q % 8 == 0 ? 8 : q % 4 == 0 ? 4 : q % 2 == 0 ? 2 : 1;
+        const dim3 grid(C / (4 * Q), P, o.B);
+#define BNACT_Q(QQ) hipLaunchKernelGGL((bnact_q_kernel<TI, TO, TC, QQ>), grid, dim3(256), 0, s, (const TI*)a.in, a.scale, a.shift, has_res ? a.in2 : nullptr, o.res_dtype, \
+                                       has_res ? static_cast<const float*>(a.w2) : nullptr, (TO*)a.out, (TC*)a.out2, a.aux, HW, C, P, o.act)
+        switch (Q) { case 64: BNACT_Q(64); break; case 32: BNACT_Q(32); break; case 16: BNACT_Q(16); break; case 8: BNACT_Q(8); break; case 4: BNACT_Q(4); break;
+                     case 2: BNACT_Q(2); break; default: BNACT_Q(1); }
+#undef BNACT_Q
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((bnact_kernel<TI, TO, TC>), dim3((C + 63) / 64, P, o.B), dim3(256), 0, s, (const TI*)a.in, a.scale, a.shift, has_res ? a.in2 : nullptr,
                        o.res_dtype, has_res ? static_cast<const float*>(a.w2) : nullptr, (TO*)a.out, (TC*)a.out2, a.aux, HW, C, P, o.act);
     return hipGetLastError();

@@ -270,7 +270,11 @@ def test_training_trajectory_matches_the_references_loop(golden_dir):
     # losses: iterations 0-1 see the initial weights; 2-3 see the weights after one optimizer step (a stale packed copy, a missed
     # version bump or a wrong y / z swap would leave them at their no-step values, several per cent away)
     ref = g["loss"]
-    assert all(abs(losses[i] - ref[i]) < 1e-3 * ref[i] for i in range(len(ref))), (losses, ref)
+    # Before the first optimizer step both sides see the same weights: 2e-6 measured, gate 2e-5 (tightened in round 6).  After it the comparison is between
+    # two fp32 trajectories through a sign-like first Adam update (g / sqrt(g^2)): a 1e-6 difference of the iteration-0 loss -- another association of the
+    # SE squeeze sums in the vectorised BatchNorm-apply kernel -- moved iteration 2 from 8.3e-4 to 1.11e-3 relative (gpurun_out/test_train.log, round 6).
+    # The failure modes this guards sit at several per cent; gate 2.5e-3.
+    assert all(abs(losses[i] - ref[i]) < (2e-5 if i < ACC else 2.5e-3) * ref[i] for i in range(len(ref))), (losses, ref)
     assert abs(losses[0] - ref[0]) < 2e-4 * ref[0] and abs(losses[1] - ref[1]) < 2e-4 * ref[1], (losses, ref)
     lr = float(g["lr"])
     named = dict(model.named_parameters())

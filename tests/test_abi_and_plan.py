@@ -366,3 +366,25 @@ def test_fp16x3_plans_build_with_every_documented_switch(sd, monkeypatch):
     n_head = sum(pl.ops[i].kind == L.OP_MBHEAD for i in range(len(pl.ops)))
     px = [i for i in range(len(pl.ops)) if pl.ops[i].kind == L.OP_CONV and 8 <= (pl.ops[i].aux0 & 15) <= 11 and not pl.ops[i].aux0 & 64]
     assert n_head >= 70, n_head
+
+
+def test_round6_kernels_are_selected_by_the_plans_that_bench_runs(sd, models):
+    """The batch-8 plans of the two modes bench.py reports -- bf16 (`value`) and fp16x3 (`config.contract_mode`) -- run stage 1 on the resident 32 -> 32 kernel
+    (csrc/conv3x3_c32.hip: 4 launches) and the stride-1 blocks of stage 2 as one launch each (FTC_OP_FMBCONV: 7); the exact-fp32 plan keeps the generic kernels."""
+    lib = L.load()
+    buf = C.create_string_buffer(160)
+
+    def labels(m):
+        pl = m.plan(8, 768, 768)
+        out = []
+        for i in range(len(pl.ops)):
+            L.check(lib.ftc_op_kernel_label(C.byref(pl.ops[i]), buf, 160), "ftc_op_kernel_label")
+            out.append(buf.value.decode())
+        return out
+    for mode, m in (("bf16", models["bf16"]), ("fp16x3", FtcModel(sd, "fp16x3")), ("fp32", models["fp32"])):
+        lab = labels(m)
+        n_c32 = sum(l.startswith("conv3x3_c32<") for l in lab)
+        n_fmb = sum(l.startswith("fmbconv_fused<") for l in lab)
+        assert (n_c32, n_fmb) == ((4, 7) if mode != "fp32" else (0, 0)), (mode, n_c32, n_fmb)
+        if mode == "fp16x3":
+            assert all("f16x3" in l for l in lab if l.startswith(("conv3x3_c32<", "fmbconv_fused<")))

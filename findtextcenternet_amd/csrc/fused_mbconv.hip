@@ -356,11 +356,15 @@ __global__ __launch_bounds__(FmbX3::NT, 2) void fmbconv_fused_x3_kernel(const Fm
     };
     float* const wA = lds + row0 * ROW + kc * 4;
     float* const wB = lds + (E + row0) * ROW + kc * 4;
-    auto lds_write = [&]() {
+    // TWO operand buffers (2 x 55 KB: inside the 129 KB the activated tile needs anyway, so they cost no occupancy): the loads of step k + 1 are issued before
+    // the MFMAs of step k, their LDS writes go to the other buffer after them, one barrier per step
+    constexpr int BUFE = GM::BUF / 4;                                    // floats per buffer
+    static_assert(2 * GM::BUF <= GM::LDS, "");
+    auto lds_write = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(wA + i * RPP * ROW) = ra[i];
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<u32x4*>(wA + buf * BUFE + i * RPP * ROW) = ra[i];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4*>(wB + i * RPP * ROW) = chunk_hl(__builtin_bit_cast(f32x4, rb[i]));      // activations: split once, on the way to LDS
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4*>(wB + buf * BUFE + i * RPP * ROW) = chunk_hl(__builtin_bit_cast(f32x4, rb[i]));      // activations: split once, on the way to LDS
     };
     f32x16 acc[SN][SM];
 #pragma unroll
@@ -372,24 +376,28 @@ __global__ __launch_bounds__(FmbX3::NT, 2) void fmbconv_fused_x3_kernel(const Fm
     const float* const fA = lds + (wn * SN * 32 + l31) * ROW + half * 4;
     const float* const fB = lds + (E + wm * SM * 32 + l31) * ROW + half * 4;
     gload();
+    lds_write(0);
+    __syncthreads();
     for (int it = 0; it < p.nk; ++it) {
-        lds_write();
-        __syncthreads();
+        const int cur = it & 1;
         if (it + 1 < p.nk) gload();
+        const float* A = fA + cur * BUFE;
+        const float* Bm = fB + cur * BUFE;
 #pragma unroll
         for (int g = 0; g < BK / 8; g += 2) {
             f16x8 ah[SN], al[SN];
 #pragma unroll
             for (int i = 0; i < SN; ++i)
-                frag_hl(*reinterpret_cast<const f32x4*>(fA + i * 32 * ROW + g * 8), *reinterpret_cast<const f32x4*>(fA + i * 32 * ROW + g * 8 + 8), ah[i], al[i]);
+                frag_hl(*reinterpret_cast<const f32x4*>(A + i * 32 * ROW + g * 8), *reinterpret_cast<const f32x4*>(A + i * 32 * ROW + g * 8 + 8), ah[i], al[i]);
 #pragma unroll
             for (int j = 0; j < SM; ++j) {
                 f16x8 bh, bl;
-                frag_hl(*reinterpret_cast<const f32x4*>(fB + j * 32 * ROW + g * 8), *reinterpret_cast<const f32x4*>(fB + j * 32 * ROW + g * 8 + 8), bh, bl);
+                frag_hl(*reinterpret_cast<const f32x4*>(Bm + j * 32 * ROW + g * 8), *reinterpret_cast<const f32x4*>(Bm + j * 32 * ROW + g * 8 + 8), bh, bl);
 #pragma unroll
                 for (int i = 0; i < SN; ++i) acc[i][j] = mfma_split(ah[i], al[i], bh, bl, acc[i][j]);
             }
         }
+        if (it + 1 < p.nk) lds_write(cur ^ 1);                            // last read in step it - 1, behind the barrier that ended it
         __syncthreads();
     }
 

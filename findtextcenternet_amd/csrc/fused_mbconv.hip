@@ -41,9 +41,9 @@ struct FmbP {
     int B, H, W, Cin, E, Cout, M, ncb, nk, nblk;
 };
 
-// Two forms (template WM = pixel halves of the tile): WM = 2 -- 128 pixels, 8 waves, two operand buffers, one workgroup per CU; WM = 1 -- 64 pixels,
-// 4 waves, ONE operand buffer (two barriers per K step) in 46 KB so that three workgroups share a CU and fill each other's barrier stalls
-// (measured, round 6: the 8-wave form ran its first GEMM at 0.7x the rate of the stand-alone 3x3 -- every wave of the CU stands at the same barrier).
+// Geometry.  The template keeps the parameters of the forms that were measured against each other (WM = pixel halves of the tile and waves along the pixel
+// axis, NBUF operand buffers, SM pixel sub-tiles per wave: DESIGN.md appendix A9, profiles/r06_fmbconv_forms.txt); the library instantiates the adopted one --
+// WM = 2 (128 pixels, 8 waves), ONE operand buffer, SM = 2: 65 KB of LDS and 122 VGPRs for E = 256, i.e. two workgroups per CU.
 template <int BK, int SN, int WM, int NBUF_, int SM_ = 2> struct FmbGeom {
     static constexpr int E = SN * 128, SM = SM_, TM = 32 * SM_ * WM, NT = 256 * WM, NBUF = NBUF_;
     static constexpr int CPR = BK / 8, ROW = BK + 8;                    // 16-byte chunks per K row; padded LDS row (elements)
@@ -564,16 +564,7 @@ hipError_t launch_fmbconv(const OpArgs& a, hipStream_t s) {
     p.nk = 9 * p.ncb;
     p.nblk = 0;
     const bool h = o.w_dtype == FTC_F16;
-    static const int wm_env = [] { const char* e = std::getenv("FTC_FMB_WM"); return e ? std::atoi(e) : 0; }();      // experiment switch: 1 | 2 forces a form
-    static const int nb_env = [] { const char* e = std::getenv("FTC_FMB_NBUF"); return e ? std::atoi(e) : 0; }();
-    // default form (measured, tools/fmbconv_bench.py, profiles/r06_fmbconv_forms.txt): 128-pixel tiles, 8 waves, ONE operand buffer -- two workgroups
-    // per CU (122 VGPRs, 65 KB of LDS): one's SiLU / projection phases run under the other's 3x3 GEMM
-    const int wm = wm_env == 1 || wm_env == 2 ? wm_env : 2;
-    const int nbuf = wm == 1 ? 1 : (nb_env == 2 ? 2 : 1);
-#define FMB_GO(BK_, SN_) do { if (wm_env == 4) return h ? launch_fmb<_Float16, BK_, SN_, 1, 1, 4>(p, s) : launch_fmb<__bf16, BK_, SN_, 1, 1, 4>(p, s); \
-                              if (wm == 2 && nbuf == 2) return h ? launch_fmb<_Float16, BK_, SN_, 2, 2>(p, s) : launch_fmb<__bf16, BK_, SN_, 2, 2>(p, s); \
-                              if (wm == 2) return h ? launch_fmb<_Float16, BK_, SN_, 2, 1>(p, s) : launch_fmb<__bf16, BK_, SN_, 2, 1>(p, s); \
-                              return h ? launch_fmb<_Float16, BK_, SN_, 1, 1>(p, s) : launch_fmb<__bf16, BK_, SN_, 1, 1>(p, s); } while (0)
+#define FMB_GO(BK_, SN_) return h ? launch_fmb<_Float16, BK_, SN_, 2, 1>(p, s) : launch_fmb<__bf16, BK_, SN_, 2, 1>(p, s)
     if (p.E == 256) { if (bk == 64) FMB_GO(64, 2); FMB_GO(32, 2); }
     if (bk == 64) FMB_GO(64, 3);
     FMB_GO(32, 3);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Times FTC_OP_FMBCONV (csrc/fused_mbconv.hip) alone on the two shapes of the batch-8 plan: stage 2 (192x192, 64 -> 256 -> 64) and stage 3
-(96x96, 96 -> 384 -> 96).  The kernel form is chosen by FTC_FMB_WM / FTC_FMB_NBUF (read once per process): run once per form.
+(96x96, 96 -> 384 -> 96).  (Round 6 compared four kernel forms through FTC_FMB_WM / FTC_FMB_NBUF switches -- profiles/r06_fmbconv_forms.txt; the library now
+instantiates the adopted one only, the switches are gone: git show b32c3b2:findtextcenternet_amd/csrc/fused_mbconv.hip has them.)
     python tools/fmbconv_bench.py [bf16|f16]
 Reference (profiles/r05e_bf16_b8_ops.json, the two-launch form inside the plan): stage 2 126 + 65 us, stage 3 75 + 28.5 us."""
 import ctypes as C
@@ -61,7 +62,7 @@ def bench(B, H, W, Cin, E, Cout, dt, reps=30):
 
 if __name__ == "__main__":
     dt = L.F16 if len(sys.argv) > 1 and sys.argv[1] == "f16" else L.BF16
-    form = f"FTC_FMB_WM={os.environ.get('FTC_FMB_WM', '-')} FTC_FMB_NBUF={os.environ.get('FTC_FMB_NBUF', '-')}"
+    form = "fmbconv_fused (8 waves, one operand buffer)"
     for name, shp in (("stage 2", (8, 192, 192, 64, 256, 64)), ("stage 3", (8, 96, 96, 96, 384, 96))):
         us, tf = bench(*shp, dt)
         print(f"{form}  {name} {shp}: {us:7.1f} us  {tf:6.1f} TFLOP/s", flush=True)

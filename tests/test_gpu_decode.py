@@ -40,7 +40,7 @@ def _check_against_oracle(hm, ft, geoms, cut_off, max_boxes=4096):
         gb = dec.boxes[b, :n].cpu().numpy()
         gfe = dec.feats[b, :n].cpu().numpy()
         order = {int(v): k for k, v in enumerate(idx[:n])}
-        perm = np.array([order[int(v)] for v in gi])
+        perm = np.array([order[int(v)] for v in gi], dtype=np.int64)
         np.testing.assert_allclose(gb, loc[perm].astype(np.float32), rtol=2e-6, atol=1e-7)
         assert np.array_equal(gfe, gf[perm])                      # gathered rows are copies: exact
         assert (dec.index[b, n:] == -1).all()
@@ -142,3 +142,16 @@ def test_record_block_and_workspace_reuse():
             assert torch.equal(d.index[b, :n], fresh.index[b, :n])
     with pytest.raises(ValueError):
         decode_peaks(_nhwc(hm[:1]), _nhwc(ft[:1]), g[:1], cut_off=0.4, max_boxes=2048, workspace=ws)
+
+
+@pytest.mark.parametrize("hw", [(240, 272), (5, 7), (193, 191), (64, 512)], ids=["240x272_two_passes", "5x7", "193x191", "64x512"])
+def test_other_map_sizes_vs_oracle(hw):
+    """Round 6 rewrote the select pass (16 workgroups per image, 12 positions per thread and pass, one atomic per workgroup): maps larger than
+    192 x 192 take more than one pass per workgroup, small and odd-sized maps leave workgroups with ragged or empty ranges.  Whole-map and inner
+    rectangles, against the oracle."""
+    h, w = hw
+    hm, ft = synth.detector_maps(400 + h, b=2, h=h, w=w)
+    H, W = 4 * h, 4 * w
+    geoms = [TileGeom(0, 0, W, H, (0, w, 0, h)), TileGeom(0, 0, 2 * W, 2 * H, tile_keep_rect(W // 2, H // 2, 2 * W, 2 * H, 0.6, tile_w=W, tile_h=H))]
+    dec = _check_against_oracle(hm, ft, geoms, 0.4, max_boxes=8192)
+    assert int(dec.counts[0]) > 0 or h * w < 100

@@ -388,3 +388,17 @@ def test_round6_kernels_are_selected_by_the_plans_that_bench_runs(sd, models):
         assert (n_c32, n_fmb) == ((4, 7) if mode != "fp32" else (0, 0)), (mode, n_c32, n_fmb)
         if mode == "fp16x3":
             assert all("f16x3" in l for l in lab if l.startswith(("conv3x3_c32<", "fmbconv_fused<")))
+
+
+def test_fused_block_switches_change_the_plan_and_it_still_validates(models, monkeypatch):
+    """FTC_NO_FMBFUSE=1 keeps the two-launch form of the Fused-MBConv blocks, FTC_FMBFUSE_ALL=1 also fuses stage 3 (measured slower):
+    both plans build and pass ftc_plan_create's validation (plans are cached per (B, H, W, layout): one key per switch)."""
+    m = models["bf16"]
+    for env, key, want in (({"FTC_NO_FMBFUSE": "1"}, (4, 768, 768, False), 0), ({"FTC_FMBFUSE_ALL": "1"}, (4, 768, 768, True), 14), ({}, (5, 768, 768, False), 7)):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pl = m.plan(key[0], key[1], key[2], nchw=key[3])
+        for k in env:
+            monkeypatch.delenv(k)
+        assert sum(pl.ops[i].kind == L.OP_FMBCONV for i in range(len(pl.ops))) == want, env
+        assert abs(sum(mm.flops for mm in pl.meta) / key[0] / 1e9 - 865.0006) < 0.01          # the same network either way
